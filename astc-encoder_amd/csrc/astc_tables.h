@@ -1,0 +1,159 @@
+// SPDX-License-Identifier: Apache-2.0
+// Flat, pointer-free table layout shared by the host table builder (host_tables.cpp) and the
+// wavefront block compressor (wave_*.h).  Everything the kernels read lives in ONE byte blob
+// that is uploaded once per context; records refer to their arrays by byte offset into the blob.
+//
+// The reference keeps the same information in block_size_descriptor (Source/astcenc_internal.h:533,
+// 14.7 MB, fixed 216x64 strides).  Here arrays are sized to the real texel/weight counts and only
+// the entries the compressor can select are kept (a few hundred KB, L2 resident).
+#pragma once
+#include <stdint.h>
+
+namespace astcd {
+
+constexpr int MAX_TEXELS       = 144;  // largest 2D footprint (12x12); 3D blocks are out of scope
+constexpr int MAX_WEIGHTS      = 64;   // ref: BLOCK_MAX_WEIGHTS           astcenc_internal.h:88
+constexpr int PLANE2_OFFSET    = 32;   // ref: WEIGHTS_PLANE2_OFFSET       astcenc_internal.h:109
+constexpr int MAX_PARTITIONS   = 4;    // ref: BLOCK_MAX_PARTITIONS        astcenc_internal.h:79
+constexpr int MAX_PARTITIONINGS = 1024;
+constexpr int MAX_KMEANS_TEXELS = 64;  // ref: BLOCK_MAX_KMEANS_TEXELS     astcenc_internal.h:85
+constexpr int MAX_BLOCK_MODES  = 2048; // ref: WEIGHTS_MAX_BLOCK_MODES     astcenc_internal.h:115
+constexpr int MAX_DECIMATION_MODES = 87;
+constexpr int MAX_TRIAL_CANDIDATES = 8;       // ref: TUNE_MAX_TRIAL_CANDIDATES
+constexpr int MAX_PARTITIONING_CANDIDATES = 8; // ref: TUNE_MAX_PARTITIONING_CANDIDATES
+constexpr int MAX_ANGULAR_QUANT = 7;          // ref: TUNE_MAX_ANGULAR_QUANT (QUANT_12)
+constexpr int ANGULAR_STEPS = 32;             // ref: astcenc_weight_align.cpp:48
+constexpr int SINCOS_STEPS  = 64;             // ref: astcenc_weight_align.cpp:58
+constexpr float ERROR_CALC_DEFAULT = 1e30f;   // ref: astcenc_internal.h:121
+
+// Endpoint formats (ref: enum endpoint_formats, astcenc_internal.h:179)
+enum {
+	FMT_LUMINANCE = 0, FMT_LUMINANCE_DELTA = 1, FMT_HDR_LUMINANCE_LARGE_RANGE = 2,
+	FMT_HDR_LUMINANCE_SMALL_RANGE = 3, FMT_LUMINANCE_ALPHA = 4, FMT_LUMINANCE_ALPHA_DELTA = 5,
+	FMT_RGB_SCALE = 6, FMT_HDR_RGB_SCALE = 7, FMT_RGB = 8, FMT_RGB_DELTA = 9,
+	FMT_RGB_SCALE_ALPHA = 10, FMT_HDR_RGB = 11, FMT_RGBA = 12, FMT_RGBA_DELTA = 13,
+	FMT_HDR_RGB_LDR_ALPHA = 14, FMT_HDR_RGBA = 15
+};
+
+// Quantization methods (ref: enum quant_method, astcenc_internal.h:204)
+enum {
+	QUANT_2 = 0, QUANT_3, QUANT_4, QUANT_5, QUANT_6, QUANT_8, QUANT_10, QUANT_12, QUANT_16,
+	QUANT_20, QUANT_24, QUANT_32, QUANT_40, QUANT_48, QUANT_64, QUANT_80, QUANT_96, QUANT_128,
+	QUANT_160, QUANT_192, QUANT_256
+};
+
+// Symbolic block types (ref: astcenc_internal.h:1059-1068)
+enum { SYM_BTYPE_ERROR = 0, SYM_BTYPE_CONST_F16 = 1, SYM_BTYPE_CONST_U16 = 2, SYM_BTYPE_NONCONST = 3 };
+
+// One legal (weight grid, weight quant, plane count) combination. (ref: struct block_mode :418)
+struct BlockMode {
+	uint16_t mode_index;      // the 11-bit value stored in the physical block
+	uint8_t  decimation_mode; // index into DecimationMode / DecimationInfo arrays
+	uint8_t  quant_mode;      // weight quant_method
+	uint8_t  weight_bits;
+	uint8_t  is_dual_plane;
+	uint8_t  pad[2];
+};
+
+// (ref: struct decimation_mode :449)
+struct DecimationMode {
+	int8_t   maxprec_1plane;
+	int8_t   maxprec_2planes;
+	uint16_t refprec_1plane;
+	uint16_t refprec_2planes;
+	uint16_t pad;
+};
+
+// Bilinear-infill tables of one weight grid. (ref: struct decimation_info :347)
+// Arrays are [row][T] or [row][W] with row stride = texel_count / weight_count.
+struct DecimationInfo {
+	uint8_t  texel_count;
+	uint8_t  weight_count;
+	uint8_t  max_texel_weight_count;
+	uint8_t  weight_x;
+	uint8_t  weight_y;
+	uint8_t  max_weight_texel_count;     // rows in the per-weight arrays
+	uint8_t  pad[2];
+	uint32_t off_texel_weights;          // u8  [4][T]   ref: texel_weights_tr
+	uint32_t off_texel_contribs_int;     // u8  [4][T]   ref: texel_weight_contribs_int_tr
+	uint32_t off_texel_contribs_f;       // f32 [4][T]   ref: texel_weight_contribs_float_tr
+	uint32_t off_weight_texel_count;     // u8  [W]      ref: weight_texel_count
+	uint32_t off_weight_texels;          // u8  [rows][W] ref: weight_texels_tr
+	uint32_t off_weight_contribs;        // f32 [rows][W] ref: weights_texel_contribs_tr
+	uint32_t off_texel_contrib_for_weight; // f32 [rows][W] ref: texel_contrib_for_weight
+};
+
+// One partitioning; fixed-stride record followed by two u8[T] arrays:
+//   partition_of_texel[T], texels_sorted[T] (texel indices grouped by partition, ascending inside
+//   each group == ref texels_of_partition[p][0..count) laid end to end).  (ref: partition_info :313)
+struct PartitionHeader {
+	uint16_t partition_index;    // the 10-bit seed stored in the physical block
+	uint8_t  partition_count;
+	uint8_t  pad;
+	uint8_t  texel_count[4];     // texels per partition
+};
+
+// Weight quantization transfer table. (ref: quant_and_transfer_table :1036)
+struct QuantXfer {
+	uint8_t  quant_to_unquant[32];
+	uint8_t  scramble_map[32];
+	uint16_t prev_next_values[65];
+	uint16_t pad;
+};
+
+// Root record at blob offset 0.
+struct TableRoot {
+	uint8_t  dim_x, dim_y, texel_count, pad0;
+	uint32_t block_mode_count_1plane_always;
+	uint32_t block_mode_count_1plane_selected;
+	uint32_t block_mode_count_1plane_2plane_selected;
+	uint32_t decimation_mode_count_always;
+	uint32_t decimation_mode_count_selected;
+	uint32_t partitioning_count_selected[4];  // [partition_count - 1]
+	uint32_t partition_stride;                // bytes per partition record
+	uint32_t off_block_modes;                 // BlockMode[]
+	uint32_t off_decimation_modes;            // DecimationMode[]
+	uint32_t off_decimation_infos;            // DecimationInfo[]
+	uint32_t off_partitions[4];               // [partition_count - 1] -> records
+	uint32_t off_coverage[4];                 // [partition_count - 1] -> u64[count][partition_count]
+	uint32_t off_kmeans_texels;               // u8[min(T,64)]
+	uint32_t off_color_unquant_to_uquant;     // u8[17][512]
+	uint32_t off_color_uquant_to_pquant;      // u8[17][256]
+	uint32_t off_quant_xfer;                  // QuantXfer[12]
+	uint32_t off_quant_mode_table;            // i8[10][128]
+	uint32_t off_integer_of_trits;            // u8[243]  index ((((t4*3+t3)*3+t2)*3+t1)*3+t0)
+	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
+	uint32_t off_sin_table;                   // f32[64][32]
+	uint32_t off_cos_table;                   // f32[64][32]
+	uint32_t total_bytes;
+};
+
+// Per-context scalars consumed by the kernels. (ref: astcenc_config + derived values)
+struct DeviceConfig {
+	int32_t  profile;
+	uint32_t flags;
+	float    cw[4];
+	float    rgbm_m_scale;
+	uint32_t tune_partition_count_limit;
+	uint32_t tune_partition_index_limit[3];       // 2,3,4 partitions
+	uint32_t tune_refinement_limit;
+	uint32_t tune_candidate_limit;
+	uint32_t tune_partitioning_candidate_limit[3];
+	float    tune_db_limit;                        // already converted (ref: astcenc_entry.cpp:816)
+	float    tune_mse_overshoot;
+	float    tune_partition_early_out_limit_factor[2]; // 2,3 partitions
+	float    tune_2plane_early_out_limit_correlation;
+	float    tune_search_mode0_enable;
+};
+
+// One image (or image slice) handed to the kernel.
+struct ImageDesc {
+	const void* data;      // device pointer, tightly packed RGBA rows
+	uint32_t dim_x, dim_y; // texels
+	uint32_t data_type;    // astcenc_type
+	uint32_t swz[4];       // astcenc_swz per output channel
+	uint32_t blocks_x, blocks_y;
+	uint32_t use_fast_load; // ref: astcenc_entry.cpp:946
+};
+
+} // namespace astcd
