@@ -1,0 +1,35 @@
+// SPDX-License-Identifier: Apache-2.0
+// Seam between the host API layer (astcenc_entry.cpp) and whatever executes the per-block
+// compressor.  The product library links backend_hip.hip (HIP kernels on the current device).
+// tests/emu links backend_emu.cpp, which runs the same wave_*.h source sequentially on the CPU as
+// a debugging aid -- it is never part of libastcenc_amd.so.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "astc_tables.h"
+
+namespace astcd {
+
+struct Backend;
+
+struct CompressJob {
+	const void* host_data;     // tightly packed RGBA rows (one 2D slice), host memory; may be null
+	const void* device_data;   // same layout already resident in HBM; used when host_data is null
+	uint32_t dim_x, dim_y;
+	uint32_t data_type;        // astcenc_type
+	uint32_t swz[4];
+	uint8_t* host_out;         // 16 bytes per block, host memory; may be null
+	uint8_t* device_out;       // HBM destination when host_out is null
+	void*    stream;           // hipStream_t for the device-resident path (null = backend's own)
+	float*   kernel_ms;        // optional: elapsed kernel time measured with HIP events
+	volatile int* cancel_flag; // polled between chunks
+	void (*progress)(float);   // optional
+};
+
+/* status: 0 ok, 1 out of memory, 2 no usable device / launch failure */
+Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status);
+void backend_destroy(Backend* b);
+int backend_compress(Backend* b, const CompressJob& job);
+const char* backend_name();
+
+} // namespace astcd

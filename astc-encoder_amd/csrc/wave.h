@@ -1,0 +1,281 @@
+// SPDX-License-Identifier: Apache-2.0
+// Execution model + exact-arithmetic helpers for the wavefront block compressor.
+//
+// EXECUTION MODEL.  One ASTC block is compressed by ONE 64-lane wavefront (workgroup = 64
+// threads).  All block state lives in LDS.  Code is written in two kinds of region:
+//
+//   * uniform code  - every lane executes it with identical operands (values come from kernel
+//                     arguments, read-only tables, or LDS).  Control flow of the search
+//                     (trial order, early outs, candidate loops) is uniform code.
+//   * WV_FOR(i, n)  - a lane-parallel loop: iteration i runs on lane i % 64.  Iterations must be
+//                     independent; they communicate only through LDS and a following WV_SYNC().
+//
+// The same source also compiles as plain C++ (ASTC_WAVE_EMU) where WV_FOR is a sequential loop and
+// WV_SYNC() is a no-op.  That build is a debugging aid for machines without a GPU (tests/emu); the
+// product library only contains the HIP build.
+//
+// NUMERICS CONTRACT.  Output bytes must equal the reference's scalar ("none") build, whose results
+// depend on evaluation order and on IEEE single precision with no contraction.  Hence:
+//   * this file's helpers restate the reference's scalar definitions operation for operation
+//     (Source/astcenc_mathlib.h, astcenc_vecmathlib_none_4.h, astcenc_vecmathlib_common_4.h,
+//     astcenc_vecmathlib.h); the translation units are built with -ffp-contract=off;
+//   * min/max are compare-selects with the reference's operand order (NaN -> second operand);
+//   * 4-lane horizontal sums use the reference's (l0 + l2) + (l1 + l3) order.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+	#define WV_DEVICE 1
+	#define WV_FN __device__ inline
+	#define WV_LANE ((int)threadIdx.x)
+	#define WV_SYNC() __syncthreads()
+	#define WV_FOR(i, n) for (int i = WV_LANE; i < (int)(n); i += 64)
+	#define WV_ONE if (WV_LANE == 0)
+#else
+	#define WV_DEVICE 0
+	#if defined(__HIPCC__)
+		#define WV_FN __host__ inline
+	#else
+		#define WV_FN inline
+	#endif
+	#define WV_SYNC() ((void)0)
+	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)
+	#define WV_ONE if (true)
+#endif
+
+namespace astcd {
+
+// ---- scalar helpers (ref: astcenc_mathlib.h:168-331) ----
+WV_FN float f_min(float p, float q) { return p < q ? p : q; }
+WV_FN float f_max(float p, float q) { return p > q ? p : q; }
+WV_FN int   i_min(int p, int q) { return p < q ? p : q; }
+WV_FN int   i_max(int p, int q) { return p > q ? p : q; }
+
+/* astc::clamp (ref: astcenc_mathlib.h:271) */
+WV_FN float f_clamp(float v, float mn, float mx)
+{
+	if (v > mx) return mx;
+	if (v > mn) return v;
+	return mn;
+}
+WV_FN int i_clamp(int v, int mn, int mx)
+{
+	if (v > mx) return mx;
+	if (v > mn) return v;
+	return mn;
+}
+WV_FN float f_clamp1(float v) { return f_clamp(v, 0.0f, 1.0f); }
+WV_FN float f_clamp255(float v) { return f_clamp(v, 0.0f, 255.0f); }
+
+/* vector-lane clamp: min(max(a, lo), hi) with compare-select (ref: vecmathlib_common_4.h:225) */
+WV_FN float v_clamp(float lo, float hi, float a)
+{
+	float t = a > lo ? a : lo;
+	return t < hi ? t : hi;
+}
+WV_FN float v_clampzo(float a) { return v_clamp(0.0f, 1.0f, a); }
+
+WV_FN int flt2int_rtn(float v) { return (int)(v + 0.5f); }
+WV_FN bool f_isnan(float v) { return v != v; }
+
+WV_FN float f_abs(float v)
+{
+#if WV_DEVICE
+	return __builtin_fabsf(v);
+#else
+	return __builtin_fabsf(v);
+#endif
+}
+
+WV_FN float f_sqrt(float v)
+{
+#if WV_DEVICE
+	return __fsqrt_rn(v);
+#else
+	return __builtin_sqrtf(v);
+#endif
+}
+
+/* round to nearest even (ref: vecmathlib_none_4.h:876 uses nearbyint under FE_TONEAREST) */
+WV_FN float f_round(float v)
+{
+#if WV_DEVICE
+	return __builtin_rintf(v);
+#else
+	return __builtin_nearbyintf(v);
+#endif
+}
+
+WV_FN int float_as_int(float v) { int i; __builtin_memcpy(&i, &v, 4); return i; }
+WV_FN float int_as_float(int v) { float f; __builtin_memcpy(&f, &v, 4); return f; }
+
+/* horizontal add of 4 lanes (ref: vecmathlib_none_4.h:907) */
+WV_FN float hadd4(float a, float b, float c, float d) { return (a + c) + (b + d); }
+/* hadd_rgb_s (ref: vecmathlib_common_4.h:287) */
+WV_FN float hadd3(float a, float b, float c) { return a + b + c; }
+/* hmin / hmax (ref: vecmathlib_none_4.h:888-902; std::min(a,b) = b < a ? b : a) */
+WV_FN float std_min(float a, float b) { return b < a ? b : a; }
+WV_FN float std_max(float a, float b) { return a < b ? b : a; }
+WV_FN float hmin4(float a, float b, float c, float d) { return std_min(std_min(a, b), std_min(c, d)); }
+WV_FN float hmax4(float a, float b, float c, float d) { return std_max(std_max(a, b), std_max(c, d)); }
+
+// ---- a 4-lane value type for the strictly scalar sections ----
+struct f4 {
+	float x, y, z, w;
+};
+WV_FN f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+WV_FN f4 splat4(float v) { return mk4(v, v, v, v); }
+WV_FN f4 operator+(f4 a, f4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+WV_FN f4 operator-(f4 a, f4 b) { return mk4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+WV_FN f4 operator*(f4 a, f4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+WV_FN f4 operator/(f4 a, f4 b) { return mk4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+WV_FN f4 operator*(f4 a, float b) { return mk4(a.x * b, a.y * b, a.z * b, a.w * b); }
+WV_FN f4 operator/(f4 a, float b) { return mk4(a.x / b, a.y / b, a.z / b, a.w / b); }
+WV_FN float lane(f4 a, int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
+WV_FN void set_lane(f4& a, int i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else if (i == 2) a.z = v; else a.w = v; }
+WV_FN float hadd_s(f4 a) { return hadd4(a.x, a.y, a.z, a.w); }
+WV_FN float hadd_rgb_s(f4 a) { return a.x + a.y + a.z; }
+WV_FN float dot_s(f4 a, f4 b) { return hadd_s(a * b); }
+WV_FN float dot3_s(f4 a, f4 b) { f4 m = a * b; return m.x + m.y + m.z; }
+WV_FN f4 v4_min(f4 a, f4 b) { return mk4(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z, a.w < b.w ? a.w : b.w); }
+WV_FN f4 v4_max(f4 a, f4 b) { return mk4(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z, a.w > b.w ? a.w : b.w); }
+WV_FN f4 v4_clamp(float lo, float hi, f4 a) { return v4_min(v4_max(a, splat4(lo)), splat4(hi)); }
+WV_FN f4 v4_abs(f4 a) { return mk4(f_abs(a.x), f_abs(a.y), f_abs(a.z), f_abs(a.w)); }
+WV_FN f4 v4_sqrt(f4 a) { return mk4(f_sqrt(a.x), f_sqrt(a.y), f_sqrt(a.z), f_sqrt(a.w)); }
+WV_FN f4 load4(const float* p) { return mk4(p[0], p[1], p[2], p[3]); }
+WV_FN void store4(float* p, f4 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+/* swz<0,1,2>: 4th lane zero */
+WV_FN f4 xyz0(f4 a) { return mk4(a.x, a.y, a.z, 0.0f); }
+
+/* normalize (ref: vecmathlib.h:353) -- note dot() is the 4-lane hadd */
+WV_FN f4 normalize4(f4 a)
+{
+	float len = dot_s(a, a);
+	return a / splat4(f_sqrt(len));
+}
+/* normalize_safe (ref: vecmathlib.h:362) */
+WV_FN f4 normalize_safe4(f4 a, f4 safe)
+{
+	float len = dot_s(a, a);
+	if (len != 0.0f)
+	{
+		return a / splat4(f_sqrt(len));
+	}
+	return safe;
+}
+WV_FN f4 unit4() { return splat4(0.5f); }
+WV_FN f4 unit3() { float v = 0.577350258827209473f; return mk4(v, v, v, 0.0f); }
+WV_FN f4 unit2() { float v = 0.707106769084930420f; return mk4(v, v, 0.0f, 0.0f); }
+
+struct i4 {
+	int x, y, z, w;
+};
+WV_FN i4 mki4(int x, int y, int z, int w) { i4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+WV_FN int ilane(i4 a, int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w; }
+WV_FN void set_ilane(i4& a, int i, int v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else if (i == 2) a.z = v; else a.w = v; }
+WV_FN i4 operator+(i4 a, i4 b) { return mki4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+WV_FN i4 operator-(i4 a, i4 b) { return mki4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+WV_FN i4 operator*(i4 a, int b) { return mki4(a.x * b, a.y * b, a.z * b, a.w * b); }
+WV_FN f4 int_to_float4(i4 a) { return mk4((float)a.x, (float)a.y, (float)a.z, (float)a.w); }
+
+/* atan2 approximation (ref: vecmathlib.h:275-306) */
+WV_FN float ref_change_sign(float a, float b)
+{
+	int ia = float_as_int(a), ib = float_as_int(b);
+	return int_as_float(ia ^ (ib & (int)0x80000000));
+}
+WV_FN float ref_atan(float x)
+{
+	const float PI_OVER_TWO = 1.57079632679489661923f;
+	bool c = f_abs(x) > 1.0f;
+	float z = ref_change_sign(PI_OVER_TWO, x);
+	float y = c ? 1.0f / x : x;
+	y = y / (y * y * 0.28f + 1.0f);
+	return c ? z - y : y;
+}
+WV_FN float ref_atan2(float y, float x)
+{
+	const float PI = 3.14159265358979323846f;
+	float z = ref_atan(f_abs(y / x));
+	bool xmask = x < 0.0f;
+	return ref_change_sign(xmask ? PI - z : z, y);
+}
+
+/* popcount of a 64-bit word */
+WV_FN int popcount64(uint64_t v)
+{
+#if WV_DEVICE
+	return __popcll(v);
+#else
+	return __builtin_popcountll(v);
+#endif
+}
+
+/* IEEE binary16 -> binary32 (exact). (ref semantics: sf16_to_float, mathlib_softfloat.cpp) */
+WV_FN float half_to_float(uint16_t h)
+{
+	uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+	uint32_t exp = (h >> 10) & 0x1F;
+	uint32_t man = h & 0x3FF;
+	uint32_t out;
+	if (exp == 0)
+	{
+		if (man == 0) out = sign;
+		else
+		{
+			// denormal: normalise
+			int e = -1;
+			do { man <<= 1; e++; } while (!(man & 0x400));
+			out = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FF) << 13);
+		}
+	}
+	else if (exp == 31)
+	{
+		// inf / nan; the reference quiets NaNs
+		out = sign | 0x7F800000u | (man << 13) | (man ? 0x400000u : 0);
+	}
+	else
+	{
+		out = sign | ((exp + 112) << 23) | (man << 13);
+	}
+	float f; __builtin_memcpy(&f, &out, 4); return f;
+}
+
+/* binary32 -> binary16, round to nearest even. (ref semantics: float_to_sf16 with SF_NEARESTEVEN) */
+WV_FN uint16_t float_to_half(float f)
+{
+	uint32_t x; __builtin_memcpy(&x, &f, 4);
+	uint32_t sign = (x >> 16) & 0x8000;
+	uint32_t ax = x & 0x7FFFFFFF;
+	if (ax >= 0x7F800000u)
+	{
+		if (ax > 0x7F800000u) return (uint16_t)(sign | 0x7C00 | ((ax >> 13) & 0x3FF) | 0x200); // quiet NaN
+		return (uint16_t)(sign | 0x7C00);
+	}
+	if (ax >= 0x477FF000u) // rounds to >= 65520 -> inf
+	{
+		return (uint16_t)(sign | 0x7C00);
+	}
+	if (ax < 0x33000001u) // below half the smallest denormal -> zero
+	{
+		return (uint16_t)sign;
+	}
+	int e = (int)(ax >> 23) - 127;
+	uint32_t m = (ax & 0x7FFFFF) | 0x800000;
+	if (e < -14)
+	{
+		// denormal half: shift so that the result has 10 fraction bits at exponent -14
+		int shift = 13 + (-14 - e);
+		uint32_t r = m >> shift;
+		uint32_t rem = m & ((1u << shift) - 1);
+		uint32_t half = 1u << (shift - 1);
+		if (rem > half || (rem == half && (r & 1))) r++;
+		return (uint16_t)(sign | r);
+	}
+	uint32_t r = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3FF);
+	uint32_t rem = m & 0x1FFF;
+	if (rem > 0x1000 || (rem == 0x1000 && (r & 1))) r++;
+	return (uint16_t)(sign | r);
+}
+
+} // namespace astcd

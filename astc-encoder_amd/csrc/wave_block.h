@@ -1,0 +1,685 @@
+// SPDX-License-Identifier: Apache-2.0
+// The per-block search controller and the two trial drivers.
+//   ref: compress_block                                  Source/astcenc_compress_symbolic.cpp:1162-1456
+//        compress_symbolic_block_for_partition_1plane    :353-702
+//        compress_symbolic_block_for_partition_2planes   :715-1037
+//        prepare_block_statistics                        :1047-1159
+// All control flow here is wave-uniform: every decision is taken on values read back from LDS.
+#pragma once
+#include "wave_ctx.h"
+#include "wave_load.h"
+#include "wave_ideal.h"
+#include "wave_weights.h"
+#include "wave_format.h"
+#include "wave_color.h"
+#include "wave_refine.h"
+#include "wave_partition.h"
+#include "wave_pack.h"
+
+namespace astcd {
+
+WV_FN void copy_scb(Scb& dst, const Scb& src)
+{
+	const uint32_t* s = reinterpret_cast<const uint32_t*>(&src);
+	uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+	WV_FOR(i, (int)(sizeof(Scb) / 4)) { d[i] = s[i]; }
+}
+
+/* Low/high weight bounds of block mode `bm` for `plane`, with the high-bound override
+ * (ref: compress_symbolic.cpp:459-462, :819-827; weight_align.cpp:404-422). */
+WV_FN void mode_weight_bounds(const Ctx& c, const BlockMode& bm, int plane, float& low, float& high)
+{
+	if (bm.quant_mode <= MAX_ANGULAR_QUANT)
+	{
+		const float* lh = c.lowhigh(plane, bm.decimation_mode);
+		low = lh[bm.quant_mode * 2];
+		high = lh[bm.quant_mode * 2 + 1];
+	}
+	else
+	{
+		low = 0.0f;
+		high = 1.0f;
+	}
+	if (high > 1.02f * c.tr().min_wt_cutoff[plane])
+	{
+		high = 1.0f;
+	}
+}
+
+/* Quantize the ideal weights of `plane` for block mode i into dst_u8 (and float copy dst_f). */
+WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, float* dst_f, uint8_t* dst_u8)
+{
+	const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+	float low, high;
+	mode_weight_bounds(c, bm, plane, low, high);
+	QuantParams qp = quant_params(low, high, bm.quant_mode);
+	const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
+	const float* ideal = c.dwi(bm.decimation_mode) + plane * PLANE2_OFFSET;
+	WV_FOR(i, di.weight_count)
+	{
+		float f;
+		int w = quantize_weight(qp, q2u, ideal[i], &f);
+		if (dst_f) dst_f[i] = f;
+		if (dst_u8) dst_u8[i] = (uint8_t)w;
+	}
+}
+
+/* Shared tail of both trials: refine the chosen candidates. Returns best error seen in this trial. */
+WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_count, int partition_packed,
+                              int plane2_component, float tune_errorval_threshold)
+{
+	TrialInfo& tr = c.tr();
+	Scb& scb = c.scb();
+	Scb& workscb = c.wscb();
+	const bool dual = plane2_component >= 0;
+	const int T = c.T;
+
+	float best_errorval_in_mode = ERROR_CALC_DEFAULT;
+	float best_errorval_in_scb = scb.errorval;
+	const int candidate_count = tr.cand_count;
+	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
+
+	for (int i = 0; i < candidate_count; i++)
+	{
+		const int bm_packed_index = tr.cand_block_mode[i];
+		const BlockMode& qw_bm = c.block_mode(bm_packed_index);
+		const DecimationInfo& di = c.dec_info(qw_bm.decimation_mode);
+		const int color_quant_level = tr.cand_quant[i];
+		const int color_quant_level_mod = tr.cand_quant_mod[i];
+
+		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
+		// recomputed here instead of being stored for every block mode
+		WV_FOR(k, partition_count * 4)
+		{
+			int p = k >> 2, ch = k & 3;
+			int plane = (dual && ch == plane2_component) ? 1 : 0;
+			tr.wep0[p][ch] = tr.ep0[plane][p][ch];
+			tr.wep1[p][ch] = tr.ep1[plane][p][ch];
+		}
+		quantize_mode_weights(c, qw_bm, 0, nullptr, workscb.weights);
+		if (dual) quantize_mode_weights(c, qw_bm, 1, nullptr, workscb.weights + PLANE2_OFFSET);
+		WV_SYNC();
+
+		bool stop_all = false;
+		for (int l = 0; l < refinement_limit; l++)
+		{
+			if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
+			else recompute_ideal_colors_1plane(c, pv, di);
+
+			// pack endpoints, one lane per partition (ref: :542-555, :925-931)
+			WV_FOR(j, partition_count)
+			{
+				workscb.color_formats[j] = (uint8_t)pack_color_endpoints(
+				    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
+				    tr.cand_formats[i][j], workscb.color_values[j], color_quant_level);
+			}
+			WV_SYNC();
+
+			int formats_matched = 0;
+			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
+			{
+				bool all_same = true;
+				for (int j = 1; j < partition_count; j++) all_same = all_same && workscb.color_formats[j] == workscb.color_formats[0];
+				if (all_same)
+				{
+					// retry at the higher quant level that matched formats allow (ref: :561-598)
+					uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8]
+					uint8_t* fmts = colorvals + 32;                                   // [4]
+					WV_FOR(j, partition_count)
+					{
+						fmts[j] = (uint8_t)pack_color_endpoints(
+						    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
+						    tr.cand_formats[i][j], colorvals + j * 8, color_quant_level_mod);
+					}
+					WV_SYNC();
+					bool all_same_mod = true;
+					for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
+					if (all_same_mod)
+					{
+						formats_matched = 1;
+						WV_FOR(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
+						WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; }
+					}
+					WV_SYNC();
+				}
+			}
+
+			WV_ONE
+			{
+				workscb.color_formats_matched = (uint8_t)formats_matched;
+				workscb.partition_count = (uint8_t)partition_count;
+				workscb.partition_index = (uint16_t)partition_packed;
+				workscb.plane2_component = (int8_t)plane2_component;
+				workscb.quant_mode = (uint8_t)(formats_matched ? color_quant_level_mod : color_quant_level);
+				workscb.block_mode = (uint16_t)bm_packed_index;
+				workscb.block_type = SYM_BTYPE_NONCONST;
+			}
+			WV_SYNC();
+
+			if (l == 0)
+			{
+				float errorval = compute_symbolic_block_difference(c, pv);
+				if (errorval == -ERROR_CALC_DEFAULT)
+				{
+					errorval = -errorval;
+					WV_ONE { workscb.block_type = SYM_BTYPE_ERROR; }
+				}
+				best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
+
+				int iters_remaining = refinement_limit - l;
+				float threshold = (0.045f * (float)iters_remaining) + 1.08f;
+				if (errorval > (threshold * best_errorval_in_scb))
+				{
+					break;
+				}
+
+				if (errorval < best_errorval_in_scb)
+				{
+					best_errorval_in_scb = errorval;
+					WV_SYNC();
+					WV_ONE { workscb.errorval = errorval; }
+					WV_SYNC();
+					copy_scb(scb, workscb);
+					WV_SYNC();
+					if (errorval < tune_errorval_threshold)
+					{
+						stop_all = true;
+						break;
+					}
+				}
+			}
+
+			WV_SYNC();
+			bool adjustments = realign_weights(c, pv);
+
+			float errorval = compute_symbolic_block_difference(c, pv);
+			if (errorval == -ERROR_CALC_DEFAULT)
+			{
+				errorval = -errorval;
+				WV_ONE { workscb.block_type = SYM_BTYPE_ERROR; }
+			}
+			best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
+
+			int iters_remaining = refinement_limit - 1 - l;
+			float threshold = (0.045f * (float)iters_remaining) + 1.0f;
+			if (errorval > (threshold * best_errorval_in_scb))
+			{
+				break;
+			}
+
+			if (errorval < best_errorval_in_scb)
+			{
+				best_errorval_in_scb = errorval;
+				WV_SYNC();
+				WV_ONE { workscb.errorval = errorval; }
+				WV_SYNC();
+				copy_scb(scb, workscb);
+				WV_SYNC();
+				if (errorval < tune_errorval_threshold)
+				{
+					stop_all = true;
+					break;
+				}
+			}
+
+			if (!adjustments)
+			{
+				break;
+			}
+		}
+		WV_SYNC();
+		if (stop_all) break;
+	}
+	(void)T;
+	return best_errorval_in_mode;
+}
+
+/* (ref: compress_symbolic_block_for_partition_1plane :353) */
+WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_errorval_threshold,
+                                  int partition_count, int partition_packed, int quant_limit)
+{
+	TrialInfo& tr = c.tr();
+	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
+	PartView pv = part_view(c, partition_count, partition_packed);
+
+	ideal_colors_and_weights_1plane(c, pv);
+
+	// ideal weights on every referenced decimation grid (ref: :388-405)
+	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
+	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
+	for (int i = 0; i < max_decimation_modes; i++)
+	{
+		if (!(c.dec_mode(i).refprec_1plane & ref_mask)) continue;
+		ideal_weights_for_decimation(c, 0, i, c.dwi(i));
+	}
+
+	// (ref: :409-418)
+	WV_ONE
+	{
+		f4 min_ep = splat4(10.0f);
+		for (int i = 0; i < partition_count; i++)
+		{
+			f4 e0 = load4(tr.ep0[0][i]), e1 = load4(tr.ep1[0][i]);
+			f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
+			for (int k = 0; k < 4; k++)
+			{
+				float v = lane(ep, k);
+				if (v > 0.5f && v < lane(min_ep, k)) set_lane(min_ep, k, v);
+			}
+		}
+		tr.min_wt_cutoff[0] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+	}
+
+	// angular bounds (ref: compute_angular_endpoints_1plane, weight_align.cpp:358-399)
+	WV_ONE
+	{
+		int n = 0;
+		for (int i = 0; i < max_decimation_modes; i++) if (c.dec_mode(i).refprec_1plane & ref_mask) tr.dm_list[n++] = (uint8_t)i;
+		tr.dm_count = n;
+	}
+	WV_SYNC();
+	{
+		auto get_set = [&](int s) {
+			int dm = tr.dm_list[s];
+			int max_precision = c.dec_mode(dm).maxprec_1plane;
+			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
+			max_precision = i_min(max_precision, max_weight_quant);
+			AngSet a;
+			a.weights = c.dwi(dm);
+			a.out = c.lowhigh(0, dm);
+			a.wcount = c.dec_info(dm).weight_count;
+			a.maxq = max_precision;
+			return a;
+		};
+		angular_endpoints(c, tr.dm_count, get_set);
+	}
+
+	// quantize + score every block mode (ref: :438-485)
+	const int max_block_modes = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
+	ModeRec* modes = c.modes();
+	float* uqf = c.wsc(0);
+	float* terms = c.tsc(0);
+	const float* eiw = c.ei_w(0);
+	const float* eiwes = c.ei_wes(0);
+	for (int i = 0; i < max_block_modes; i++)
+	{
+		const BlockMode& bm = c.block_mode(i);
+		int bitcount = mode_bitcount(partition_count, bm);
+		if (bm.quant_mode > max_weight_quant || bitcount <= 0)
+		{
+			WV_ONE { modes[i].qwt_error = 1e38f; }
+			continue;
+		}
+		const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+		const int T = di.texel_count;
+		quantize_mode_weights(c, bm, 0, uqf, nullptr);
+		WV_SYNC();
+
+		// (ref: compute_error_of_weight_set_1plane, ideal_endpoints_and_weights.cpp:688-749)
+		const uint8_t* tw = c.tab + di.off_texel_weights;
+		const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+		const int mtwc = di.max_texel_weight_count;
+		WV_FOR(t, T)
+		{
+			float current = mtwc > 2 ? infill4(uqf, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf, tw, tcf, T, t) : uqf[t];
+			float diff = current - eiw[t];
+			terms[t] = diff * diff * eiwes[t];
+		}
+		WV_SYNC();
+		float err = sum4(terms, T);
+		WV_ONE { modes[i].qwt_error = err; }
+		WV_SYNC();
+	}
+	WV_SYNC();
+
+	compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], 0, max_block_modes);
+
+	return refine_candidates(c, pv, partition_count, partition_packed, -1, tune_errorval_threshold);
+}
+
+/* (ref: compress_symbolic_block_for_partition_2planes :715) */
+WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, int plane2_component, int quant_limit)
+{
+	TrialInfo& tr = c.tr();
+	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
+	PartView pv = part_view(c, 1, 0);
+
+	ideal_colors_and_weights_2planes(c, pv, plane2_component);
+
+	const int ndm = (int)c.root->decimation_mode_count_selected;
+	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
+	for (int i = 0; i < ndm; i++)
+	{
+		if (!(c.dec_mode(i).refprec_2planes & ref_mask)) continue;
+		ideal_weights_for_decimation(c, 0, i, c.dwi(i));
+		ideal_weights_for_decimation(c, 1, i, c.dwi(i) + PLANE2_OFFSET);
+	}
+
+	// (ref: :765-785)
+	WV_ONE
+	{
+		float cut[2];
+		for (int plane = 0; plane < 2; plane++)
+		{
+			f4 e0 = load4(tr.ep0[plane][0]), e1 = load4(tr.ep1[plane][0]);
+			f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
+			f4 min_ep = splat4(10.0f);
+			for (int k = 0; k < 4; k++)
+			{
+				float v = lane(ep, k);
+				if (v > 0.5f && v < 10.0f) set_lane(min_ep, k, v);
+			}
+			// plane 0 ignores the separated component, plane 1 only looks at it
+			for (int k = 0; k < 4; k++)
+			{
+				bool is_p2 = k == plane2_component;
+				if (plane == 0 ? is_p2 : !is_p2) set_lane(min_ep, k, ERROR_CALC_DEFAULT);
+			}
+			cut[plane] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+		}
+		tr.min_wt_cutoff[0] = cut[0];
+		tr.min_wt_cutoff[1] = cut[1];
+	}
+
+	WV_ONE
+	{
+		int n = 0;
+		for (int i = 0; i < ndm; i++) if (c.dec_mode(i).refprec_2planes & ref_mask) tr.dm_list[n++] = (uint8_t)i;
+		tr.dm_count = n;
+	}
+	WV_SYNC();
+	{
+		auto get_set = [&](int s) {
+			int plane = s & 1;
+			int dm = tr.dm_list[s >> 1];
+			int max_precision = c.dec_mode(dm).maxprec_2planes;
+			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
+			max_precision = i_min(max_precision, max_weight_quant);
+			AngSet a;
+			a.weights = c.dwi(dm) + plane * PLANE2_OFFSET;
+			a.out = c.lowhigh(plane, dm);
+			a.wcount = c.dec_info(dm).weight_count;
+			a.maxq = max_precision;
+			return a;
+		};
+		angular_endpoints(c, tr.dm_count * 2, get_set);
+	}
+
+	const int start_2plane = (int)c.root->block_mode_count_1plane_selected;
+	const int end_2plane = (int)c.root->block_mode_count_1plane_2plane_selected;
+	ModeRec* modes = c.modes();
+	float* uqf1 = c.wsc(0);
+	float* uqf2 = c.wsc(1);
+	float* terms = c.tsc(0);
+	for (int i = start_2plane; i < end_2plane; i++)
+	{
+		const BlockMode& bm = c.block_mode(i);
+		if (bm.quant_mode > max_weight_quant)
+		{
+			WV_ONE { modes[i].qwt_error = 1e38f; }
+			continue;
+		}
+		const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+		const int T = di.texel_count;
+		quantize_mode_weights(c, bm, 0, uqf1, nullptr);
+		quantize_mode_weights(c, bm, 1, uqf2, nullptr);
+		WV_SYNC();
+
+		// (ref: compute_error_of_weight_set_2planes, ideal_endpoints_and_weights.cpp:752-842)
+		const uint8_t* tw = c.tab + di.off_texel_weights;
+		const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+		const int mtwc = di.max_texel_weight_count;
+		WV_FOR(t, T)
+		{
+			float cur1 = mtwc > 2 ? infill4(uqf1, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf1, tw, tcf, T, t) : uqf1[t];
+			float diff = cur1 - c.ei_w(0)[t];
+			float error1 = diff * diff * c.ei_wes(0)[t];
+			float cur2 = mtwc > 2 ? infill4(uqf2, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf2, tw, tcf, T, t) : uqf2[t];
+			diff = cur2 - c.ei_w(1)[t];
+			float error2 = diff * diff * c.ei_wes(1)[t];
+			terms[t] = error1 + error2;
+		}
+		WV_SYNC();
+		float err = sum4(terms, T);
+		WV_ONE { modes[i].qwt_error = err; }
+		WV_SYNC();
+	}
+	WV_SYNC();
+
+	// merged endpoints (ref: merge_endpoints :37) -> wep0/wep1 used as the format-search input
+	WV_FOR(ch, 4)
+	{
+		int plane = ch == plane2_component ? 1 : 0;
+		tr.rgbs[1][ch] = tr.ep0[plane][0][ch];   // staging rows (rgbs[1..2] are unused with 1 partition)
+		tr.rgbs[2][ch] = tr.ep1[plane][0][ch];
+	}
+	WV_SYNC();
+	compute_ideal_endpoint_formats(c, pv, &tr.rgbs[1], &tr.rgbs[2], start_2plane, end_2plane);
+
+	return refine_candidates(c, pv, 1, 0, plane2_component, tune_errorval_threshold);
+}
+
+/* (ref: prepare_block_statistics :1047) */
+WV_FN float prepare_block_statistics(const Ctx& c)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+
+	// chains: 0 weight_sum, 1-4 rs gs bs as, 5 rr 6 gg 7 bb 8 aa, 9 rg 10 rb 11 ra 12 gb 13 ga 14 ba
+	WV_FOR(k, 15)
+	{
+		const int ca[15] = { 0, 0, 1, 2, 3, 0, 1, 2, 3, 0, 0, 0, 1, 1, 2 };
+		const int cb[15] = { -1, -1, -1, -1, -1, 0, 1, 2, 3, 1, 2, 3, 2, 3, 3 };
+		const float* da = c.data(ca[k]);
+		const float* db = cb[k] >= 0 ? c.data(cb[k]) : da;
+		float acc = 0.0f;
+		for (int i = 0; i < T; i++)
+		{
+			float weight = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) / 4.0f;
+			if (k == 0) acc += weight;
+			else
+			{
+				float aw = da[i] * weight;
+				if (cb[k] < 0) acc += aw;
+				else acc += db[i] * aw;
+			}
+		}
+		tr.fbox[k] = acc;
+	}
+	WV_SYNC();
+
+	const float* s = tr.fbox;
+	float weight_sum = s[0], rs = s[1], gs = s[2], bs = s[3], as = s[4];
+	float rr_var = s[5], gg_var = s[6], bb_var = s[7], aa_var = s[8];
+	float rg_cov = s[9], rb_cov = s[10], ra_cov = s[11], gb_cov = s[12], ga_cov = s[13], ba_cov = s[14];
+
+	float rpt = 1.0f / f_max(weight_sum, 1e-7f);
+
+	rr_var -= rs * (rs * rpt);
+	rg_cov -= gs * (rs * rpt);
+	rb_cov -= bs * (rs * rpt);
+	ra_cov -= as * (rs * rpt);
+
+	gg_var -= gs * (gs * rpt);
+	gb_cov -= bs * (gs * rpt);
+	ga_cov -= as * (gs * rpt);
+
+	bb_var -= bs * (bs * rpt);
+	ba_cov -= as * (bs * rpt);
+
+	aa_var -= as * (as * rpt);
+
+	rg_cov *= 1.0f / f_sqrt(rr_var * gg_var);
+	rb_cov *= 1.0f / f_sqrt(rr_var * bb_var);
+	ra_cov *= 1.0f / f_sqrt(rr_var * aa_var);
+	gb_cov *= 1.0f / f_sqrt(gg_var * bb_var);
+	ga_cov *= 1.0f / f_sqrt(gg_var * aa_var);
+	ba_cov *= 1.0f / f_sqrt(bb_var * aa_var);
+
+	if (f_isnan(rg_cov)) rg_cov = 1.0f;
+	if (f_isnan(rb_cov)) rb_cov = 1.0f;
+	if (f_isnan(ra_cov)) ra_cov = 1.0f;
+	if (f_isnan(gb_cov)) gb_cov = 1.0f;
+	if (f_isnan(ga_cov)) ga_cov = 1.0f;
+	if (f_isnan(ba_cov)) ba_cov = 1.0f;
+
+	float lowest_correlation = f_min(f_abs(rg_cov), f_abs(rb_cov));
+	lowest_correlation = f_min(lowest_correlation, f_abs(ra_cov));
+	lowest_correlation = f_min(lowest_correlation, f_abs(gb_cov));
+	lowest_correlation = f_min(lowest_correlation, f_abs(ga_cov));
+	lowest_correlation = f_min(lowest_correlation, f_abs(ba_cov));
+	WV_SYNC();
+	return lowest_correlation;
+}
+
+/* Compress the block currently loaded in LDS and write 16 bytes to pcb. (ref: compress_block :1162) */
+WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
+{
+	const BlkInfo& blk = c.blk();
+	const DeviceConfig& cfg = *c.cfg;
+	Scb& scb = c.scb();
+	const int T = c.T;
+
+	bool block_is_l = blk_is_luminance(blk);
+	float block_is_l_scale = block_is_l ? 1.0f / 1.5f : 1.0f;
+	bool block_is_la = blk_is_luminancealpha(blk);
+	float block_is_la_scale = block_is_la ? 1.0f / 1.05f : 1.0f;
+
+	// constant colour -> void extent (ref: :1216-1245)
+	if (blk.data_min[0] == blk.data_max[0] && blk.data_min[1] == blk.data_max[1] &&
+	    blk.data_min[2] == blk.data_max[2] && blk.data_min[3] == blk.data_max[3])
+	{
+		WV_ONE
+		{
+			scb.partition_count = 0;
+			if (cfg.profile == 3 || cfg.profile == 2)
+			{
+				scb.block_type = SYM_BTYPE_CONST_F16;
+				for (int k = 0; k < 4; k++) scb.constant_color[k] = float_to_half(blk.origin[k]);
+			}
+			else
+			{
+				scb.block_type = SYM_BTYPE_CONST_U16;
+				for (int k = 0; k < 4; k++)
+				{
+					float v = v_clamp(0.0f, 1.0f, blk.origin[k]) * 65535.0f;
+					scb.constant_color[k] = (int)(v + 0.5f);
+				}
+			}
+			symbolic_to_physical(c, scb, pcb);
+		}
+		return;
+	}
+
+	float error_weight_sum = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) * (float)T;
+	float error_threshold = cfg.tune_db_limit * error_weight_sum * block_is_l_scale * block_is_la_scale;
+
+	WV_ONE
+	{
+		scb.errorval = ERROR_CALC_DEFAULT;
+		scb.block_type = SYM_BTYPE_ERROR;
+	}
+	WV_SYNC();
+
+	float best_errorvals_for_pcount[4] = { ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT };
+	float exit_thresholds_for_pcount[4] = { 0.0f, cfg.tune_partition_early_out_limit_factor[0], cfg.tune_partition_early_out_limit_factor[1], 0.0f };
+	float errorval_mult[2] = { 1.0f / cfg.tune_mse_overshoot, 1.0f };
+	const float errorval_overshoot = 1.0f / cfg.tune_mse_overshoot;
+
+	int start_trial = 1;
+	if (cfg.tune_search_mode0_enable >= 0.85f) start_trial = 0;
+
+	int quant_limit = QUANT_32;
+	bool done = false;
+
+	// trial A: 1 partition, 1 plane (ref: :1292-1318)
+	for (int i = start_trial; i < 2 && !done; i++)
+	{
+		float errorval = compress_block_1plane(c, i == 0, error_threshold * errorval_mult[i] * errorval_overshoot, 1, 0, QUANT_32);
+		WV_SYNC();
+		if (scb.block_type != SYM_BTYPE_ERROR)
+		{
+			quant_limit = c.block_mode(scb.block_mode).quant_mode;
+		}
+		best_errorvals_for_pcount[0] = f_min(best_errorvals_for_pcount[0], errorval);
+		if (errorval < (error_threshold * errorval_mult[i])) done = true;
+	}
+
+	// trial B: 1 partition, 2 planes (ref: :1320-1369)
+	if (!done)
+	{
+		float lowest_correl = prepare_block_statistics(c);
+		bool block_skip_two_plane = lowest_correl > cfg.tune_2plane_early_out_limit_correlation;
+		for (int i = 3; i >= 0 && !done; i--)
+		{
+			if (block_skip_two_plane) continue;
+			if (blk.grayscale && i != 3) continue;
+			if (is_constant_channel(blk, i)) continue;
+
+			float errorval = compress_block_2planes(c, error_threshold * errorval_overshoot, i, quant_limit);
+			WV_SYNC();
+			if (errorval > (best_errorvals_for_pcount[0] * 1.85f)) break;
+			if (errorval < error_threshold) done = true;
+		}
+	}
+
+	// trial C: 2..4 partitions (ref: :1372-1429)
+	if (!done)
+	{
+		const int max_partitions = (int)cfg.tune_partition_count_limit;
+		for (int partition_count = 2; partition_count <= max_partitions && !done; partition_count++)
+		{
+			int requested_indices = (int)cfg.tune_partition_index_limit[partition_count - 2];
+			int requested_trials = (int)cfg.tune_partitioning_candidate_limit[partition_count - 2];
+			requested_trials = i_min(requested_trials, requested_indices);
+
+			int actual_trials = find_best_partition_candidates(c, partition_count, requested_indices, requested_trials);
+			// copy out of the scratch region: the trials below reuse it
+			int partition_indices[MAX_PARTITIONING_CANDIDATES];
+			{
+				const PartScratch& ps = *reinterpret_cast<const PartScratch*>(c.part());
+				for (int i = 0; i < MAX_PARTITIONING_CANDIDATES; i++) partition_indices[i] = i < actual_trials ? ps.best[i] : 0;
+			}
+			WV_SYNC();
+
+			float best_error_in_prev = best_errorvals_for_pcount[partition_count - 2];
+
+			for (int i = 0; i < actual_trials; i++)
+			{
+				float errorval = compress_block_1plane(c, false, error_threshold * errorval_overshoot,
+				                                       partition_count, partition_indices[i], quant_limit);
+				WV_SYNC();
+				best_errorvals_for_pcount[partition_count - 1] = f_min(best_errorvals_for_pcount[partition_count - 1], errorval);
+
+				float best_error = best_errorvals_for_pcount[partition_count - 1];
+				float best_error_scale = exit_thresholds_for_pcount[partition_count - 1] * 1.85f;
+				if (best_error > (best_error_in_prev * best_error_scale)) { done = true; break; }
+				if (errorval < error_threshold) { done = true; break; }
+			}
+			if (done) break;
+
+			float best_error = best_errorvals_for_pcount[partition_count - 1];
+			float best_error_scale = exit_thresholds_for_pcount[partition_count - 1];
+			if (best_error > (best_error_in_prev * best_error_scale)) { done = true; break; }
+		}
+	}
+
+	WV_SYNC();
+	WV_ONE
+	{
+		if (scb.block_type == SYM_BTYPE_ERROR)
+		{
+			// no valid encoding found: constant colour of texel 0 (ref: :1436-1452)
+			scb.block_type = SYM_BTYPE_CONST_U16;
+			for (int k = 0; k < 4; k++)
+			{
+				float v = v_clamp(0.0f, 1.0f, blk.origin[k]) * 65535.0f;
+				scb.constant_color[k] = (int)(v + 0.5f);
+			}
+		}
+		symbolic_to_physical(c, scb, pcb);
+	}
+}
+
+} // namespace astcd

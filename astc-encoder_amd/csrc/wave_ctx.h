@@ -1,0 +1,210 @@
+// SPDX-License-Identifier: Apache-2.0
+// Per-block working set of the wavefront compressor: LDS layout and the uniform context object.
+//
+// The reference keeps this state in image_block (astcenc_internal.h:749), symbolic_compressed_block
+// (:1077) and compression_working_buffers (:946; 231 KB per thread).  Here it is an LDS region whose
+// layout is computed once per context from the real texel / mode counts (15 KB for 6x6 -medium).
+#pragma once
+#include "astc_tables.h"
+#include "wave.h"
+
+namespace astcd {
+
+/* Block-lifetime scalars. (ref: image_block :749) */
+struct BlkInfo {
+	float data_min[4];
+	float data_mean[4];
+	float data_max[4];
+	float origin[4];
+	float cw[4];          // channel_weight
+	int   grayscale;
+	int   rgb_lns;        // blk.rgb_lns[0]
+	int   alpha_lns;      // blk.alpha_lns[0]
+	int   pad;
+};
+
+/* Symbolic block. (ref: symbolic_compressed_block :1077).  block_mode / partition_index hold PACKED
+ * table indices while searching; they are translated when the physical block is written. */
+struct Scb {
+	uint8_t  block_type;
+	uint8_t  partition_count;
+	uint8_t  color_formats_matched;
+	int8_t   plane2_component;
+	uint16_t block_mode;
+	uint16_t partition_index;
+	uint8_t  color_formats[4];
+	uint8_t  quant_mode;
+	uint8_t  pad[3];
+	float    errorval;
+	union {
+		uint8_t color_values[4][8];
+		int     constant_color[4];
+	};
+	uint8_t  weights[64];
+};
+
+/* Trial-lifetime scalars: ideal endpoints of both planes etc. (ref: endpoints_and_weights :904) */
+struct TrialInfo {
+	float ep0[2][4][4];       // [plane][partition][channel]  endpt0
+	float ep1[2][4][4];
+	int   is_constant_wes[2];
+	float min_wt_cutoff[2];
+	// candidate search results (ref: compute_ideal_endpoint_formats outputs)
+	int   cand_count;
+	int   cand_block_mode[MAX_TRIAL_CANDIDATES];
+	int   cand_quant[MAX_TRIAL_CANDIDATES];
+	int   cand_quant_mod[MAX_TRIAL_CANDIDATES];
+	uint8_t cand_formats[MAX_TRIAL_CANDIDATES][4];
+	// working endpoints of the candidate being refined
+	float wep0[4][4];
+	float wep1[4][4];
+	float rgbs[4][4];
+	float rgbo[4][4];
+	// partition metrics
+	float pm_avg[4][4];
+	float pm_dir[4][4];
+	// encoding choice errors per partition (ref: encoding_choice_errors :922)
+	float eci_rgb_scale[4], eci_rgb_luma[4], eci_luminance[4], eci_alpha_drop[4];
+	int   eci_can_offset[4], eci_can_blue_contract[4];
+	// generic small uniform mailboxes
+	float fbox[128];
+	int   ibox[64];
+	// decimation modes referenced by the current trial (compacted list)
+	int   dm_count;
+	uint8_t dm_list[96];
+};
+
+/* Per block mode record of one trial. */
+struct ModeRec {
+	float qwt_error;
+	float total_error;        // errors_of_best_combination
+	uint8_t quant_level;
+	uint8_t quant_level_mod;
+	uint8_t formats[4];
+	uint8_t pad[2];
+};
+
+struct LdsLayout {
+	uint32_t data;       // f32 [4][Tp]
+	uint32_t blk;        // BlkInfo
+	uint32_t scb;        // Scb (best so far)
+	uint32_t wscb;       // Scb (candidate being refined)
+	uint32_t trial;      // TrialInfo
+	uint32_t ei_w;       // f32 [2][Tp]    ideal weights per plane
+	uint32_t ei_wes;     // f32 [2][Tp]    weight error scale per plane
+	uint32_t dwi;        // f32 [NDM][64]  dec_weights_ideal
+	uint32_t lowhigh;    // f32 [2][NDM][8][2]   angular low/high per plane, decimation mode, quant
+	uint32_t ang;        // f32 [64][8]    one batch of (decimation mode, angular step) results
+	uint32_t modes;      // ModeRec [NBM]
+	uint32_t tsc;        // f32 [12][Tp]   per-texel scratch rows
+	uint32_t wsc;        // f32 [4][64]    per-weight scratch rows
+	uint32_t fmt;        // format-search scratch (best_error[4][21][4] etc.)
+	uint32_t part;       // partition-search scratch
+	uint32_t total;
+};
+
+/* Sizes in bytes of the two variable scratch regions. */
+constexpr uint32_t FMT_SCRATCH_BYTES = 4 * 21 * 4 * 4      /* best_error */
+                                     + 4 * 21 * 4          /* format_of_choice */
+                                     + 21 * 13 * 4         /* combined error */
+                                     + 21 * 13 * 4;        /* combined formats */
+
+WV_FN uint32_t part_scratch_bytes()
+{
+	// ordering u16[1024] + mismatch u8[1024] + errors f32[2][1024] -> sized for the worst case
+	return 1024 * 2 + 1024 + 2 * 1024 * 4 + 256;
+}
+
+WV_FN void make_lds_layout(const TableRoot& r, LdsLayout& L)
+{
+	uint32_t Tp = (r.texel_count + 3u) & ~3u;
+	uint32_t ndm = r.decimation_mode_count_selected;
+	uint32_t nbm = r.block_mode_count_1plane_2plane_selected;
+	uint32_t o = 0;
+	auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
+	L.data = take(4 * Tp * 4);
+	L.blk = take(sizeof(BlkInfo));
+	L.scb = take(sizeof(Scb));
+	L.wscb = take(sizeof(Scb));
+	L.trial = take(sizeof(TrialInfo));
+	L.ei_w = take(2 * Tp * 4);
+	L.ei_wes = take(2 * Tp * 4);
+	// the partition search runs between trials, so its scratch aliases the trial-only regions
+	uint32_t trial_begin = o;
+	L.dwi = take(ndm * 64 * 4);
+	L.lowhigh = take(2 * ndm * 8 * 2 * 4);
+	L.ang = take(64 * 8 * 4);
+	L.modes = take(nbm * sizeof(ModeRec));
+	L.fmt = take(FMT_SCRATCH_BYTES);
+	L.part = trial_begin;
+	uint32_t part_end = trial_begin + ((part_scratch_bytes() + 15u) & ~15u);
+	if (o < part_end) o = part_end;
+	L.tsc = take(12 * Tp * 4);
+	L.wsc = take(4 * 64 * 4);
+	L.total = o;
+}
+
+/* Uniform per-wave context. */
+struct Ctx {
+	const uint8_t* tab;          // table blob (HBM, read-only)
+	const TableRoot* root;
+	const DeviceConfig* cfg;
+	uint8_t* lds;
+	LdsLayout L;
+	int T;                       // texels per block
+	int Tp;                      // T rounded up to 4
+
+	// typed views
+	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L.data) + c * Tp; }
+	WV_FN BlkInfo& blk() const { return *reinterpret_cast<BlkInfo*>(lds + L.blk); }
+	WV_FN Scb& scb() const { return *reinterpret_cast<Scb*>(lds + L.scb); }
+	WV_FN Scb& wscb() const { return *reinterpret_cast<Scb*>(lds + L.wscb); }
+	WV_FN TrialInfo& tr() const { return *reinterpret_cast<TrialInfo*>(lds + L.trial); }
+	WV_FN float* ei_w(int plane) const { return reinterpret_cast<float*>(lds + L.ei_w) + plane * Tp; }
+	WV_FN float* ei_wes(int plane) const { return reinterpret_cast<float*>(lds + L.ei_wes) + plane * Tp; }
+	WV_FN float* dwi(int dm) const { return reinterpret_cast<float*>(lds + L.dwi) + dm * 64; }
+	WV_FN float* lowhigh(int plane, int dm) const { return reinterpret_cast<float*>(lds + L.lowhigh) + (plane * (int)root->decimation_mode_count_selected + dm) * 16; }
+	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.ang); }
+	WV_FN ModeRec* modes() const { return reinterpret_cast<ModeRec*>(lds + L.modes); }
+	WV_FN float* tsc(int row) const { return reinterpret_cast<float*>(lds + L.tsc) + row * Tp; }
+	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L.wsc) + row * 64; }
+	WV_FN uint8_t* fmt() const { return lds + L.fmt; }
+	WV_FN uint8_t* part() const { return lds + L.part; }
+
+	// table accessors
+	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }
+	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(tab + root->off_decimation_modes)[i]; }
+	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(tab + root->off_decimation_infos)[i]; }
+	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
+	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
+};
+
+/* View of one partition record. */
+struct PartView {
+	const PartitionHeader* h;
+	const uint8_t* of_texel;    // [T]
+	const uint8_t* sorted;      // [T]  texels grouped by partition
+	int offset[4];              // start of each partition's run in sorted[]
+	int count[4];
+	int pcount;
+};
+
+WV_FN PartView part_view(const Ctx& c, int pcount, int packed)
+{
+	PartView v;
+	const uint8_t* rec = c.part_rec(pcount, packed);
+	v.h = reinterpret_cast<const PartitionHeader*>(rec);
+	v.of_texel = rec + sizeof(PartitionHeader);
+	v.sorted = v.of_texel + c.T;
+	v.pcount = pcount;
+	int o = 0;
+	for (int i = 0; i < 4; i++)
+	{
+		v.offset[i] = o;
+		v.count[i] = v.h->texel_count[i];
+		o += v.count[i];
+	}
+	return v;
+}
+
+} // namespace astcd

@@ -1,0 +1,554 @@
+// SPDX-License-Identifier: Apache-2.0
+// Endpoint format / colour quant level selection for every block mode of a trial, and the top-N
+// candidate pick.
+//   ref: compute_error_squared_rgb_single_partition  Source/astcenc_pick_best_endpoint_format.cpp:72-208
+//        compute_encoding_choice_errors              :222-300
+//        compute_color_error_for_every_integer_count_and_quant_level :315-665
+//        {one..four}_partition(s)_find_best_combination_* :678-1093
+//        compute_ideal_endpoint_formats              :1096-1357
+#pragma once
+#include "wave_ctx.h"
+#include "wave_ideal.h"
+#include "wave_weights.h"
+
+namespace astcd {
+
+/* Wave-wide argmin with lowest-index tie break over v(i), i in [start, end); entries >= 1e30 are
+ * never selected (returns -1 if none).  Uniform result. */
+template <typename ValFn>
+WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
+{
+#if WV_DEVICE
+	float best = ERROR_CALC_DEFAULT;
+	int idx = -1;
+	for (int i = start + WV_LANE; i < end; i += 64)
+	{
+		float e = v(i);
+		if (e < best) { best = e; idx = i; }
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		float oe = __shfl_xor(best, off, 64);
+		int oi = __shfl_xor(idx, off, 64);
+		bool take = (oi >= 0) && (idx < 0 || oe < best || (oe == best && oi < idx));
+		if (take) { best = oe; idx = oi; }
+	}
+	(void)c;
+	return idx;
+#else
+	(void)c;
+	float best = ERROR_CALC_DEFAULT;
+	int idx = -1;
+	for (int i = start; i < end; i++)
+	{
+		float e = v(i);
+		if (e < best) { best = e; idx = i; }
+	}
+	return idx;
+#endif
+}
+
+struct FmtScratch {
+	float   best_error[4][21][4];
+	uint8_t format_of_choice[4][21][4];
+	float   comb_error[21][13];
+	uint8_t comb_format[21][13][4];
+};
+static_assert(sizeof(FmtScratch) == FMT_SCRATCH_BYTES, "format scratch size");
+
+WV_FN float blk_default_alpha(const BlkInfo& blk) { return blk.alpha_lns ? (float)0x7800 : (float)0xFFFF; }
+WV_FN bool blk_is_luminance(const BlkInfo& blk)
+{
+	float da = blk_default_alpha(blk);
+	bool alpha1 = (blk.data_min[3] == da) && (blk.data_max[3] == da);
+	return blk.grayscale && alpha1;
+}
+WV_FN bool blk_is_luminancealpha(const BlkInfo& blk)
+{
+	float da = blk_default_alpha(blk);
+	bool alpha1 = (blk.data_min[3] == da) && (blk.data_max[3] == da);
+	return blk.grayscale && !alpha1;
+}
+
+/* (ref: compute_encoding_choice_errors :222) ep = endpoints [partition][channel] */
+WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, const float (*ep0)[4], const float (*ep1)[4])
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, pc = pv.pcount;
+
+	CompSel rgb; rgb.ncomp = 3; rgb.comps[0] = 0; rgb.comps[1] = 1; rgb.comps[2] = 2; rgb.comps[3] = 0;
+	compute_avgs_and_dirs(c, pv, rgb);
+
+	// processed lines per partition -> fbox[p*16 + ..]: uncor amod(3) bs(3), samec bs(3), rgbl amod(3)
+	WV_FOR(p, pc)
+	{
+		f4 avg = load4(tr.pm_avg[p]);
+		f4 dir = load4(tr.pm_dir[p]);
+		f4 uncor_b = normalize_safe4(dir, unit3());
+		f4 samec_b = normalize_safe4(avg, unit3());
+		f4 luma_b = unit3();
+		float d_uncor = dot3_s(avg, uncor_b);
+		f4 uncor_amod = avg - uncor_b * mk4(d_uncor, d_uncor, d_uncor, 0.0f);
+		float d_luma = dot3_s(avg, luma_b);
+		f4 luma_amod = avg - luma_b * mk4(d_luma, d_luma, d_luma, 0.0f);
+		float* o = &tr.fbox[p * 16];
+		o[0] = uncor_amod.x; o[1] = uncor_amod.y; o[2] = uncor_amod.z;
+		o[3] = uncor_b.x;    o[4] = uncor_b.y;    o[5] = uncor_b.z;
+		o[6] = samec_b.x;    o[7] = samec_b.y;    o[8] = samec_b.z;
+		o[9] = luma_amod.x;  o[10] = luma_amod.y; o[11] = luma_amod.z;
+	}
+	WV_SYNC();
+
+	// per-texel error terms in partition order (ref: :124-201)
+	const float default_a = blk_default_alpha(blk);
+	const float ew0 = blk.cw[0], ew1 = blk.cw[1], ew2 = blk.cw[2];
+	WV_FOR(i, T)
+	{
+		int t = pv.sorted[i];
+		int p = pv.of_texel[t];
+		const float* o = &tr.fbox[p * 16];
+		float r = c.data(0)[t], g = c.data(1)[t], b = c.data(2)[t], a = c.data(3)[t];
+
+		float alpha_diff = a - default_a;
+		c.tsc(0)[i] = alpha_diff * alpha_diff;
+
+		float param = r * o[3] + g * o[4] + b * o[5];
+		float dist0 = (o[0] + param * o[3]) - r;
+		float dist1 = (o[1] + param * o[4]) - g;
+		float dist2 = (o[2] + param * o[5]) - b;
+		c.tsc(1)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+
+		param = r * o[6] + g * o[7] + b * o[8];
+		dist0 = (param * o[6]) - r;
+		dist1 = (param * o[7]) - g;
+		dist2 = (param * o[8]) - b;
+		c.tsc(2)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+
+		const float u = 0.577350258827209473f;
+		param = r * u + g * u + b * u;
+		dist0 = (o[9] + param * u) - r;
+		dist1 = (o[10] + param * u) - g;
+		dist2 = (o[11] + param * u) - b;
+		c.tsc(3)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+
+		dist0 = (param * u) - r;
+		dist1 = (param * u) - g;
+		dist2 = (param * u) - b;
+		c.tsc(4)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+	}
+	WV_SYNC();
+
+	WV_FOR(k, pc * 5)
+	{
+		int p = k / 5, which = k % 5;
+		tr.fbox[64 - 20 + k] = sum4(c.tsc(which) + pv.offset[p], pv.count[p]);
+	}
+	WV_SYNC();
+
+	WV_FOR(p, pc)
+	{
+		const float* s = &tr.fbox[64 - 20 + p * 5];
+		float a_drop = s[0] * blk.cw[3];
+		float uncor = s[1], samec = s[2], rgbl = s[3], lum = s[4];
+		bool can_offset = true;
+		for (int k = 0; k < 3; k++)
+		{
+			float diff = f_abs(ep1[p][k] - ep0[p][k]);
+			can_offset = can_offset && (diff < (0.12f * 65535.0f));
+		}
+		tr.eci_rgb_scale[p] = (samec - uncor) * 0.7f;
+		tr.eci_rgb_luma[p] = (rgbl - uncor) * 1.5f;
+		tr.eci_luminance[p] = (lum - uncor) * 3.0f;
+		tr.eci_alpha_drop[p] = a_drop * 3.0f;
+		tr.eci_can_offset[p] = can_offset ? 1 : 0;
+		tr.eci_can_blue_contract[p] = blk_is_luminance(blk) ? 0 : 1;
+	}
+	WV_SYNC();
+}
+
+WV_FN float baseline_quant_error(int i /* quant - QUANT_6 */)
+{
+	const float t[17] = {
+		(65536.0f * 65536.0f / 18.0f) / (5 * 5),
+		(65536.0f * 65536.0f / 18.0f) / (7 * 7),
+		(65536.0f * 65536.0f / 18.0f) / (9 * 9),
+		(65536.0f * 65536.0f / 18.0f) / (11 * 11),
+		(65536.0f * 65536.0f / 18.0f) / (15 * 15),
+		(65536.0f * 65536.0f / 18.0f) / (19 * 19),
+		(65536.0f * 65536.0f / 18.0f) / (23 * 23),
+		(65536.0f * 65536.0f / 18.0f) / (31 * 31),
+		(65536.0f * 65536.0f / 18.0f) / (39 * 39),
+		(65536.0f * 65536.0f / 18.0f) / (47 * 47),
+		(65536.0f * 65536.0f / 18.0f) / (63 * 63),
+		(65536.0f * 65536.0f / 18.0f) / (79 * 79),
+		(65536.0f * 65536.0f / 18.0f) / (95 * 95),
+		(65536.0f * 65536.0f / 18.0f) / (127 * 127),
+		(65536.0f * 65536.0f / 18.0f) / (159 * 159),
+		(65536.0f * 65536.0f / 18.0f) / (191 * 191),
+		(65536.0f * 65536.0f / 18.0f) / (255 * 255)
+	};
+	return t[i];
+}
+
+/* One (partition, quant level) cell of the table. (ref: :315-665) */
+WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, int i,
+                                       const float* ep0p, const float* ep1p, FmtScratch& fs)
+{
+	const TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	bool encode_hdr_rgb = blk.rgb_lns != 0;
+	bool encode_hdr_alpha = blk.alpha_lns != 0;
+	int partition_size = pv.count[p];
+	float* best_error = fs.best_error[p][i];
+	uint8_t* fmt = fs.format_of_choice[p][i];
+
+	f4 ep0 = load4(ep0p), ep1 = load4(ep1p);
+	f4 ew = load4(blk.cw);
+
+	float ep1_min = hmin4(ep1.x, ep1.y, ep1.z, ep1.x);
+	ep1_min = f_max(ep1_min, 0.0f);
+
+	float error_weight_rgbsum = hadd_rgb_s(ew);
+	float range_upper_limit_rgb = encode_hdr_rgb ? 61440.0f : 65535.0f;
+	float range_upper_limit_alpha = encode_hdr_alpha ? 61440.0f : 65535.0f;
+
+	f4 offset = mk4(range_upper_limit_rgb, range_upper_limit_rgb, range_upper_limit_rgb, range_upper_limit_alpha);
+	f4 ep0_high = v4_max(ep0 - offset, splat4(0.0f));
+	f4 ep1_high = v4_max(ep1 - offset, splat4(0.0f));
+	f4 ep0_low = v4_min(ep0, splat4(0.0f));
+	f4 ep1_low = v4_min(ep1, splat4(0.0f));
+
+	f4 sum_range_error = (ep0_low * ep0_low) + (ep1_low * ep1_low) + (ep0_high * ep0_high) + (ep1_high * ep1_high);
+
+	float rgb_range_error = dot3_s(sum_range_error, ew) * 0.5f * (float)partition_size;
+	float alpha_range_error = sum_range_error.w * ew.w * 0.5f * (float)partition_size;
+
+	float eci_alpha_drop = tr.eci_alpha_drop[p], eci_rgb_luma = tr.eci_rgb_luma[p];
+	float eci_luminance = tr.eci_luminance[p], eci_rgb_scale = tr.eci_rgb_scale[p];
+
+	if (encode_hdr_rgb)
+	{
+		if (i < QUANT_16)
+		{
+			best_error[3] = best_error[2] = best_error[1] = best_error[0] = ERROR_CALC_DEFAULT;
+			fmt[3] = (uint8_t)(encode_hdr_alpha ? FMT_HDR_RGBA : FMT_HDR_RGB_LDR_ALPHA);
+			fmt[2] = FMT_HDR_RGB;
+			fmt[1] = FMT_HDR_RGB_SCALE;
+			fmt[0] = FMT_HDR_LUMINANCE_LARGE_RANGE;
+			return;
+		}
+
+		// heuristic sub-mode pick from the endpoint spread (ref: :383-512)
+		float af, cf;
+		if (ep1.x > ep1.y && ep1.x > ep1.z) { af = ep1.x; cf = ep1.x - ep0.x; }
+		else if (ep1.y > ep1.z) { af = ep1.y; cf = ep1.y - ep0.y; }
+		else { af = ep1.z; cf = ep1.z - ep0.z; }
+
+		float bf = af - ep1_min;
+		f4 prd = xyz0(ep1 - splat4(cf));
+		f4 pdif = prd - xyz0(ep0);
+		f4 ap = v4_abs(pdif);
+		float df = hmax4(ap.x, ap.y, ap.z, ap.w);
+
+		int b = (int)f_clamp(bf, 0.0f, 65536.0f);
+		int cc = (int)f_clamp(cf, 0.0f, 65536.0f);
+		int d = (int)f_clamp(df, 0.0f, 65536.0f);
+
+		int rgbo_mode = 5;
+		if (b < 32768 && cc < 16384) rgbo_mode = 4;
+		if (b < 8192 && cc < 16384) rgbo_mode = 3;
+		if (b < 2048 && cc < 16384) rgbo_mode = 2;
+		if (b < 2048 && cc < 1024) rgbo_mode = 1;
+		if (b < 1024 && cc < 4096) rgbo_mode = 0;
+
+		int rgb_mode = 8;
+		if (b < 16384 && cc < 8192 && d < 8192) rgb_mode = 0;
+		if (b < 32768 && cc < 8192 && d < 4096) rgb_mode = 1;
+		if (b < 4096 && cc < 8192 && d < 4096) rgb_mode = 2;
+		if (b < 8192 && cc < 8192 && d < 2048) rgb_mode = 3;
+		if (b < 8192 && cc < 2048 && d < 512) rgb_mode = 4;
+		if (b < 2048 && cc < 8192 && d < 1024) rgb_mode = 5;
+		if (b < 2048 && cc < 2048 && d < 256) rgb_mode = 6;
+		if (b < 1024 && cc < 2048 && d < 512) rgb_mode = 7;
+
+		const float rgbo_error_scales[6] = { 4.0f, 4.0f, 16.0f, 64.0f, 256.0f, 1024.0f };
+		const float rgb_error_scales[9] = { 64.0f, 64.0f, 16.0f, 16.0f, 4.0f, 4.0f, 1.0f, 1.0f, 384.0f };
+
+		float mode7mult = rgbo_error_scales[rgbo_mode] * 0.0015f;
+		float mode11mult = rgb_error_scales[rgb_mode] * 0.010f;
+
+		float lum_high = hadd_rgb_s(ep1) * (1.0f / 3.0f);
+		float lum_low = hadd_rgb_s(ep0) * (1.0f / 3.0f);
+		float lumdif = lum_high - lum_low;
+		float mode23mult = lumdif < 960 ? 4.0f : lumdif < 3968 ? 16.0f : 128.0f;
+		mode23mult *= 0.0005f;
+
+		float base_quant_error = baseline_quant_error(i - QUANT_6) * (float)partition_size;
+		float rgb_quantization_error = error_weight_rgbsum * base_quant_error * 2.0f;
+		float alpha_quantization_error = ew.w * base_quant_error * 2.0f;
+		float rgba_quantization_error = rgb_quantization_error + alpha_quantization_error;
+
+		best_error[3] = rgba_quantization_error + rgb_range_error + alpha_range_error;
+		fmt[3] = (uint8_t)(encode_hdr_alpha ? FMT_HDR_RGBA : FMT_HDR_RGB_LDR_ALPHA);
+
+		best_error[2] = (rgb_quantization_error * mode11mult) + rgb_range_error + eci_alpha_drop;
+		fmt[2] = FMT_HDR_RGB;
+
+		best_error[1] = (rgb_quantization_error * mode7mult) + rgb_range_error + eci_alpha_drop + eci_rgb_luma;
+		fmt[1] = FMT_HDR_RGB_SCALE;
+
+		best_error[0] = (rgb_quantization_error * mode23mult) + rgb_range_error + eci_alpha_drop + eci_luminance;
+		fmt[0] = FMT_HDR_LUMINANCE_LARGE_RANGE;
+		return;
+	}
+
+	if (i < QUANT_6)
+	{
+		best_error[3] = best_error[2] = best_error[1] = best_error[0] = ERROR_CALC_DEFAULT;
+		fmt[3] = FMT_RGBA; fmt[2] = FMT_RGB; fmt[1] = FMT_RGB_SCALE; fmt[0] = FMT_LUMINANCE;
+		return;
+	}
+
+	float base_quant_error_rgb = error_weight_rgbsum * (float)partition_size;
+	float base_quant_error_a = ew.w * (float)partition_size;
+	float base_quant_error_rgba = base_quant_error_rgb + base_quant_error_a;
+
+	float error_scale_bc_rgba = tr.eci_can_blue_contract[p] ? 0.625f : 1.0f;
+	float error_scale_oe_rgba = tr.eci_can_offset[p] ? 0.5f : 1.0f;
+	float error_scale_bc_rgb = tr.eci_can_blue_contract[p] ? 0.5f : 1.0f;
+	float error_scale_oe_rgb = tr.eci_can_offset[p] ? 0.25f : 1.0f;
+	if (i >= QUANT_192)
+	{
+		error_scale_oe_rgba = 1.0f;
+		error_scale_oe_rgb = 1.0f;
+	}
+
+	float base_quant_error = baseline_quant_error(i - QUANT_6);
+	float quant_error_rgb = base_quant_error_rgb * base_quant_error;
+	float quant_error_rgba = base_quant_error_rgba * base_quant_error;
+
+	float full_ldr_rgba_error = quant_error_rgba * error_scale_bc_rgba * error_scale_oe_rgba + rgb_range_error + alpha_range_error;
+	best_error[3] = full_ldr_rgba_error;
+	fmt[3] = FMT_RGBA;
+
+	float full_ldr_rgb_error = quant_error_rgb * error_scale_bc_rgb * error_scale_oe_rgb + rgb_range_error + eci_alpha_drop;
+	float rgbs_alpha_error = quant_error_rgba + eci_rgb_scale + rgb_range_error + alpha_range_error;
+	if (rgbs_alpha_error < full_ldr_rgb_error)
+	{
+		best_error[2] = rgbs_alpha_error;
+		fmt[2] = FMT_RGB_SCALE_ALPHA;
+	}
+	else
+	{
+		best_error[2] = full_ldr_rgb_error;
+		fmt[2] = FMT_RGB;
+	}
+
+	float ldr_rgbs_error = quant_error_rgb + rgb_range_error + eci_alpha_drop + eci_rgb_scale;
+	float lum_alpha_error = quant_error_rgba + rgb_range_error + alpha_range_error + eci_luminance;
+	if (ldr_rgbs_error < lum_alpha_error)
+	{
+		best_error[1] = ldr_rgbs_error;
+		fmt[1] = FMT_RGB_SCALE;
+	}
+	else
+	{
+		best_error[1] = lum_alpha_error;
+		fmt[1] = FMT_LUMINANCE_ALPHA;
+	}
+
+	best_error[0] = quant_error_rgb + rgb_range_error + eci_alpha_drop + eci_luminance;
+	fmt[0] = FMT_LUMINANCE;
+}
+
+/* Combine the per-partition tables for one quant level (ref: :728-766, :842-891, :967-1027). */
+WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
+{
+	const int ncols = pc == 2 ? 7 : pc == 3 ? 10 : 13;
+	for (int j = 0; j < ncols; j++) fs.comb_error[quant][j] = ERROR_CALC_DEFAULT;
+	if (quant < QUANT_6) return;
+
+	for (int i = 0; i < 4; i++)
+	{
+		for (int j = 0; j < 4; j++)
+		{
+			int low2 = i_min(i, j), high2 = i_max(i, j);
+			if ((high2 - low2) > 1) continue;
+			if (pc == 2)
+			{
+				int intcnt = i + j;
+				float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j], 1e10f);
+				if (errorterm <= fs.comb_error[quant][intcnt])
+				{
+					fs.comb_error[quant][intcnt] = errorterm;
+					fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
+					fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
+				}
+				continue;
+			}
+			for (int k = 0; k < 4; k++)
+			{
+				int low3 = i_min(k, low2), high3 = i_max(k, high2);
+				if ((high3 - low3) > 1) continue;
+				if (pc == 3)
+				{
+					int intcnt = i + j + k;
+					float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j] + fs.best_error[2][quant][k], 1e10f);
+					if (errorterm <= fs.comb_error[quant][intcnt])
+					{
+						fs.comb_error[quant][intcnt] = errorterm;
+						fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
+						fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
+						fs.comb_format[quant][intcnt][2] = fs.format_of_choice[2][quant][k];
+					}
+					continue;
+				}
+				for (int l = 0; l < 4; l++)
+				{
+					int low4 = i_min(l, low3), high4 = i_max(l, high3);
+					if ((high4 - low4) > 1) continue;
+					int intcnt = i + j + k + l;
+					float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j] + fs.best_error[2][quant][k] + fs.best_error[3][quant][l], 1e10f);
+					if (errorterm <= fs.comb_error[quant][intcnt])
+					{
+						fs.comb_error[quant][intcnt] = errorterm;
+						fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
+						fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
+						fs.comb_format[quant][intcnt][2] = fs.format_of_choice[2][quant][k];
+						fs.comb_format[quant][intcnt][3] = fs.format_of_choice[3][quant][l];
+					}
+				}
+			}
+		}
+	}
+}
+
+/* Best (quant level, formats) for one block mode's colour bit budget. (ref: :678-718, :780-832,
+ * :905-957, :1041-1093) */
+WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch& fs, int bits_available, ModeRec& m)
+{
+	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.tab + c.root->off_quant_mode_table);
+	float best_integer_count_error = ERROR_CALC_DEFAULT;
+
+	if (pc == 1)
+	{
+		int best_integer_count = 0;
+		for (int integer_count = 1; integer_count <= 4; integer_count++)
+		{
+			int quant_level = qmt[integer_count * 128 + bits_available];
+			if (quant_level < QUANT_6) continue;
+			float e = fs.best_error[0][quant_level][integer_count - 1];
+			if (e < best_integer_count_error)
+			{
+				best_integer_count_error = e;
+				best_integer_count = integer_count - 1;
+			}
+		}
+		int ql = qmt[(best_integer_count + 1) * 128 + bits_available];
+		m.quant_level = (uint8_t)ql;
+		m.quant_level_mod = (uint8_t)ql;
+		m.formats[0] = FMT_LUMINANCE;
+		if (ql >= QUANT_6) m.formats[0] = fs.format_of_choice[0][ql][best_integer_count];
+		return best_integer_count_error;
+	}
+
+	const int lo = pc;                       // minimum integer-pair count
+	const int hi = pc == 2 ? 8 : 9;
+	const int mod_bits = pc == 2 ? 2 : pc == 3 ? 5 : 8;
+	int best_integer_count = 0;
+	for (int integer_count = lo; integer_count <= hi; integer_count++)
+	{
+		int quant_level = qmt[integer_count * 128 + bits_available];
+		if (quant_level < QUANT_6) break;
+		float e = fs.comb_error[quant_level][integer_count - lo];
+		if (e < best_integer_count_error)
+		{
+			best_integer_count_error = e;
+			best_integer_count = integer_count;
+		}
+	}
+	int ql = qmt[best_integer_count * 128 + bits_available];
+	int ql_mod = qmt[best_integer_count * 128 + bits_available + mod_bits];
+	m.quant_level = (uint8_t)ql;
+	m.quant_level_mod = (uint8_t)ql_mod;
+	for (int i = 0; i < pc; i++)
+	{
+		m.formats[i] = ql >= QUANT_6 ? fs.comb_format[ql][best_integer_count - lo][i] : (uint8_t)FMT_LUMINANCE;
+	}
+	return best_integer_count_error;
+}
+
+/* Colour bits left after the weights. (ref: compress_symbolic.cpp:434-453, :817) */
+WV_FN int mode_bitcount(int partition_count, const BlockMode& bm)
+{
+	if (bm.is_dual_plane) return 109 - bm.weight_bits;
+	const int free_bits[4] = { 111, 97, 94, 91 };
+	return free_bits[partition_count - 1] - bm.weight_bits;
+}
+
+/* (ref: compute_ideal_endpoint_formats :1096).  modes()[i].qwt_error must be filled for
+ * [start, end).  Results in tr.cand_*. */
+WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, const float (*ep0)[4], const float (*ep1)[4],
+                                          int start_block_mode, int end_block_mode)
+{
+	TrialInfo& tr = c.tr();
+	const int pc = pv.pcount;
+	FmtScratch& fs = *reinterpret_cast<FmtScratch*>(c.fmt());
+	ModeRec* modes = c.modes();
+
+	compute_encoding_choice_errors(c, pv, ep0, ep1);
+
+	WV_FOR(k, pc * 21)
+	{
+		int p = k / 21, i = k % 21;
+		color_error_for_quant_level(c, pv, p, i, ep0[p], ep1[p], fs);
+	}
+	WV_SYNC();
+
+	if (pc >= 2)
+	{
+		WV_FOR(q, 21) { combine_partitions_for_quant(pc, q, fs); }
+		WV_SYNC();
+	}
+
+	WV_FOR(i, end_block_mode - start_block_mode)
+	{
+		ModeRec& m = modes[start_block_mode + i];
+		if (m.qwt_error >= ERROR_CALC_DEFAULT)
+		{
+			m.total_error = ERROR_CALC_DEFAULT;
+		}
+		else
+		{
+			int bitcount = mode_bitcount(pc, c.block_mode(start_block_mode + i));
+			float error_of_best = best_combination_for_bitcount(c, pc, fs, bitcount, m);
+			m.total_error = error_of_best + m.qwt_error;
+		}
+	}
+	WV_SYNC();
+
+	// top-N by repeated argmin, lowest index on ties (ref: :1156-1333)
+	int limit = (int)c.cfg->tune_candidate_limit;
+	int count = 0;
+	for (int n = 0; n < limit; n++)
+	{
+		int best = wave_argmin(c, start_block_mode, end_block_mode, [&](int i) { return modes[i].total_error; });
+		if (best < 0) break;
+		WV_SYNC();
+		WV_ONE
+		{
+			tr.cand_block_mode[n] = best;
+			tr.cand_quant[n] = modes[best].quant_level;
+			tr.cand_quant_mod[n] = modes[best].quant_level_mod;
+			for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = modes[best].formats[j];
+			modes[best].total_error = ERROR_CALC_DEFAULT;
+		}
+		WV_SYNC();
+		count++;
+	}
+	WV_ONE { tr.cand_count = count; }
+	WV_SYNC();
+}
+
+} // namespace astcd

@@ -1,0 +1,334 @@
+// SPDX-License-Identifier: Apache-2.0
+// Ideal endpoints and per-texel weights for one plane.
+//   ref: compute_partition_averages_{rgb,rgba}        Source/astcenc_averages_and_directions.cpp:47-385
+//        compute_avgs_and_dirs_{4,3,3_rgb,2}_comp      Source/astcenc_averages_and_directions.cpp:388-720
+//        compute_ideal_colors_and_weights_{1..4}_comp  Source/astcenc_ideal_endpoints_and_weights.cpp:107-609
+//        compute_ideal_colors_and_weights_{1,2}plane(s) Source/astcenc_ideal_endpoints_and_weights.cpp:612-685
+//
+// Vectors are handled in "component-lane space": lane j holds image channel comps[j]; lanes >= ncomp
+// are zero, exactly like the reference's vfloat2/vfloat3 helpers.
+#pragma once
+#include "wave_ctx.h"
+
+namespace astcd {
+
+struct CompSel {
+	int ncomp;
+	int comps[4];
+};
+
+/* Partition means and dominant directions -> tr.pm_avg / tr.pm_dir (component-lane space). */
+WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel& cs)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, n = cs.ncomp, pc = pv.pcount;
+
+	if (pc == 1)
+	{
+		WV_FOR(j, 4)
+		{
+			tr.pm_avg[0][j] = j < n ? blk.data_mean[cs.comps[j]] : 0.0f;
+		}
+	}
+	else
+	{
+		// 4-accumulator masked sums for all but the last partition (ref: :67-84, :238-258)
+		WV_FOR(k, (pc - 1) * n * 4)
+		{
+			int l = k & 3, j = (k >> 2) % n, p = (k >> 2) / n;
+			const float* d = c.data(cs.comps[j]);
+			float acc = 0.0f;
+			for (int i = l; i < T; i += 4)
+			{
+				float v = pv.of_texel[i] == p ? d[i] : 0.0f;
+				acc = acc + v;
+			}
+			tr.fbox[k] = acc;
+		}
+		WV_SYNC();
+		WV_FOR(j, 4)
+		{
+			if (j < n)
+			{
+				float block_total = blk.data_mean[cs.comps[j]] * (float)T;
+				float rest = block_total;
+				for (int p = 0; p < pc - 1; p++)
+				{
+					const float* a = &tr.fbox[(p * n + j) * 4];
+					float total = hadd4(a[0], a[1], a[2], a[3]);
+					rest = rest - total;
+					tr.pm_avg[p][j] = total / (float)pv.count[p];
+				}
+				tr.pm_avg[pc - 1][j] = rest / (float)pv.count[pc - 1];
+			}
+			else
+			{
+				for (int p = 0; p < pc; p++) tr.pm_avg[p][j] = 0.0f;
+			}
+		}
+	}
+	WV_SYNC();
+
+	// sum of offsets over the texels whose component `which` is above the mean (ref: :409-433)
+	WV_FOR(k, pc * n * n)
+	{
+		int j = k % n, which = (k / n) % n, p = k / (n * n);
+		const float* dj = c.data(cs.comps[j]);
+		const float* dw = c.data(cs.comps[which]);
+		float avg_j = tr.pm_avg[p][j], avg_w = tr.pm_avg[p][which];
+		const uint8_t* tix = pv.sorted + pv.offset[p];
+		float sum = 0.0f;
+		for (int i = 0; i < pv.count[p]; i++)
+		{
+			int t = tix[i];
+			float dat_w = dw[t] - avg_w;
+			float dat_j = dj[t] - avg_j;
+			sum = sum + (dat_w > 0.0f ? dat_j : 0.0f);
+		}
+		tr.fbox[(p * 4 + which) * 4 + j] = sum;
+	}
+	WV_SYNC();
+
+	WV_FOR(p, pc)
+	{
+		float best[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+		float best_sum = 0.0f;
+		for (int which = 0; which < n; which++)
+		{
+			float s[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+			for (int j = 0; j < n; j++) s[j] = tr.fbox[(p * 4 + which) * 4 + j];
+			float prod = hadd4(s[0] * s[0], s[1] * s[1], s[2] * s[2], s[3] * s[3]);
+			if (which == 0 || prod > best_sum)
+			{
+				best_sum = prod;
+				for (int j = 0; j < 4; j++) best[j] = s[j];
+			}
+		}
+		for (int j = 0; j < 4; j++) tr.pm_dir[p][j] = best[j];
+	}
+	WV_SYNC();
+}
+
+/* One-component plane: endpoints are the channel's min/max. (ref: :107-206) */
+WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int plane, int component)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, pc = pv.pcount;
+	const float* d = c.data(component);
+	float* w = c.ei_w(plane);
+	float* wes = c.ei_wes(plane);
+	float error_weight = blk.cw[component];
+
+	WV_FOR(p, pc)
+	{
+		float lowvalue = 1e10f, highvalue = -1e10f;
+		const uint8_t* tix = pv.sorted + pv.offset[p];
+		for (int j = 0; j < pv.count[p]; j++)
+		{
+			float value = d[tix[j]];
+			lowvalue = f_min(value, lowvalue);
+			highvalue = f_max(value, highvalue);
+		}
+		if (highvalue <= lowvalue)
+		{
+			lowvalue = 0.0f;
+			highvalue = 1e-7f;
+		}
+		float length = highvalue - lowvalue;
+		tr.fbox[p * 4 + 0] = lowvalue;
+		tr.fbox[p * 4 + 1] = 1.0f / length;
+		tr.fbox[p * 4 + 2] = length * length;
+		for (int k = 0; k < 4; k++)
+		{
+			tr.ep0[plane][p][k] = k == component ? lowvalue : blk.data_min[k];
+			tr.ep1[plane][p][k] = k == component ? highvalue : blk.data_max[k];
+		}
+	}
+	WV_SYNC();
+	WV_FOR(t, c.Tp)
+	{
+		if (t < T)
+		{
+			int p = pv.of_texel[t];
+			float value = (d[t] - tr.fbox[p * 4 + 0]) * tr.fbox[p * 4 + 1];
+			w[t] = f_clamp1(value);
+			wes[t] = tr.fbox[p * 4 + 2] * error_weight;
+		}
+		else
+		{
+			w[t] = 0.0f;
+			wes[t] = 0.0f;
+		}
+	}
+	WV_ONE
+	{
+		bool cw = true;
+		for (int p = 1; p < pc; p++) cw = cw && tr.fbox[p * 4 + 2] == tr.fbox[2];
+		tr.is_constant_wes[plane] = cw ? 1 : 0;
+	}
+	WV_SYNC();
+}
+
+/* 2-, 3- or 4-component plane: least-squares-ish line through the partition mean. (ref: :217-609) */
+WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int plane, const CompSel& cs, float error_weight)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, pc = pv.pcount, n = cs.ncomp;
+	float* w = c.ei_w(plane);
+	float* wes = c.ei_wes(plane);
+
+	compute_avgs_and_dirs(c, pv, cs);
+
+	// normalised line direction per partition -> fbox[32 + p*4 + j]
+	WV_FOR(p, pc)
+	{
+		f4 dir = load4(tr.pm_dir[p]);
+		float s = n == 2 ? hadd_s(dir) : hadd_rgb_s(dir);
+		if (s < 0.0f)
+		{
+			dir = splat4(0.0f) - dir;
+		}
+		f4 safe = n == 4 ? unit4() : n == 3 ? unit3() : unit2();
+		f4 b = normalize_safe4(dir, safe);
+		store4(&tr.fbox[32 + p * 4], b);
+	}
+	WV_SYNC();
+
+	// raw line parameter of every texel (ref: :282-291, :431-440, :553-562)
+	WV_FOR(t, T)
+	{
+		int p = pv.of_texel[t];
+		f4 pt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+		for (int j = 0; j < n; j++) set_lane(pt, j, c.data(cs.comps[j])[t]);
+		f4 a = load4(tr.pm_avg[p]);
+		f4 b = load4(&tr.fbox[32 + p * 4]);
+		float param = n == 3 ? dot3_s(pt - a, b) : dot_s(pt - a, b);
+		w[t] = param;
+	}
+	WV_SYNC();
+
+	WV_FOR(p, pc)
+	{
+		float lowparam = 1e10f, highparam = -1e10f;
+		const uint8_t* tix = pv.sorted + pv.offset[p];
+		for (int j = 0; j < pv.count[p]; j++)
+		{
+			float param = w[tix[j]];
+			lowparam = f_min(param, lowparam);
+			highparam = f_max(param, highparam);
+		}
+		if (highparam <= lowparam)
+		{
+			lowparam = 0.0f;
+			highparam = 1e-7f;
+		}
+		float length = highparam - lowparam;
+		tr.fbox[p * 4 + 0] = lowparam;
+		tr.fbox[p * 4 + 1] = 1.0f / length;
+		tr.fbox[p * 4 + 2] = length * length;
+
+		f4 a = load4(tr.pm_avg[p]);
+		f4 b = load4(&tr.fbox[32 + p * 4]);
+		f4 lo = a + b * lowparam;
+		f4 hi = a + b * highparam;
+		for (int k = 0; k < 4; k++)
+		{
+			tr.ep0[plane][p][k] = blk.data_min[k];
+			tr.ep1[plane][p][k] = blk.data_max[k];
+		}
+		for (int j = 0; j < n; j++)
+		{
+			tr.ep0[plane][p][cs.comps[j]] = lane(lo, j);
+			tr.ep1[plane][p][cs.comps[j]] = lane(hi, j);
+		}
+	}
+	WV_SYNC();
+
+	WV_FOR(t, c.Tp)
+	{
+		if (t < T)
+		{
+			int p = pv.of_texel[t];
+			float idx = (w[t] - tr.fbox[p * 4 + 0]) * tr.fbox[p * 4 + 1];
+			w[t] = f_clamp1(idx);
+			wes[t] = tr.fbox[p * 4 + 2] * error_weight;
+		}
+		else
+		{
+			w[t] = 0.0f;
+			wes[t] = 0.0f;
+		}
+	}
+	WV_ONE
+	{
+		bool cw = true;
+		for (int p = 1; p < pc; p++) cw = cw && tr.fbox[p * 4 + 2] == tr.fbox[2];
+		tr.is_constant_wes[plane] = cw ? 1 : 0;
+	}
+	WV_SYNC();
+}
+
+WV_FN bool is_constant_channel(const BlkInfo& blk, int ch) { return blk.data_min[ch] == blk.data_max[ch]; }
+
+/* (ref: compute_ideal_colors_and_weights_1plane :612) */
+WV_FN void ideal_colors_and_weights_1plane(const Ctx& c, const PartView& pv)
+{
+	const BlkInfo& blk = c.blk();
+	bool uses_alpha = !is_constant_channel(blk, 3);
+	CompSel cs;
+	float ew;
+	if (uses_alpha)
+	{
+		cs.ncomp = 4; cs.comps[0] = 0; cs.comps[1] = 1; cs.comps[2] = 2; cs.comps[3] = 3;
+		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) / 4.0f;
+	}
+	else
+	{
+		cs.ncomp = 3; cs.comps[0] = 0; cs.comps[1] = 1; cs.comps[2] = 2; cs.comps[3] = 0;
+		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], 0.0f) * (1.0f / 3.0f);
+	}
+	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
+}
+
+/* (ref: compute_ideal_colors_and_weights_2planes :630) plane 0 = everything but the separated
+ * component, plane 1 = the separated component. */
+WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, int plane2_component)
+{
+	const BlkInfo& blk = c.blk();
+	bool uses_alpha = !is_constant_channel(blk, 3);
+	CompSel cs;
+	float ew;
+	if (uses_alpha || plane2_component == 3)
+	{
+		// three remaining components; NB the reference's weight for omitted component 0 uses
+		// channels <0,1,2> (ref: ideal_endpoints_and_weights.cpp:373-404)
+		cs.ncomp = 3;
+		int k = 0;
+		for (int ch = 0; ch < 4; ch++) if (ch != plane2_component) cs.comps[k++] = ch;
+		cs.comps[3] = 0;
+		float a, b, d;
+		switch (plane2_component)
+		{
+		case 0: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[2]; break;
+		case 1: a = blk.cw[0]; b = blk.cw[2]; d = blk.cw[3]; break;
+		case 2: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[3]; break;
+		default: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[2]; break;
+		}
+		ew = hadd4(a, b, d, 0.0f) * (1.0f / 3.0f);
+	}
+	else
+	{
+		cs.ncomp = 2;
+		int k = 0;
+		for (int ch = 0; ch < 3; ch++) if (ch != plane2_component) cs.comps[k++] = ch;
+		cs.comps[2] = 0; cs.comps[3] = 0;
+		ew = hadd4(blk.cw[cs.comps[0]], blk.cw[cs.comps[1]], 0.0f, 0.0f) / 2.0f;
+	}
+	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
+	ideal_colors_and_weights_1comp(c, pv, 1, plane2_component);
+}
+
+} // namespace astcd

@@ -1,0 +1,470 @@
+// SPDX-License-Identifier: Apache-2.0
+// Partition search: k-means clustering of the block, ranking of the partition table by bitmap
+// mismatch, then line-fit error estimate of the best-ranked partitionings.
+//   ref: kmeans_init / kmeans_assign / kmeans_update       Source/astcenc_find_best_partitioning.cpp:60-243
+//        partition_mismatch{2,3,4}, count/ordering          :253-446
+//        compute_kmeans_partition_ordering                  :458-501
+//        insert_result, find_best_partition_candidates      :512-779
+//        compute_error_squared_{rgba,rgb}                   Source/astcenc_averages_and_directions.cpp:723-946
+//
+// Wave mapping: lanes own texels during k-means, partition table entries during the mismatch
+// count, and candidate partitionings during the line-fit scoring (each lane walks all texels of its
+// candidate sequentially, which is what keeps the reference's summation order).
+#pragma once
+#include "wave_ctx.h"
+
+namespace astcd {
+
+struct PartScratch {
+	uint16_t ordering[1024];
+	uint8_t  mismatch[1024];
+	float    uncor_err[1024];
+	float    samec_err[1024];
+	uint64_t bitmaps[4];
+	uint16_t mscount[64];
+	int      best_count;
+	int      best[MAX_PARTITIONING_CANDIDATES];
+};
+
+WV_FN int mismatch2(const uint64_t* a, const uint64_t* b)
+{
+	int v1 = popcount64(a[0] ^ b[0]) + popcount64(a[1] ^ b[1]);
+	int v2 = popcount64(a[0] ^ b[1]) + popcount64(a[1] ^ b[0]);
+	return i_min(v1, v2) / 2;
+}
+
+WV_FN int mismatch3(const uint64_t* a, const uint64_t* b)
+{
+	int p00 = popcount64(a[0] ^ b[0]), p01 = popcount64(a[0] ^ b[1]), p02 = popcount64(a[0] ^ b[2]);
+	int p10 = popcount64(a[1] ^ b[0]), p11 = popcount64(a[1] ^ b[1]), p12 = popcount64(a[1] ^ b[2]);
+	int p20 = popcount64(a[2] ^ b[0]), p21 = popcount64(a[2] ^ b[1]), p22 = popcount64(a[2] ^ b[2]);
+	int v0 = i_min(p11 + p22, p12 + p21) + p00;
+	int v1 = i_min(p10 + p22, p12 + p20) + p01;
+	int v2 = i_min(p10 + p21, p11 + p20) + p02;
+	return i_min(i_min(v0, v1), v2) / 2;
+}
+
+WV_FN int mismatch4(const uint64_t* a, const uint64_t* b)
+{
+	int p[4][4];
+	for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p[i][j] = popcount64(a[i] ^ b[j]);
+	int mx23 = i_min(p[2][2] + p[3][3], p[2][3] + p[3][2]);
+	int mx13 = i_min(p[2][1] + p[3][3], p[2][3] + p[3][1]);
+	int mx12 = i_min(p[2][1] + p[3][2], p[2][2] + p[3][1]);
+	int mx03 = i_min(p[2][0] + p[3][3], p[2][3] + p[3][0]);
+	int mx02 = i_min(p[2][0] + p[3][2], p[2][2] + p[3][0]);
+	int mx01 = i_min(p[2][1] + p[3][0], p[2][0] + p[3][1]);
+	int v0 = p[0][0] + i_min(i_min(p[1][1] + mx23, p[1][2] + mx13), p[1][3] + mx12);
+	int v1 = p[0][1] + i_min(i_min(p[1][0] + mx23, p[1][2] + mx03), p[1][3] + mx02);
+	int v2 = p[0][2] + i_min(i_min(p[1][1] + mx03, p[1][0] + mx13), p[1][3] + mx01);
+	int v3 = p[0][3] + i_min(i_min(p[1][1] + mx02, p[1][2] + mx01), p[1][0] + mx12);
+	return i_min(i_min(v0, v1), i_min(v2, v3)) / 2;
+}
+
+/* (ref: compute_kmeans_partition_ordering :458) -> ps.ordering[0..count) */
+WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+	float* dist = c.tsc(0);
+	float* assign = c.tsc(1);          // partition of texel, as float
+	const f4 cw = load4(blk.cw);
+	float* centers = &tr.fbox[0];      // [4][4]
+
+	// ---- kmeans_init (ref: :60-135): sequential prefix scans, run by all lanes uniformly ----
+	{
+		int sample = 145897 % T;
+		WV_ONE { for (int k = 0; k < 4; k++) centers[k] = c.data(k)[sample]; }
+		WV_SYNC();
+		int clusters_selected = 1;
+
+		WV_FOR(i, T)
+		{
+			f4 color = mk4(c.data(0)[i], c.data(1)[i], c.data(2)[i], c.data(3)[i]);
+			f4 diff = color - load4(centers);
+			dist[i] = dot_s(diff * diff, cw);
+		}
+		WV_SYNC();
+
+		const float cluster_cutoffs[9] = {
+			0.626220f, 0.932770f, 0.275454f,
+			0.318558f, 0.240113f, 0.009190f,
+			0.347661f, 0.731960f, 0.156391f
+		};
+		int cutoff = (clusters_selected - 1) + 3 * (pc - 2);
+
+		while (true)
+		{
+			float distance_sum = 0.0f;
+			for (int i = 0; i < T; i++) distance_sum += dist[i];
+
+			float summa = 0.0f;
+			float distance_cutoff = distance_sum * cluster_cutoffs[cutoff++];
+			for (sample = 0; sample < T; sample++)
+			{
+				summa += dist[sample];
+				if (summa >= distance_cutoff) break;
+			}
+			sample = i_min(sample, T - 1);
+
+			WV_SYNC();
+			WV_ONE { for (int k = 0; k < 4; k++) centers[clusters_selected * 4 + k] = c.data(k)[sample]; }
+			WV_SYNC();
+			clusters_selected++;
+			if (clusters_selected >= pc) break;
+
+			WV_FOR(i, T)
+			{
+				f4 color = mk4(c.data(0)[i], c.data(1)[i], c.data(2)[i], c.data(3)[i]);
+				f4 diff = color - load4(&centers[(clusters_selected - 1) * 4]);
+				float distance = dot_s(diff * diff, cw);
+				dist[i] = f_min(distance, dist[i]);
+			}
+			WV_SYNC();
+		}
+	}
+
+	// ---- 3 x assign, 2 x update (ref: :468-480) ----
+	for (int iter = 0; iter < 3; iter++)
+	{
+		if (iter > 0)
+		{
+			// kmeans_update: per (partition, channel) sequential sums in texel order (ref: :210-243)
+			WV_FOR(k, pc * 4)
+			{
+				int p = k >> 2, ch = k & 3;
+				const float* d = c.data(ch);
+				float sum = 0.0f;
+				int cnt = 0;
+				for (int i = 0; i < T; i++)
+				{
+					if ((int)assign[i] == p) { sum += d[i]; cnt++; }
+				}
+				float scale = 1.0f / (float)cnt;
+				tr.fbox[16 + k] = sum * scale;
+			}
+			WV_SYNC();
+			WV_FOR(k, pc * 4) { centers[k] = tr.fbox[16 + k]; }
+			WV_SYNC();
+		}
+
+		// kmeans_assign (ref: :146-199)
+		WV_FOR(i, T)
+		{
+			float best_distance = 3.402823466e+38f;
+			int best_partition = 0;
+			f4 color = mk4(c.data(0)[i], c.data(1)[i], c.data(2)[i], c.data(3)[i]);
+			for (int j = 0; j < pc; j++)
+			{
+				f4 diff = color - load4(&centers[j * 4]);
+				float distance = dot_s(diff * diff, cw);
+				if (distance < best_distance)
+				{
+					best_distance = distance;
+					best_partition = j;
+				}
+			}
+			assign[i] = (float)best_partition;
+		}
+		WV_SYNC();
+
+		// empty-cluster repair, strictly sequential (ref: :184-198)
+		WV_ONE
+		{
+			int cnt[4] = { 0, 0, 0, 0 };
+			for (int i = 0; i < T; i++) cnt[(int)assign[i]]++;
+			bool problem_case;
+			do
+			{
+				problem_case = false;
+				for (int i = 0; i < pc; i++)
+				{
+					if (cnt[i] == 0)
+					{
+						cnt[(int)assign[i]]--;
+						cnt[i]++;
+						assign[i] = (float)i;
+						problem_case = true;
+					}
+				}
+			} while (problem_case);
+		}
+		WV_SYNC();
+	}
+
+	// ---- bitmaps over the k-means texel subset (ref: :483-490) ----
+	const int texels_to_process = i_min(T, MAX_KMEANS_TEXELS);
+	const uint8_t* km = c.tab + c.root->off_kmeans_texels;
+	WV_FOR(p, pc)
+	{
+		uint64_t bm = 0;
+		for (int i = 0; i < texels_to_process; i++)
+		{
+			if ((int)assign[km[i]] == p) bm |= 1ULL << i;
+		}
+		ps.bitmaps[p] = bm;
+	}
+	WV_SYNC();
+
+	// ---- mismatch counts against every selected partitioning (ref: :365-401) ----
+	const int count = (int)c.root->partitioning_count_selected[pc - 1];
+	const uint64_t* cov = reinterpret_cast<const uint64_t*>(c.tab + c.root->off_coverage[pc - 1]);
+	WV_FOR(i, count)
+	{
+		int m;
+		if (pc == 2) m = mismatch2(ps.bitmaps, cov + i * 2);
+		else if (pc == 3) m = mismatch3(ps.bitmaps, cov + i * 3);
+		else m = mismatch4(ps.bitmaps, cov + i * 4);
+		ps.mismatch[i] = (uint8_t)m;
+	}
+	WV_SYNC();
+
+	// ---- stable counting sort (ref: :412-446) ----
+	WV_ONE
+	{
+		for (int i = 0; i < 64; i++) ps.mscount[i] = 0;
+		for (int i = 0; i < count; i++) ps.mscount[ps.mismatch[i]]++;
+		uint16_t sum = 0;
+		for (int i = 0; i < texels_to_process; i++)
+		{
+			uint16_t cnt = ps.mscount[i];
+			ps.mscount[i] = sum;
+			sum = (uint16_t)(sum + cnt);
+		}
+		for (int i = 0; i < count; i++)
+		{
+			unsigned int idx = ps.mscount[ps.mismatch[i]]++;
+			ps.ordering[idx] = (uint16_t)i;
+		}
+	}
+	WV_SYNC();
+	return count;
+}
+
+/* Line-fit error of one candidate partitioning, all work on one lane.
+ * (ref: compute_avgs_and_dirs_{4_comp,3_comp_rgb} + compute_error_squared_{rgba,rgb} + :660-670 / :726-738) */
+WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha, float weight_imprecision_estim, float& uncor_out, float& samec_out)
+{
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+	const int n = uses_alpha ? 4 : 3;
+	PartView pv = part_view(c, pc, packed);
+
+	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385)
+	float avg[4][4];
+	{
+		float rest[4];
+		for (int ch = 0; ch < n; ch++) rest[ch] = blk.data_mean[ch] * (float)T;
+		for (int p = 0; p < pc - 1; p++)
+		{
+			for (int ch = 0; ch < n; ch++)
+			{
+				const float* d = c.data(ch);
+				float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+				int i = 0;
+				for (; i + 3 < T; i += 4)
+				{
+					a0 = a0 + (pv.of_texel[i] == p ? d[i] : 0.0f);
+					a1 = a1 + (pv.of_texel[i + 1] == p ? d[i + 1] : 0.0f);
+					a2 = a2 + (pv.of_texel[i + 2] == p ? d[i + 2] : 0.0f);
+					a3 = a3 + (pv.of_texel[i + 3] == p ? d[i + 3] : 0.0f);
+				}
+				if (i < T) a0 = a0 + (pv.of_texel[i] == p ? d[i] : 0.0f);
+				if (i + 1 < T) a1 = a1 + (pv.of_texel[i + 1] == p ? d[i + 1] : 0.0f);
+				if (i + 2 < T) a2 = a2 + (pv.of_texel[i + 2] == p ? d[i + 2] : 0.0f);
+				float total = hadd4(a0, a1, a2, a3);
+				rest[ch] = rest[ch] - total;
+				avg[p][ch] = total / (float)pv.count[p];
+			}
+			if (n == 3) avg[p][3] = 0.0f;
+		}
+		for (int ch = 0; ch < n; ch++) avg[pc - 1][ch] = rest[ch] / (float)pv.count[pc - 1];
+		if (n == 3) avg[pc - 1][3] = 0.0f;
+	}
+
+	float uncor_acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	float samec_acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	float tail_uncor = 0.0f, tail_samec = 0.0f;   // accumulated after the texel loop (ref: :660-670)
+	float line_len[4];
+	f4 uncor_b[4], samec_b[4];
+
+	for (int p = 0; p < pc; p++)
+	{
+		const uint8_t* tix = pv.sorted + pv.offset[p];
+		const int cnt = pv.count[p];
+		f4 average = load4(avg[p]);
+
+		// dominant direction (ref: :409-454)
+		f4 sum[4];
+		for (int k = 0; k < 4; k++) sum[k] = splat4(0.0f);
+		for (int i = 0; i < cnt; i++)
+		{
+			int t = tix[i];
+			f4 d = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], n == 4 ? c.data(3)[t] : 0.0f) - average;
+			if (d.x > 0.0f) sum[0] = sum[0] + d;
+			if (d.y > 0.0f) sum[1] = sum[1] + d;
+			if (d.z > 0.0f) sum[2] = sum[2] + d;
+			if (n == 4 && d.w > 0.0f) sum[3] = sum[3] + d;
+		}
+		f4 best_vector = sum[0];
+		float best_sum = dot_s(sum[0], sum[0]);
+		for (int k = 1; k < n; k++)
+		{
+			float prod = dot_s(sum[k], sum[k]);
+			if (prod > best_sum) { best_vector = sum[k]; best_sum = prod; }
+		}
+
+		f4 ub = normalize_safe4(best_vector, n == 4 ? unit4() : unit3());
+		f4 sb = normalize_safe4(average, n == 4 ? unit4() : unit3());
+		float dd = n == 4 ? dot_s(average, ub) : dot3_s(average, ub);
+		f4 amod = average - ub * (n == 4 ? splat4(dd) : mk4(dd, dd, dd, 0.0f));
+		uncor_b[p] = ub;
+		samec_b[p] = sb;
+
+		// squared distance to both lines; accumulators run on across partitions, lane = position
+		// within the partition mod 4 (ref: :778-831, :892-937)
+		float lo = 1e10f, hi = -1e10f;
+		for (int i = 0; i < cnt; i++)
+		{
+			int t = tix[i];
+			float r = c.data(0)[t], g = c.data(1)[t], b = c.data(2)[t];
+			float ue, se, uncor_param;
+			if (n == 4)
+			{
+				float a = c.data(3)[t];
+				uncor_param = (r * ub.x) + (g * ub.y) + (b * ub.z) + (a * ub.w);
+				float d0 = (amod.x - r) + (uncor_param * ub.x);
+				float d1 = (amod.y - g) + (uncor_param * ub.y);
+				float d2 = (amod.z - b) + (uncor_param * ub.z);
+				float d3 = (amod.w - a) + (uncor_param * ub.w);
+				ue = (blk.cw[0] * d0 * d0) + (blk.cw[1] * d1 * d1) + (blk.cw[2] * d2 * d2) + (blk.cw[3] * d3 * d3);
+				float sp = (r * sb.x) + (g * sb.y) + (b * sb.z) + (a * sb.w);
+				float s0 = sp * sb.x - r, s1 = sp * sb.y - g, s2 = sp * sb.z - b, s3 = sp * sb.w - a;
+				se = (blk.cw[0] * s0 * s0) + (blk.cw[1] * s1 * s1) + (blk.cw[2] * s2 * s2) + (blk.cw[3] * s3 * s3);
+			}
+			else
+			{
+				uncor_param = (r * ub.x) + (g * ub.y) + (b * ub.z);
+				float d0 = (amod.x - r) + (uncor_param * ub.x);
+				float d1 = (amod.y - g) + (uncor_param * ub.y);
+				float d2 = (amod.z - b) + (uncor_param * ub.z);
+				ue = (blk.cw[0] * d0 * d0) + (blk.cw[1] * d1 * d1) + (blk.cw[2] * d2 * d2);
+				float sp = (r * sb.x) + (g * sb.y) + (b * sb.z);
+				float s0 = sp * sb.x - r, s1 = sp * sb.y - g, s2 = sp * sb.z - b;
+				se = (blk.cw[0] * s0 * s0) + (blk.cw[1] * s1 * s1) + (blk.cw[2] * s2 * s2);
+			}
+			lo = uncor_param < lo ? uncor_param : lo;
+			hi = uncor_param > hi ? uncor_param : hi;
+			uncor_acc[i & 3] += ue;
+			samec_acc[i & 3] += se;
+		}
+		float linelen = hi - lo;
+		line_len[p] = f_max(linelen, 1e-7f);
+	}
+
+	float uncor_error = hadd4(uncor_acc[0], uncor_acc[1], uncor_acc[2], uncor_acc[3]);
+	float samec_error = hadd4(samec_acc[0], samec_acc[1], samec_acc[2], samec_acc[3]);
+	(void)tail_uncor; (void)tail_samec;
+
+	for (int p = 0; p < pc; p++)
+	{
+		float tpp = (float)pv.count[p];
+		f4 error_weights = splat4(tpp * weight_imprecision_estim);
+		f4 uncor_vector = uncor_b[p] * line_len[p];
+		f4 samec_vector = samec_b[p] * line_len[p];
+		if (n == 4)
+		{
+			uncor_error += dot_s(uncor_vector * uncor_vector, error_weights);
+			samec_error += dot_s(samec_vector * samec_vector, error_weights);
+		}
+		else
+		{
+			uncor_error += dot3_s(uncor_vector * uncor_vector, error_weights);
+			samec_error += dot3_s(samec_vector * samec_vector, error_weights);
+		}
+	}
+	uncor_out = uncor_error;
+	samec_out = samec_error;
+}
+
+/* (ref: insert_result :512) */
+WV_FN void insert_result(int max_values, float this_error, int this_partition, float* best_errors, int* best_partitions)
+{
+	if (this_error >= best_errors[max_values - 1]) return;
+	for (int i = 0; i < max_values; i++)
+	{
+		if (this_error > best_errors[i]) continue;
+		for (int j = max_values - 1; j > i; j--)
+		{
+			best_errors[j] = best_errors[j - 1];
+			best_partitions[j] = best_partitions[j - 1];
+		}
+		best_errors[i] = this_error;
+		best_partitions[i] = this_partition;
+		break;
+	}
+}
+
+/* (ref: find_best_partition_candidates :551).  Returns the number of PACKED partition indices
+ * written to ps.best[]. */
+WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_search_limit, int requested_candidates)
+{
+	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+
+	float weight_imprecision_estim = 0.055f;
+	if (T <= 20) weight_imprecision_estim = 0.03f;
+	else if (T <= 31) weight_imprecision_estim = 0.04f;
+	else if (T <= 41) weight_imprecision_estim = 0.05f;
+	weight_imprecision_estim = weight_imprecision_estim * weight_imprecision_estim;
+
+	int sequence_len = kmeans_partition_ordering(c, pc, ps);
+	partition_search_limit = i_min(partition_search_limit, sequence_len);
+	requested_candidates = i_min(partition_search_limit, requested_candidates);
+
+	bool uses_alpha = !(blk.data_min[3] == blk.data_max[3]);
+
+	WV_FOR(i, partition_search_limit)
+	{
+		float ue, se;
+		score_partitioning(c, pc, ps.ordering[i], uses_alpha, weight_imprecision_estim, ue, se);
+		ps.uncor_err[i] = ue;
+		ps.samec_err[i] = se;
+	}
+	WV_SYNC();
+
+	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
+	WV_ONE
+	{
+		float uncor_best_errors[MAX_PARTITIONING_CANDIDATES], samec_best_errors[MAX_PARTITIONING_CANDIDATES];
+		int uncor_best_partitions[MAX_PARTITIONING_CANDIDATES], samec_best_partitions[MAX_PARTITIONING_CANDIDATES];
+		for (int i = 0; i < MAX_PARTITIONING_CANDIDATES; i++)
+		{
+			uncor_best_errors[i] = ERROR_CALC_DEFAULT; samec_best_errors[i] = ERROR_CALC_DEFAULT;
+			uncor_best_partitions[i] = 0; samec_best_partitions[i] = 0;
+		}
+		for (int i = 0; i < partition_search_limit; i++)
+		{
+			int partition = ps.ordering[i];
+			insert_result(requested_candidates, ps.uncor_err[i], partition, uncor_best_errors, uncor_best_partitions);
+			insert_result(requested_candidates, ps.samec_err[i], partition, samec_best_errors, samec_best_partitions);
+		}
+
+		// interleave + dedupe (ref: :745-776); packed indices are unique per seed, so dedupe on them
+		int emitted = 0;
+		for (int i = 0; i < requested_candidates * 2 && emitted < requested_candidates; i++)
+		{
+			int partition = (i & 1) ? samec_best_partitions[i >> 1] : uncor_best_partitions[i >> 1];
+			bool written = false;
+			for (int j = 0; j < emitted; j++) written = written || ps.best[j] == partition;
+			if (!written) ps.best[emitted++] = partition;
+		}
+		ps.best_count = emitted;
+	}
+	WV_SYNC();
+	return ps.best_count;
+}
+
+} // namespace astcd

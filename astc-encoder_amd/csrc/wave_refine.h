@@ -1,0 +1,712 @@
+// SPDX-License-Identifier: Apache-2.0
+// Candidate refinement: re-fit endpoints to quantized weights, score by decoding, nudge weights.
+//   ref: recompute_ideal_colors_{1plane,2planes}, compute_rgbo_vector
+//                                   Source/astcenc_ideal_endpoints_and_weights.cpp:1099-1650
+//        unpack_weights, lerp_color_int, compute_symbolic_block_difference_{1plane_1partition,1plane,2plane}
+//                                   Source/astcenc_decompress_symbolic.cpp:37-155, :313-618
+//        realign_weights_{undecimated,decimated}
+//                                   Source/astcenc_compress_symbolic.cpp:69-338
+#pragma once
+#include "wave_ctx.h"
+#include "wave_weights.h"
+#include "wave_color.h"
+
+namespace astcd {
+
+/* (ref: compute_rgbo_vector :1099) */
+WV_FN f4 compute_rgbo_vector(f4 rgba_weight_sum, f4 weight_weight_sum, f4 rgbq_sum, float psum)
+{
+	float X = rgba_weight_sum.x, Y = rgba_weight_sum.y, Z = rgba_weight_sum.z;
+	float P = weight_weight_sum.x, Q = weight_weight_sum.y, R = weight_weight_sum.z;
+	float S = psum;
+
+	float PP = P * P, QQ = Q * Q, RR = R * R;
+	float SZmRR = S * Z - RR;
+	float DT = SZmRR * Y - Z * QQ;
+	float YP = Y * P, QX = Q * X, YX = Y * X;
+	float mZYP = -Z * YP, mZQX = -Z * QX, mRYX = -R * YX;
+	float ZQP = Z * Q * P, RYP = R * YP, RQX = R * QX;
+
+	float rdet = 1.0f / (DT * X + mZYP * P);
+
+	f4 mat0 = mk4(DT, ZQP, RYP, mZYP);
+	f4 mat1 = mk4(ZQP, SZmRR * X - Z * PP, RQX, mZQX);
+	f4 mat2 = mk4(RYP, RQX, (S * Y - QQ) * X - Y * PP, mRYX);
+	f4 mat3 = mk4(mZYP, mZQX, mRYX, Z * YX);
+	f4 vect = rgbq_sum * rdet;
+
+	return mk4(dot_s(mat0, vect), dot_s(mat1, vect), dot_s(mat2, vect), dot_s(mat3, vect));
+}
+
+/* Expand quantized grid weights (0..64 in `uq`) to per-texel float weights in dst[0..T). */
+WV_FN void expand_weights(const Ctx& c, const DecimationInfo& di, const uint8_t* uq, float* grid, float* dst)
+{
+	const int T = di.texel_count, W = di.weight_count;
+	WV_FOR(i, W) { grid[i] = (float)uq[i] * (1.0f / 64.0f); }
+	WV_SYNC();
+	const uint8_t* tw = c.tab + di.off_texel_weights;
+	const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+	if (di.max_texel_weight_count == 1)
+	{
+		WV_FOR(t, T) { dst[t] = grid[t]; }
+	}
+	else if (di.max_texel_weight_count <= 2)
+	{
+		WV_FOR(t, T) { dst[t] = infill2(grid, tw, tcf, T, t); }
+	}
+	else
+	{
+		WV_FOR(t, T) { dst[t] = infill4(grid, tw, tcf, T, t); }
+	}
+	WV_SYNC();
+}
+
+/* Endpoint solve shared by both recompute variants: given the accumulated sums of one weight
+ * plane, produce (ep0, ep1, mask) for the lanes it owns. */
+struct PlaneSolve {
+	f4 ep0, ep1;
+	bool m[4];
+};
+
+WV_FN PlaneSolve solve_plane(f4 left_sum, f4 middle_sum, f4 right_sum, f4 color_vec_x, f4 color_vec_y)
+{
+	PlaneSolve r;
+	f4 color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
+	f4 color_rdet1 = splat4(1.0f) / color_det1;
+	f4 color_mss1 = (left_sum * left_sum) + (splat4(2.0f) * middle_sum * middle_sum) + (right_sum * right_sum);
+	r.ep0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
+	r.ep1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
+	f4 ad = v4_abs(color_det1);
+	f4 th = color_mss1 * 1e-4f;
+	for (int k = 0; k < 4; k++)
+	{
+		float e0 = lane(r.ep0, k), e1 = lane(r.ep1, k);
+		r.m[k] = (lane(ad, k) > lane(th, k)) && (e0 == e0) && (e1 == e1);
+	}
+	return r;
+}
+
+/* (ref: recompute_ideal_colors_1plane :1146).  Reads wscb().weights, updates tr.wep0/wep1/rgbs/rgbo. */
+WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const DecimationInfo& di)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, pc = pv.pcount;
+	float* undec = c.tsc(0);
+	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec);
+
+	// pass 1: weighted partition colour sum -> scale direction (ref: :1198-1219)
+	if (pc > 1)
+	{
+		WV_FOR(k, pc * 4)
+		{
+			int p = k >> 2, ch = k & 3;
+			const float* d = c.data(ch);
+			const uint8_t* tix = pv.sorted + pv.offset[p];
+			float s = 0.0f;
+			for (int j = 0; j < pv.count[p]; j++) s += d[tix[j]];
+			tr.fbox[96 + k] = s;
+		}
+	}
+	else
+	{
+		WV_FOR(k, 4) { tr.fbox[96 + k] = blk.data_mean[k] * (float)c.T; }
+	}
+	WV_SYNC();
+	WV_FOR(p, pc)
+	{
+		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * load4(blk.cw);
+		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.count[p], splat4(1e-17f));
+		f4 scale_dir = normalize4(xyz0(rgba_sum / rgba_weight_sum));
+		store4(&tr.fbox[112 + p * 4], scale_dir);
+	}
+	WV_SYNC();
+
+	// pass 2: 18 sequential chains per partition over its texels (ref: :1241-1269)
+	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	WV_FOR(k, pc * 18)
+	{
+		int p = k / 18, ch = k % 18;
+		const uint8_t* tix = pv.sorted + pv.offset[p];
+		const int n = pv.count[p];
+		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
+		float acc;
+		if (ch == 0) acc = 1.0f;          // wmin1
+		else if (ch == 1) acc = 0.0f;     // wmax1
+		else if (ch == 2) acc = 1e10f;    // scale_min
+		else if (ch == 3) acc = 0.0f;     // scale_max
+		else if (ch == 7) acc = 1e-17f;   // weight_weight_sum
+		else acc = 0.0f;
+		for (int j = 0; j < n; j++)
+		{
+			int t = tix[j];
+			float idx0 = undec[t];
+			float om_idx0 = 1.0f - idx0;
+			if (ch == 0) acc = f_min(idx0, acc);
+			else if (ch == 1) acc = f_max(idx0, acc);
+			else if (ch == 2 || ch == 3 || ch >= 16)
+			{
+				f4 rgba = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
+				float scale = dot3_s(scale_dir, rgba);
+				if (ch == 2) acc = f_min(scale, acc);
+				else if (ch == 3) acc = f_max(scale, acc);
+				else if (ch == 16) acc += om_idx0 * (scale * ls_weight);
+				else acc += idx0 * (scale * ls_weight);
+			}
+			else if (ch == 4) acc += om_idx0 * om_idx0;
+			else if (ch == 5) acc += om_idx0 * idx0;
+			else if (ch == 6) acc += idx0 * idx0;
+			else if (ch == 7) acc += idx0;
+			else
+			{
+				int comp = ch & 3;
+				float cw = c.data(comp)[t];
+				float cwi = cw * idx0;
+				if (ch < 12) acc += cw - cwi;   // color_vec_x
+				else acc += cwi;                // color_vec_y
+			}
+		}
+		tr.fbox[p * 24 + ch] = acc;
+	}
+	WV_SYNC();
+
+	WV_FOR(p, pc)
+	{
+		const float* s = &tr.fbox[p * 24];
+		float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
+		float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6], weight_weight_sum_s = s[7];
+		f4 color_vec_x = load4(&s[8]), color_vec_y = load4(&s[12]);
+		float scale_vec0 = s[16], scale_vec1 = s[17];
+		f4 color_weight = load4(blk.cw);
+		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
+		f4 rgba_weight_sum = v4_max(color_weight * (float)pv.count[p], splat4(1e-17f));
+
+		f4 left_sum = splat4(left_sum_s) * color_weight;
+		f4 middle_sum = splat4(middle_sum_s) * color_weight;
+		f4 right_sum = splat4(right_sum_s) * color_weight;
+		f4 lmrs_sum = mk4(left_sum_s, middle_sum_s, right_sum_s, 0.0f) * ls_weight;
+
+		color_vec_x = color_vec_x * color_weight;
+		color_vec_y = color_vec_y * color_weight;
+
+		float scalediv = scale_min / f_max(scale_max, 1e-10f);
+		scalediv = f_clamp1(scalediv);
+		f4 sds = scale_dir * scale_max;
+		f4 rgbs = mk4(sds.x, sds.y, sds.z, scalediv);
+
+		f4 ep0 = load4(tr.wep0[p]), ep1 = load4(tr.wep1[p]);
+
+		if (wmin1 >= wmax1 * 0.999f)
+		{
+			// all weights (nearly) equal: both endpoints become the mean
+			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+			for (int k = 0; k < 4; k++)
+			{
+				float a = lane(avg, k);
+				if (a == a) { set_lane(ep0, k, a); set_lane(ep1, k, a); }
+			}
+			rgbs = mk4(sds.x, sds.y, sds.z, 1.0f);
+		}
+		else
+		{
+			PlaneSolve ps = solve_plane(left_sum, middle_sum, right_sum, color_vec_x, color_vec_y);
+			for (int k = 0; k < 4; k++)
+			{
+				if (ps.m[k]) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
+			}
+
+			float ls_det1 = (lmrs_sum.x * lmrs_sum.z) - (lmrs_sum.y * lmrs_sum.y);
+			float ls_rdet1 = 1.0f / ls_det1;
+			float ls_mss1 = (lmrs_sum.x * lmrs_sum.x) + (2.0f * lmrs_sum.y * lmrs_sum.y) + (lmrs_sum.z * lmrs_sum.z);
+			float scale_ep0 = (lmrs_sum.z * scale_vec0 - lmrs_sum.y * scale_vec1) * ls_rdet1;
+			float scale_ep1 = (lmrs_sum.x * scale_vec1 - lmrs_sum.y * scale_vec0) * ls_rdet1;
+
+			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
+			{
+				float scalediv2 = scale_ep0 / scale_ep1;
+				f4 sdsm = scale_dir * scale_ep1;
+				rgbs = mk4(sdsm.x, sdsm.y, sdsm.z, scalediv2);
+			}
+		}
+
+		if (blk.rgb_lns || blk.alpha_lns)
+		{
+			f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
+			float psum = right_sum_s * hadd_rgb_s(color_weight);
+			f4 rgbq_sum = color_vec_x + color_vec_y;
+			rgbq_sum.w = hadd_rgb_s(color_vec_y);
+			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
+			if (f_isnan(dot_s(rgbovec, rgbovec)))
+			{
+				f4 v0 = ep0, v1 = ep1;
+				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
+				avgdif = f_max(avgdif, 0.0f);
+				f4 avg = (v0 + v1) * 0.5f;
+				f4 e0 = avg - splat4(avgdif) * 0.5f;
+				rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
+			}
+			store4(tr.rgbo[p], rgbovec);
+		}
+
+		store4(tr.wep0[p], ep0);
+		store4(tr.wep1[p], ep1);
+		store4(tr.rgbs[p], rgbs);
+	}
+	WV_SYNC();
+}
+
+/* (ref: recompute_ideal_colors_2planes :1369) */
+WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecimationInfo& di, int plane2_component)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+	float* undec1 = c.tsc(0);
+	float* undec2 = c.tsc(1);
+	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec1);
+	expand_weights(c, di, c.wscb().weights + PLANE2_OFFSET, c.wsc(1), undec2);
+
+	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	const f4 scale_dir = normalize4(xyz0(load4(blk.data_mean)));
+
+	// chains: 0 wmin1 1 wmax1 2 wmin2 3 wmax2 4 scale_min 5 scale_max 6-8 l/m/r plane1 9-11 l/m/r plane2
+	//         12-15 color_vec_x 16-19 color_vec_y 20-21 scale_vec 22-25 weight_weight_sum
+	WV_FOR(ch, 26)
+	{
+		float acc = 0.0f;
+		if (ch == 0 || ch == 2) acc = 1.0f;
+		else if (ch == 4) acc = 1e10f;
+		else if (ch >= 22) acc = 1e-17f;
+		for (int j = 0; j < T; j++)
+		{
+			float idx0 = undec1[j], idx1 = undec2[j];
+			float om_idx0 = 1.0f - idx0, om_idx1 = 1.0f - idx1;
+			if (ch == 0) acc = f_min(idx0, acc);
+			else if (ch == 1) acc = f_max(idx0, acc);
+			else if (ch == 2) acc = f_min(idx1, acc);
+			else if (ch == 3) acc = f_max(idx1, acc);
+			else if (ch == 4 || ch == 5 || ch == 20 || ch == 21)
+			{
+				f4 rgba = mk4(c.data(0)[j], c.data(1)[j], c.data(2)[j], c.data(3)[j]);
+				float scale = dot3_s(scale_dir, rgba);
+				if (ch == 4) acc = f_min(scale, acc);
+				else if (ch == 5) acc = f_max(scale, acc);
+				else if (ch == 20) acc += om_idx0 * (ls_weight * scale);
+				else acc += idx0 * (ls_weight * scale);
+			}
+			else if (ch == 6) acc += om_idx0 * om_idx0;
+			else if (ch == 7) acc += om_idx0 * idx0;
+			else if (ch == 8) acc += idx0 * idx0;
+			else if (ch == 9) acc += om_idx1 * om_idx1;
+			else if (ch == 10) acc += om_idx1 * idx1;
+			else if (ch == 11) acc += idx1 * idx1;
+			else
+			{
+				int comp = ch & 3;          // 12..15, 16..19, (22..25 -> comp = ch - 22)
+				if (ch >= 22) comp = ch - 22;
+				float color_idx = comp == plane2_component ? idx1 : idx0;
+				if (ch >= 22) acc += color_idx;
+				else
+				{
+					float cw = c.data(comp)[j];
+					float cwi = cw * color_idx;
+					if (ch < 16) acc += cw - cwi;
+					else acc += cwi;
+				}
+			}
+		}
+		tr.fbox[ch] = acc;
+	}
+	WV_SYNC();
+
+	WV_ONE
+	{
+		const float* s = tr.fbox;
+		float wmin1 = s[0], wmax1 = s[1], wmin2 = s[2], wmax2 = s[3], scale_min = s[4], scale_max = s[5];
+		f4 color_weight = load4(blk.cw);
+		f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
+
+		f4 left1_sum = splat4(s[6]) * color_weight, middle1_sum = splat4(s[7]) * color_weight, right1_sum = splat4(s[8]) * color_weight;
+		f4 lmrs_sum = mk4(s[6], s[7], s[8], 0.0f) * ls_weight;
+		f4 left2_sum = splat4(s[9]) * color_weight, middle2_sum = splat4(s[10]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
+
+		f4 color_vec_x = load4(&s[12]) * color_weight;
+		f4 color_vec_y = load4(&s[16]) * color_weight;
+		float scale_vec0 = s[20], scale_vec1 = s[21];
+		f4 weight_weight_sum = load4(&s[22]);
+
+		float scalediv = scale_min / f_max(scale_max, 1e-10f);
+		scalediv = f_clamp1(scalediv);
+		f4 sds = scale_dir * scale_max;
+		f4 rgbs = mk4(sds.x, sds.y, sds.z, scalediv);
+
+		f4 ep0 = load4(tr.wep0[0]), ep1 = load4(tr.wep1[0]);
+
+		if (wmin1 >= wmax1 * 0.999f)
+		{
+			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+			for (int k = 0; k < 4; k++)
+			{
+				float a = lane(avg, k);
+				if (k != plane2_component && a == a) { set_lane(ep0, k, a); set_lane(ep1, k, a); }
+			}
+			rgbs = mk4(sds.x, sds.y, sds.z, 1.0f);
+		}
+		else
+		{
+			PlaneSolve ps = solve_plane(left1_sum, middle1_sum, right1_sum, color_vec_x, color_vec_y);
+			float ls_det1 = (lmrs_sum.x * lmrs_sum.z) - (lmrs_sum.y * lmrs_sum.y);
+			float ls_rdet1 = 1.0f / ls_det1;
+			float ls_mss1 = (lmrs_sum.x * lmrs_sum.x) + (2.0f * lmrs_sum.y * lmrs_sum.y) + (lmrs_sum.z * lmrs_sum.z);
+			float scale_ep0 = (lmrs_sum.z * scale_vec0 - lmrs_sum.y * scale_vec1) * ls_rdet1;
+			float scale_ep1 = (lmrs_sum.x * scale_vec1 - lmrs_sum.y * scale_vec0) * ls_rdet1;
+			for (int k = 0; k < 4; k++)
+			{
+				if (k != plane2_component && ps.m[k]) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
+			}
+			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
+			{
+				float scalediv2 = scale_ep0 / scale_ep1;
+				f4 sdsm = scale_dir * scale_ep1;
+				rgbs = mk4(sdsm.x, sdsm.y, sdsm.z, scalediv2);
+			}
+		}
+
+		if (wmin2 >= wmax2 * 0.999f)
+		{
+			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+			float a = lane(avg, plane2_component);
+			if (a == a) { set_lane(ep0, plane2_component, a); set_lane(ep1, plane2_component, a); }
+		}
+		else
+		{
+			PlaneSolve ps = solve_plane(left2_sum, middle2_sum, right2_sum, color_vec_x, color_vec_y);
+			if (ps.m[plane2_component])
+			{
+				set_lane(ep0, plane2_component, lane(ps.ep0, plane2_component));
+				set_lane(ep1, plane2_component, lane(ps.ep1, plane2_component));
+			}
+		}
+
+		if (blk.rgb_lns || blk.alpha_lns)
+		{
+			weight_weight_sum = weight_weight_sum * color_weight;
+			f4 sel = mk4(plane2_component == 0 ? right2_sum.x : right1_sum.x, plane2_component == 1 ? right2_sum.y : right1_sum.y,
+			             plane2_component == 2 ? right2_sum.z : right1_sum.z, plane2_component == 3 ? right2_sum.w : right1_sum.w);
+			float psum = dot3_s(sel, color_weight);
+			f4 rgbq_sum = color_vec_x + color_vec_y;
+			rgbq_sum.w = hadd_rgb_s(color_vec_y);
+			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
+			if (f_isnan(dot_s(rgbovec, rgbovec)))
+			{
+				f4 v0 = ep0, v1 = ep1;
+				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
+				avgdif = f_max(avgdif, 0.0f);
+				f4 avg = (v0 + v1) * 0.5f;
+				f4 e0 = avg - splat4(avgdif) * 0.5f;
+				rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
+			}
+			store4(tr.rgbo[0], rgbovec);
+		}
+
+		store4(tr.wep0[0], ep0);
+		store4(tr.wep1[0], ep1);
+		store4(tr.rgbs[0], rgbs);
+	}
+	WV_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decode-and-score
+// ---------------------------------------------------------------------------------------------
+
+/* Integer texel weights of one plane (ref: unpack_weights :89). */
+WV_FN int unpack_texel_weight(const uint8_t* uq, const uint8_t* tw, const uint8_t* tci, int T, int t)
+{
+	int sum = 8;
+	for (int j = 0; j < 4; j++) sum += uq[tw[j * T + t]] * tci[j * T + t];
+	return sum >> 4;
+}
+
+WV_FN int lerp_channel(bool u8, int c0, int c1, int w)
+{
+	int color = (c0 * (64 - w)) + (c1 * w) + 32;
+	color = color >> 6;
+	if (u8) color = (color >> 8) * 257;
+	return color;
+}
+
+/* Squared error of wscb() against the block, with the reference's summation order for each of
+ * its three variants (ref: :313, :407, :505).  Uniform return value. */
+WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv)
+{
+	const Scb& scb = c.wscb();
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+	if (scb.block_type == SYM_BTYPE_ERROR) return ERROR_CALC_DEFAULT;
+
+	const BlockMode& bm = c.block_mode(scb.block_mode);
+	const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+	const uint8_t* tw = c.tab + di.off_texel_weights;
+	const uint8_t* tci = c.tab + di.off_texel_contribs_int;
+	const bool dual = bm.is_dual_plane != 0;
+	const int pc = scb.partition_count;
+	const int profile = c.cfg->profile;
+	const bool u8 = (c.cfg->flags & (1u << 1)) || profile == 0;
+	const bool rgbm = (c.cfg->flags & (1u << 6)) != 0;
+	const bool fast_1p = !dual && pc == 1 && !rgbm;
+	const int p2c = scb.plane2_component;
+
+	// endpoints per partition -> ibox[p*8 ..]
+	WV_FOR(p, pc)
+	{
+		i4 e0, e1;
+		unpack_color_endpoints(profile, scb.color_formats[p], scb.color_values[p], e0, e1);
+		int* o = &tr.ibox[p * 8];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+	}
+	WV_SYNC();
+
+	float* term = c.tsc(2);
+	float* flag = c.tsc(3);
+	WV_FOR(i, T)
+	{
+		// 1-plane multi-partition sums in partition order, the other two in texel order
+		int t = (!dual && !fast_1p) ? pv.sorted[i] : i;
+		int p = pv.of_texel[t];
+		const int* e = &tr.ibox[p * 8];
+		int w1 = unpack_texel_weight(scb.weights, tw, tci, T, t);
+		int w2 = dual ? unpack_texel_weight(scb.weights + PLANE2_OFFSET, tw, tci, T, t) : w1;
+
+		float col[4], old[4];
+		for (int k = 0; k < 4; k++)
+		{
+			int w = (k == p2c) ? w2 : w1;
+			col[k] = (float)lerp_channel(u8, e[k], e[4 + k], w);
+			old[k] = c.data(k)[t];
+		}
+
+		float bad = 0.0f;
+		if (rgbm)
+		{
+			if (col[3] == 0.0f) bad = 1.0f;
+			float ms = c.cfg->rgbm_m_scale;
+			for (int k = 0; k < 3; k++)
+			{
+				col[k] = col[k] * col[3] * ms;
+				old[k] = old[k] * old[3] * ms;
+			}
+			col[3] = 1.0f; old[3] = 1.0f;
+		}
+		flag[i] = bad;
+
+		float err[4];
+		for (int k = 0; k < 4; k++)
+		{
+			float e1 = f_abs(old[k] - col[k]);
+			e1 = e1 < 1e15f ? e1 : 1e15f;
+			err[k] = e1 * e1;
+		}
+
+		if (fast_1p)
+		{
+			term[i] = err[0] * blk.cw[0] + err[1] * blk.cw[1] + err[2] * blk.cw[2] + err[3] * blk.cw[3];
+		}
+		else
+		{
+			float d = hadd4(err[0] * blk.cw[0], err[1] * blk.cw[1], err[2] * blk.cw[2], err[3] * blk.cw[3]);
+			term[i] = d < ERROR_CALC_DEFAULT ? d : ERROR_CALC_DEFAULT;
+		}
+	}
+	WV_SYNC();
+
+	if (fast_1p)
+	{
+		return sum4(term, T);
+	}
+
+	float summa = 0.0f;
+	for (int i = 0; i < T; i++)
+	{
+		if (rgbm && flag[i] != 0.0f) return -ERROR_CALC_DEFAULT;
+		summa += term[i];
+	}
+	return summa;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight realignment
+// ---------------------------------------------------------------------------------------------
+
+/* (ref: realign_weights_undecimated :69, realign_weights_decimated :188).  Operates on wscb();
+ * uniform return: true if any weight moved. */
+WV_FN bool realign_weights(const Ctx& c, const PartView& pv)
+{
+	Scb& scb = c.wscb();
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
+	const BlockMode& bm = c.block_mode(scb.block_mode);
+	const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+	const QuantXfer& qat = c.qxfer(bm.quant_mode);
+	const int W = di.weight_count;
+	const int pc = scb.partition_count;
+	const int max_plane = bm.is_dual_plane;
+	const int p2c = scb.plane2_component;
+	const bool decimated = W != T;
+
+	WV_FOR(p, pc)
+	{
+		i4 e0, e1;
+		unpack_color_endpoints(c.cfg->profile, scb.color_formats[p], scb.color_values[p], e0, e1);
+		int* o = &tr.ibox[p * 8];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+	}
+	WV_SYNC();
+
+	bool adjustments = false;
+	const f4 error_weight = load4(blk.cw);
+
+	for (int pl = 0; pl <= max_plane; pl++)
+	{
+		uint8_t* uq = scb.weights + pl * PLANE2_OFFSET;
+
+		// endpoint base and per-weight-step offset, with the other plane's channels frozen
+		// -> fbox[p*8 + 0..3] = endpnt0f, fbox[p*8 + 4..7] = offset
+		WV_FOR(k, pc * 4)
+		{
+			int p = k >> 2, ch = k & 3;
+			const int* e = &tr.ibox[p * 8];
+			bool masked = (pl == 0) ? (ch == p2c) : (ch != p2c);
+			int epd = masked ? 0 : e[4 + ch] - e[ch];
+			tr.fbox[p * 8 + ch] = (float)e[ch];
+			tr.fbox[p * 8 + 4 + ch] = (float)epd * (1.0f / 64.0f);
+		}
+		WV_SYNC();
+
+		if (!decimated)
+		{
+			float* moved = c.tsc(4);
+			WV_FOR(texel, T)
+			{
+				int uqw = uq[texel];
+				uint32_t prev_and_next = qat.prev_next_values[uqw];
+				int uqw_down = prev_and_next & 0xFF;
+				int uqw_up = (prev_and_next >> 8) & 0xFF;
+
+				float weight_base = (float)uqw;
+				float weight_down = (float)(uqw_down - uqw);
+				float weight_up = (float)(uqw_up - uqw);
+
+				int p = pv.of_texel[texel];
+				f4 color_offset = load4(&tr.fbox[p * 8 + 4]);
+				f4 color_base = load4(&tr.fbox[p * 8]);
+
+				f4 color = color_base + color_offset * weight_base;
+				f4 orig_color = mk4(c.data(0)[texel], c.data(1)[texel], c.data(2)[texel], c.data(3)[texel]);
+
+				f4 color_diff = color - orig_color;
+				f4 color_diff_down = color_diff + color_offset * weight_down;
+				f4 color_diff_up = color_diff + color_offset * weight_up;
+
+				float error_base = dot_s(color_diff * color_diff, error_weight);
+				float error_down = dot_s(color_diff_down * color_diff_down, error_weight);
+				float error_up = dot_s(color_diff_up * color_diff_up, error_weight);
+
+				float mv = 0.0f;
+				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64))
+				{
+					uq[texel] = (uint8_t)uqw_up;
+					mv = 1.0f;
+				}
+				else if ((error_down < error_base) && (uqw > 0))
+				{
+					uq[texel] = (uint8_t)uqw_down;
+					mv = 1.0f;
+				}
+				moved[texel] = mv;
+			}
+			WV_SYNC();
+			for (int t = 0; t < T; t++) adjustments = adjustments || (moved[t] != 0.0f);
+			WV_SYNC();
+		}
+		else
+		{
+			const uint8_t* wtc = c.tab + di.off_weight_texel_count;
+			const uint8_t* wt = c.tab + di.off_weight_texels;
+			const float* tcw = reinterpret_cast<const float*>(c.tab + di.off_texel_contrib_for_weight);
+			const uint8_t* tw = c.tab + di.off_texel_weights;
+			const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+			float* uqf = c.wsc(2);
+
+			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }
+			WV_SYNC();
+
+			for (int we = 0; we < W; we++)
+			{
+				int uqw = uq[we];
+				uint32_t prev_and_next = qat.prev_next_values[uqw];
+				float uqw_base = uqf[we];
+				float uqw_down = (float)(prev_and_next & 0xFF);
+				float uqw_up = (float)((prev_and_next >> 8) & 0xFF);
+				float uqw_diff_down = uqw_down - uqw_base;
+				float uqw_diff_up = uqw_up - uqw_base;
+				int n = wtc[we];
+
+				// per-texel squared differences for base / down / up, 4 channels each -> tsc(0..11)
+				WV_FOR(te, n)
+				{
+					int texel = wt[te * W + we];
+					float tw_base = tcw[te * W + we];
+					float weight_base = infill4(uqf, tw, tcf, T, texel);
+					float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
+					float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
+
+					int p = pv.of_texel[texel];
+					f4 color_offset = load4(&tr.fbox[p * 8 + 4]);
+					f4 color_base = load4(&tr.fbox[p * 8]);
+					f4 color = color_base + color_offset * weight_base;
+					f4 orig_color = mk4(c.data(0)[texel], c.data(1)[texel], c.data(2)[texel], c.data(3)[texel]);
+					f4 color_diff = color - orig_color;
+					f4 color_down_diff = color_diff + color_offset * weight_down;
+					f4 color_up_diff = color_diff + color_offset * weight_up;
+					f4 b = color_diff * color_diff, d = color_down_diff * color_down_diff, u = color_up_diff * color_up_diff;
+					c.tsc(0)[te] = b.x; c.tsc(1)[te] = b.y; c.tsc(2)[te] = b.z; c.tsc(3)[te] = b.w;
+					c.tsc(4)[te] = d.x; c.tsc(5)[te] = d.y; c.tsc(6)[te] = d.z; c.tsc(7)[te] = d.w;
+					c.tsc(8)[te] = u.x; c.tsc(9)[te] = u.y; c.tsc(10)[te] = u.z; c.tsc(11)[te] = u.w;
+				}
+				WV_SYNC();
+				WV_FOR(k, 12)
+				{
+					const float* v = c.tsc(k);
+					float acc = 0.0f;
+					for (int te = 0; te < n; te++) acc += v[te];
+					tr.fbox[64 + k] = acc;
+				}
+				WV_SYNC();
+
+				float error_base = hadd_s(load4(&tr.fbox[64]) * error_weight);
+				float error_down = hadd_s(load4(&tr.fbox[68]) * error_weight);
+				float error_up = hadd_s(load4(&tr.fbox[72]) * error_weight);
+
+				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64))
+				{
+					WV_ONE { uqf[we] = uqw_up; uq[we] = (uint8_t)uqw_up; }
+					adjustments = true;
+				}
+				else if ((error_down < error_base) && (uqw > 0))
+				{
+					WV_ONE { uqf[we] = uqw_down; uq[we] = (uint8_t)uqw_down; }
+					adjustments = true;
+				}
+				WV_SYNC();
+			}
+		}
+	}
+	return adjustments;
+}
+
+} // namespace astcd

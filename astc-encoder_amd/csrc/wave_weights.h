@@ -1,0 +1,347 @@
+// SPDX-License-Identifier: Apache-2.0
+// Weight-grid stages of one trial:
+//   * ideal weights on every decimated grid      ref: compute_ideal_weights_for_decimation
+//                                                     Source/astcenc_ideal_endpoints_and_weights.cpp:845-971
+//   * angular search for low/high weight bounds  ref: compute_angular_offsets / compute_lowest_and_highest_weight /
+//                                                     compute_angular_endpoints_for_quant_levels
+//                                                     Source/astcenc_weight_align.cpp:94-355
+//   * quantize a grid and score it               ref: compute_quantized_weights_for_decimation :974-1080
+//                                                     compute_error_of_weight_set_{1plane,2planes} :688-842
+#pragma once
+#include "wave_ctx.h"
+
+namespace astcd {
+
+/* Bilinear infill of one texel from a weight array (ref: bilinear_infill_vla[_2] :38-97).  Unused
+ * taps have zero contribution, so the 4-tap form equals the reference's count-specialised forms
+ * whenever max_texel_weight_count > 2; the 2-tap form must be used otherwise. */
+WV_FN float infill4(const float* wts, const uint8_t* tw, const float* tcf, int T, int t)
+{
+	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]) +
+	       (wts[tw[2 * T + t]] * tcf[2 * T + t] + wts[tw[3 * T + t]] * tcf[3 * T + t]);
+}
+WV_FN float infill2(const float* wts, const uint8_t* tw, const float* tcf, int T, int t)
+{
+	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]);
+}
+
+/* Ideal weights of plane `plane` on decimation grid `dm` -> out[0..W). */
+WV_FN void ideal_weights_for_decimation(const Ctx& c, int plane, int dm, float* out)
+{
+	const DecimationInfo& di = c.dec_info(dm);
+	const int T = di.texel_count, W = di.weight_count;
+	const float* eiw = c.ei_w(plane);
+	const float* eiwes = c.ei_wes(plane);
+
+	if (T == W)
+	{
+		WV_FOR(i, T) { out[i] = eiw[i]; }
+		WV_SYNC();
+		return;
+	}
+
+	const uint8_t* wtc = c.tab + di.off_weight_texel_count;
+	const uint8_t* wt = c.tab + di.off_weight_texels;
+	const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
+	const uint8_t* tw = c.tab + di.off_texel_weights;
+	const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
+	const float wes0 = eiwes[0];
+	float* infilled = c.tsc(0);
+
+	// initial guess: error-weighted average of the texels each weight touches (ref: :877-905)
+	WV_FOR(i, W)
+	{
+		float weight_weight = 1e-10f;
+		float initial_weight = 0.0f;
+		int cnt = wtc[i];
+		for (int j = 0; j < cnt; j++)
+		{
+			int texel = wt[j * W + i];
+			float weight = wc[j * W + i];
+			float wes = constant_wes ? wes0 : eiwes[texel];
+			float contrib_weight = weight * wes;
+			weight_weight += contrib_weight;
+			initial_weight += eiw[texel] * contrib_weight;
+		}
+		out[i] = initial_weight / weight_weight;
+	}
+	WV_SYNC();
+
+	// infill to texel resolution (ref: :910-926)
+	if (di.max_texel_weight_count <= 2)
+	{
+		WV_FOR(t, T) { infilled[t] = infill2(out, tw, tcf, T, t); }
+	}
+	else
+	{
+		WV_FOR(t, T) { infilled[t] = infill4(out, tw, tcf, T, t); }
+	}
+	WV_SYNC();
+
+	// one clamped gradient step (ref: :930-970)
+	WV_FOR(i, W)
+	{
+		float weight_val = out[i];
+		float error_change0 = 1e-10f;
+		float error_change1 = 0.0f;
+		int cnt = wtc[i];
+		for (int j = 0; j < cnt; j++)
+		{
+			int texel = wt[j * W + i];
+			float contrib_weight = wc[j * W + i];
+			float wes = constant_wes ? wes0 : eiwes[texel];
+			float scale = wes * contrib_weight;
+			float old_weight = infilled[texel];
+			float ideal_weight = eiw[texel];
+			error_change0 += contrib_weight * scale;
+			error_change1 += (old_weight - ideal_weight) * scale;
+		}
+		float step = (error_change1 * -16.0f) / error_change0;
+		step = v_clamp(-0.25f, 0.25f, step);
+		out[i] = weight_val + step;
+	}
+	WV_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Angular endpoint search
+// ---------------------------------------------------------------------------------------------
+
+WV_FN int steps_for_quant_level(int q)
+{
+	const uint8_t s[12] = { 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32 };
+	return s[q];
+}
+
+/* Run the angular search for `nsets` weight sets at once.  Set s reads its ideal weights from
+ * set_weights(s) (W = set_wcount(s) values) with max quant level set_maxq(s) and writes
+ * low/high[quant 0..maxq] to set_out(s)[q*2 + {0,1}].
+ *
+ * Phase 1: one lane per (set, angular step)   -> offset, lowest weight, span, 3 error terms
+ * Phase 2: one lane per (set, quant level)    -> best (error, step, cut) for that span, low/high
+ * Sets are processed in batches of up to 64 (set, step) pairs. */
+struct AngSet {
+	const float* weights;
+	float* out;
+	int wcount;
+	int maxq;
+};
+
+template <typename SetFn>
+WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
+{
+	float* ang = c.ang();               // [64][8]: offset, lowest, span, err, cut_low, cut_high
+	TrialInfo& tr = c.tr();
+	const float* sin_table = reinterpret_cast<const float*>(c.tab + c.root->off_sin_table);
+	const float* cos_table = reinterpret_cast<const float*>(c.tab + c.root->off_cos_table);
+
+	int s0 = 0;
+	while (s0 < nsets)
+	{
+		// batch [s0, s1): total steps <= 64; ibox[s - s0] = first pair slot of set s
+		int s1 = s0, pairs = 0;
+		while (s1 < nsets && s1 - s0 < 32)
+		{
+			AngSet a = get_set(s1);
+			int steps = steps_for_quant_level(a.maxq);
+			if (pairs + steps > 64) break;
+			pairs += steps;
+			s1++;
+		}
+
+		WV_FOR(k, pairs)
+		{
+			// locate (set, step) of pair k
+			int s = s0, base = 0;
+			AngSet a = get_set(s);
+			int steps = steps_for_quant_level(a.maxq);
+			while (k >= base + steps)
+			{
+				base += steps;
+				s++;
+				a = get_set(s);
+				steps = steps_for_quant_level(a.maxq);
+			}
+			int sp = k - base;
+			const int W = a.wcount;
+			const float* wv = a.weights;
+
+			// compute_angular_offsets (ref: weight_align.cpp:94-140)
+			float anglesum_x = 0.0f, anglesum_y = 0.0f;
+			float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
+			for (int j = 0; j < W; j++)
+			{
+				float wj = wv[j];
+				float sample = v_clampzo(wj) * (SINCOS_STEPS - 1.0f);
+				int isample = (int)(sample + 0.5f);
+				anglesum_x += cos_table[isample * ANGULAR_STEPS + sp];
+				anglesum_y += sin_table[isample * ANGULAR_STEPS + sp];
+				min_weight = wj < min_weight ? wj : min_weight;
+				max_weight = wj > max_weight ? wj : max_weight;
+			}
+			float angle = ref_atan2(anglesum_y, anglesum_x);
+			angle = angle == angle ? angle : 0.0f;
+			float offset = angle * (1.0f / (2.0f * 3.14159265358979323846f));
+
+			// compute_lowest_and_highest_weight (ref: weight_align.cpp:160-245)
+			float rcp_stepsize = (float)sp + 1.0f;
+			float errval = 0.0f, cut_low = 0.0f, cut_high = 0.0f;
+			float minidx = f_round(min_weight * rcp_stepsize - offset);
+			float maxidx = f_round(max_weight * rcp_stepsize - offset);
+			for (int j = 0; j < W; j++)
+			{
+				float sval = wv[j] * rcp_stepsize - offset;
+				float svalrte = f_round(sval);
+				float diff = sval - svalrte;
+				errval += diff * diff;
+				if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
+				if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+			}
+			int max_quant_steps = steps;
+			int span = (int)(maxidx - minidx + 1.0f);
+			span = i_min(span, max_quant_steps + 3);
+			span = i_max(span, 2);
+			float ssize = 1.0f / rcp_stepsize;
+			float errscale = ssize * ssize;
+
+			float* o = ang + k * 8;
+			o[0] = offset;
+			o[1] = minidx;
+			o[2] = int_as_float(span);
+			o[3] = errval * errscale;
+			o[4] = cut_low * errscale;
+			o[5] = cut_high * errscale;
+		}
+		// slot table for phase 2
+		WV_ONE
+		{
+			int base = 0;
+			for (int s = s0; s < s1; s++)
+			{
+				tr.ibox[s - s0] = base;
+				base += steps_for_quant_level(get_set(s).maxq);
+			}
+		}
+		WV_SYNC();
+
+		// phase 2: (set, quant) lanes (ref: weight_align.cpp:285-354)
+		WV_FOR(k, (s1 - s0) * 8)
+		{
+			int s = s0 + (k >> 3), qi = k & 7;
+			AngSet a = get_set(s);
+			if (qi <= a.maxq)
+			{
+				int steps = steps_for_quant_level(a.maxq);
+				const float* base = ang + tr.ibox[s - s0] * 8;
+				int q = steps_for_quant_level(qi);
+
+				// sequential scan with the reference's update order and strict '>' tests,
+				// restricted to the updates that land on span index q
+				float best_err = ERROR_CALC_DEFAULT;
+				float best_idx = -1.0f;
+				float best_cut = 0.0f;
+				for (int i = 0; i < steps; i++)
+				{
+					const float* r = base + i * 8;
+					int idx_span = float_as_int(r[2]);
+					float err = r[3], cl = r[4], ch = r[5];
+					if (idx_span == q)
+					{
+						if (best_err > err) { best_err = err; best_idx = (float)i; best_cut = 0.0f; }
+					}
+					else if (idx_span - 1 == q)
+					{
+						float e_low = err + cl;
+						float e_high = err + ch;
+						if (best_err > e_low) { best_err = e_low; best_idx = (float)i; best_cut = 1.0f; }
+						if (best_err > e_high) { best_err = e_high; best_idx = (float)i; best_cut = 0.0f; }
+					}
+					else if (idx_span - 2 == q)
+					{
+						float e_lh = err + cl + ch;
+						if (best_err > e_lh) { best_err = e_lh; best_idx = (float)i; best_cut = 1.0f; }
+					}
+				}
+
+				int bsi = (int)best_idx;
+				bsi = i_max(0, bsi);
+				const float* r = base + bsi * 8;
+				float lwi = r[1] + best_cut;
+				float hwi = lwi + (float)q - 1.0f;
+				float stepsize = 1.0f / (1.0f + (float)bsi);
+				a.out[qi * 2 + 0] = (r[0] + lwi) * stepsize;
+				a.out[qi * 2 + 1] = (r[0] + hwi) * stepsize;
+			}
+		}
+		WV_SYNC();
+		s0 = s1;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantize + score
+// ---------------------------------------------------------------------------------------------
+
+/* Quantization of one ideal weight (ref: compute_quantized_weights_for_decimation :1023-1046).
+ * Returns the unquantized integer level 0..64; *outf receives the float reconstruction. */
+struct QuantParams {
+	float scale, scaled_low_bound, quant_level_m1, rscale, low_bound;
+	int steps_m1;
+};
+
+WV_FN QuantParams quant_params(float low_bound, float high_bound, int quant_level)
+{
+	const float quant_levels_m1[12] = { 1.0f, 2.0f, 3.0f, 4.0f, 5.0f, 7.0f, 9.0f, 11.0f, 15.0f, 19.0f, 23.0f, 31.0f };
+	const uint8_t levels[12] = { 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32 };
+	QuantParams p;
+	if (high_bound <= low_bound)
+	{
+		low_bound = 0.0f;
+		high_bound = 1.0f;
+	}
+	float rscale = high_bound - low_bound;
+	p.scale = 1.0f / rscale;
+	p.scaled_low_bound = low_bound * p.scale;
+	p.rscale = rscale * (1.0f / 64.0f);
+	p.quant_level_m1 = quant_levels_m1[quant_level];
+	p.low_bound = low_bound;
+	p.steps_m1 = levels[quant_level] - 1;
+	return p;
+}
+
+WV_FN int quantize_weight(const QuantParams& p, const uint8_t* quant_to_unquant, float ideal, float* outf)
+{
+	float ix = ideal * p.scale - p.scaled_low_bound;
+	ix = v_clampzo(ix);
+	float ix1 = ix * p.quant_level_m1;
+	int weightl = (int)ix1;
+	int weighth = i_min(weightl + 1, p.steps_m1);
+	int ixli = quant_to_unquant[weightl];
+	int ixhi = quant_to_unquant[weighth];
+	float ixl = (float)ixli;
+	float ixh = (float)ixhi;
+	bool mask = (ixl + ixh) < (128.0f * ix);
+	int weight = mask ? ixhi : ixli;
+	ixl = mask ? ixh : ixl;
+	*outf = ixl * p.rscale + p.low_bound;
+	return weight;
+}
+
+/* 4-accumulator sum of v[0..n) in the reference's order: acc[l] += v[i] for i = l mod 4, then
+ * (acc0 + acc2) + (acc1 + acc3).  Uniform (every lane computes the same value). */
+WV_FN float sum4(const float* v, int n)
+{
+	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+	int i = 0;
+	for (; i + 3 < n; i += 4)
+	{
+		a0 += v[i]; a1 += v[i + 1]; a2 += v[i + 2]; a3 += v[i + 3];
+	}
+	if (i < n) a0 += v[i];
+	if (i + 1 < n) a1 += v[i + 1];
+	if (i + 2 < n) a2 += v[i + 2];
+	return (a0 + a2) + (a1 + a3);
+}
+
+} // namespace astcd

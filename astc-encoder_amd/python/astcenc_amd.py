@@ -1,0 +1,237 @@
+# SPDX-License-Identifier: Apache-2.0
+"""ctypes binding of the astcenc C ABI (include/astcenc.h + include/astcenc_amd.h).
+
+The same binding drives three shared objects, selected by path:
+  * astc-encoder_amd/libastcenc_amd.so   -- the product (HIP kernels, gfx950)
+  * oracle/_ref/libastcenc-{none,avx2}.so -- the reference encoder built from /root/reference (oracle)
+  * tests/emu/_build/libastcenc_emu.so    -- CPU wave emulator (debugging aid)
+so parity tests read: compress with A, compress with B, compare bytes.
+
+Names mirror the C API (ref: Source/astcenc.h); see include/astcenc.h for field meaning.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+LIB_PRODUCT = os.path.join(REPO, "astc-encoder_amd", "libastcenc_amd.so")
+LIB_REF_NONE = os.path.join(REPO, "oracle", "_ref", "libastcenc-none.so")
+LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
+LIB_EMU = os.path.join(REPO, "tests", "emu", "_build", "libastcenc_emu.so")
+
+# enum astcenc_error
+(SUCCESS, ERR_OUT_OF_MEM, ERR_BAD_CPU_FLOAT, ERR_BAD_PARAM, ERR_BAD_BLOCK_SIZE, ERR_BAD_PROFILE,
+ ERR_BAD_QUALITY, ERR_BAD_SWIZZLE, ERR_BAD_FLAGS, ERR_BAD_CONTEXT, ERR_NOT_IMPLEMENTED,
+ ERR_BAD_DECODE_MODE) = range(12)
+# enum astcenc_profile
+PRF_LDR_SRGB, PRF_LDR, PRF_HDR_RGB_LDR_A, PRF_HDR = range(4)
+# presets
+PRE_FASTEST, PRE_FAST, PRE_MEDIUM, PRE_THOROUGH, PRE_VERYTHOROUGH, PRE_EXHAUSTIVE = 0.0, 10.0, 60.0, 98.0, 99.0, 100.0
+# enum astcenc_swz
+SWZ_R, SWZ_G, SWZ_B, SWZ_A, SWZ_0, SWZ_1, SWZ_Z = range(7)
+# enum astcenc_type
+TYPE_U8, TYPE_F16, TYPE_F32 = range(3)
+# flags
+FLG_MAP_NORMAL = 1 << 0
+FLG_USE_DECODE_UNORM8 = 1 << 1
+FLG_USE_ALPHA_WEIGHT = 1 << 2
+FLG_USE_PERCEPTUAL = 1 << 3
+FLG_DECOMPRESS_ONLY = 1 << 4
+FLG_SELF_DECOMPRESS_ONLY = 1 << 5
+FLG_MAP_RGBM = 1 << 6
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_float)
+
+
+class Config(C.Structure):
+    """struct astcenc_config (ref: astcenc.h:427)."""
+    _fields_ = [
+        ("profile", C.c_int), ("flags", C.c_uint),
+        ("block_x", C.c_uint), ("block_y", C.c_uint), ("block_z", C.c_uint),
+        ("cw_r_weight", C.c_float), ("cw_g_weight", C.c_float), ("cw_b_weight", C.c_float), ("cw_a_weight", C.c_float),
+        ("a_scale_radius", C.c_uint), ("rgbm_m_scale", C.c_float),
+        ("tune_partition_count_limit", C.c_uint),
+        ("tune_2partition_index_limit", C.c_uint), ("tune_3partition_index_limit", C.c_uint), ("tune_4partition_index_limit", C.c_uint),
+        ("tune_block_mode_limit", C.c_uint), ("tune_refinement_limit", C.c_uint), ("tune_candidate_limit", C.c_uint),
+        ("tune_2partitioning_candidate_limit", C.c_uint), ("tune_3partitioning_candidate_limit", C.c_uint),
+        ("tune_4partitioning_candidate_limit", C.c_uint),
+        ("tune_db_limit", C.c_float), ("tune_mse_overshoot", C.c_float),
+        ("tune_2partition_early_out_limit_factor", C.c_float), ("tune_3partition_early_out_limit_factor", C.c_float),
+        ("tune_2plane_early_out_limit_correlation", C.c_float), ("tune_search_mode0_enable", C.c_float),
+        ("progress_callback", PROGRESS_CB),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "progress_callback"}
+
+
+class Image(C.Structure):
+    """struct astcenc_image (ref: astcenc.h:613)."""
+    _fields_ = [("dim_x", C.c_uint), ("dim_y", C.c_uint), ("dim_z", C.c_uint), ("data_type", C.c_int),
+                ("data", C.POINTER(C.c_void_p))]
+
+
+class Swizzle(C.Structure):
+    """struct astcenc_swizzle (ref: astcenc.h:294)."""
+    _fields_ = [("r", C.c_int), ("g", C.c_int), ("b", C.c_int), ("a", C.c_int)]
+
+
+SWZ_RGBA = (SWZ_R, SWZ_G, SWZ_B, SWZ_A)
+
+EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_image", "astcenc_compress_reset",
+           "astcenc_compress_cancel", "astcenc_decompress_image", "astcenc_decompress_reset",
+           "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
+EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_backend_name"]
+
+
+class AstcError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__("%s failed with astcenc_error %d" % (where, code))
+        self.code = code
+
+
+class Library:
+    """One loaded astcenc-ABI shared object."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.astcenc_config_init.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_float, C.c_uint, C.POINTER(Config)]
+        L.astcenc_config_init.restype = C.c_int
+        L.astcenc_context_alloc.argtypes = [C.POINTER(Config), C.c_uint, C.POINTER(C.c_void_p), C.c_void_p]
+        L.astcenc_context_alloc.restype = C.c_int
+        L.astcenc_compress_image.argtypes = [C.c_void_p, C.POINTER(Image), C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_uint]
+        L.astcenc_compress_image.restype = C.c_int
+        L.astcenc_compress_reset.argtypes = [C.c_void_p]
+        L.astcenc_compress_reset.restype = C.c_int
+        L.astcenc_compress_cancel.argtypes = [C.c_void_p]
+        L.astcenc_compress_cancel.restype = C.c_int
+        L.astcenc_decompress_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Image), C.POINTER(Swizzle), C.c_uint]
+        L.astcenc_decompress_image.restype = C.c_int
+        L.astcenc_decompress_reset.argtypes = [C.c_void_p]
+        L.astcenc_decompress_reset.restype = C.c_int
+        L.astcenc_context_free.argtypes = [C.c_void_p]
+        L.astcenc_context_free.restype = None
+        L.astcenc_get_error_string.argtypes = [C.c_int]
+        L.astcenc_get_error_string.restype = C.c_char_p
+        self.has_amd = hasattr(L, "astcenc_amd_compress_image_device")
+        if self.has_amd:
+            L.astcenc_amd_compress_image_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int,
+                                                            C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,
+                                                            C.POINTER(C.c_float)]
+            L.astcenc_amd_compress_image_device.restype = C.c_int
+            L.astcenc_amd_backend_name.restype = C.c_char_p
+
+    # -- thin wrappers returning error codes, as the C API does --
+    def config_init(self, profile, bx, by, bz, quality, flags):
+        cfg = Config()
+        err = self.lib.astcenc_config_init(profile, bx, by, bz, quality, flags, C.byref(cfg))
+        return err, cfg
+
+    def context_alloc(self, cfg, thread_count=1, parent=None):
+        ctx = C.c_void_p()
+        err = self.lib.astcenc_context_alloc(C.byref(cfg) if cfg is not None else None, thread_count, C.byref(ctx), parent)
+        return err, ctx
+
+    def context_free(self, ctx):
+        self.lib.astcenc_context_free(ctx)
+
+    def error_string(self, code):
+        s = self.lib.astcenc_get_error_string(code)
+        return s.decode() if s else None
+
+    def backend_name(self):
+        return self.lib.astcenc_amd_backend_name().decode() if self.has_amd else "reference"
+
+    def compress_raw(self, ctx, pixels, out, swizzle=SWZ_RGBA, thread_index=0, data_len=None):
+        """pixels: contiguous array [H, W, 4] of uint8 / float16 / float32; out: uint8 array."""
+        h, w = pixels.shape[0], pixels.shape[1]
+        dtype = {np.dtype(np.uint8): TYPE_U8, np.dtype(np.float16): TYPE_F16, np.dtype(np.float32): TYPE_F32}[pixels.dtype]
+        slices = (C.c_void_p * 1)(pixels.ctypes.data)
+        img = Image(w, h, 1, dtype, slices)
+        swz = Swizzle(*swizzle)
+        return self.lib.astcenc_compress_image(ctx, C.byref(img), C.byref(swz), out.ctypes.data,
+                                               out.nbytes if data_len is None else data_len, thread_index)
+
+    def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None):
+        """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16]."""
+        err, cfg = self.config_init(profile, block[0], block[1], 1, quality, flags)
+        if err:
+            raise AstcError(err, "astcenc_config_init")
+        if tweak:
+            tweak(cfg)
+        err, ctx = self.context_alloc(cfg, 1)
+        if err:
+            raise AstcError(err, "astcenc_context_alloc")
+        try:
+            h, w = pixels.shape[0], pixels.shape[1]
+            bx, by = (w + block[0] - 1) // block[0], (h + block[1] - 1) // block[1]
+            out = np.zeros(bx * by * 16, dtype=np.uint8)
+            err = self.compress_raw(ctx, np.ascontiguousarray(pixels), out, swizzle)
+            if err:
+                raise AstcError(err, "astcenc_compress_image")
+            return out
+        finally:
+            self.context_free(ctx)
+
+    def decompress(self, data, width, height, block=(6, 6), profile=PRF_LDR, out_type=np.uint8):
+        """Decode blocks back to [H, W, 4] (reference library only; used for PSNR)."""
+        err, cfg = self.config_init(profile, block[0], block[1], 1, PRE_MEDIUM, FLG_DECOMPRESS_ONLY)
+        if err:
+            raise AstcError(err, "astcenc_config_init")
+        err, ctx = self.context_alloc(cfg, 1)
+        if err:
+            raise AstcError(err, "astcenc_context_alloc")
+        try:
+            out = np.zeros((height, width, 4), dtype=out_type)
+            dtype = {np.dtype(np.uint8): TYPE_U8, np.dtype(np.float16): TYPE_F16, np.dtype(np.float32): TYPE_F32}[out.dtype]
+            slices = (C.c_void_p * 1)(out.ctypes.data)
+            img = Image(width, height, 1, dtype, slices)
+            swz = Swizzle(*SWZ_RGBA)
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            err = self.lib.astcenc_decompress_image(ctx, data.ctypes.data, data.nbytes, C.byref(img), C.byref(swz), 0)
+            if err:
+                raise AstcError(err, "astcenc_decompress_image")
+            return out
+        finally:
+            self.context_free(ctx)
+
+
+def synthetic_image(width, height, seed=0x9E3779B1):
+    """Deterministic integer-only RGBA8 test image: smooth ramps, a 32x32 checker of
+    hard edges on R, and per-channel hash noise.  No libm, so every host produces identical bytes."""
+    y, x = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
+
+    def tri(v):
+        m = v & 511
+        return np.where(m < 256, m, 511 - m)
+
+    r = (3 * tri(x + 2 * y) + tri((3 * x - y) >> 1)) >> 2
+    checker = ((x >> 5) + (y >> 5)) & 1
+    r = np.where(checker == 1, 255 - r, r)
+    g = (3 * tri(2 * x - y + 128) + tri((x + 3 * y) >> 2)) >> 2
+    b = 255 - ((tri(x + y) + tri((x - y) >> 1)) >> 1)
+    a = 192 + (tri((x >> 1) + (y >> 2)) >> 2)
+
+    def noise(c, amp):
+        h = (x * 0x85EBCA6B + y * 0xC2B2AE35 + c * 0x27D4EB2F + seed) & 0xFFFFFFFF
+        h ^= h >> 15
+        h = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+        h ^= h >> 12
+        h = (h * 0x297A2D39) & 0xFFFFFFFF
+        h ^= h >> 15
+        return (h % (2 * amp + 1)) - amp
+
+    out = np.stack([r + noise(0, 10), g + noise(1, 10), b + noise(2, 10), a + noise(3, 3)], axis=-1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def psnr_rgba8(a, b):
+    """10*log10(samples / sum((a-b)^2)) on values/255, double accumulation (ref: astcenccli_error_metrics.cpp:240-346)."""
+    d = (a.astype(np.float64) - b.astype(np.float64)) / 255.0
+    s = float((d * d).sum())
+    return float("inf") if s == 0 else 10.0 * np.log10(a.size / s)

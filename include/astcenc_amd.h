@@ -1,0 +1,40 @@
+/* SPDX-License-Identifier: Apache-2.0
+ *
+ * astcenc_amd.h -- MI355X-specific additions to the astcenc C ABI (libastcenc_amd.so).
+ *
+ * The reference API (include/astcenc.h) takes host pointers, so every astcenc_compress_image()
+ * pays a PCIe round trip.  Pipelines that already hold their textures in HBM (and the benchmark,
+ * which must time the kernels with inputs resident) use the entry point below instead.  It runs
+ * the same kernels with the same context; nothing else about the contract changes.
+ */
+#ifndef ASTCENC_AMD_INCLUDED
+#define ASTCENC_AMD_INCLUDED
+
+#include "astcenc.h"
+
+/* Compress a 2D image that is already resident in device memory.
+ *
+ *   device_image : device pointer, tightly packed RGBA rows, dim_x * dim_y texels of data_type
+ *   device_out   : device pointer, receives 16 bytes per block in raster block order
+ *   data_len     : bytes available at device_out (>= 16 * blocks, else ASTCENC_ERR_OUT_OF_MEM)
+ *   hip_stream   : hipStream_t to launch on (NULL = the context's own stream); the call returns
+ *                  after the work on that stream has completed
+ *   kernel_ms    : optional; receives the elapsed time of the compression kernel(s) measured with
+ *                  HIP events recorded on that stream around the launches
+ *
+ * Same argument checks and error codes as astcenc_compress_image (ref: Source/astcenc_entry.cpp:1134-1182).
+ * Single caller per context (no thread_index rendezvous). */
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_image_device(
+	struct astcenc_context* context,
+	const void* device_image,
+	unsigned int dim_x, unsigned int dim_y,
+	enum astcenc_type data_type,
+	const struct astcenc_swizzle* swizzle,
+	void* device_out, size_t data_len,
+	void* hip_stream,
+	float* kernel_ms);
+
+/* "hip:gfx950" for the product library. */
+ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
+
+#endif

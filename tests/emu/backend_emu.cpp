@@ -1,0 +1,76 @@
+// SPDX-License-Identifier: Apache-2.0
+// TEST INFRASTRUCTURE ONLY -- CPU "wave emulator" backend.
+//
+// Compiles the very same wave_*.h source that the HIP kernels are built from with ASTC_WAVE_EMU
+// semantics (WV_FOR = sequential loop, WV_SYNC = no-op) so that the block compressor can be
+// debugged against oracle/_ref on machines without a GPU.  It is linked only into
+// tests/emu/_build/libastcenc_emu.so and is never part of the product library.
+#include "backend.h"
+#include "wave_block.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace astcd {
+
+struct Backend {
+	std::vector<uint8_t> blob;
+	DeviceConfig cfg;
+};
+
+Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
+{
+	Backend* b = new Backend;
+	b->blob.assign(blob, blob + blob_bytes);
+	b->cfg = cfg;
+	*status = 0;
+	return b;
+}
+
+void backend_destroy(Backend* b) { delete b; }
+const char* backend_name() { return "emu:cpu"; }
+
+int backend_compress(Backend* b, const CompressJob& job)
+{
+	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data());
+	Ctx c;
+	c.tab = b->blob.data();
+	c.root = root;
+	c.cfg = &b->cfg;
+	make_lds_layout(*root, c.L);
+	std::vector<uint8_t> lds(c.L.total + 64, 0xCD);
+	c.lds = lds.data();
+	c.T = root->texel_count;
+	c.Tp = (c.T + 3) & ~3;
+
+	ImageDesc img;
+	img.data = job.host_data ? job.host_data : job.device_data;
+	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
+	img.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
+	img.blocks_x = (job.dim_x + root->dim_x - 1) / root->dim_x;
+	img.blocks_y = (job.dim_y + root->dim_y - 1) / root->dim_y;
+	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
+	bool hdr = b->cfg.profile >= 2;
+	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;
+
+	uint8_t* out = job.host_out ? job.host_out : job.device_out;
+	const char* only = getenv("ASTC_EMU_ONLY_BLOCK");
+	long only_idx = only ? atol(only) : -1;
+	for (uint32_t by = 0; by < img.blocks_y; by++)
+	{
+		for (uint32_t bx = 0; bx < img.blocks_x; bx++)
+		{
+			size_t idx = (size_t)by * img.blocks_x + bx;
+			if (only_idx >= 0 && (long)idx != only_idx) continue;
+			load_block(c, img, bx, by);
+			compress_block(c, out + idx * 16);
+		}
+		if (job.cancel_flag && *job.cancel_flag) break;
+	}
+	if (job.kernel_ms) *job.kernel_ms = 0.0f;
+	return 0;
+}
+
+} // namespace astcd
