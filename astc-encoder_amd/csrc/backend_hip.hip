@@ -1,0 +1,200 @@
+// SPDX-License-Identifier: Apache-2.0
+// HIP backend for gfx950 (MI355X): device-resident tables, staging buffers, and the compression
+// kernel launch.  One 64-lane wavefront (one workgroup) compresses one ASTC block; its working
+// set is a dynamic-LDS region laid out by make_lds_layout().
+//
+// Replaces the reference's CPU block loop (compress_image, Source/astcenc_entry.cpp:891-1043):
+// instead of threads pulling 16-block tickets from an atomic counter, the block range of a chunk
+// is one kernel launch; chunks give the host cancel/progress points.
+#include "backend.h"
+#include "wave_block.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+
+namespace astcd {
+
+/* blockIdx -> ASTC block.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8),
+ * each with its own L2.  Raster-adjacent ASTC blocks share input cache lines, so every XCD gets a
+ * contiguous run of the chunk rather than every 8th block. */
+__device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
+{
+	const uint32_t per = n / 8u;           // blocks per XCD in the evenly divisible part
+	const uint32_t even = per * 8u;
+	if (b >= even) return b;               // ragged tail keeps identity order
+	return (b % 8u) * per + (b / 8u);
+}
+
+__global__ void __launch_bounds__(64)
+astc_compress_blocks_kernel(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
+                            uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
+	uint32_t by = b / img.blocks_x;
+	uint32_t bx = b - by * img.blocks_x;
+
+	Ctx c;
+	c.tab = tab;
+	c.root = reinterpret_cast<const TableRoot*>(tab);
+	c.cfg = &cfg;
+	c.lds = lds;
+	c.L = L;
+	c.T = c.root->texel_count;
+	c.Tp = (c.T + 3) & ~3;
+
+	load_block(c, img, bx, by);
+	compress_block(c, out + (size_t)b * 16);
+}
+
+struct Backend {
+	int device;
+	uint8_t* d_tab;
+	size_t tab_bytes;
+	DeviceConfig cfg;
+	LdsLayout L;
+	TableRoot root;
+	hipStream_t stream;
+	hipEvent_t ev0, ev1;
+	// staging for the host-pointer API
+	void* d_image; size_t image_cap;
+	uint8_t* d_out; size_t out_cap;
+};
+
+#define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	fprintf(stderr, "astcenc_amd: %s -> %s\n", #expr, hipGetErrorString(e_)); fail; } } while (0)
+
+const char* backend_name() { return "hip:gfx950"; }
+
+Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+	{
+		fprintf(stderr, "astcenc_amd: no HIP device available; this library has no CPU fallback\n");
+		*status = 2;
+		return nullptr;
+	}
+
+	Backend* b = new Backend;
+	memset(b, 0, sizeof(*b));
+	HIP_TRY(hipGetDevice(&b->device), { delete b; *status = 2; return nullptr; });
+	b->cfg = cfg;
+	b->tab_bytes = blob_bytes;
+	memcpy(&b->root, blob, sizeof(TableRoot));
+	make_lds_layout(b->root, b->L);
+
+	if (b->L.total > 160 * 1024)
+	{
+		fprintf(stderr, "astcenc_amd: block working set %u B exceeds the 160 KiB LDS of a CU\n", b->L.total);
+		delete b; *status = 2; return nullptr;
+	}
+
+	HIP_TRY(hipMalloc(&b->d_tab, blob_bytes), { delete b; *status = 1; return nullptr; });
+	HIP_TRY(hipMemcpy(b->d_tab, blob, blob_bytes, hipMemcpyHostToDevice), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
+	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
+	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(astc_compress_blocks_kernel),
+	                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->L.total),
+	        { *status = 2; return nullptr; });
+	*status = 0;
+	return b;
+}
+
+void backend_destroy(Backend* b)
+{
+	if (!b) return;
+	hipSetDevice(b->device);
+	if (b->d_image) hipFree(b->d_image);
+	if (b->d_out) hipFree(b->d_out);
+	hipEventDestroy(b->ev0);
+	hipEventDestroy(b->ev1);
+	hipStreamDestroy(b->stream);
+	hipFree(b->d_tab);
+	delete b;
+}
+
+int backend_compress(Backend* b, const CompressJob& job)
+{
+	HIP_TRY(hipSetDevice(b->device), return 2);
+
+	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y;
+	const uint32_t blocks_x = (job.dim_x + bsx - 1) / bsx;
+	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
+	const size_t nblocks = (size_t)blocks_x * blocks_y;
+	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
+	const size_t image_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	const size_t out_bytes = nblocks * 16;
+
+	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+
+	const void* d_image = job.device_data;
+	uint8_t* d_out = job.device_out;
+
+	if (job.host_data)
+	{
+		if (b->image_cap < image_bytes)
+		{
+			if (b->d_image) hipFree(b->d_image);
+			b->d_image = nullptr; b->image_cap = 0;
+			HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
+			b->image_cap = image_bytes;
+		}
+		HIP_TRY(hipMemcpyAsync(b->d_image, job.host_data, image_bytes, hipMemcpyHostToDevice, stream), return 2);
+		d_image = b->d_image;
+	}
+	if (job.host_out)
+	{
+		if (b->out_cap < out_bytes)
+		{
+			if (b->d_out) hipFree(b->d_out);
+			b->d_out = nullptr; b->out_cap = 0;
+			HIP_TRY(hipMalloc(&b->d_out, out_bytes), return 1);
+			b->out_cap = out_bytes;
+		}
+		d_out = b->d_out;
+	}
+	if (!d_image || !d_out) return 2;
+
+	ImageDesc img;
+	img.data = d_image;
+	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
+	img.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
+	img.blocks_x = blocks_x; img.blocks_y = blocks_y;
+	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
+	bool hdr = b->cfg.profile >= 2;
+	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;   // ref: astcenc_entry.cpp:946
+
+	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is
+	// still tens of thousands of workgroups, far more than the 256 CUs need to stay full.
+	const size_t chunk = (job.progress || job.host_data) ? (size_t)1 << 18 : nblocks;
+	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev0, stream), return 2);
+	for (size_t first = 0; first < nblocks; first += chunk)
+	{
+		if (job.cancel_flag && *job.cancel_flag) break;
+		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
+		hipLaunchKernelGGL(astc_compress_blocks_kernel, dim3((uint32_t)n), dim3(64), b->L.total, stream,
+		                   b->d_tab, b->cfg, b->L, img, d_out, (uint32_t)first, (uint32_t)n);
+		HIP_TRY(hipGetLastError(), return 2);
+		if (job.progress)
+		{
+			HIP_TRY(hipStreamSynchronize(stream), return 2);
+			job.progress(100.0f * (float)(first + n) / (float)nblocks);
+		}
+	}
+	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev1, stream), return 2);
+
+	if (job.host_out)
+	{
+		HIP_TRY(hipMemcpyAsync(job.host_out, d_out, out_bytes, hipMemcpyDeviceToHost, stream), return 2);
+	}
+	HIP_TRY(hipStreamSynchronize(stream), return 2);
+	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
+	return 0;
+}
+
+} // namespace astcd

@@ -23,10 +23,13 @@
 //   * 4-lane horizontal sums use the reference's (l0 + l2) + (l1 + l3) order.
 #pragma once
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 	#define WV_DEVICE 1
-	#define WV_FN __device__ inline
+	#define WV_FN __host__ __device__ inline
 	#define WV_LANE ((int)threadIdx.x)
 	#define WV_SYNC() __syncthreads()
 	#define WV_FOR(i, n) for (int i = WV_LANE; i < (int)(n); i += 64)
@@ -34,7 +37,7 @@
 #else
 	#define WV_DEVICE 0
 	#if defined(__HIPCC__)
-		#define WV_FN __host__ inline
+		#define WV_FN __host__ __device__ inline
 	#else
 		#define WV_FN inline
 	#endif
@@ -89,11 +92,8 @@ WV_FN float f_abs(float v)
 
 WV_FN float f_sqrt(float v)
 {
-#if WV_DEVICE
-	return __fsqrt_rn(v);
-#else
+	// correctly rounded on both sides (device build: -fhip-fp32-correctly-rounded-divide-sqrt)
 	return __builtin_sqrtf(v);
-#endif
 }
 
 /* round to nearest even (ref: vecmathlib_none_4.h:876 uses nearbyint under FE_TONEAREST) */

@@ -1,0 +1,51 @@
+# SPDX-License-Identifier: Apache-2.0
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have(path):
+    return os.path.exists(path)
+
+
+@pytest.fixture(scope="session")
+def A():
+    import astcenc_amd
+    return astcenc_amd
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build product + emulator (+ oracle when the reference tree is present) once per session."""
+    import astcenc_amd as A
+    if not (_have(A.LIB_PRODUCT) and _have(A.LIB_EMU) and (_have(A.LIB_REF_NONE) or not os.path.isdir("/root/reference"))):
+        import __graft_entry__
+        __graft_entry__.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def ref(built, A):
+    """The real reference encoder (oracle/_ref). Built here from /root/reference; travels prebuilt to the GPU box."""
+    if not _have(A.LIB_REF_NONE):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    return A.Library(A.LIB_REF_NONE)
+
+
+@pytest.fixture(scope="session")
+def emu(built, A):
+    return A.Library(A.LIB_EMU)
+
+
+@pytest.fixture(scope="session")
+def product(built, A):
+    return A.Library(A.LIB_PRODUCT)

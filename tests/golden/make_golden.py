@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+# SPDX-License-Identifier: Apache-2.0
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference encoder
+(oracle/_ref/libastcenc-none.so, built from /root/reference by oracle/Makefile) on seeded inputs.
+
+/root/reference does not exist on the GPU box; these files let the parity tests there check the HIP
+path against reference output even if oracle/_ref were unavailable.  Inputs are regenerated from
+tests/images.py (integer-only generators), only the compressed blocks are stored.
+
+Run in the dev container:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import astcenc_amd as A  # noqa: E402
+import images  # noqa: E402
+
+# name -> (image generator, (w, h), block, quality, partition limit override)
+CASES = {
+    "c1_noisy_128_4x4_fastest_p1": ("noisy", (128, 128), (4, 4), 0.0, 1),
+    "c2_noisy_192_6x6_medium": ("noisy", (192, 192), (6, 6), 60.0, None),
+    "c3_noisy_128_8x8_thorough": ("noisy", (128, 128), (8, 8), 98.0, None),
+    "flat_96_6x6_medium": ("flat", (96, 96), (6, 6), 60.0, None),
+    "gray_96_6x6_medium": ("gray", (96, 96), (6, 6), 60.0, None),
+    "two_colour_96_6x6_medium": ("two_colour", (96, 96), (6, 6), 60.0, None),
+    "random_50x45_5x5_fast": ("random", (50, 45), (5, 5), 10.0, None),
+    "smooth_64x40_8x5_medium": ("smooth", (64, 40), (8, 5), 60.0, None),
+    "noisy_96_10x10_medium": ("noisy", (96, 96), (10, 10), 60.0, None),
+    "noisy_96_12x12_fast": ("noisy", (96, 96), (12, 12), 10.0, None),
+}
+
+
+def main():
+    ref = A.Library(A.LIB_REF_NONE)
+    manifest = {}
+    for name, (gen, size, block, quality, plimit) in CASES.items():
+        img = images.ALL[gen](*size)
+        tweak = (lambda c: setattr(c, "tune_partition_count_limit", plimit)) if plimit else None
+        blocks = ref.compress(img, block, quality, tweak=tweak)
+        np.save(os.path.join(HERE, name + ".npy"), blocks)
+        manifest[name] = {"image": gen, "size": size, "block": block, "quality": quality, "partition_limit": plimit,
+                          "input_sha256": hashlib.sha256(img.tobytes()).hexdigest(),
+                          "blocks_sha256": hashlib.sha256(blocks.tobytes()).hexdigest()}
+        print(name, blocks.size // 16, "blocks")
+    # the image __graft_entry__.smoke() uses
+    img = A.synthetic_image(96, 94)
+    img[:12, :12] = (10, 200, 30, 255)
+    img[40:60, 40:60, 3] = 255
+    np.save(os.path.join(HERE, "smoke_96x94_6x6_medium.npy"), ref.compress(img, (6, 6), A.PRE_MEDIUM))
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+# SPDX-License-Identifier: Apache-2.0
+"""Seeded test images covering the content classes the reference's search treats differently."""
+import numpy as np
+
+import astcenc_amd as A
+
+
+def noisy(w, h, seed=0x9E3779B1):
+    return A.synthetic_image(w, h, seed)
+
+
+def flat_regions(w, h):
+    img = A.synthetic_image(w, h, 1)
+    img[: h // 2, : w // 2] = (17, 99, 201, 255)      # constant -> void-extent blocks
+    img[h // 2:, : w // 2, 3] = 255                    # opaque -> 3-component paths
+    return img
+
+
+def grayscale(w, h):
+    img = A.synthetic_image(w, h, 2)
+    img[..., 1] = img[..., 0]
+    img[..., 2] = img[..., 0]
+    img[: h // 2, :, 3] = 255                          # luminance vs luminance+alpha blocks
+    return img
+
+
+def smooth(w, h):
+    y, x = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    img = np.stack([(x * 255) // max(w - 1, 1), (y * 255) // max(h - 1, 1), ((x + y) * 255) // max(w + h - 2, 1),
+                    np.full_like(x, 255)], axis=-1)
+    return img.astype(np.uint8)
+
+
+def random_u8(w, h, seed=7):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+
+
+def two_colour(w, h, seed=3):
+    """Hard two-region blocks: exercises 2+ partition encodings."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    mask = ((x * 3 + y * 5) // 7) % 2
+    a = np.array([220, 40, 30, 255]); b = np.array([20, 60, 230, 128])
+    img = np.where(mask[..., None] == 1, a, b) + rng.integers(-6, 7, size=(h, w, 4))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+ALL = {"noisy": noisy, "flat": flat_regions, "gray": grayscale, "smooth": smooth, "random": random_u8, "two_colour": two_colour}
+
+
+def mismatches(a, b):
+    a = a.reshape(-1, 16); b = b.reshape(-1, 16)
+    return np.where((a != b).any(axis=1))[0]
