@@ -81,6 +81,7 @@ struct DecimationInfo {
 	uint32_t off_weight_texels;          // u8  [rows][W] ref: weight_texels_tr
 	uint32_t off_weight_contribs;        // f32 [rows][W] ref: weights_texel_contribs_tr
 	uint32_t off_texel_contrib_for_weight; // f32 [rows][W] ref: texel_contrib_for_weight
+	uint32_t table_bytes;                // the seven arrays are contiguous from off_texel_weights
 };
 
 // One partitioning; fixed-stride record followed by two u8[T] arrays:
@@ -125,6 +126,7 @@ struct TableRoot {
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
+	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t total_bytes;
 };
 

@@ -28,7 +28,7 @@ __device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
 
 __global__ void __launch_bounds__(64)
 astc_compress_blocks_kernel(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
-                            uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks)
+                            uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -44,8 +44,10 @@ astc_compress_blocks_kernel(const uint8_t* __restrict__ tab, DeviceConfig cfg, L
 	c.L = L;
 	c.T = c.root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
+	c.prof = prof;
 
-	load_block(c, img, bx, by);
+	PROF_SCOPE(c, PS_TOTAL);
+	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
 	compress_block(c, out + (size_t)b * 16);
 }
 
@@ -61,6 +63,7 @@ struct Backend {
 	// staging for the host-pointer API
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
+	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds)
 };
 
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -100,6 +103,10 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(astc_compress_blocks_kernel),
 	                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->L.total),
 	        { *status = 2; return nullptr; });
+#if defined(ASTC_PROFILE)
+	HIP_TRY(hipMalloc(&b->d_prof, PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
+	HIP_TRY(hipMemset(b->d_prof, 0, PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
+#endif
 	*status = 0;
 	return b;
 }
@@ -178,7 +185,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		if (job.cancel_flag && *job.cancel_flag) break;
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
 		hipLaunchKernelGGL(astc_compress_blocks_kernel, dim3((uint32_t)n), dim3(64), b->L.total, stream,
-		                   b->d_tab, b->cfg, b->L, img, d_out, (uint32_t)first, (uint32_t)n);
+		                   b->d_tab, b->cfg, b->L, img, d_out, (uint32_t)first, (uint32_t)n, b->d_prof);
 		HIP_TRY(hipGetLastError(), return 2);
 		if (job.progress)
 		{
@@ -194,6 +201,18 @@ int backend_compress(Backend* b, const CompressJob& job)
 	}
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
+#if defined(ASTC_PROFILE)
+	{
+		static const char* names[PS_COUNT] = { "load", "ideal", "decimate", "angular", "modes", "formats", "recompute", "pack", "diff",
+		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks" };
+		unsigned long long h[PS_COUNT];
+		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
+		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);
+		fprintf(stderr, "stage cycles per block (lane-0 shader clock), %zu blocks:\n", nblocks);
+		for (int i = 0; i < PS_COUNT - 1; i++)
+			fprintf(stderr, "  %-18s %12.0f  %5.1f%%\n", names[i], (double)h[i] / (double)nblocks, 100.0 * (double)h[i] / (double)h[PS_TOTAL]);
+	}
+#endif
 	return 0;
 }
 

@@ -236,6 +236,7 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	di->off_weight_texels = o_wt;
 	di->off_weight_contribs = o_wc;
 	di->off_texel_contrib_for_weight = o_tcw;
+	di->table_bytes = (uint32_t)(o_tcw + rows * W * sizeof(float) - o_tw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -838,6 +839,11 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	r->off_integer_of_quints = off_qu;
 	r->off_sin_table = off_sin;
 	r->off_cos_table = off_cos;
+	{
+		uint32_t mx = 0;
+		for (size_t i = 0; i < dms.size(); i++) mx = std::max(mx, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->table_bytes);
+		r->max_decimation_table_bytes = mx;
+	}
 	blob.alloc(0, 256);
 	r = blob.at<TableRoot>(0);
 	r->total_bytes = (uint32_t)blob.d.size();

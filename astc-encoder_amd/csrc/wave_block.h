@@ -83,9 +83,14 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 	{
 		const int bm_packed_index = tr.cand_block_mode[i];
 		const BlockMode& qw_bm = c.block_mode(bm_packed_index);
-		const DecimationInfo& di = c.dec_info(qw_bm.decimation_mode);
 		const int color_quant_level = tr.cand_quant[i];
 		const int color_quant_level_mod = tr.cand_quant_mod[i];
+
+		// stage what the refinement loop reads in serial, latency-bound code into LDS
+		const DecView di = dec_view_staged(c, qw_bm.decimation_mode);
+		stage_words(c.lds + c.L.qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
+		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L.qtab);
+		stage_color_rows(c, color_quant_level, color_quant_level_mod);
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
 		// recomputed here instead of being stored for every block mode
@@ -103,10 +108,12 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
+			{ PROF_SCOPE(c, PS_RECOMPUTE);
 			if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
-			else recompute_ideal_colors_1plane(c, pv, di);
+			else recompute_ideal_colors_1plane(c, pv, di); }
 
 			// pack endpoints, one lane per partition (ref: :542-555, :925-931)
+			PROF_SCOPE(c, PS_PACK);
 			WV_FOR(j, partition_count)
 			{
 				workscb.color_formats[j] = (uint8_t)pack_color_endpoints(
@@ -158,7 +165,8 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 			if (l == 0)
 			{
-				float errorval = compute_symbolic_block_difference(c, pv);
+				float errorval;
+				{ PROF_SCOPE(c, PS_DIFF); errorval = compute_symbolic_block_difference(c, pv, di); }
 				if (errorval == -ERROR_CALC_DEFAULT)
 				{
 					errorval = -errorval;
@@ -190,9 +198,11 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			}
 
 			WV_SYNC();
-			bool adjustments = realign_weights(c, pv);
+			bool adjustments;
+			{ PROF_SCOPE(c, PS_REALIGN); adjustments = realign_weights(c, pv, di, qat); }
 
-			float errorval = compute_symbolic_block_difference(c, pv);
+			float errorval;
+			{ PROF_SCOPE(c, PS_DIFF); errorval = compute_symbolic_block_difference(c, pv, di); }
 			if (errorval == -ERROR_CALC_DEFAULT)
 			{
 				errorval = -errorval;
@@ -240,17 +250,20 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 {
 	TrialInfo& tr = c.tr();
 	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
-	PartView pv = part_view(c, partition_count, partition_packed);
+	PartView pv = part_view_staged(c, partition_count, partition_packed);
 
-	ideal_colors_and_weights_1plane(c, pv);
+	{ PROF_SCOPE(c, PS_IDEAL); ideal_colors_and_weights_1plane(c, pv); }
 
 	// ideal weights on every referenced decimation grid (ref: :388-405)
 	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
 	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
-	for (int i = 0; i < max_decimation_modes; i++)
 	{
-		if (!(c.dec_mode(i).refprec_1plane & ref_mask)) continue;
-		ideal_weights_for_decimation(c, 0, i, c.dwi(i));
+		PROF_SCOPE(c, PS_DECIMATE);
+		for (int i = 0; i < max_decimation_modes; i++)
+		{
+			if (!(c.dec_mode(i).refprec_1plane & ref_mask)) continue;
+			ideal_weights_for_decimation(c, 0, i, c.dwi(i));
+		}
 	}
 
 	// (ref: :409-418)
@@ -291,6 +304,7 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 			a.maxq = max_precision;
 			return a;
 		};
+		PROF_SCOPE(c, PS_ANGULAR);
 		angular_endpoints(c, tr.dm_count, get_set);
 	}
 
@@ -301,6 +315,7 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 	float* terms = c.tsc(0);
 	const float* eiw = c.ei_w(0);
 	const float* eiwes = c.ei_wes(0);
+	{ PROF_SCOPE(c, PS_MODES);
 	for (int i = 0; i < max_block_modes; i++)
 	{
 		const BlockMode& bm = c.block_mode(i);
@@ -330,9 +345,10 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 		WV_ONE { modes[i].qwt_error = err; }
 		WV_SYNC();
 	}
+	}
 	WV_SYNC();
 
-	compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], 0, max_block_modes);
+	{ PROF_SCOPE(c, PS_FORMATS); compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], 0, max_block_modes); }
 
 	return refine_candidates(c, pv, partition_count, partition_packed, -1, tune_errorval_threshold);
 }
@@ -342,17 +358,20 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 {
 	TrialInfo& tr = c.tr();
 	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
-	PartView pv = part_view(c, 1, 0);
+	PartView pv = part_view_staged(c, 1, 0);
 
-	ideal_colors_and_weights_2planes(c, pv, plane2_component);
+	{ PROF_SCOPE(c, PS_IDEAL); ideal_colors_and_weights_2planes(c, pv, plane2_component); }
 
 	const int ndm = (int)c.root->decimation_mode_count_selected;
 	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
-	for (int i = 0; i < ndm; i++)
 	{
-		if (!(c.dec_mode(i).refprec_2planes & ref_mask)) continue;
-		ideal_weights_for_decimation(c, 0, i, c.dwi(i));
-		ideal_weights_for_decimation(c, 1, i, c.dwi(i) + PLANE2_OFFSET);
+		PROF_SCOPE(c, PS_DECIMATE);
+		for (int i = 0; i < ndm; i++)
+		{
+			if (!(c.dec_mode(i).refprec_2planes & ref_mask)) continue;
+			ideal_weights_for_decimation(c, 0, i, c.dwi(i));
+			ideal_weights_for_decimation(c, 1, i, c.dwi(i) + PLANE2_OFFSET);
+		}
 	}
 
 	// (ref: :765-785)
@@ -402,6 +421,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 			a.maxq = max_precision;
 			return a;
 		};
+		PROF_SCOPE(c, PS_ANGULAR);
 		angular_endpoints(c, tr.dm_count * 2, get_set);
 	}
 
@@ -411,6 +431,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 	float* uqf1 = c.wsc(0);
 	float* uqf2 = c.wsc(1);
 	float* terms = c.tsc(0);
+	{ PROF_SCOPE(c, PS_MODES);
 	for (int i = start_2plane; i < end_2plane; i++)
 	{
 		const BlockMode& bm = c.block_mode(i);
@@ -444,6 +465,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 		WV_ONE { modes[i].qwt_error = err; }
 		WV_SYNC();
 	}
+	}
 	WV_SYNC();
 
 	// merged endpoints (ref: merge_endpoints :37) -> wep0/wep1 used as the format-search input
@@ -454,7 +476,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 		tr.rgbs[2][ch] = tr.ep1[plane][0][ch];
 	}
 	WV_SYNC();
-	compute_ideal_endpoint_formats(c, pv, &tr.rgbs[1], &tr.rgbs[2], start_2plane, end_2plane);
+	{ PROF_SCOPE(c, PS_FORMATS); compute_ideal_endpoint_formats(c, pv, &tr.rgbs[1], &tr.rgbs[2], start_2plane, end_2plane); }
 
 	return refine_candidates(c, pv, 1, 0, plane2_component, tune_errorval_threshold);
 }
@@ -579,6 +601,8 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	{
 		scb.errorval = ERROR_CALC_DEFAULT;
 		scb.block_type = SYM_BTYPE_ERROR;
+		c.tr().staged_color_quant[0] = -1;
+		c.tr().staged_color_quant[1] = -1;
 	}
 	WV_SYNC();
 
@@ -609,7 +633,8 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	// trial B: 1 partition, 2 planes (ref: :1320-1369)
 	if (!done)
 	{
-		float lowest_correl = prepare_block_statistics(c);
+		float lowest_correl;
+		{ PROF_SCOPE(c, PS_STATS); lowest_correl = prepare_block_statistics(c); }
 		bool block_skip_two_plane = lowest_correl > cfg.tune_2plane_early_out_limit_correlation;
 		for (int i = 3; i >= 0 && !done; i--)
 		{
@@ -634,7 +659,8 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			int requested_trials = (int)cfg.tune_partitioning_candidate_limit[partition_count - 2];
 			requested_trials = i_min(requested_trials, requested_indices);
 
-			int actual_trials = find_best_partition_candidates(c, partition_count, requested_indices, requested_trials);
+			int actual_trials;
+			{ PROF_SCOPE(c, PS_KMEANS); actual_trials = find_best_partition_candidates(c, partition_count, requested_indices, requested_trials); }
 			// copy out of the scratch region: the trials below reuse it
 			int partition_indices[MAX_PARTITIONING_CANDIDATES];
 			{

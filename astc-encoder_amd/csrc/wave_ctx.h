@@ -71,6 +71,7 @@ struct TrialInfo {
 	int   ibox[64];
 	// decimation modes referenced by the current trial (compacted list)
 	int   dm_count;
+	int   staged_color_quant[2];
 	uint8_t dm_list[96];
 };
 
@@ -100,6 +101,10 @@ struct LdsLayout {
 	uint32_t wsc;        // f32 [4][64]    per-weight scratch rows
 	uint32_t fmt;        // format-search scratch (best_error[4][21][4] etc.)
 	uint32_t part;       // partition-search scratch
+	uint32_t ptab;       // u8 [2][Tp]    staged partition record of the current trial
+	uint32_t ctab;       // u8 [2][512]   staged colour quant rows (candidate quant level, mod level)
+	uint32_t qtab;       // QuantXfer     staged weight quant transfer table of the candidate
+	uint32_t dtab;       // staged decimation tables of the candidate being refined
 	uint32_t total;
 };
 
@@ -141,6 +146,10 @@ WV_FN void make_lds_layout(const TableRoot& r, LdsLayout& L)
 	if (o < part_end) o = part_end;
 	L.tsc = take(12 * Tp * 4);
 	L.wsc = take(4 * 64 * 4);
+	L.ptab = take(2 * Tp);
+	L.ctab = take(2 * 512);
+	L.qtab = take(sizeof(QuantXfer));
+	L.dtab = take(r.max_decimation_table_bytes);
 	L.total = o;
 }
 
@@ -153,6 +162,7 @@ struct Ctx {
 	LdsLayout L;
 	int T;                       // texels per block
 	int Tp;                      // T rounded up to 4
+	unsigned long long* prof;    // stage cycle counters (profiling builds only), else null
 
 	// typed views
 	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L.data) + c * Tp; }
@@ -178,6 +188,21 @@ struct Ctx {
 	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
 	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
 };
+
+/* Stage timers for profiling builds (-DASTC_PROFILE): lane 0 accumulates shader-clock cycles per
+ * stage into c.prof[].  Compiled out otherwise. */
+enum { PS_LOAD, PS_IDEAL, PS_DECIMATE, PS_ANGULAR, PS_MODES, PS_FORMATS, PS_RECOMPUTE, PS_PACK, PS_DIFF, PS_REALIGN,
+       PS_KMEANS, PS_PSCORE, PS_PHYSICAL, PS_STATS, PS_TOTAL, PS_BLOCKS, PS_COUNT };
+#if defined(ASTC_PROFILE) && WV_DEVICE
+struct ProfScope {
+	unsigned long long* p; unsigned long long t0;
+	__device__ ProfScope(unsigned long long* prof, int id) : p(prof ? prof + id : nullptr), t0(__builtin_amdgcn_s_memtime()) {}
+	__device__ ~ProfScope() { if (p && threadIdx.x == 0) atomicAdd(p, __builtin_amdgcn_s_memtime() - t0); }
+};
+#define PROF_SCOPE(c, id) ProfScope prof_scope_##id((c).prof, id)
+#else
+#define PROF_SCOPE(c, id) ((void)0)
+#endif
 
 /* View of one partition record. */
 struct PartView {
@@ -205,6 +230,71 @@ WV_FN PartView part_view(const Ctx& c, int pcount, int packed)
 		o += v.count[i];
 	}
 	return v;
+}
+
+
+/* Copy `words` 32-bit words global -> LDS with all lanes (coalesced), then sync. */
+WV_FN void stage_words(uint8_t* lds_dst, const uint8_t* src, int words)
+{
+	const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+	uint32_t* d = reinterpret_cast<uint32_t*>(lds_dst);
+	WV_FOR(i, words) { d[i] = s[i]; }
+	WV_SYNC();
+}
+
+/* Partition view whose texel arrays are staged in LDS: every trial walks them in serial loops, and
+ * an L2 round trip per element is what those loops would otherwise pay. */
+WV_FN PartView part_view_staged(const Ctx& c, int pcount, int packed)
+{
+	PartView v = part_view(c, pcount, packed);
+	uint8_t* dst = c.lds + c.L.ptab;
+	// of_texel[T] and sorted[T] are adjacent in the record; record stride is a multiple of 4
+	const uint8_t* src = reinterpret_cast<const uint8_t*>(v.h) + sizeof(PartitionHeader);
+	stage_words(dst, src, (2 * c.T + 3) / 4);
+	v.of_texel = dst;
+	v.sorted = dst + c.T;
+	return v;
+}
+
+/* Pointer view of one decimation mode's tables (global or staged in LDS). */
+struct DecView {
+	int T, W, max_texel_weight_count, rows;
+	const uint8_t* tw;     // [4][T]
+	const uint8_t* tci;    // [4][T]
+	const float*   tcf;    // [4][T]
+	const uint8_t* wtc;    // [W]
+	const uint8_t* wt;     // [rows][W]
+	const float*   wc;     // [rows][W]
+	const float*   tcw;    // [rows][W]
+};
+
+WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* address of the texel_weights array */)
+{
+	DecView v;
+	v.T = di.texel_count; v.W = di.weight_count; v.max_texel_weight_count = di.max_texel_weight_count;
+	v.rows = di.max_weight_texel_count;
+	v.tw = base;
+	v.tci = base + (di.off_texel_contribs_int - di.off_texel_weights);
+	v.tcf = reinterpret_cast<const float*>(base + (di.off_texel_contribs_f - di.off_texel_weights));
+	v.wtc = base + (di.off_weight_texel_count - di.off_texel_weights);
+	v.wt = base + (di.off_weight_texels - di.off_texel_weights);
+	v.wc = reinterpret_cast<const float*>(base + (di.off_weight_contribs - di.off_texel_weights));
+	v.tcw = reinterpret_cast<const float*>(base + (di.off_texel_contrib_for_weight - di.off_texel_weights));
+	return v;
+}
+
+WV_FN DecView dec_view_global(const Ctx& c, int dm)
+{
+	const DecimationInfo& di = c.dec_info(dm);
+	return dec_view_at(di, c.tab + di.off_texel_weights);
+}
+
+WV_FN DecView dec_view_staged(const Ctx& c, int dm)
+{
+	const DecimationInfo& di = c.dec_info(dm);
+	uint8_t* dst = c.lds + c.L.dtab;
+	stage_words(dst, c.tab + di.off_texel_weights, (int)((di.table_bytes + 3) / 4));
+	return dec_view_at(di, dst);
 }
 
 } // namespace astcd

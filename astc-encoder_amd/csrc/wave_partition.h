@@ -426,6 +426,7 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 
 	bool uses_alpha = !(blk.data_min[3] == blk.data_max[3]);
 
+	{ PROF_SCOPE(c, PS_PSCORE);
 	WV_FOR(i, partition_search_limit)
 	{
 		float ue, se;
@@ -433,7 +434,7 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 		ps.uncor_err[i] = ue;
 		ps.samec_err[i] = se;
 	}
-	WV_SYNC();
+	WV_SYNC(); }
 
 	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
 	WV_ONE

@@ -39,13 +39,14 @@ WV_FN f4 compute_rgbo_vector(f4 rgba_weight_sum, f4 weight_weight_sum, f4 rgbq_s
 }
 
 /* Expand quantized grid weights (0..64 in `uq`) to per-texel float weights in dst[0..T). */
-WV_FN void expand_weights(const Ctx& c, const DecimationInfo& di, const uint8_t* uq, float* grid, float* dst)
+WV_FN void expand_weights(const Ctx& c, const DecView& di, const uint8_t* uq, float* grid, float* dst)
 {
-	const int T = di.texel_count, W = di.weight_count;
+	(void)c;
+	const int T = di.T, W = di.W;
 	WV_FOR(i, W) { grid[i] = (float)uq[i] * (1.0f / 64.0f); }
 	WV_SYNC();
-	const uint8_t* tw = c.tab + di.off_texel_weights;
-	const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+	const uint8_t* tw = di.tw;
+	const float* tcf = di.tcf;
 	if (di.max_texel_weight_count == 1)
 	{
 		WV_FOR(t, T) { dst[t] = grid[t]; }
@@ -87,7 +88,7 @@ WV_FN PlaneSolve solve_plane(f4 left_sum, f4 middle_sum, f4 right_sum, f4 color_
 }
 
 /* (ref: recompute_ideal_colors_1plane :1146).  Reads wscb().weights, updates tr.wep0/wep1/rgbs/rgbo. */
-WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const DecimationInfo& di)
+WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const DecView& di)
 {
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
@@ -256,7 +257,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 }
 
 /* (ref: recompute_ideal_colors_2planes :1369) */
-WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecimationInfo& di, int plane2_component)
+WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int plane2_component)
 {
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
@@ -438,7 +439,7 @@ WV_FN int lerp_channel(bool u8, int c0, int c1, int w)
 
 /* Squared error of wscb() against the block, with the reference's summation order for each of
  * its three variants (ref: :313, :407, :505).  Uniform return value. */
-WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv)
+WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, const DecView& di)
 {
 	const Scb& scb = c.wscb();
 	TrialInfo& tr = c.tr();
@@ -447,9 +448,8 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv)
 	if (scb.block_type == SYM_BTYPE_ERROR) return ERROR_CALC_DEFAULT;
 
 	const BlockMode& bm = c.block_mode(scb.block_mode);
-	const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-	const uint8_t* tw = c.tab + di.off_texel_weights;
-	const uint8_t* tci = c.tab + di.off_texel_contribs_int;
+	const uint8_t* tw = di.tw;
+	const uint8_t* tci = di.tci;
 	const bool dual = bm.is_dual_plane != 0;
 	const int pc = scb.partition_count;
 	const int profile = c.cfg->profile;
@@ -542,16 +542,14 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv)
 
 /* (ref: realign_weights_undecimated :69, realign_weights_decimated :188).  Operates on wscb();
  * uniform return: true if any weight moved. */
-WV_FN bool realign_weights(const Ctx& c, const PartView& pv)
+WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, const QuantXfer& qat)
 {
 	Scb& scb = c.wscb();
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
 	const BlockMode& bm = c.block_mode(scb.block_mode);
-	const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-	const QuantXfer& qat = c.qxfer(bm.quant_mode);
-	const int W = di.weight_count;
+	const int W = di.W;
 	const int pc = scb.partition_count;
 	const int max_plane = bm.is_dual_plane;
 	const int p2c = scb.plane2_component;
@@ -635,11 +633,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv)
 		}
 		else
 		{
-			const uint8_t* wtc = c.tab + di.off_weight_texel_count;
-			const uint8_t* wt = c.tab + di.off_weight_texels;
-			const float* tcw = reinterpret_cast<const float*>(c.tab + di.off_texel_contrib_for_weight);
-			const uint8_t* tw = c.tab + di.off_texel_weights;
-			const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+			const uint8_t* wtc = di.wtc;
+			const uint8_t* wt = di.wt;
+			const float* tcw = di.tcw;
+			const uint8_t* tw = di.tw;
+			const float* tcf = di.tcf;
 			float* uqf = c.wsc(2);
 
 			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }

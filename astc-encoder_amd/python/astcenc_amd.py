@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-LIB_PRODUCT = os.path.join(REPO, "astc-encoder_amd", "libastcenc_amd.so")
+LIB_PRODUCT = os.environ.get("ASTCENC_AMD_LIB", os.path.join(REPO, "astc-encoder_amd", "libastcenc_amd.so"))
 LIB_REF_NONE = os.path.join(REPO, "oracle", "_ref", "libastcenc-none.so")
 LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
 LIB_EMU = os.path.join(REPO, "tests", "emu", "_build", "libastcenc_emu.so")

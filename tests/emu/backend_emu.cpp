@@ -43,6 +43,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.lds = lds.data();
 	c.T = root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
+	c.prof = nullptr;
 
 	ImageDesc img;
 	img.data = job.host_data ? job.host_data : job.device_data;
