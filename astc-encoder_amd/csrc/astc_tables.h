@@ -61,7 +61,9 @@ struct DecimationMode {
 	int8_t   maxprec_2planes;
 	uint16_t refprec_1plane;
 	uint16_t refprec_2planes;
-	uint16_t pad;
+	// LDS slots of this grid's per-trial results (planes that the grid cannot encode get no slot)
+	uint16_t dwi_offset[2];      // float offset of the ideal weights of plane 0 / 1 in the packed dwi region
+	uint8_t  lowhigh_slot[2];    // 16-float slot of the angular low/high bounds of plane 0 / 1
 };
 
 // Bilinear-infill tables of one weight grid. (ref: struct decimation_info :347)
@@ -127,6 +129,11 @@ struct TableRoot {
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
+	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
+	uint32_t dwi_total_floats;                // size of the packed ideal-weight region
+	uint32_t off_dwi_owner;                   // u16[dwi_total_floats]: (decimation mode << 1) | plane owning each packed slot
+	uint32_t lowhigh_slots;                   // number of 16-float low/high slots
+	uint32_t max_partitionings;               // largest partitioning_count_selected[1..3]
 	uint32_t total_bytes;
 };
 

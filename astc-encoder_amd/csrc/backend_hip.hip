@@ -26,7 +26,11 @@ __device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
 	return (b % 8u) * per + (b / 8u);
 }
 
-__global__ void __launch_bounds__(64)
+#ifndef ASTC_WAVES_PER_EU
+#define ASTC_WAVES_PER_EU 3
+#endif
+
+__global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
 astc_compress_blocks_kernel(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
                             uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
 {
@@ -87,7 +91,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	b->cfg = cfg;
 	b->tab_bytes = blob_bytes;
 	memcpy(&b->root, blob, sizeof(TableRoot));
-	make_lds_layout(b->root, b->L);
+	make_lds_layout(b->root, b->cfg, b->L);
 
 	if (b->L.total > 160 * 1024)
 	{

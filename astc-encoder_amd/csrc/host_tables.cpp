@@ -670,7 +670,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 						if (b2 >= 24 && b2 <= 96) mp2 = q;
 					}
 				}
-				DecimationMode d = { (int8_t)mp1, (int8_t)mp2, 0, 0, 0 };
+				DecimationMode d = { (int8_t)mp1, (int8_t)mp2, 0, 0, {0, 0}, {0, 0} };
 				dms.push_back(d);
 				dm_grid.push_back({ wx, wy });
 				dm_counts[pass]++;
@@ -685,6 +685,22 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		}
 	}
 	if (bm_counts[0] == 0 || dms.empty()) return false;
+
+	// packed LDS slots for the per-trial ideal weights and angular bounds of each grid
+	uint32_t dwi_total = 0, lh_slots = 0, max_rows_unused = 0;
+	(void)max_rows_unused;
+	for (size_t i = 0; i < dms.size(); i++)
+	{
+		uint32_t wc = dm_grid[i].first * dm_grid[i].second;
+		uint32_t wc4 = (wc + 3u) & ~3u;
+		dms[i].dwi_offset[0] = (uint16_t)dwi_total; dwi_total += wc4;
+		dms[i].lowhigh_slot[0] = (uint8_t)lh_slots++;
+		if (dms[i].maxprec_2planes >= 0)
+		{
+			dms[i].dwi_offset[1] = (uint16_t)dwi_total; dwi_total += wc4;
+			dms[i].lowhigh_slot[1] = (uint8_t)lh_slots++;
+		}
+	}
 
 	uint32_t off_bm = blob.alloc(bms.size() * sizeof(BlockMode));
 	memcpy(blob.at<uint8_t>(off_bm), bms.data(), bms.size() * sizeof(BlockMode));
@@ -782,6 +798,19 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		}
 	}
 
+	// owner of every packed ideal-weight slot (lets one lane-parallel loop cover all grids)
+	uint32_t off_owner = blob.alloc(std::max<uint32_t>(dwi_total, 1) * sizeof(uint16_t));
+	{
+		uint16_t* own = blob.at<uint16_t>(off_owner);
+		for (size_t i = 0; i < dms.size(); i++)
+		{
+			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
+			for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[0] + k] = (uint16_t)(i << 1);
+			if (dms[i].maxprec_2planes >= 0)
+				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[1] + k] = (uint16_t)((i << 1) | 1);
+		}
+	}
+
 	// ---- static tables ----
 	uint32_t off_cq = blob.alloc(17 * 512);
 	uint32_t off_cp = blob.alloc(17 * 256);
@@ -843,6 +872,13 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		uint32_t mx = 0;
 		for (size_t i = 0; i < dms.size(); i++) mx = std::max(mx, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->table_bytes);
 		r->max_decimation_table_bytes = mx;
+		uint32_t mr = 0;
+		for (size_t i = 0; i < dms.size(); i++) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
+		r->max_weight_texel_rows = mr;
+		r->dwi_total_floats = dwi_total;
+		r->off_dwi_owner = off_owner;
+		r->lowhigh_slots = lh_slots;
+		r->max_partitionings = std::max(pcounts[1], std::max(pcounts[2], pcounts[3]));
 	}
 	blob.alloc(0, 256);
 	r = blob.at<TableRoot>(0);

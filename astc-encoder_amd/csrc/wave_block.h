@@ -54,13 +54,100 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 	mode_weight_bounds(c, bm, plane, low, high);
 	QuantParams qp = quant_params(low, high, bm.quant_mode);
 	const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
-	const float* ideal = c.dwi(bm.decimation_mode) + plane * PLANE2_OFFSET;
+	const float* ideal = c.dwi(bm.decimation_mode, plane);
 	WV_FOR(i, di.weight_count)
 	{
 		float f;
 		int w = quantize_weight(qp, q2u, ideal[i], &f);
 		if (dst_f) dst_f[i] = f;
 		if (dst_u8) dst_u8[i] = (uint8_t)w;
+	}
+}
+
+/* Quantize-and-score every block mode in [start, end) (ref: compress_symbolic.cpp:438-485 / :806-860 with
+ * compute_quantized_weights_for_decimation + compute_error_of_weight_set_{1plane,2planes}).
+ *
+ * The reference walks the modes one by one.  Here a chunk of modes is scored at once: one lane per
+ * (mode, texel) quantizes the <= 4 grid weights that texel interpolates (same quantize_weight() on
+ * the same inputs as a per-weight pass would use) and writes the texel's error term; then four lanes
+ * per mode run the reference's 4 interleaved accumulators over the terms in texel order. */
+WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
+{
+	ModeRec* modes = c.modes();
+	const int T = c.T, Tp = c.Tp;
+	float* buf = c.uni_f();
+	const int chunk_modes = (int)(c.L.uni_bytes / 4) / Tp;
+	const float* eiw0 = c.ei_w(0); const float* eiwes0 = c.ei_wes(0);
+	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
+
+	for (int first = start; first < end; first += chunk_modes)
+	{
+		const int nm = i_min(chunk_modes, end - first);
+
+		WV_FOR(k, nm * T)
+		{
+			int m = k / T, t = k - m * T;
+			const BlockMode& bm = c.block_mode(first + m);
+			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
+			float term = 0.0f;
+			if (valid)
+			{
+				const DecimationInfo& di = c.dec_info(bm.decimation_mode);
+				const uint8_t* tw = c.tab + di.off_texel_weights;
+				const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+				const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
+				const int mtwc = di.max_texel_weight_count;
+				const int taps = mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1;
+				for (int plane = 0; plane <= (dual ? 1 : 0); plane++)
+				{
+					float low, high;
+					mode_weight_bounds(c, bm, plane, low, high);
+					QuantParams qp = quant_params(low, high, bm.quant_mode);
+					const float* ideal = c.dwi(bm.decimation_mode, plane);
+					float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+					float current;
+					if (taps == 1)
+					{
+						quantize_weight(qp, q2u, ideal[t], &current);
+					}
+					else
+					{
+						for (int j = 0; j < taps; j++)
+						{
+							float f;
+							quantize_weight(qp, q2u, ideal[tw[j * T + t]], &f);
+							v[j] = f * tcf[j * T + t];
+						}
+						current = taps == 4 ? (v[0] + v[1]) + (v[2] + v[3]) : (v[0] + v[1]);
+					}
+					float diff = current - (plane ? eiw1[t] : eiw0[t]);
+					float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
+					term = plane ? term + e : e;
+				}
+			}
+			buf[m * Tp + t] = term;
+		}
+		WV_SYNC();
+
+		// 4 interleaved accumulators per mode, in place (lane l only touches indices = l mod 4)
+		WV_FOR(k, nm * 4)
+		{
+			int m = k >> 2, l = k & 3;
+			float* v = buf + m * Tp;
+			float acc = 0.0f;
+			for (int i = l; i < T; i += 4) acc += v[i];
+			v[l] = acc;
+		}
+		WV_SYNC();
+
+		WV_FOR(m, nm)
+		{
+			const BlockMode& bm = c.block_mode(first + m);
+			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
+			const float* v = buf + m * Tp;
+			modes[first + m].qwt_error = valid ? (v[0] + v[2]) + (v[1] + v[3]) : 1e38f;
+		}
+		WV_SYNC();
 	}
 }
 
@@ -77,6 +164,17 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 	float best_errorval_in_mode = ERROR_CALC_DEFAULT;
 	float best_errorval_in_scb = scb.errorval;
 	const int candidate_count = tr.cand_count;
+
+	// The quantized weights of the chosen candidates are produced now (the reference keeps them
+	// for every block mode, compress_symbolic.cpp:469-478); after this the search-phase LDS
+	// (ideal weights, angular bounds, mode records) is dead and the refine-phase tables reuse it.
+	for (int i = 0; i < candidate_count; i++)
+	{
+		const BlockMode& bm = c.block_mode(tr.cand_block_mode[i]);
+		quantize_mode_weights(c, bm, 0, nullptr, c.candw(i));
+		if (dual) quantize_mode_weights(c, bm, 1, nullptr, c.candw(i) + PLANE2_OFFSET);
+	}
+	WV_SYNC();
 	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
 
 	for (int i = 0; i < candidate_count; i++)
@@ -101,8 +199,11 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			tr.wep0[p][ch] = tr.ep0[plane][p][ch];
 			tr.wep1[p][ch] = tr.ep1[plane][p][ch];
 		}
-		quantize_mode_weights(c, qw_bm, 0, nullptr, workscb.weights);
-		if (dual) quantize_mode_weights(c, qw_bm, 1, nullptr, workscb.weights + PLANE2_OFFSET);
+		{
+			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.candw(i));
+			uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
+			WV_FOR(k, 16) { dst[k] = src[k]; }
+		}
 		WV_SYNC();
 
 		bool stop_all = false;
@@ -259,11 +360,7 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
 	{
 		PROF_SCOPE(c, PS_DECIMATE);
-		for (int i = 0; i < max_decimation_modes; i++)
-		{
-			if (!(c.dec_mode(i).refprec_1plane & ref_mask)) continue;
-			ideal_weights_for_decimation(c, 0, i, c.dwi(i));
-		}
+		ideal_weights_all_grids(c, 1, ref_mask, max_decimation_modes);
 	}
 
 	// (ref: :409-418)
@@ -298,7 +395,7 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
 			max_precision = i_min(max_precision, max_weight_quant);
 			AngSet a;
-			a.weights = c.dwi(dm);
+			a.weights = c.dwi(dm, 0);
 			a.out = c.lowhigh(0, dm);
 			a.wcount = c.dec_info(dm).weight_count;
 			a.maxq = max_precision;
@@ -310,43 +407,10 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 
 	// quantize + score every block mode (ref: :438-485)
 	const int max_block_modes = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
-	ModeRec* modes = c.modes();
-	float* uqf = c.wsc(0);
-	float* terms = c.tsc(0);
-	const float* eiw = c.ei_w(0);
-	const float* eiwes = c.ei_wes(0);
-	{ PROF_SCOPE(c, PS_MODES);
-	for (int i = 0; i < max_block_modes; i++)
 	{
-		const BlockMode& bm = c.block_mode(i);
-		int bitcount = mode_bitcount(partition_count, bm);
-		if (bm.quant_mode > max_weight_quant || bitcount <= 0)
-		{
-			WV_ONE { modes[i].qwt_error = 1e38f; }
-			continue;
-		}
-		const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-		const int T = di.texel_count;
-		quantize_mode_weights(c, bm, 0, uqf, nullptr);
-		WV_SYNC();
-
-		// (ref: compute_error_of_weight_set_1plane, ideal_endpoints_and_weights.cpp:688-749)
-		const uint8_t* tw = c.tab + di.off_texel_weights;
-		const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-		const int mtwc = di.max_texel_weight_count;
-		WV_FOR(t, T)
-		{
-			float current = mtwc > 2 ? infill4(uqf, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf, tw, tcf, T, t) : uqf[t];
-			float diff = current - eiw[t];
-			terms[t] = diff * diff * eiwes[t];
-		}
-		WV_SYNC();
-		float err = sum4(terms, T);
-		WV_ONE { modes[i].qwt_error = err; }
-		WV_SYNC();
+		PROF_SCOPE(c, PS_MODES);
+		score_block_modes(c, partition_count, 0, max_block_modes, max_weight_quant, false);
 	}
-	}
-	WV_SYNC();
 
 	{ PROF_SCOPE(c, PS_FORMATS); compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], 0, max_block_modes); }
 
@@ -366,12 +430,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
 	{
 		PROF_SCOPE(c, PS_DECIMATE);
-		for (int i = 0; i < ndm; i++)
-		{
-			if (!(c.dec_mode(i).refprec_2planes & ref_mask)) continue;
-			ideal_weights_for_decimation(c, 0, i, c.dwi(i));
-			ideal_weights_for_decimation(c, 1, i, c.dwi(i) + PLANE2_OFFSET);
-		}
+		ideal_weights_all_grids(c, 2, ref_mask, ndm);
 	}
 
 	// (ref: :765-785)
@@ -415,7 +474,7 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
 			max_precision = i_min(max_precision, max_weight_quant);
 			AngSet a;
-			a.weights = c.dwi(dm) + plane * PLANE2_OFFSET;
+			a.weights = c.dwi(dm, plane);
 			a.out = c.lowhigh(plane, dm);
 			a.wcount = c.dec_info(dm).weight_count;
 			a.maxq = max_precision;
@@ -427,46 +486,10 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 
 	const int start_2plane = (int)c.root->block_mode_count_1plane_selected;
 	const int end_2plane = (int)c.root->block_mode_count_1plane_2plane_selected;
-	ModeRec* modes = c.modes();
-	float* uqf1 = c.wsc(0);
-	float* uqf2 = c.wsc(1);
-	float* terms = c.tsc(0);
-	{ PROF_SCOPE(c, PS_MODES);
-	for (int i = start_2plane; i < end_2plane; i++)
 	{
-		const BlockMode& bm = c.block_mode(i);
-		if (bm.quant_mode > max_weight_quant)
-		{
-			WV_ONE { modes[i].qwt_error = 1e38f; }
-			continue;
-		}
-		const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-		const int T = di.texel_count;
-		quantize_mode_weights(c, bm, 0, uqf1, nullptr);
-		quantize_mode_weights(c, bm, 1, uqf2, nullptr);
-		WV_SYNC();
-
-		// (ref: compute_error_of_weight_set_2planes, ideal_endpoints_and_weights.cpp:752-842)
-		const uint8_t* tw = c.tab + di.off_texel_weights;
-		const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-		const int mtwc = di.max_texel_weight_count;
-		WV_FOR(t, T)
-		{
-			float cur1 = mtwc > 2 ? infill4(uqf1, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf1, tw, tcf, T, t) : uqf1[t];
-			float diff = cur1 - c.ei_w(0)[t];
-			float error1 = diff * diff * c.ei_wes(0)[t];
-			float cur2 = mtwc > 2 ? infill4(uqf2, tw, tcf, T, t) : mtwc > 1 ? infill2(uqf2, tw, tcf, T, t) : uqf2[t];
-			diff = cur2 - c.ei_w(1)[t];
-			float error2 = diff * diff * c.ei_wes(1)[t];
-			terms[t] = error1 + error2;
-		}
-		WV_SYNC();
-		float err = sum4(terms, T);
-		WV_ONE { modes[i].qwt_error = err; }
-		WV_SYNC();
+		PROF_SCOPE(c, PS_MODES);
+		score_block_modes(c, 1, start_2plane, end_2plane, max_weight_quant, true);
 	}
-	}
-	WV_SYNC();
 
 	// merged endpoints (ref: merge_endpoints :37) -> wep0/wep1 used as the format-search input
 	WV_FOR(ch, 4)

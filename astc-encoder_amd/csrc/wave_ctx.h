@@ -86,6 +86,7 @@ struct ModeRec {
 };
 
 struct LdsLayout {
+	// ---- block / trial lifetime ----
 	uint32_t data;       // f32 [4][Tp]
 	uint32_t blk;        // BlkInfo
 	uint32_t scb;        // Scb (best so far)
@@ -93,37 +94,42 @@ struct LdsLayout {
 	uint32_t trial;      // TrialInfo
 	uint32_t ei_w;       // f32 [2][Tp]    ideal weights per plane
 	uint32_t ei_wes;     // f32 [2][Tp]    weight error scale per plane
-	uint32_t dwi;        // f32 [NDM][64]  dec_weights_ideal
-	uint32_t lowhigh;    // f32 [2][NDM][8][2]   angular low/high per plane, decimation mode, quant
-	uint32_t ang;        // f32 [64][8]    one batch of (decimation mode, angular step) results
-	uint32_t modes;      // ModeRec [NBM]
-	uint32_t tsc;        // f32 [12][Tp]   per-texel scratch rows
-	uint32_t wsc;        // f32 [4][64]    per-weight scratch rows
-	uint32_t fmt;        // format-search scratch (best_error[4][21][4] etc.)
-	uint32_t part;       // partition-search scratch
-	uint32_t ptab;       // u8 [2][Tp]    staged partition record of the current trial
-	uint32_t ctab;       // u8 [2][512]   staged colour quant rows (candidate quant level, mod level)
-	uint32_t qtab;       // QuantXfer     staged weight quant transfer table of the candidate
-	uint32_t dtab;       // staged decimation tables of the candidate being refined
+	uint32_t ptab;       // u8  [2][Tp]    staged partition record of the current trial
+	uint32_t candw;      // u8  [candidates][64]  quantized weights of the chosen candidates
+	uint32_t tsc;        // f32 scratch rows (tsc_stride floats apart)
+	uint32_t wsc;        // f32 [3][64]    per-weight scratch rows
+	// ---- phase-multiplexed region: {search | refine | partition search} never overlap in time ----
+	uint32_t dwi;        // f32 packed     search: ideal weights of every grid (DecimationMode::dwi_offset)
+	uint32_t lowhigh;    // f32 [slots][16] search: angular low/high per quant level
+	uint32_t modes;      // ModeRec [NBM]  search
+	uint32_t uni;        // search: angular batch [64][8] f32, then mode-score terms, then FmtScratch
+	uint32_t dtab;       // refine: staged decimation tables of the candidate
+	uint32_t ctab;       // refine: u8 [2][512] staged colour quant rows
+	uint32_t qtab;       // refine: QuantXfer of the candidate's weight quant level
+	uint32_t rsc;        // refine: f32 [19][Tp] per-texel term rows of the endpoint re-fit
+	uint32_t part;       // partition search scratch
+	uint32_t uni_bytes;  // size of the `uni` region
+	uint32_t tsc_stride; // floats between tsc rows
 	uint32_t total;
 };
 
-/* Sizes in bytes of the two variable scratch regions. */
+/* Sizes in bytes of the variable scratch regions. */
 constexpr uint32_t FMT_SCRATCH_BYTES = 4 * 21 * 4 * 4      /* best_error */
                                      + 4 * 21 * 4          /* format_of_choice */
                                      + 21 * 13 * 4         /* combined error */
                                      + 21 * 13 * 4;        /* combined formats */
 
-WV_FN uint32_t part_scratch_bytes()
+WV_FN uint32_t part_scratch_bytes(uint32_t max_partitionings, uint32_t max_index_limit)
 {
-	// ordering u16[1024] + mismatch u8[1024] + errors f32[2][1024] -> sized for the worst case
-	return 1024 * 2 + 1024 + 2 * 1024 * 4 + 256;
+	// see struct PartScratch (wave_partition.h): fixed header, then ordering u16[n], errors f32[2][limit], mismatch u8[n]
+	uint32_t n = (max_partitionings + 3u) & ~3u;
+	uint32_t lim = max_index_limit < n ? max_index_limit : n;
+	return 256 + n * 2 + lim * 8 + n;
 }
 
-WV_FN void make_lds_layout(const TableRoot& r, LdsLayout& L)
+WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayout& L)
 {
 	uint32_t Tp = (r.texel_count + 3u) & ~3u;
-	uint32_t ndm = r.decimation_mode_count_selected;
 	uint32_t nbm = r.block_mode_count_1plane_2plane_selected;
 	uint32_t o = 0;
 	auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
@@ -134,23 +140,38 @@ WV_FN void make_lds_layout(const TableRoot& r, LdsLayout& L)
 	L.trial = take(sizeof(TrialInfo));
 	L.ei_w = take(2 * Tp * 4);
 	L.ei_wes = take(2 * Tp * 4);
-	// the partition search runs between trials, so its scratch aliases the trial-only regions
-	uint32_t trial_begin = o;
-	L.dwi = take(ndm * 64 * 4);
-	L.lowhigh = take(2 * ndm * 8 * 2 * 4);
-	L.ang = take(64 * 8 * 4);
-	L.modes = take(nbm * sizeof(ModeRec));
-	L.fmt = take(FMT_SCRATCH_BYTES);
-	L.part = trial_begin;
-	uint32_t part_end = trial_begin + ((part_scratch_bytes() + 15u) & ~15u);
-	if (o < part_end) o = part_end;
-	L.tsc = take(12 * Tp * 4);
-	L.wsc = take(4 * 64 * 4);
 	L.ptab = take(2 * Tp);
+	L.candw = take(cfg.tune_candidate_limit * 64);
+	// scratch rows: 5 texel-length rows (format search) or 12 rows of one weight's texel list (realign)
+	uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
+	L.tsc_stride = Tp;
+	uint32_t tsc_floats = 5 * Tp > 12 * rs ? 5 * Tp : 12 * rs;
+	L.tsc = take(tsc_floats * 4);
+	L.wsc = take(3 * 64 * 4);
+
+	const uint32_t begin = o;
+	// search phase
+	L.dwi = take(r.dwi_total_floats * 4);
+	L.lowhigh = take(r.lowhigh_slots * 16 * 4);
+	L.modes = take(nbm * sizeof(ModeRec));
+	L.uni_bytes = FMT_SCRATCH_BYTES > 64 * 8 * 4 ? FMT_SCRATCH_BYTES : 64 * 8 * 4;
+	L.uni = take(L.uni_bytes);
+	uint32_t end = o;
+	// refine phase
+	o = begin;
+	L.dtab = take(r.max_decimation_table_bytes);
 	L.ctab = take(2 * 512);
 	L.qtab = take(sizeof(QuantXfer));
-	L.dtab = take(r.max_decimation_table_bytes);
-	L.total = o;
+	L.rsc = take(19 * Tp * 4);
+	if (o > end) end = o;
+	// partition search phase
+	o = begin;
+	uint32_t lim = cfg.tune_partition_index_limit[0];
+	if (cfg.tune_partition_index_limit[1] > lim) lim = cfg.tune_partition_index_limit[1];
+	if (cfg.tune_partition_index_limit[2] > lim) lim = cfg.tune_partition_index_limit[2];
+	L.part = take(part_scratch_bytes(r.max_partitionings, lim));
+	if (o > end) end = o;
+	L.total = end;
 }
 
 /* Uniform per-wave context. */
@@ -172,14 +193,18 @@ struct Ctx {
 	WV_FN TrialInfo& tr() const { return *reinterpret_cast<TrialInfo*>(lds + L.trial); }
 	WV_FN float* ei_w(int plane) const { return reinterpret_cast<float*>(lds + L.ei_w) + plane * Tp; }
 	WV_FN float* ei_wes(int plane) const { return reinterpret_cast<float*>(lds + L.ei_wes) + plane * Tp; }
-	WV_FN float* dwi(int dm) const { return reinterpret_cast<float*>(lds + L.dwi) + dm * 64; }
-	WV_FN float* lowhigh(int plane, int dm) const { return reinterpret_cast<float*>(lds + L.lowhigh) + (plane * (int)root->decimation_mode_count_selected + dm) * 16; }
-	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.ang); }
+	WV_FN float* dwi(int dm, int plane) const { return reinterpret_cast<float*>(lds + L.dwi) + dec_mode(dm).dwi_offset[plane]; }
+	WV_FN float* lowhigh(int plane, int dm) const { return reinterpret_cast<float*>(lds + L.lowhigh) + dec_mode(dm).lowhigh_slot[plane] * 16; }
+	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.uni); }
+	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L.uni); }
 	WV_FN ModeRec* modes() const { return reinterpret_cast<ModeRec*>(lds + L.modes); }
-	WV_FN float* tsc(int row) const { return reinterpret_cast<float*>(lds + L.tsc) + row * Tp; }
+	WV_FN float* tsc(int row) const { return reinterpret_cast<float*>(lds + L.tsc) + row * L.tsc_stride; }
+	WV_FN float* tsc_base() const { return reinterpret_cast<float*>(lds + L.tsc); }
 	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L.wsc) + row * 64; }
-	WV_FN uint8_t* fmt() const { return lds + L.fmt; }
+	WV_FN uint8_t* fmt() const { return lds + L.uni; }
 	WV_FN uint8_t* part() const { return lds + L.part; }
+	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L.rsc) + row * Tp; }
+	WV_FN uint8_t* candw(int n) const { return lds + L.candw + n * 64; }
 
 	// table accessors
 	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }

@@ -15,16 +15,23 @@
 
 namespace astcd {
 
+/* Scratch of the partition search; lives in the phase-multiplexed LDS region (LdsLayout::part).
+ * Fixed header followed by arrays sized for this context (see part_scratch_bytes()). */
 struct PartScratch {
-	uint16_t ordering[1024];
-	uint8_t  mismatch[1024];
-	float    uncor_err[1024];
-	float    samec_err[1024];
 	uint64_t bitmaps[4];
 	uint16_t mscount[64];
 	int      best_count;
 	int      best[MAX_PARTITIONING_CANDIDATES];
+	int      n;                 // capacity of ordering / mismatch
+	int      lim;               // capacity of the error arrays
+	uint8_t  pad[256 - 32 - 128 - 4 - 32 - 8];
+	// u16 ordering[n]; f32 uncor_err[lim]; f32 samec_err[lim]; u8 mismatch[n];
+	WV_FN uint16_t* ordering() { return reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(this) + 256); }
+	WV_FN float* uncor_err() { return reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(this) + 256 + n * 2); }
+	WV_FN float* samec_err() { return uncor_err() + lim; }
+	WV_FN uint8_t* mismatch() { return reinterpret_cast<uint8_t*>(samec_err() + lim); }
 };
+static_assert(sizeof(PartScratch) == 256, "PartScratch header");
 
 WV_FN int mismatch2(const uint64_t* a, const uint64_t* b)
 {
@@ -216,7 +223,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		if (pc == 2) m = mismatch2(ps.bitmaps, cov + i * 2);
 		else if (pc == 3) m = mismatch3(ps.bitmaps, cov + i * 3);
 		else m = mismatch4(ps.bitmaps, cov + i * 4);
-		ps.mismatch[i] = (uint8_t)m;
+		ps.mismatch()[i] = (uint8_t)m;
 	}
 	WV_SYNC();
 
@@ -224,7 +231,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	WV_ONE
 	{
 		for (int i = 0; i < 64; i++) ps.mscount[i] = 0;
-		for (int i = 0; i < count; i++) ps.mscount[ps.mismatch[i]]++;
+		for (int i = 0; i < count; i++) ps.mscount[ps.mismatch()[i]]++;
 		uint16_t sum = 0;
 		for (int i = 0; i < texels_to_process; i++)
 		{
@@ -234,8 +241,8 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		}
 		for (int i = 0; i < count; i++)
 		{
-			unsigned int idx = ps.mscount[ps.mismatch[i]]++;
-			ps.ordering[idx] = (uint16_t)i;
+			unsigned int idx = ps.mscount[ps.mismatch()[i]]++;
+			ps.ordering()[idx] = (uint16_t)i;
 		}
 	}
 	WV_SYNC();
@@ -255,11 +262,16 @@ WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha,
 	float avg[4][4];
 	{
 		float rest[4];
-		for (int ch = 0; ch < n; ch++) rest[ch] = blk.data_mean[ch] * (float)T;
-		for (int p = 0; p < pc - 1; p++)
+		#pragma unroll
+		for (int ch = 0; ch < 4; ch++) rest[ch] = blk.data_mean[ch] * (float)T;
+		#pragma unroll
+		for (int p = 0; p < 3; p++)
 		{
-			for (int ch = 0; ch < n; ch++)
+			if (p >= pc - 1) break;
+			#pragma unroll
+			for (int ch = 0; ch < 4; ch++)
 			{
+				if (ch >= n) break;
 				const float* d = c.data(ch);
 				float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 				int i = 0;
@@ -279,24 +291,32 @@ WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha,
 			}
 			if (n == 3) avg[p][3] = 0.0f;
 		}
-		for (int ch = 0; ch < n; ch++) avg[pc - 1][ch] = rest[ch] / (float)pv.count[pc - 1];
-		if (n == 3) avg[pc - 1][3] = 0.0f;
+		#pragma unroll
+		for (int p = 1; p < 4; p++)
+		{
+			if (p != pc - 1) continue;
+			#pragma unroll
+			for (int ch = 0; ch < 4; ch++) avg[p][ch] = ch < n ? rest[ch] / (float)pv.count[p] : 0.0f;
+		}
 	}
 
-	float uncor_acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-	float samec_acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	float ua0 = 0.0f, ua1 = 0.0f, ua2 = 0.0f, ua3 = 0.0f;
+	float sa0 = 0.0f, sa1 = 0.0f, sa2 = 0.0f, sa3 = 0.0f;
 	float tail_uncor = 0.0f, tail_samec = 0.0f;   // accumulated after the texel loop (ref: :660-670)
 	float line_len[4];
 	f4 uncor_b[4], samec_b[4];
 
-	for (int p = 0; p < pc; p++)
+	#pragma unroll
+	for (int p = 0; p < 4; p++)
 	{
+		if (p >= pc) break;
 		const uint8_t* tix = pv.sorted + pv.offset[p];
 		const int cnt = pv.count[p];
 		f4 average = load4(avg[p]);
 
 		// dominant direction (ref: :409-454)
 		f4 sum[4];
+		#pragma unroll
 		for (int k = 0; k < 4; k++) sum[k] = splat4(0.0f);
 		for (int i = 0; i < cnt; i++)
 		{
@@ -309,8 +329,10 @@ WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha,
 		}
 		f4 best_vector = sum[0];
 		float best_sum = dot_s(sum[0], sum[0]);
-		for (int k = 1; k < n; k++)
+		#pragma unroll
+		for (int k = 1; k < 4; k++)
 		{
+			if (k >= n) break;
 			float prod = dot_s(sum[k], sum[k]);
 			if (prod > best_sum) { best_vector = sum[k]; best_sum = prod; }
 		}
@@ -356,19 +378,25 @@ WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha,
 			}
 			lo = uncor_param < lo ? uncor_param : lo;
 			hi = uncor_param > hi ? uncor_param : hi;
-			uncor_acc[i & 3] += ue;
-			samec_acc[i & 3] += se;
+			// accumulator lane = position mod 4 (kept in named registers, no indexed array)
+			int l = i & 3;
+			if (l == 0) { ua0 += ue; sa0 += se; }
+			else if (l == 1) { ua1 += ue; sa1 += se; }
+			else if (l == 2) { ua2 += ue; sa2 += se; }
+			else { ua3 += ue; sa3 += se; }
 		}
 		float linelen = hi - lo;
 		line_len[p] = f_max(linelen, 1e-7f);
 	}
 
-	float uncor_error = hadd4(uncor_acc[0], uncor_acc[1], uncor_acc[2], uncor_acc[3]);
-	float samec_error = hadd4(samec_acc[0], samec_acc[1], samec_acc[2], samec_acc[3]);
+	float uncor_error = hadd4(ua0, ua1, ua2, ua3);
+	float samec_error = hadd4(sa0, sa1, sa2, sa3);
 	(void)tail_uncor; (void)tail_samec;
 
-	for (int p = 0; p < pc; p++)
+	#pragma unroll
+	for (int p = 0; p < 4; p++)
 	{
+		if (p >= pc) break;
 		float tpp = (float)pv.count[p];
 		f4 error_weights = splat4(tpp * weight_imprecision_estim);
 		f4 uncor_vector = uncor_b[p] * line_len[p];
@@ -413,6 +441,16 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
+	WV_ONE
+	{
+		uint32_t lim = c.cfg->tune_partition_index_limit[0];
+		if (c.cfg->tune_partition_index_limit[1] > lim) lim = c.cfg->tune_partition_index_limit[1];
+		if (c.cfg->tune_partition_index_limit[2] > lim) lim = c.cfg->tune_partition_index_limit[2];
+		uint32_t n = (c.root->max_partitionings + 3u) & ~3u;
+		ps.n = (int)n;
+		ps.lim = (int)(lim < n ? lim : n);
+	}
+	WV_SYNC();
 
 	float weight_imprecision_estim = 0.055f;
 	if (T <= 20) weight_imprecision_estim = 0.03f;
@@ -430,9 +468,9 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	WV_FOR(i, partition_search_limit)
 	{
 		float ue, se;
-		score_partitioning(c, pc, ps.ordering[i], uses_alpha, weight_imprecision_estim, ue, se);
-		ps.uncor_err[i] = ue;
-		ps.samec_err[i] = se;
+		score_partitioning(c, pc, ps.ordering()[i], uses_alpha, weight_imprecision_estim, ue, se);
+		ps.uncor_err()[i] = ue;
+		ps.samec_err()[i] = se;
 	}
 	WV_SYNC(); }
 
@@ -448,9 +486,9 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 		}
 		for (int i = 0; i < partition_search_limit; i++)
 		{
-			int partition = ps.ordering[i];
-			insert_result(requested_candidates, ps.uncor_err[i], partition, uncor_best_errors, uncor_best_partitions);
-			insert_result(requested_candidates, ps.samec_err[i], partition, samec_best_errors, samec_best_partitions);
+			int partition = ps.ordering()[i];
+			insert_result(requested_candidates, ps.uncor_err()[i], partition, uncor_best_errors, uncor_best_partitions);
+			insert_result(requested_candidates, ps.samec_err()[i], partition, samec_best_errors, samec_best_partitions);
 		}
 
 		// interleave + dedupe (ref: :745-776); packed indices are unique per seed, so dedupe on them

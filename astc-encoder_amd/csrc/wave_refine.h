@@ -123,51 +123,54 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	}
 	WV_SYNC();
 
-	// pass 2: 18 sequential chains per partition over its texels (ref: :1241-1269)
+	// pass 2 (ref: :1241-1269): the reference accumulates 18 running values per partition in
+	// partition-texel order.  Per-texel terms are produced lane-parallel (row r, position i in the
+	// partition-sorted order), then each chain is summed sequentially by its own lane.
 	const float ls_weight = hadd_rgb_s(load4(blk.cw));
-	WV_FOR(k, pc * 18)
+	WV_FOR(i, T)
 	{
-		int p = k / 18, ch = k % 18;
-		const uint8_t* tix = pv.sorted + pv.offset[p];
-		const int n = pv.count[p];
+		int t = pv.sorted[i];
+		int p = pv.of_texel[t];
 		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
-		float acc;
-		if (ch == 0) acc = 1.0f;          // wmin1
-		else if (ch == 1) acc = 0.0f;     // wmax1
-		else if (ch == 2) acc = 1e10f;    // scale_min
-		else if (ch == 3) acc = 0.0f;     // scale_max
-		else if (ch == 7) acc = 1e-17f;   // weight_weight_sum
-		else acc = 0.0f;
+		f4 rgba = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
+		float idx0 = undec[t];
+		float om_idx0 = 1.0f - idx0;
+		float scale = dot3_s(scale_dir, rgba);
+		c.rsc(0)[i] = idx0;
+		c.rsc(1)[i] = scale;
+		c.rsc(2)[i] = om_idx0 * om_idx0;
+		c.rsc(3)[i] = om_idx0 * idx0;
+		c.rsc(4)[i] = idx0 * idx0;
+		f4 cwiprod = rgba * splat4(idx0);
+		f4 xterm = rgba - cwiprod;
+		c.rsc(5)[i] = xterm.x; c.rsc(6)[i] = xterm.y; c.rsc(7)[i] = xterm.z; c.rsc(8)[i] = xterm.w;
+		c.rsc(9)[i] = cwiprod.x; c.rsc(10)[i] = cwiprod.y; c.rsc(11)[i] = cwiprod.z; c.rsc(12)[i] = cwiprod.w;
+		c.rsc(13)[i] = om_idx0 * (scale * ls_weight);
+		c.rsc(14)[i] = idx0 * (scale * ls_weight);
+	}
+	WV_SYNC();
+	WV_FOR(k, pc * 15)
+	{
+		int p = k / 15, r = k % 15;
+		const float* v = c.rsc(r) + pv.offset[p];
+		const int n = pv.count[p];
+		// one branch-free loop for all chains: running sum, min and max of the row
+		float acc = r == 0 ? 1e-17f : 0.0f;   // row 0 doubles as weight_weight_sum (starts at 1e-17)
+		float mn = r == 0 ? 1.0f : 1e10f;
+		float mx = 0.0f;
 		for (int j = 0; j < n; j++)
 		{
-			int t = tix[j];
-			float idx0 = undec[t];
-			float om_idx0 = 1.0f - idx0;
-			if (ch == 0) acc = f_min(idx0, acc);
-			else if (ch == 1) acc = f_max(idx0, acc);
-			else if (ch == 2 || ch == 3 || ch >= 16)
-			{
-				f4 rgba = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
-				float scale = dot3_s(scale_dir, rgba);
-				if (ch == 2) acc = f_min(scale, acc);
-				else if (ch == 3) acc = f_max(scale, acc);
-				else if (ch == 16) acc += om_idx0 * (scale * ls_weight);
-				else acc += idx0 * (scale * ls_weight);
-			}
-			else if (ch == 4) acc += om_idx0 * om_idx0;
-			else if (ch == 5) acc += om_idx0 * idx0;
-			else if (ch == 6) acc += idx0 * idx0;
-			else if (ch == 7) acc += idx0;
-			else
-			{
-				int comp = ch & 3;
-				float cw = c.data(comp)[t];
-				float cwi = cw * idx0;
-				if (ch < 12) acc += cw - cwi;   // color_vec_x
-				else acc += cwi;                // color_vec_y
-			}
+			float x = v[j];
+			acc += x;
+			mn = x < mn ? x : mn;
+			mx = x > mx ? x : mx;
 		}
-		tr.fbox[p * 24 + ch] = acc;
+		float* s = &tr.fbox[p * 24];
+		if (r == 0) { s[0] = mn; s[1] = mx; s[7] = acc; }       // wmin1, wmax1; sum(idx0) completes weight_weight_sum below
+		else if (r == 1) { s[2] = mn; s[3] = mx; }              // scale_min, scale_max
+		else if (r <= 4) s[4 + (r - 2)] = acc;                  // left, middle, right
+		else if (r <= 12) s[8 + (r - 5)] = acc;                 // color_vec_x[4], color_vec_y[4]
+		else s[16 + (r - 13)] = acc;                            // scale_vec
 	}
 	WV_SYNC();
 
@@ -270,54 +273,51 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	const float ls_weight = hadd_rgb_s(load4(blk.cw));
 	const f4 scale_dir = normalize4(xyz0(load4(blk.data_mean)));
 
-	// chains: 0 wmin1 1 wmax1 2 wmin2 3 wmax2 4 scale_min 5 scale_max 6-8 l/m/r plane1 9-11 l/m/r plane2
-	//         12-15 color_vec_x 16-19 color_vec_y 20-21 scale_vec 22-25 weight_weight_sum
-	WV_FOR(ch, 26)
+	// Per-texel terms lane-parallel, then one sequential lane per running value (ref: :1474-1512).
+	// rows: 0 idx0, 1 idx1, 2 scale, 3-5 l/m/r plane1, 6-8 l/m/r plane2, 9-12 x, 13-16 y, 17-18 scale_vec
+	WV_FOR(j, T)
 	{
-		float acc = 0.0f;
-		if (ch == 0 || ch == 2) acc = 1.0f;
-		else if (ch == 4) acc = 1e10f;
-		else if (ch >= 22) acc = 1e-17f;
+		f4 rgba = mk4(c.data(0)[j], c.data(1)[j], c.data(2)[j], c.data(3)[j]);
+		float idx0 = undec1[j], idx1 = undec2[j];
+		float om_idx0 = 1.0f - idx0, om_idx1 = 1.0f - idx1;
+		float scale = dot3_s(scale_dir, rgba);
+		c.rsc(0)[j] = idx0; c.rsc(1)[j] = idx1; c.rsc(2)[j] = scale;
+		c.rsc(3)[j] = om_idx0 * om_idx0; c.rsc(4)[j] = om_idx0 * idx0; c.rsc(5)[j] = idx0 * idx0;
+		c.rsc(6)[j] = om_idx1 * om_idx1; c.rsc(7)[j] = om_idx1 * idx1; c.rsc(8)[j] = idx1 * idx1;
+		f4 color_idx = mk4(plane2_component == 0 ? idx1 : idx0, plane2_component == 1 ? idx1 : idx0,
+		                   plane2_component == 2 ? idx1 : idx0, plane2_component == 3 ? idx1 : idx0);
+		f4 cwiprod = rgba * color_idx;
+		f4 xterm = rgba - cwiprod;
+		c.rsc(9)[j] = xterm.x; c.rsc(10)[j] = xterm.y; c.rsc(11)[j] = xterm.z; c.rsc(12)[j] = xterm.w;
+		c.rsc(13)[j] = cwiprod.x; c.rsc(14)[j] = cwiprod.y; c.rsc(15)[j] = cwiprod.z; c.rsc(16)[j] = cwiprod.w;
+		c.rsc(17)[j] = om_idx0 * (ls_weight * scale);
+		c.rsc(18)[j] = idx0 * (ls_weight * scale);
+	}
+	WV_SYNC();
+	// outputs: fbox 0 wmin1 1 wmax1 2 wmin2 3 wmax2 4 scale_min 5 scale_max 6-8 lmr1 9-11 lmr2
+	//          12-15 color_vec_x 16-19 color_vec_y 20-21 scale_vec 22-25 weight_weight_sum
+	WV_FOR(r, 19)
+	{
+		const float* v = c.rsc(r);
+		float acc = r <= 1 ? 1e-17f : 0.0f;      // rows 0/1 double as the per-plane weight sums
+		float mn = r == 2 ? 1e10f : 1.0f;
+		float mx = 0.0f;
 		for (int j = 0; j < T; j++)
 		{
-			float idx0 = undec1[j], idx1 = undec2[j];
-			float om_idx0 = 1.0f - idx0, om_idx1 = 1.0f - idx1;
-			if (ch == 0) acc = f_min(idx0, acc);
-			else if (ch == 1) acc = f_max(idx0, acc);
-			else if (ch == 2) acc = f_min(idx1, acc);
-			else if (ch == 3) acc = f_max(idx1, acc);
-			else if (ch == 4 || ch == 5 || ch == 20 || ch == 21)
-			{
-				f4 rgba = mk4(c.data(0)[j], c.data(1)[j], c.data(2)[j], c.data(3)[j]);
-				float scale = dot3_s(scale_dir, rgba);
-				if (ch == 4) acc = f_min(scale, acc);
-				else if (ch == 5) acc = f_max(scale, acc);
-				else if (ch == 20) acc += om_idx0 * (ls_weight * scale);
-				else acc += idx0 * (ls_weight * scale);
-			}
-			else if (ch == 6) acc += om_idx0 * om_idx0;
-			else if (ch == 7) acc += om_idx0 * idx0;
-			else if (ch == 8) acc += idx0 * idx0;
-			else if (ch == 9) acc += om_idx1 * om_idx1;
-			else if (ch == 10) acc += om_idx1 * idx1;
-			else if (ch == 11) acc += idx1 * idx1;
-			else
-			{
-				int comp = ch & 3;          // 12..15, 16..19, (22..25 -> comp = ch - 22)
-				if (ch >= 22) comp = ch - 22;
-				float color_idx = comp == plane2_component ? idx1 : idx0;
-				if (ch >= 22) acc += color_idx;
-				else
-				{
-					float cw = c.data(comp)[j];
-					float cwi = cw * color_idx;
-					if (ch < 16) acc += cw - cwi;
-					else acc += cwi;
-				}
-			}
+			float x = v[j];
+			acc += x;
+			mn = x < mn ? x : mn;
+			mx = x > mx ? x : mx;
 		}
-		tr.fbox[ch] = acc;
+		if (r == 0) { tr.fbox[0] = mn; tr.fbox[1] = mx; tr.fbox[26] = acc; }
+		else if (r == 1) { tr.fbox[2] = mn; tr.fbox[3] = mx; tr.fbox[27] = acc; }
+		else if (r == 2) { tr.fbox[4] = mn; tr.fbox[5] = mx; }
+		else if (r <= 8) tr.fbox[6 + (r - 3)] = acc;
+		else if (r <= 16) tr.fbox[12 + (r - 9)] = acc;
+		else tr.fbox[20 + (r - 17)] = acc;
 	}
+	WV_SYNC();
+	WV_FOR(k, 4) { tr.fbox[22 + k] = k == plane2_component ? tr.fbox[27] : tr.fbox[26]; }
 	WV_SYNC();
 
 	WV_ONE
@@ -639,6 +639,8 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
 			float* uqf = c.wsc(2);
+			float* rt = c.tsc_base();
+			const int rs = ((int)c.root->max_weight_texel_rows + 3) & ~3;
 
 			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }
 			WV_SYNC();
@@ -672,14 +674,15 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					f4 color_down_diff = color_diff + color_offset * weight_down;
 					f4 color_up_diff = color_diff + color_offset * weight_up;
 					f4 b = color_diff * color_diff, d = color_down_diff * color_down_diff, u = color_up_diff * color_up_diff;
-					c.tsc(0)[te] = b.x; c.tsc(1)[te] = b.y; c.tsc(2)[te] = b.z; c.tsc(3)[te] = b.w;
-					c.tsc(4)[te] = d.x; c.tsc(5)[te] = d.y; c.tsc(6)[te] = d.z; c.tsc(7)[te] = d.w;
-					c.tsc(8)[te] = u.x; c.tsc(9)[te] = u.y; c.tsc(10)[te] = u.z; c.tsc(11)[te] = u.w;
+					float* o = rt + te;
+					o[0] = b.x; o[rs] = b.y; o[2 * rs] = b.z; o[3 * rs] = b.w;
+					o[4 * rs] = d.x; o[5 * rs] = d.y; o[6 * rs] = d.z; o[7 * rs] = d.w;
+					o[8 * rs] = u.x; o[9 * rs] = u.y; o[10 * rs] = u.z; o[11 * rs] = u.w;
 				}
 				WV_SYNC();
 				WV_FOR(k, 12)
 				{
-					const float* v = c.tsc(k);
+					const float* v = rt + k * rs;
 					float acc = 0.0f;
 					for (int te = 0; te < n; te++) acc += v[te];
 					tr.fbox[64 + k] = acc;

@@ -55,6 +55,7 @@ WV_FN void ideal_weights_for_decimation(const Ctx& c, int plane, int dm, float* 
 		float weight_weight = 1e-10f;
 		float initial_weight = 0.0f;
 		int cnt = wtc[i];
+		#pragma unroll 4
 		for (int j = 0; j < cnt; j++)
 		{
 			int texel = wt[j * W + i];
@@ -86,6 +87,7 @@ WV_FN void ideal_weights_for_decimation(const Ctx& c, int plane, int dm, float* 
 		float error_change0 = 1e-10f;
 		float error_change1 = 0.0f;
 		int cnt = wtc[i];
+		#pragma unroll 4
 		for (int j = 0; j < cnt; j++)
 		{
 			int texel = wt[j * W + i];
@@ -102,6 +104,132 @@ WV_FN void ideal_weights_for_decimation(const Ctx& c, int plane, int dm, float* 
 		out[i] = weight_val + step;
 	}
 	WV_SYNC();
+}
+
+/* Ideal weights on ALL referenced grids of a trial in three lane-parallel sweeps instead of three
+ * per grid (same arithmetic as ideal_weights_for_decimation above).
+ *   nplanes        : 1 or 2 weight planes in this trial
+ *   ref_mask       : quant levels allowed in this trial (grid is used if refprec & ref_mask)
+ *   max_dm         : grids [0, max_dm) are considered
+ * Uses the `uni` LDS region for the texel-resolution infill of up to uni/Tp (grid, plane) sets at a time. */
+WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask, int max_dm)
+{
+	const TableRoot& r = *c.root;
+	const int T = c.T, Tp = c.Tp;
+	const uint16_t* owner = reinterpret_cast<const uint16_t*>(c.tab + r.off_dwi_owner);
+	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L.dwi);
+	float* infilled = c.uni_f();
+	const int cap_sets = (int)(c.L.uni_bytes / 4) / Tp;
+
+	auto grid_used = [&](int dm, int plane) {
+		const DecimationMode& m = c.dec_mode(dm);
+		if (dm >= max_dm || plane >= nplanes) return false;
+		return ((nplanes == 2 ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
+	};
+
+	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
+	WV_FOR(k, (int)r.dwi_total_floats)
+	{
+		int dm = owner[k] >> 1, plane = owner[k] & 1;
+		if (!grid_used(dm, plane)) continue;
+		const DecimationInfo& di = c.dec_info(dm);
+		const int W = di.weight_count;
+		int i = k - c.dec_mode(dm).dwi_offset[plane];
+		if (i >= W) continue;
+		const float* eiw = c.ei_w(plane);
+		const float* eiwes = c.ei_wes(plane);
+		if (di.texel_count == W)
+		{
+			dwi_base[k] = eiw[i];
+			continue;
+		}
+		const uint8_t* wt = c.tab + di.off_weight_texels;
+		const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
+		const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
+		const float wes0 = eiwes[0];
+		float weight_weight = 1e-10f;
+		float initial_weight = 0.0f;
+		int cnt = (c.tab + di.off_weight_texel_count)[i];
+		#pragma unroll 4
+		for (int j = 0; j < cnt; j++)
+		{
+			int texel = wt[j * W + i];
+			float weight = wc[j * W + i];
+			float wes = constant_wes ? wes0 : eiwes[texel];
+			float contrib_weight = weight * wes;
+			weight_weight += contrib_weight;
+			initial_weight += eiw[texel] * contrib_weight;
+		}
+		dwi_base[k] = initial_weight / weight_weight;
+	}
+	WV_SYNC();
+
+	// sweeps 2+3 over chunks of grids whose infill fits the scratch region
+	int dm0 = 0;
+	while (dm0 < max_dm)
+	{
+		// chunk [dm0, dm1): sets are numbered (dm - dm0) * nplanes + plane
+		int dm1 = dm0 + cap_sets / nplanes;
+		if (dm1 > max_dm) dm1 = max_dm;
+		const int nsets = (dm1 - dm0) * nplanes;
+
+		// sweep 2: infill to texel resolution (ref: :910-926)
+		WV_FOR(k, nsets * T)
+		{
+			int set = k / T, t = k - set * T;
+			int dm = dm0 + set / nplanes, plane = set % nplanes;
+			if (!grid_used(dm, plane)) continue;
+			const DecimationInfo& di = c.dec_info(dm);
+			if (di.texel_count == di.weight_count) continue;
+			const uint8_t* tw = c.tab + di.off_texel_weights;
+			const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
+			const float* wts = dwi_base + c.dec_mode(dm).dwi_offset[plane];
+			infilled[set * Tp + t] = di.max_texel_weight_count <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
+		}
+		WV_SYNC();
+
+		// sweep 3: one clamped gradient step (ref: :930-970)
+		const int k_begin = c.dec_mode(dm0).dwi_offset[0];
+		const int k_end = dm1 < (int)r.decimation_mode_count_selected ? (int)c.dec_mode(dm1).dwi_offset[0] : (int)r.dwi_total_floats;
+		WV_FOR(kk, k_end - k_begin)
+		{
+			int k = k_begin + kk;
+			int dm = owner[k] >> 1, plane = owner[k] & 1;
+			if (!grid_used(dm, plane)) continue;
+			const DecimationInfo& di = c.dec_info(dm);
+			const int W = di.weight_count;
+			int i = k - c.dec_mode(dm).dwi_offset[plane];
+			if (i >= W || di.texel_count == W) continue;
+			const float* eiw = c.ei_w(plane);
+			const float* eiwes = c.ei_wes(plane);
+			const uint8_t* wt = c.tab + di.off_weight_texels;
+			const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
+			const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
+			const float wes0 = eiwes[0];
+			const float* inf = infilled + ((dm - dm0) * nplanes + plane) * Tp;
+			float weight_val = dwi_base[k];
+			float error_change0 = 1e-10f;
+			float error_change1 = 0.0f;
+			int cnt = (c.tab + di.off_weight_texel_count)[i];
+			#pragma unroll 4
+			for (int j = 0; j < cnt; j++)
+			{
+				int texel = wt[j * W + i];
+				float contrib_weight = wc[j * W + i];
+				float wes = constant_wes ? wes0 : eiwes[texel];
+				float scale = wes * contrib_weight;
+				float old_weight = inf[texel];
+				float ideal_weight = eiw[texel];
+				error_change0 += contrib_weight * scale;
+				error_change1 += (old_weight - ideal_weight) * scale;
+			}
+			float step = (error_change1 * -16.0f) / error_change0;
+			step = v_clamp(-0.25f, 0.25f, step);
+			dwi_base[k] = weight_val + step;
+		}
+		WV_SYNC();
+		dm0 = dm1;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,6 +298,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
 			float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
+			#pragma unroll 4
 			for (int j = 0; j < W; j++)
 			{
 				float wj = wv[j];
@@ -189,6 +318,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			float errval = 0.0f, cut_low = 0.0f, cut_high = 0.0f;
 			float minidx = f_round(min_weight * rcp_stepsize - offset);
 			float maxidx = f_round(max_weight * rcp_stepsize - offset);
+			#pragma unroll 4
 			for (int j = 0; j < W; j++)
 			{
 				float sval = wv[j] * rcp_stepsize - offset;

@@ -38,7 +38,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.tab = b->blob.data();
 	c.root = root;
 	c.cfg = &b->cfg;
-	make_lds_layout(*root, c.L);
+	make_lds_layout(*root, b->cfg, c.L);
 	std::vector<uint8_t> lds(c.L.total + 64, 0xCD);
 	c.lds = lds.data();
 	c.T = root->texel_count;
