@@ -402,10 +402,10 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 
 	const astcenc_config& config = ctx->config;
 
-	// Scope of this library: 2D footprints, LDR profiles, no alpha-scale RDO.
+	// Scope of this library: 2D footprints, no alpha-scale RDO pre-pass.
 	bool is_hdr = config.profile == ASTCENC_PRF_HDR || config.profile == ASTCENC_PRF_HDR_RGB_LDR_A;
 	bool compress = !(config.flags & ASTCENC_FLG_DECOMPRESS_ONLY);
-	if (config.block_z > 1 || (compress && (is_hdr || config.a_scale_radius != 0)))
+	if (config.block_z > 1 || (compress && config.a_scale_radius != 0))
 	{
 		delete ctx;
 		return ASTCENC_ERR_NOT_IMPLEMENTED;
@@ -433,7 +433,8 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 	// dB limit -> per-texel squared error threshold (ref: astcenc_entry.cpp:814-821)
 	if (compress)
 	{
-		ctx->config.tune_db_limit = ref_pow(0.1f, ctx->config.tune_db_limit * 0.1f) * 65535.0f * 65535.0f;
+		if (!is_hdr) ctx->config.tune_db_limit = ref_pow(0.1f, ctx->config.tune_db_limit * 0.1f) * 65535.0f * 65535.0f;
+		else ctx->config.tune_db_limit = 0.0f;
 	}
 
 	if (compress)

@@ -32,4 +32,25 @@ void backend_destroy(Backend* b);
 int backend_compress(Backend* b, const CompressJob& job);
 const char* backend_name();
 
+
+/* One kernel launch over blocks [first, first + count) of an image.  The kernel exists in two
+ * builds of the same source (kernel_ldr.hip / kernel_hdr.hip). */
+struct KernelLaunch {
+	const uint8_t* d_tab;            // table blob in HBM
+	const TableRoot* root;           // host copy of the blob's root record
+	DeviceConfig cfg;
+	ImageDesc img;
+	uint8_t* d_out;
+	uint32_t first, count;
+	void* stream;                    // hipStream_t
+	unsigned long long* d_prof;      // stage timers (profiling builds) or null
+};
+
+/* Return 0 on success, a hipError_t value otherwise. `prepare` sets the dynamic-LDS attribute and
+ * reports the per-workgroup LDS bytes. */
+int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes);
+int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes);
+int astc_kernel_launch_ldr(const KernelLaunch& k);
+int astc_kernel_launch_hdr(const KernelLaunch& k);
+
 } // namespace astcd

@@ -7,7 +7,6 @@
 // instead of threads pulling 16-block tickets from an atomic counter, the block range of a chunk
 // is one kernel launch; chunks give the host cancel/progress points.
 #include "backend.h"
-#include "wave_block.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,52 +14,13 @@
 
 namespace astcd {
 
-/* blockIdx -> ASTC block.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8),
- * each with its own L2.  Raster-adjacent ASTC blocks share input cache lines, so every XCD gets a
- * contiguous run of the chunk rather than every 8th block. */
-__device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
-{
-	const uint32_t per = n / 8u;           // blocks per XCD in the evenly divisible part
-	const uint32_t even = per * 8u;
-	if (b >= even) return b;               // ragged tail keeps identity order
-	return (b % 8u) * per + (b / 8u);
-}
-
-#ifndef ASTC_WAVES_PER_EU
-#define ASTC_WAVES_PER_EU 3
-#endif
-
-__global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
-astc_compress_blocks_kernel(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
-                            uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-
-	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
-	uint32_t by = b / img.blocks_x;
-	uint32_t bx = b - by * img.blocks_x;
-
-	Ctx c;
-	c.tab = tab;
-	c.root = reinterpret_cast<const TableRoot*>(tab);
-	c.cfg = &cfg;
-	c.lds = lds;
-	c.L = L;
-	c.T = c.root->texel_count;
-	c.Tp = (c.T + 3) & ~3;
-	c.prof = prof;
-
-	PROF_SCOPE(c, PS_TOTAL);
-	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
-	compress_block(c, out + (size_t)b * 16);
-}
-
 struct Backend {
 	int device;
 	uint8_t* d_tab;
 	size_t tab_bytes;
 	DeviceConfig cfg;
-	LdsLayout L;
+	uint32_t lds_bytes;
+	bool hdr;
 	TableRoot root;
 	hipStream_t stream;
 	hipEvent_t ev0, ev1;
@@ -91,11 +51,12 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	b->cfg = cfg;
 	b->tab_bytes = blob_bytes;
 	memcpy(&b->root, blob, sizeof(TableRoot));
-	make_lds_layout(b->root, b->cfg, b->L);
+	b->hdr = cfg.profile >= 2;
+	int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes) : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes);
 
-	if (b->L.total > 160 * 1024)
+	if (prc != 0 || b->lds_bytes > 160 * 1024)
 	{
-		fprintf(stderr, "astcenc_amd: block working set %u B exceeds the 160 KiB LDS of a CU\n", b->L.total);
+		fprintf(stderr, "astcenc_amd: kernel setup failed (hip error %d, block working set %u B; a CU has 160 KiB of LDS)\n", prc, b->lds_bytes);
 		delete b; *status = 2; return nullptr;
 	}
 
@@ -104,10 +65,8 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
-	HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(astc_compress_blocks_kernel),
-	                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->L.total),
-	        { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
+	enum { PS_COUNT = 16, PS_TOTAL = 14 };
 	HIP_TRY(hipMalloc(&b->d_prof, PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
 	HIP_TRY(hipMemset(b->d_prof, 0, PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
 #endif
@@ -188,9 +147,11 @@ int backend_compress(Backend* b, const CompressJob& job)
 	{
 		if (job.cancel_flag && *job.cancel_flag) break;
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
-		hipLaunchKernelGGL(astc_compress_blocks_kernel, dim3((uint32_t)n), dim3(64), b->L.total, stream,
-		                   b->d_tab, b->cfg, b->L, img, d_out, (uint32_t)first, (uint32_t)n, b->d_prof);
-		HIP_TRY(hipGetLastError(), return 2);
+		KernelLaunch k;
+		k.d_tab = b->d_tab; k.root = &b->root; k.cfg = b->cfg; k.img = img; k.d_out = d_out;
+		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = b->d_prof;
+		int lrc = b->hdr ? astc_kernel_launch_hdr(k) : astc_kernel_launch_ldr(k);
+		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }
 		if (job.progress)
 		{
 			HIP_TRY(hipStreamSynchronize(stream), return 2);
@@ -207,6 +168,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
 #if defined(ASTC_PROFILE)
 	{
+		enum { PS_COUNT = 16, PS_TOTAL = 14 };
 		static const char* names[PS_COUNT] = { "load", "ideal", "decimate", "angular", "modes", "formats", "recompute", "pack", "diff",
 		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks" };
 		unsigned long long h[PS_COUNT];

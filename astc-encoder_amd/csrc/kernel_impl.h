@@ -1,0 +1,72 @@
+// SPDX-License-Identifier: Apache-2.0
+// The compression kernel.  Included by kernel_ldr.hip and kernel_hdr.hip, which set
+//   ASTC_VARIANT     inline-namespace tag of this build of the wave_*.h code
+//   ASTC_ENABLE_HDR  0: LDR/sRGB profiles only (HDR endpoint coders compiled out), 1: everything
+//   ASTC_KERNEL_NAME / ASTC_PREPARE_NAME / ASTC_LAUNCH_NAME
+// One 64-lane wavefront (= one workgroup) compresses one ASTC block; its working set is a
+// dynamic-LDS region laid out by make_lds_layout().
+#include "backend.h"
+#include "wave_block.h"
+#include <hip/hip_runtime.h>
+
+#ifndef ASTC_WAVES_PER_EU
+#define ASTC_WAVES_PER_EU 3
+#endif
+
+namespace astcd {
+
+/* blockIdx -> ASTC block.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8),
+ * each with its own L2.  Raster-adjacent ASTC blocks share input cache lines, so every XCD gets a
+ * contiguous run of the chunk rather than every 8th block. */
+__device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
+{
+	const uint32_t per = n / 8u;
+	const uint32_t even = per * 8u;
+	if (b >= even) return b;               // ragged tail keeps identity order
+	return (b % 8u) * per + (b / 8u);
+}
+
+__global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
+ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
+                 uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
+	uint32_t by = b / img.blocks_x;
+	uint32_t bx = b - by * img.blocks_x;
+
+	Ctx c;
+	c.tab = tab;
+	c.root = reinterpret_cast<const TableRoot*>(tab);
+	c.cfg = &cfg;
+	c.lds = lds;
+	c.L = L;
+	c.T = c.root->texel_count;
+	c.Tp = (c.T + 3) & ~3;
+	c.prof = prof;
+
+	PROF_SCOPE(c, PS_TOTAL);
+	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
+	compress_block(c, out + (size_t)b * 16);
+}
+
+int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes)
+{
+	LdsLayout L;
+	make_lds_layout(root, cfg, L);
+	*lds_bytes = L.total;
+	return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(ASTC_KERNEL_NAME),
+	                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+}
+
+int ASTC_LAUNCH_NAME(const KernelLaunch& k)
+{
+	LdsLayout L;
+	make_lds_layout(*k.root, k.cfg, L);
+	hipLaunchKernelGGL(ASTC_KERNEL_NAME, dim3(k.count), dim3(64), L.total, static_cast<hipStream_t>(k.stream),
+	                   k.d_tab, k.cfg, L, k.img, k.d_out, k.first, k.count, k.d_prof);
+	return (int)hipGetLastError();
+}
+
+} // namespace astcd

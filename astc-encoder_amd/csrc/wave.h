@@ -23,6 +23,15 @@
 //   * 4-lane horizontal sums use the reference's (l0 + l2) + (l1 + l3) order.
 #pragma once
 #include <stdint.h>
+
+// Build variant: the LDR and HDR kernels are separate translation units of the same source so that
+// the HDR endpoint coders do not weigh on the register allocation of the LDR hot path.
+#ifndef ASTC_VARIANT
+	#define ASTC_VARIANT v_all
+#endif
+#ifndef ASTC_ENABLE_HDR
+	#define ASTC_ENABLE_HDR 1
+#endif
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #endif
@@ -46,7 +55,17 @@
 	#define WV_ONE if (true)
 #endif
 
-namespace astcd {
+// Cold, bulky routines (HDR endpoint coders) are kept out of line so that they do not inflate the
+// register pressure and code size of the LDR hot path.
+#if defined(__HIPCC__)
+	#define WV_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+	#define WV_NOINLINE __attribute__((noinline)) inline
+#endif
+
+namespace astcd { inline namespace ASTC_VARIANT {
+
+constexpr bool kHdr = ASTC_ENABLE_HDR != 0;
 
 // ---- scalar helpers (ref: astcenc_mathlib.h:168-331) ----
 WV_FN float f_min(float p, float q) { return p < q ? p : q; }
@@ -278,4 +297,4 @@ WV_FN uint16_t float_to_half(float f)
 	return (uint16_t)(sign | r);
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -16,7 +16,7 @@
 #include "wave_partition.h"
 #include "wave_pack.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 WV_FN void copy_scb(Scb& dst, const Scb& src)
 {
@@ -731,4 +731,4 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	}
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

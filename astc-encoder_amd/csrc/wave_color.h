@@ -6,7 +6,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 struct ColorTabs {
 	const uint8_t* unq_to_uq;   // [512] for the current quant level
@@ -45,6 +45,10 @@ WV_FN int quant_color(const ColorTabs& t, int value, float valuef)
 	if (residual >= -0.1f) index++;
 	return t.unq_to_uq[index];
 }
+
+} } // namespace astcd::ASTC_VARIANT
+#include "wave_color_hdr.h"
+namespace astcd { inline namespace ASTC_VARIANT {
 
 WV_FN i4 quant_color3(const ColorTabs& t, i4 v) { return mki4(quant_color(t, v.x), quant_color(t, v.y), quant_color(t, v.z), 0); }
 WV_FN i4 quant_color3(const ColorTabs& t, i4 v, f4 f) { return mki4(quant_color(t, v.x, f.x), quant_color(t, v.y, f.y), quant_color(t, v.z, f.z), 0); }
@@ -109,7 +113,7 @@ WV_FN void rgba_unpack(i4 input0, i4 input1, i4& output0, i4& output1)
  * HDR formats decode to the LDR error colour in LDR profiles, as in the reference. */
 WV_FN void unpack_color_endpoints(int profile, int format, const uint8_t* in, i4& out0, i4& out1)
 {
-	bool hdr_format = false;
+	bool rgb_hdr = false, alpha_hdr = false, alpha_hdr_default = false;
 	switch (format)
 	{
 	case FMT_LUMINANCE:
@@ -175,16 +179,65 @@ WV_FN void unpack_color_endpoints(int profile, int format, const uint8_t* in, i4
 	case FMT_RGBA_DELTA:
 		rgba_delta_unpack(mki4(in[0], in[2], in[4], in[6]), mki4(in[1], in[3], in[5], in[7]), out0, out1);
 		break;
-	default:
-		hdr_format = true;
-		out0 = mki4(0, 0, 0, 0);
-		out1 = mki4(0, 0, 0, 0);
+#if ASTC_ENABLE_HDR
+	case FMT_HDR_LUMINANCE_SMALL_RANGE:
+		rgb_hdr = true; alpha_hdr_default = true;
+		hdr_luminance_small_range_unpack(in, out0, out1);
 		break;
+	case FMT_HDR_LUMINANCE_LARGE_RANGE:
+		rgb_hdr = true; alpha_hdr_default = true;
+		hdr_luminance_large_range_unpack(in, out0, out1);
+		break;
+	case FMT_HDR_RGB_SCALE:
+		rgb_hdr = true; alpha_hdr_default = true;
+		hdr_rgbo_unpack(in, out0, out1);
+		break;
+	case FMT_HDR_RGB:
+		rgb_hdr = true; alpha_hdr_default = true;
+		hdr_rgb_unpack(in, out0, out1);
+		break;
+	case FMT_HDR_RGB_LDR_ALPHA:
+		rgb_hdr = true;
+		hdr_rgb_unpack(in, out0, out1);
+		out0.w = in[6]; out1.w = in[7];
+		break;
+	default: // FMT_HDR_RGBA
+		{
+			rgb_hdr = true; alpha_hdr = true;
+			hdr_rgb_unpack(in, out0, out1);
+			int a0, a1;
+			hdr_alpha_unpack(in + 6, a0, a1);
+			out0.w = a0; out1.w = a1;
+		}
+		break;
+#else
+	default:
+		// LDR-only kernel: HDR formats never reach the encoder's decode loops
+		rgb_hdr = true; alpha_hdr_default = true;
+		out0 = mki4(0, 0, 0, 0); out1 = mki4(0, 0, 0, 0);
+		break;
+#endif
+	}
+
+	// formats without their own alpha take the profile's default (ref: color_unquantize.cpp:963-977)
+	if (alpha_hdr_default)
+	{
+		if (profile == 3 /* HDR */)
+		{
+			out0.w = 0x7800; out1.w = 0x7800;
+			alpha_hdr = true;
+		}
+		else
+		{
+			out0.w = 0x00FF; out1.w = 0x00FF;
+			alpha_hdr = false;
+		}
 	}
 
 	if (profile == 1 /* LDR */)
 	{
-		if (hdr_format)
+		// an HDR endpoint format in an LDR profile decodes to the error colour
+		if (rgb_hdr || alpha_hdr)
 		{
 			out0 = mki4(0xFF, 0x00, 0xFF, 0xFF);
 			out1 = mki4(0xFF, 0x00, 0xFF, 0xFF);
@@ -194,7 +247,7 @@ WV_FN void unpack_color_endpoints(int profile, int format, const uint8_t* in, i4
 	}
 	else if (profile == 0 /* LDR_SRGB */)
 	{
-		if (hdr_format)
+		if (rgb_hdr || alpha_hdr)
 		{
 			out0 = mki4(0xFF, 0x00, 0xFF, 0xFF);
 			out1 = mki4(0xFF, 0x00, 0xFF, 0xFF);
@@ -204,9 +257,10 @@ WV_FN void unpack_color_endpoints(int profile, int format, const uint8_t* in, i4
 	}
 	else
 	{
-		// HDR profiles with an LDR format: plain 8 -> 16 bit expansion
-		out0 = out0 * 257;
-		out1 = out1 * 257;
+		// HDR profiles: LDR lanes expand 8 -> 16 bit, HDR lanes are already 16-bit LNS codes
+		int sr = rgb_hdr ? 1 : 257, sa = alpha_hdr ? 1 : 257;
+		out0 = mki4(out0.x * sr, out0.y * sr, out0.z * sr, out0.w * sa);
+		out1 = mki4(out1.x * sr, out1.y * sr, out1.z * sr, out1.w * sa);
 	}
 }
 
@@ -574,8 +628,48 @@ WV_FN int pack_color_endpoints(const Ctx& c, f4 color0, f4 color1, f4 rgbs_color
 		}
 		break;
 
+#if ASTC_ENABLE_HDR
+	case FMT_HDR_RGB_SCALE:
+		quantize_hdr_rgbo(t, rgbo_color, output);
+		retval = FMT_HDR_RGB_SCALE;
+		break;
+
+	case FMT_HDR_RGB:
+		quantize_hdr_rgb(t, color0, color1, output);
+		retval = FMT_HDR_RGB;
+		break;
+
+	case FMT_HDR_LUMINANCE_SMALL_RANGE:
+	case FMT_HDR_LUMINANCE_LARGE_RANGE:
+		if (try_quantize_hdr_luminance_small_range(t, color0, color1, output))
+		{
+			retval = FMT_HDR_LUMINANCE_SMALL_RANGE;
+			break;
+		}
+		quantize_hdr_luminance_large_range(t, color0, color1, output);
+		retval = FMT_HDR_LUMINANCE_LARGE_RANGE;
+		break;
+
+	case FMT_HDR_RGB_LDR_ALPHA:
+		{
+			float scale = 1.0f / 257.0f;
+			float a0 = f_clamp255(color0.w * scale);
+			float a1 = f_clamp255(color1.w * scale);
+			output[6] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
+			output[7] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
+			quantize_hdr_rgb(t, color0, color1, output);
+			retval = FMT_HDR_RGB_LDR_ALPHA;
+		}
+		break;
+
+	case FMT_HDR_RGBA:
+		quantize_hdr_rgb(t, color0, color1, output);
+		quantize_hdr_alpha(t, color0.w, color1.w, output + 6);
+		retval = FMT_HDR_RGBA;
+		break;
+#endif
+
 	default:
-		// HDR endpoint formats are not implemented in this round; the host rejects HDR profiles.
 		retval = format;
 		break;
 	}
@@ -583,4 +677,4 @@ WV_FN int pack_color_endpoints(const Ctx& c, f4 color0, f4 color1, f4 rgbs_color
 	return retval;
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -8,7 +8,7 @@
 #include "astc_tables.h"
 #include "wave.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* Block-lifetime scalars. (ref: image_block :749) */
 struct BlkInfo {
@@ -322,4 +322,4 @@ WV_FN DecView dec_view_staged(const Ctx& c, int dm)
 	return dec_view_at(di, dst);
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -11,7 +11,7 @@
 #include "wave_ideal.h"
 #include "wave_weights.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* Wave-wide argmin with lowest-index tie break over v(i), i in [start, end); entries >= 1e30 are
  * never selected (returns -1 if none).  Uniform result. */
@@ -197,8 +197,8 @@ WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, 
 {
 	const TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
-	bool encode_hdr_rgb = blk.rgb_lns != 0;
-	bool encode_hdr_alpha = blk.alpha_lns != 0;
+	bool encode_hdr_rgb = kHdr && blk.rgb_lns != 0;
+	bool encode_hdr_alpha = kHdr && blk.alpha_lns != 0;
 	int partition_size = pv.count[p];
 	float* best_error = fs.best_error[p][i];
 	uint8_t* fmt = fs.format_of_choice[p][i];
@@ -551,4 +551,4 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	WV_SYNC();
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -10,7 +10,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 struct CompSel {
 	int ncomp;
@@ -331,4 +331,4 @@ WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, in
 	ideal_colors_and_weights_1comp(c, pv, 1, plane2_component);
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

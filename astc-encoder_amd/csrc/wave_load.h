@@ -8,7 +8,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* (ref: vecmathlib.h:582 float_to_lns, scalar form) */
 WV_FN float float_to_lns(float a)
@@ -69,8 +69,8 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 	float* dr = c.data(0); float* dg = c.data(1); float* db = c.data(2); float* da = c.data(3);
 
 	const bool fast = img.use_fast_load != 0;
-	const int rgb_lns = (profile == 3 /*HDR*/ || profile == 2 /*HDR_RGB_LDR_A*/) ? 1 : 0;
-	const int a_lns = profile == 3 ? 1 : 0;
+	const int rgb_lns = (kHdr && (profile == 3 /*HDR*/ || profile == 2 /*HDR_RGB_LDR_A*/)) ? 1 : 0;
+	const int a_lns = (kHdr && profile == 3) ? 1 : 0;
 
 	WV_FOR(t, T)
 	{
@@ -184,4 +184,4 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 	}
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

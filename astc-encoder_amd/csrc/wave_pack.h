@@ -6,7 +6,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 WV_FN void pk_write_bits(unsigned int value, unsigned int bitcount, unsigned int bitoffset, uint8_t* ptr)
 {
@@ -252,4 +252,4 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 	for (int i = 0; i < 16; i++) pcb_out[i] = pcb[i];
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -13,7 +13,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* Scratch of the partition search; lives in the phase-multiplexed LDS region (LdsLayout::part).
  * Fixed header followed by arrays sized for this context (see part_scratch_bytes()). */
@@ -506,4 +506,4 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	return ps.best_count;
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -11,7 +11,7 @@
 #include "wave_weights.h"
 #include "wave_color.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* (ref: compute_rgbo_vector :1099) */
 WV_FN f4 compute_rgbo_vector(f4 rgba_weight_sum, f4 weight_weight_sum, f4 rgbq_sum, float psum)
@@ -233,7 +233,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 			}
 		}
 
-		if (blk.rgb_lns || blk.alpha_lns)
+		if (kHdr && (blk.rgb_lns || blk.alpha_lns))
 		{
 			f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
 			float psum = right_sum_s * hadd_rgb_s(color_weight);
@@ -389,7 +389,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 			}
 		}
 
-		if (blk.rgb_lns || blk.alpha_lns)
+		if (kHdr && (blk.rgb_lns || blk.alpha_lns))
 		{
 			weight_weight_sum = weight_weight_sum * color_weight;
 			f4 sel = mk4(plane2_component == 0 ? right2_sum.x : right1_sum.x, plane2_component == 1 ? right2_sum.y : right1_sum.y,
@@ -710,4 +710,4 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	return adjustments;
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

@@ -10,7 +10,7 @@
 #pragma once
 #include "wave_ctx.h"
 
-namespace astcd {
+namespace astcd { inline namespace ASTC_VARIANT {
 
 /* Bilinear infill of one texel from a weight array (ref: bilinear_infill_vla[_2] :38-97).  Unused
  * taps have zero contribution, so the 4-tap form equals the reference's count-specialised forms
@@ -474,4 +474,4 @@ WV_FN float sum4(const float* v, int n)
 	return (a0 + a2) + (a1 + a3);
 }
 
-} // namespace astcd
+} } // namespace astcd::ASTC_VARIANT

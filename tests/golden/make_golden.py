@@ -35,6 +35,7 @@ CASES = {
     "smooth_64x40_8x5_medium": ("smooth", (64, 40), (8, 5), 60.0, None),
     "noisy_96_10x10_medium": ("noisy", (96, 96), (10, 10), 60.0, None),
     "noisy_96_12x12_fast": ("noisy", (96, 96), (12, 12), 10.0, None),
+    "c4_hdr_96_6x6_medium": ("hdr", (96, 96), (6, 6), 60.0, None),
 }
 
 
@@ -42,9 +43,10 @@ def main():
     ref = A.Library(A.LIB_REF_NONE)
     manifest = {}
     for name, (gen, size, block, quality, plimit) in CASES.items():
-        img = images.ALL[gen](*size)
+        img = images.hdr_f16(*size) if gen == "hdr" else images.ALL[gen](*size)
+        profile = A.PRF_HDR if gen == "hdr" else A.PRF_LDR
         tweak = (lambda c: setattr(c, "tune_partition_count_limit", plimit)) if plimit else None
-        blocks = ref.compress(img, block, quality, tweak=tweak)
+        blocks = ref.compress(img, block, quality, profile=profile, tweak=tweak)
         np.save(os.path.join(HERE, name + ".npy"), blocks)
         manifest[name] = {"image": gen, "size": size, "block": block, "quality": quality, "partition_limit": plimit,
                           "input_sha256": hashlib.sha256(img.tobytes()).hexdigest(),

@@ -52,3 +52,30 @@ ALL = {"noisy": noisy, "flat": flat_regions, "gray": grayscale, "smooth": smooth
 def mismatches(a, b):
     a = a.reshape(-1, 16); b = b.reshape(-1, 16)
     return np.where((a != b).any(axis=1))[0]
+
+
+def hdr_f16(w, h, seed=0x9E3779B1):
+    """HDR test image: the LDR generator scaled by 2^(-2..5) in 8x8 patches,
+    alpha kept in 0..1, stored as RGBA16F."""
+    base = A.synthetic_image(w, h, seed).astype(np.float32) / 255.0
+    y, x = np.meshgrid(np.arange(h, dtype=np.int64), np.arange(w, dtype=np.int64), indexing="ij")
+
+    def tri(v):
+        m = v & 511
+        return np.where(m < 256, m, 511 - m)
+
+    expo = ((tri(x >> 3) + tri(y >> 3)) >> 6) - 2
+    scale = np.ldexp(np.float32(1.0), expo.astype(np.int32)).astype(np.float32)
+    out = base.copy()
+    out[..., :3] *= scale[..., None]
+    return out.astype(np.float16)
+
+
+def hdr_variants(w, h):
+    """HDR images that steer the encoder into the different HDR endpoint formats."""
+    base = hdr_f16(w, h).astype(np.float32)
+    opaque = base.copy(); opaque[..., 3] = 1.0                       # HDR RGB / RGB+offset
+    gray = base.copy(); gray[..., 1] = gray[..., 0]; gray[..., 2] = gray[..., 0]; gray[..., 3] = 1.0   # HDR luminance
+    dim = base.copy(); dim[..., :3] *= 0.02                            # small magnitudes / small-range modes
+    bright = base.copy(); bright[..., :3] *= 400.0                     # near the fp16 limit
+    return {"rgba": base, "opaque": opaque, "gray": gray, "dim": dim, "bright": bright}

@@ -62,3 +62,20 @@ def test_emu_large_footprints_and_limits(ref, emu, block, quality):
     want = ref.compress(img, block, quality)
     got = emu.compress(img, block, quality)
     assert len(images.mismatches(want, got)) == 0
+
+
+@pytest.mark.parametrize("profile_name", ["PRF_HDR", "PRF_HDR_RGB_LDR_A"])
+def test_emu_hdr_profiles(ref, emu, A, profile_name):
+    import numpy as np
+    profile = getattr(A, profile_name)
+    for name, img in images.hdr_variants(48, 48).items():
+        for dt in (np.float16, np.float32):
+            im = img.astype(dt)
+            want = ref.compress(im, (6, 6), 60.0, profile=profile)
+            got = emu.compress(im, (6, 6), 60.0, profile=profile)
+            assert len(images.mismatches(want, got)) == 0, (name, dt)
+    im = images.hdr_f16(40, 40)
+    for block, q in [((4, 4), 0.0), ((8, 8), 98.0), ((5, 4), 60.0)]:
+        want = ref.compress(im, block, q, profile=profile)
+        got = emu.compress(im, block, q, profile=profile)
+        assert len(images.mismatches(want, got)) == 0, (block, q)
