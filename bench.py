@@ -46,7 +46,7 @@ def cpu_reference_baseline(img, gpu_blocks, blocks_x):
     if not os.path.exists(A.LIB_REF_AVX2):
         return None
     ref = A.Library(A.LIB_REF_AVX2)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
     def run(crop):
         err, cfg = ref.config_init(A.PRF_LDR, BLOCK[0], BLOCK[1], 1, QUALITY, 0)
@@ -68,11 +68,12 @@ def cpu_reference_baseline(img, gpu_blocks, blocks_x):
         assert not any(errs), errs
         return dt, out
 
-    # calibrate on 768x768, then scale the crop to ~15 s (capped at 3072x3072 = 9.4 Mtexels)
-    probe = np.ascontiguousarray(img[:768, :768])
+    # calibrate on 1536x1536 (enough work for every thread), then scale the crop to ~15 s of CPU time
+    probe = np.ascontiguousarray(img[:1536, :1536])
+    run(probe)
     dt, _ = run(probe)
     rate = probe.shape[0] * probe.shape[1] / dt
-    side = int(min(3072, max(768, (rate * 15.0) ** 0.5)))
+    side = int(min(8190, max(1536, (rate * 15.0) ** 0.5)))
     side = (side // 6) * 6
     crop = np.ascontiguousarray(img[:side, :side])
     dt, out = run(crop)
