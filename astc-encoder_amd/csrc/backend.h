@@ -1,7 +1,7 @@
 // SPDX-License-Identifier: Apache-2.0
 // Seam between the host API layer (astcenc_entry.cpp) and whatever executes the per-block
 // compressor.  The product library links backend_hip.hip (HIP kernels on the current device).
-// tests/emu links backend_emu.cpp, which runs the same wave_*.h source sequentially on the CPU as
+// oracle/emu links backend_emu.cpp, which runs the same wave_*.h source sequentially on the CPU as
 // a debugging aid -- it is never part of libastcenc_amd.so.
 #pragma once
 #include <stddef.h>

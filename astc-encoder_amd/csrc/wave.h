@@ -11,7 +11,7 @@
 //                     independent; they communicate only through LDS and a following WV_SYNC().
 //
 // The same source also compiles as plain C++ (ASTC_WAVE_EMU) where WV_FOR is a sequential loop and
-// WV_SYNC() is a no-op.  That build is a debugging aid for machines without a GPU (tests/emu); the
+// WV_SYNC() is a no-op.  That build is a debugging aid for machines without a GPU (oracle/emu); the
 // product library only contains the HIP build.
 //
 // NUMERICS CONTRACT.  Output bytes must equal the reference's scalar ("none") build, whose results

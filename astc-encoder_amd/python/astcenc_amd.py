@@ -4,7 +4,7 @@
 The same binding drives three shared objects, selected by path:
   * astc-encoder_amd/libastcenc_amd.so   -- the product (HIP kernels, gfx950)
   * oracle/_ref/libastcenc-{none,avx2}.so -- the reference encoder built from /root/reference (oracle)
-  * tests/emu/_build/libastcenc_emu.so    -- CPU wave emulator (debugging aid)
+  * oracle/emu/_build/libastcenc_emu.so   -- scalar CPU build of the kernel source (oracle/README.md)
 so parity tests read: compress with A, compress with B, compare bytes.
 
 Names mirror the C API (ref: Source/astcenc.h); see include/astcenc.h for field meaning.
@@ -18,7 +18,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 LIB_PRODUCT = os.environ.get("ASTCENC_AMD_LIB", os.path.join(REPO, "astc-encoder_amd", "libastcenc_amd.so"))
 LIB_REF_NONE = os.path.join(REPO, "oracle", "_ref", "libastcenc-none.so")
 LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
-LIB_EMU = os.path.join(REPO, "tests", "emu", "_build", "libastcenc_emu.so")
+LIB_EMU = os.path.join(REPO, "oracle", "emu", "_build", "libastcenc_emu.so")
 
 # enum astcenc_error
 (SUCCESS, ERR_OUT_OF_MEM, ERR_BAD_CPU_FLOAT, ERR_BAD_PARAM, ERR_BAD_BLOCK_SIZE, ERR_BAD_PROFILE,

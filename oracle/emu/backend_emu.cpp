@@ -4,7 +4,7 @@
 // Compiles the very same wave_*.h source that the HIP kernels are built from with ASTC_WAVE_EMU
 // semantics (WV_FOR = sequential loop, WV_SYNC = no-op) so that the block compressor can be
 // debugged against oracle/_ref on machines without a GPU.  It is linked only into
-// tests/emu/_build/libastcenc_emu.so and is never part of the product library.
+// oracle/emu/_build/libastcenc_emu.so and is never part of the product library.
 #include "backend.h"
 #include "wave_block.h"
 

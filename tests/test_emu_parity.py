@@ -1,7 +1,7 @@
 # SPDX-License-Identifier: Apache-2.0
 """CPU-side parity: the wave-emulator build of the kernel source vs the real reference encoder.
 
-This is how the block compressor is debugged without a GPU: tests/emu runs the same wave_*.h code
+This is how the block compressor is debugged without a GPU: oracle/emu runs the same wave_*.h code
 sequentially.  (The GPU parity tests in test_gpu_parity.py are the ones that count for the product.)
 """
 import pytest
