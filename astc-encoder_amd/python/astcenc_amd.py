@@ -235,3 +235,40 @@ def psnr_rgba8(a, b):
     d = (a.astype(np.float64) - b.astype(np.float64)) / 255.0
     s = float((d * d).sum())
     return float("inf") if s == 0 else 10.0 * np.log10(a.size / s)
+
+
+# ---- multi-GPU sharding: contiguous block rows per rank, no data-path collective ----
+
+def block_row_shard(dim_y, block_y, rank, world):
+    """Rows of blocks [row0, row1) owned by `rank`, and the texel rows [y0, y1) that feed them.
+
+    Blocks are independent (ref: astcenc_entry.cpp:1009-1038: compress_block reads only its own
+    texels and writes its own 16 bytes), so a shard is just a sub-image whose top edge sits on a block
+    boundary; only the last shard can contain a partial (edge-clamped) block row.  Ranks beyond the
+    number of block rows get an empty shard.
+    """
+    blocks_y = (dim_y + block_y - 1) // block_y
+    per = (blocks_y + world - 1) // world
+    row0 = min(rank * per, blocks_y)
+    row1 = min(row0 + per, blocks_y)
+    return row0, row1, min(row0 * block_y, dim_y), min(row1 * block_y, dim_y)
+
+
+def compress_shard(lib, ctx, pixels, block, rank, world, out=None):
+    """Compress this rank's block rows of `pixels` ([H, W, 4]) with context `ctx`.
+
+    Returns (byte offset into the whole image's block stream, uint8 blocks of the shard).  When
+    `out` (the whole image's output array) is given, the shard is also written in place.
+    """
+    h, w = pixels.shape[0], pixels.shape[1]
+    row0, row1, y0, y1 = block_row_shard(h, block[1], rank, world)
+    blocks_x = (w + block[0] - 1) // block[0]
+    offset = row0 * blocks_x * 16
+    part = np.zeros((row1 - row0) * blocks_x * 16, dtype=np.uint8)
+    if row1 > row0:
+        err = lib.compress_raw(ctx, np.ascontiguousarray(pixels[y0:y1]), part)
+        if err:
+            raise AstcError(err, "astcenc_compress_image (shard %d/%d)" % (rank, world))
+    if out is not None:
+        out[offset: offset + part.size] = part
+    return offset, part

@@ -1,0 +1,669 @@
+/* SPDX-License-Identifier: Apache-2.0
+ *
+ * TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's checker legs may use anything under oracle/.
+ *
+ * Independent plain-C restatement of the 2D LDR ASTC *decoder*, written from the data-format rules
+ * (Khronos Data Format Specification, chapter "ASTC Compressed Texture Image Formats") and the
+ * behaviour of the reference decoder:
+ *   physical_to_symbolic        /root/reference/Source/astcenc_symbolic_physical.cpp:291-556
+ *   decode_ise                  /root/reference/Source/astcenc_integer_sequence.cpp:651-739
+ *   decompress_symbolic_block   /root/reference/Source/astcenc_decompress_symbolic.cpp:170-308
+ *   unpack_color_endpoints      /root/reference/Source/astcenc_color_unquantize.cpp:844-1023
+ *   store_image_block (U8)      /root/reference/Source/astcenc_image.cpp:380-460
+ *
+ * Purpose: an oracle for the 128-bit block *format* that shares no tables and no code with either
+ * the product (astc-encoder_amd/csrc) or the reference.  It answers "do the bytes the HIP encoder
+ * wrote mean what the encoder thinks they mean" -- every table here (block modes, BISE trits and
+ * quints, weight/colour unquantisation, partition hash, infill weights) is computed from the
+ * format's closed-form rules rather than looked up.  It is pinned against the reference's own
+ * astcenc_decompress_image() (oracle/_ref) in tests/test_oracle_decode.py, on encoder output for
+ * every footprint and on random 128-bit patterns (which reach the reserved / illegal encodings).
+ *
+ * Scope: 2D footprints, LDR and LDR_SRGB decode profiles, RGBA8 output (decode_unorm8 rules).
+ * HDR endpoint formats decode to the error colour in these profiles, exactly like the reference.
+ *
+ * Build: gcc -O2 -shared -fPIC -o oracle/_build/libastc_decode.so oracle/astc_decode.c
+ */
+#include <stdint.h>
+#include <string.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ bits */
+
+static unsigned rd_bits(const uint8_t *p, unsigned off, unsigned n)
+{
+	unsigned v = 0;
+	for (unsigned i = 0; i < n; i++)
+	{
+		unsigned b = off + i;
+		if (b < 128)
+		{
+			v |= (unsigned)((p[b >> 3] >> (b & 7)) & 1) << i;
+		}
+	}
+	return v;
+}
+
+/* quantisation levels in format order: index 0..20 -> 2,3,4,5,6,8,10,12,16,20,24,32,40,48,64,80,96,128,160,192,256 */
+static void quant_shape(int q, int *bits, int *trit, int *quint)
+{
+	/* each group of three levels is (pow2, 3*pow2/2... ) -- derive from the level count */
+	static const int levels[21] = { 2,3,4,5,6,8,10,12,16,20,24,32,40,48,64,80,96,128,160,192,256 };
+	int n = levels[q];
+	*trit = 0; *quint = 0;
+	if (n % 3 == 0) { *trit = 1; n /= 3; }
+	else if (n % 5 == 0) { *quint = 1; n /= 5; }
+	int b = 0;
+	while ((1 << b) < n) b++;
+	*bits = b;
+}
+
+static int ise_bits(int count, int q)
+{
+	int b, t, qn;
+	quant_shape(q, &b, &t, &qn);
+	int total = b * count;
+	if (t) total += (8 * count + 4) / 5;
+	if (qn) total += (7 * count + 2) / 3;
+	return total;
+}
+
+/* Five trits from the 8-bit packed group (format spec, "Integer Sequence Encoding"). */
+static void unpack_trits(unsigned T, int t[5])
+{
+	unsigned C;
+	if (((T >> 2) & 7) == 7)
+	{
+		C = (((T >> 5) & 7) << 2) | (T & 3);
+		t[4] = 2; t[3] = 2;
+	}
+	else
+	{
+		C = T & 0x1F;
+		if (((T >> 5) & 3) == 3) { t[4] = 2; t[3] = (T >> 7) & 1; }
+		else { t[4] = (T >> 7) & 1; t[3] = (T >> 5) & 3; }
+	}
+	if ((C & 3) == 3)
+	{
+		t[2] = 2; t[1] = (C >> 4) & 1;
+		t[0] = (((C >> 3) & 1) << 1) | (((C >> 2) & 1) & ~((C >> 3) & 1));
+	}
+	else if (((C >> 2) & 3) == 3)
+	{
+		t[2] = 2; t[1] = 2; t[0] = C & 3;
+	}
+	else
+	{
+		t[2] = (C >> 4) & 1; t[1] = (C >> 2) & 3;
+		t[0] = (((C >> 1) & 1) << 1) | ((C & 1) & ~((C >> 1) & 1));
+	}
+}
+
+/* Three quints from the 7-bit packed group. */
+static void unpack_quints(unsigned Q, int q[3])
+{
+	if (((Q >> 1) & 3) == 3 && ((Q >> 5) & 3) == 0)
+	{
+		unsigned n0 = ~Q & 1;
+		q[2] = (int)(((Q & 1) << 2) | ((((Q >> 4) & 1) & n0) << 1) | (((Q >> 3) & 1) & n0));
+		q[1] = 4; q[0] = 4;
+	}
+	else
+	{
+		unsigned C;
+		if (((Q >> 1) & 3) == 3)
+		{
+			q[2] = 4;
+			C = (((Q >> 3) & 3) << 3) | ((~(Q >> 5) & 3) << 1) | (Q & 1);
+		}
+		else
+		{
+			q[2] = (Q >> 5) & 3;
+			C = Q & 0x1F;
+		}
+		if ((C & 7) == 5) { q[1] = 4; q[0] = (C >> 3) & 3; }
+		else { q[1] = (C >> 3) & 3; q[0] = C & 7; }
+	}
+}
+
+/* Decode `count` BISE symbols; out[i] = (trit_or_quint << bits) | low_bits. */
+static void ise_decode(const uint8_t *src, unsigned off, int q, int count, uint8_t *out)
+{
+	int bits, trit, quint;
+	quant_shape(q, &bits, &trit, &quint);
+
+	if (trit)
+	{
+		static const int tb[5] = { 2, 2, 1, 2, 1 };
+		static const int ts[5] = { 0, 2, 4, 5, 7 };
+		for (int i = 0; i < count; i += 5)
+		{
+			unsigned T = 0, low[5] = { 0, 0, 0, 0, 0 };
+			for (int k = 0; k < 5 && i + k < count; k++)
+			{
+				low[k] = rd_bits(src, off, (unsigned)bits); off += (unsigned)bits;
+				T |= rd_bits(src, off, (unsigned)tb[k]) << ts[k]; off += (unsigned)tb[k];
+			}
+			int t[5];
+			unpack_trits(T, t);
+			for (int k = 0; k < 5 && i + k < count; k++) out[i + k] = (uint8_t)(((unsigned)t[k] << bits) | low[k]);
+		}
+	}
+	else if (quint)
+	{
+		static const int qb[3] = { 3, 2, 2 };
+		static const int qs[3] = { 0, 3, 5 };
+		for (int i = 0; i < count; i += 3)
+		{
+			unsigned Q = 0, low[3] = { 0, 0, 0 };
+			for (int k = 0; k < 3 && i + k < count; k++)
+			{
+				low[k] = rd_bits(src, off, (unsigned)bits); off += (unsigned)bits;
+				Q |= rd_bits(src, off, (unsigned)qb[k]) << qs[k]; off += (unsigned)qb[k];
+			}
+			int qv[3];
+			unpack_quints(Q, qv);
+			for (int k = 0; k < 3 && i + k < count; k++) out[i + k] = (uint8_t)(((unsigned)qv[k] << bits) | low[k]);
+		}
+	}
+	else
+	{
+		for (int i = 0; i < count; i++) { out[i] = (uint8_t)rd_bits(src, off, (unsigned)bits); off += (unsigned)bits; }
+	}
+}
+
+/* ---------------------------------------------------------------------------- unquantisation */
+
+/* Weight symbol -> 0..64 ("Weight Unquantization"). */
+static int unquant_weight(int v, int q)
+{
+	int bits, trit, quint;
+	quant_shape(q, &bits, &trit, &quint);
+	int r;
+	if (!trit && !quint)
+	{
+		/* replicate the bit pattern to 6 bits */
+		r = 0;
+		int have = 0;
+		while (have < 6) { r = (r << bits) | v; have += bits; }
+		r >>= (have - 6);
+	}
+	else if (bits == 0)
+	{
+		static const int t3[3] = { 0, 32, 63 };
+		static const int t5[5] = { 0, 16, 32, 47, 63 };
+		r = trit ? t3[v] : t5[v];
+	}
+	else
+	{
+		int D = v >> bits;
+		int m = v & ((1 << bits) - 1);
+		int a = m & 1, b = (m >> 1) & 1, c = (m >> 2) & 1;
+		int A = a ? 0x7F : 0;
+		int B = 0, C = 0;
+		if (trit)
+		{
+			if (bits == 1) { C = 50; B = 0; }
+			else if (bits == 2) { C = 23; B = (b << 6) | (b << 2) | b; }
+			else { C = 11; B = (c << 6) | (b << 5) | (c << 1) | b; }
+		}
+		else
+		{
+			if (bits == 1) { C = 28; B = 0; }
+			else { C = 13; B = (b << 6) | (b << 1); }
+		}
+		int T = D * C + B;
+		T ^= A;
+		r = (A & 0x20) | (T >> 2);
+	}
+	if (r > 32) r += 1;
+	return r;
+}
+
+/* Colour symbol -> 0..255 ("Endpoint Unquantization"). */
+static int unquant_color(int v, int q)
+{
+	int bits, trit, quint;
+	quant_shape(q, &bits, &trit, &quint);
+	if (!trit && !quint)
+	{
+		int r = 0, have = 0;
+		while (have < 8) { r = (r << bits) | v; have += bits; }
+		return r >> (have - 8);
+	}
+	int D = v >> bits;
+	int m = v & ((1 << bits) - 1);
+	int a = m & 1, b = (m >> 1) & 1, c = (m >> 2) & 1, d = (m >> 3) & 1, e = (m >> 4) & 1, f = (m >> 5) & 1;
+	int A = a ? 0x1FF : 0;
+	int B = 0, C = 0;
+	if (trit)
+	{
+		switch (bits)
+		{
+		case 1: C = 204; B = 0; break;
+		case 2: C = 93; B = (b << 8) | (b << 4) | (b << 2) | (b << 1); break;
+		case 3: C = 44; B = (c << 8) | (b << 7) | (c << 3) | (b << 2) | (c << 1) | b; break;
+		case 4: C = 22; B = (d << 8) | (c << 7) | (b << 6) | (d << 2) | (c << 1) | b; break;
+		case 5: C = 11; B = (e << 8) | (d << 7) | (c << 6) | (b << 5) | (e << 1) | d; break;
+		default: C = 5; B = (f << 8) | (e << 7) | (d << 6) | (c << 5) | (b << 4) | f; break;
+		}
+	}
+	else
+	{
+		switch (bits)
+		{
+		case 1: C = 113; B = 0; break;
+		case 2: C = 54; B = (b << 8) | (b << 3) | (b << 2); break;
+		case 3: C = 26; B = (c << 8) | (b << 7) | (c << 2) | (b << 1) | c; break;
+		case 4: C = 13; B = (d << 8) | (c << 7) | (b << 6) | (d << 1) | c; break;
+		default: C = 6; B = (e << 8) | (d << 7) | (c << 6) | (b << 5) | e; break;
+		}
+	}
+	int T = D * C + B;
+	T ^= A;
+	return (A & 0x80) | (T >> 2);
+}
+
+/* ------------------------------------------------------------------------------- block mode */
+
+typedef struct { int ok, void_extent, wx, wy, dual, wq; } BlockModeInfo;
+
+static BlockModeInfo decode_block_mode(unsigned mode, int bx, int by)
+{
+	BlockModeInfo m; memset(&m, 0, sizeof m);
+	int R, H, D, W = 0, Ht = 0;
+	if ((mode & 0x1FF) == 0x1FC) { m.void_extent = 1; m.ok = 1; return m; }
+
+	if (mode & 3)
+	{
+		R = (int)(((mode >> 4) & 1) | ((mode & 3) << 1));
+		int A = (int)((mode >> 5) & 3), B = (int)((mode >> 7) & 3);
+		switch ((mode >> 2) & 3)
+		{
+		case 0: W = B + 4; Ht = A + 2; break;
+		case 1: W = B + 8; Ht = A + 2; break;
+		case 2: W = A + 2; Ht = B + 8; break;
+		default:
+			B &= 1;
+			if (mode & 0x100) { W = B + 2; Ht = A + 2; }
+			else { W = A + 2; Ht = B + 6; }
+			break;
+		}
+		D = (int)((mode >> 10) & 1); H = (int)((mode >> 9) & 1);
+	}
+	else
+	{
+		if ((mode & 0xF) == 0) return m;            /* reserved */
+		R = (int)(((mode >> 4) & 1) | (((mode >> 2) & 3) << 1));
+		int A = (int)((mode >> 5) & 3), B = (int)((mode >> 9) & 3);
+		D = (int)((mode >> 10) & 1); H = (int)((mode >> 9) & 1);
+		switch ((mode >> 7) & 3)
+		{
+		case 0: W = 12; Ht = A + 2; break;
+		case 1: W = A + 2; Ht = 12; break;
+		case 2: W = A + 6; Ht = B + 6; D = 0; H = 0; break;
+		default:
+			if (((mode >> 5) & 3) == 0) { W = 6; Ht = 10; }
+			else if (((mode >> 5) & 3) == 1) { W = 10; Ht = 6; }
+			else return m;                           /* reserved */
+			break;
+		}
+	}
+	if (R < 2) return m;                             /* reserved weight ranges */
+	m.wq = (R - 2) + 6 * H;
+	m.wx = W; m.wy = Ht; m.dual = D;
+	if (W > bx || Ht > by) return m;
+	int count = W * Ht * (D ? 2 : 1);
+	if (count > 64) return m;
+	int wbits = ise_bits(count, m.wq);
+	if (wbits < 24 || wbits > 96) return m;
+	m.ok = 1;
+	return m;
+}
+
+/* ------------------------------------------------------------------------------- partitions */
+
+static uint32_t hash52(uint32_t p)
+{
+	p ^= p >> 15; p -= p << 17; p += p << 7; p += p << 4;
+	p ^= p >> 5; p += p << 16; p ^= p >> 7; p ^= p >> 3;
+	p ^= p << 6; p ^= p >> 17;
+	return p;
+}
+
+static int select_partition(int seed, int x, int y, int z, int partition_count, int small_block)
+{
+	if (small_block) { x <<= 1; y <<= 1; z <<= 1; }
+	seed += (partition_count - 1) * 1024;
+	uint32_t rnum = hash52((uint32_t)seed);
+	uint8_t s[12];
+	s[0] = rnum & 0xF; s[1] = (rnum >> 4) & 0xF; s[2] = (rnum >> 8) & 0xF; s[3] = (rnum >> 12) & 0xF;
+	s[4] = (rnum >> 16) & 0xF; s[5] = (rnum >> 20) & 0xF; s[6] = (rnum >> 24) & 0xF; s[7] = (rnum >> 28) & 0xF;
+	s[8] = (rnum >> 18) & 0xF; s[9] = (rnum >> 22) & 0xF; s[10] = (rnum >> 26) & 0xF; s[11] = ((rnum >> 30) | (rnum << 2)) & 0xF;
+	for (int i = 0; i < 12; i++) s[i] = (uint8_t)(s[i] * s[i]);
+
+	int sh1, sh2, sh3;
+	if (seed & 1) { sh1 = (seed & 2) ? 4 : 5; sh2 = (partition_count == 3) ? 6 : 5; }
+	else { sh1 = (partition_count == 3) ? 6 : 5; sh2 = (seed & 2) ? 4 : 5; }
+	sh3 = (seed & 0x10) ? sh1 : sh2;
+	s[0] >>= sh1; s[1] >>= sh2; s[2] >>= sh1; s[3] >>= sh2; s[4] >>= sh1; s[5] >>= sh2;
+	s[6] >>= sh1; s[7] >>= sh2; s[8] >>= sh3; s[9] >>= sh3; s[10] >>= sh3; s[11] >>= sh3;
+
+	int a = s[0] * x + s[1] * y + s[10] * z + (int)(rnum >> 14);
+	int b = s[2] * x + s[3] * y + s[11] * z + (int)(rnum >> 10);
+	int c = s[4] * x + s[5] * y + s[8] * z + (int)(rnum >> 6);
+	int d = s[6] * x + s[7] * y + s[9] * z + (int)(rnum >> 2);
+	a &= 0x3F; b &= 0x3F; c &= 0x3F; d &= 0x3F;
+	if (partition_count < 4) d = 0;
+	if (partition_count < 3) c = 0;
+	if (a >= b && a >= c && a >= d) return 0;
+	if (b >= c && b >= d) return 1;
+	if (c >= d) return 2;
+	return 3;
+}
+
+/* ----------------------------------------------------------------------------- endpoints (LDR) */
+
+static int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+static void bit_transfer_signed(int *a, int *b)
+{
+	*b >>= 1;
+	*b |= *a & 0x80;
+	*a >>= 1;
+	*a &= 0x3F;
+	if (*a & 0x20) *a -= 0x40;
+}
+
+static void blue_contract(int c[4])
+{
+	c[0] = (c[0] + c[2]) >> 1;
+	c[1] = (c[1] + c[2]) >> 1;
+}
+
+/* Returns 0 for an LDR format, 1 for an HDR format (-> error colour in LDR profiles). */
+static int unpack_endpoints(int fmt, const int *v, int e0[4], int e1[4])
+{
+	switch (fmt)
+	{
+	case 0:
+		e0[0] = e0[1] = e0[2] = v[0]; e0[3] = 255;
+		e1[0] = e1[1] = e1[2] = v[1]; e1[3] = 255;
+		return 0;
+	case 1:
+	{
+		int l0 = (v[0] >> 2) | (v[1] & 0xC0);
+		int l1 = l0 + (v[1] & 0x3F);
+		if (l1 > 255) l1 = 255;
+		e0[0] = e0[1] = e0[2] = l0; e0[3] = 255;
+		e1[0] = e1[1] = e1[2] = l1; e1[3] = 255;
+		return 0;
+	}
+	case 4:
+		e0[0] = e0[1] = e0[2] = v[0]; e0[3] = v[2];
+		e1[0] = e1[1] = e1[2] = v[1]; e1[3] = v[3];
+		return 0;
+	case 5:
+	{
+		int l0 = v[0], l1 = v[1], a0 = v[2], a1 = v[3];
+		bit_transfer_signed(&l1, &l0);
+		bit_transfer_signed(&a1, &a0);
+		e0[0] = e0[1] = e0[2] = l0; e0[3] = a0;
+		e1[0] = e1[1] = e1[2] = clamp255(l0 + l1); e1[3] = clamp255(a0 + a1);
+		return 0;
+	}
+	case 6:
+	case 10:
+		e1[0] = v[0]; e1[1] = v[1]; e1[2] = v[2];
+		e0[0] = (v[0] * v[3]) >> 8; e0[1] = (v[1] * v[3]) >> 8; e0[2] = (v[2] * v[3]) >> 8;
+		if (fmt == 6) { e0[3] = 255; e1[3] = 255; }
+		else { e0[3] = v[4]; e1[3] = v[5]; }
+		return 0;
+	case 8:
+	case 12:
+	{
+		int a[4] = { v[0], v[2], v[4], fmt == 12 ? v[6] : 255 };
+		int b[4] = { v[1], v[3], v[5], fmt == 12 ? v[7] : 255 };
+		if (v[1] + v[3] + v[5] >= v[0] + v[2] + v[4])
+		{
+			memcpy(e0, a, sizeof a); memcpy(e1, b, sizeof b);
+		}
+		else
+		{
+			blue_contract(a); blue_contract(b);
+			memcpy(e0, b, sizeof b); memcpy(e1, a, sizeof a);
+		}
+		return 0;
+	}
+	case 9:
+	case 13:
+	{
+		int a[4] = { v[0], v[2], v[4], fmt == 13 ? v[6] : 0 };
+		int b[4] = { v[1], v[3], v[5], fmt == 13 ? v[7] : 0 };
+		for (int k = 0; k < 4; k++) bit_transfer_signed(&b[k], &a[k]);
+		int sum = b[0] + b[1] + b[2];
+		for (int k = 0; k < 4; k++) b[k] += a[k];
+		if (sum >= 0)
+		{
+			for (int k = 0; k < 4; k++) { e0[k] = clamp255(a[k]); e1[k] = clamp255(b[k]); }
+		}
+		else
+		{
+			blue_contract(a); blue_contract(b);
+			for (int k = 0; k < 4; k++) { e0[k] = clamp255(b[k]); e1[k] = clamp255(a[k]); }
+		}
+		if (fmt == 9) { e0[3] = 255; e1[3] = 255; }
+		return 0;
+	}
+	default:
+		return 1;   /* 2, 3, 7, 11, 14, 15: HDR endpoint formats */
+	}
+}
+
+/* ------------------------------------------------------------------------------------- block */
+
+static void fill_block(uint8_t *texels, int count, int r, int g, int b, int a)
+{
+	for (int i = 0; i < count; i++)
+	{
+		texels[4 * i] = (uint8_t)r; texels[4 * i + 1] = (uint8_t)g; texels[4 * i + 2] = (uint8_t)b; texels[4 * i + 3] = (uint8_t)a;
+	}
+}
+
+/* Decode one 128-bit block to bx*by RGBA8 texels.  Returns 0 ok, 1 error block (magenta written). */
+EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int srgb, uint8_t *texels)
+{
+	const int T = bx * by;
+	unsigned mode = rd_bits(pcb, 0, 11);
+	BlockModeInfo bm = decode_block_mode(mode, bx, by);
+
+	if (bm.void_extent)
+	{
+		/* 2D void extent: two reserved bits must be set, coordinates either all-ones or ordered */
+		unsigned ls = rd_bits(pcb, 12, 13), hs = rd_bits(pcb, 25, 13), lt = rd_bits(pcb, 38, 13), ht = rd_bits(pcb, 51, 13);
+		int all_ones = ls == 0x1FFF && hs == 0x1FFF && lt == 0x1FFF && ht == 0x1FFF;
+		int bad = rd_bits(pcb, 10, 2) != 3 || ((ls >= hs || lt >= ht) && !all_ones);
+		if (bad || (mode & 0x200))      /* FP16 constant colour is an error in LDR profiles */
+		{
+			fill_block(texels, T, 0xFF, 0, 0xFF, 0xFF);
+			return 1;
+		}
+		int c[4];
+		for (int k = 0; k < 4; k++) c[k] = (pcb[8 + 2 * k] | (pcb[9 + 2 * k] << 8)) >> 8;   /* UNORM16 -> top 8 bits */
+		fill_block(texels, T, c[0], c[1], c[2], c[3]);
+		return 0;
+	}
+	if (!bm.ok) goto error;
+
+	{
+		int wcount = bm.wx * bm.wy;
+		int real_wcount = bm.dual ? 2 * wcount : wcount;
+		int wbits = ise_bits(real_wcount, bm.wq);
+		int parts = (int)rd_bits(pcb, 11, 2) + 1;
+		if (bm.dual && parts == 4) goto error;
+
+		/* the weight stream is stored bit-reversed from the top of the block */
+		uint8_t rev[16];
+		for (int i = 0; i < 16; i++)
+		{
+			unsigned b = pcb[15 - i], r = 0;
+			for (int k = 0; k < 8; k++) r |= ((b >> k) & 1) << (7 - k);
+			rev[i] = (uint8_t)r;
+		}
+		uint8_t wsym[64];
+		ise_decode(rev, 0, bm.wq, real_wcount, wsym);
+		int w[2][64];
+		for (int i = 0; i < wcount; i++)
+		{
+			if (bm.dual) { w[0][i] = unquant_weight(wsym[2 * i], bm.wq); w[1][i] = unquant_weight(wsym[2 * i + 1], bm.wq); }
+			else { w[0][i] = unquant_weight(wsym[i], bm.wq); w[1][i] = 0; }
+		}
+
+		/* colour endpoint modes */
+		int fmt[4] = { 0, 0, 0, 0 };
+		int below = 128 - wbits;
+		int extra = 0, seed = 0, color_start;
+		if (parts == 1)
+		{
+			fmt[0] = (int)rd_bits(pcb, 13, 4);
+			color_start = 17;
+		}
+		else
+		{
+			seed = (int)rd_bits(pcb, 13, 10);
+			color_start = 29;
+			unsigned cem = rd_bits(pcb, 23, 6);
+			if ((cem & 3) == 0)
+			{
+				for (int i = 0; i < parts; i++) fmt[i] = (int)((cem >> 2) & 0xF);
+			}
+			else
+			{
+				extra = 3 * parts - 4;
+				below -= extra;
+				unsigned enc = cem | (rd_bits(pcb, (unsigned)below, (unsigned)extra) << 6);
+				int base = (int)(enc & 3) - 1;
+				for (int i = 0; i < parts; i++)
+				{
+					int cls = base + (int)((enc >> (2 + i)) & 1);
+					int low = (int)((enc >> (2 + parts + 2 * i)) & 3);
+					fmt[i] = cls * 4 + low;
+				}
+			}
+		}
+		int plane2 = -1;
+		if (bm.dual)
+		{
+			below -= 2;
+			plane2 = (int)rd_bits(pcb, (unsigned)below, 2);
+		}
+
+		int nvals = 0;
+		for (int i = 0; i < parts; i++) nvals += 2 * (fmt[i] >> 2) + 2;
+		if (nvals > 18) goto error;
+
+		/* the colour stream uses the largest quantisation whose BISE size fits the space left */
+		int cbits = below - color_start;
+		if (cbits < 0) cbits = 0;
+		int cq = -1;
+		for (int q = 20; q >= 0; q--)
+		{
+			if (ise_bits(nvals, q) <= cbits) { cq = q; break; }
+		}
+		if (cq < 4) goto error;      /* fewer than 6 levels is not a legal endpoint encoding */
+
+		uint8_t csym[18];
+		ise_decode(pcb, (unsigned)color_start, cq, nvals, csym);
+
+		int ep0[4][4], ep1[4][4], hdr[4];
+		int pos = 0;
+		for (int i = 0; i < parts; i++)
+		{
+			int v[8] = { 0 };
+			int n = 2 * (fmt[i] >> 2) + 2;
+			for (int j = 0; j < n; j++) v[j] = unquant_color(csym[pos + j], cq);
+			pos += n;
+			hdr[i] = unpack_endpoints(fmt[i], v, ep0[i], ep1[i]);
+			if (hdr[i])
+			{
+				int m[4] = { 0xFF, 0, 0xFF, 0xFF };
+				memcpy(ep0[i], m, sizeof m); memcpy(ep1[i], m, sizeof m);
+			}
+			for (int k = 0; k < 4; k++)
+			{
+				/* 8 -> 16 bit expansion: replicate for linear, append 0x80 for sRGB (all four
+				 * channels, as the reference does for unorm8 output) */
+				ep0[i][k] = srgb ? ((ep0[i][k] << 8) | 0x80) : ep0[i][k] * 257;
+				ep1[i][k] = srgb ? ((ep1[i][k] << 8) | 0x80) : ep1[i][k] * 257;
+			}
+		}
+
+		int small_block = T < 31;
+		int Ds = (1024 + bx / 2) / (bx - 1);
+		int Dt = (1024 + by / 2) / (by - 1);
+		for (int y = 0; y < by; y++)
+		{
+			for (int x = 0; x < bx; x++)
+			{
+				int cs = Ds * x, ct = Dt * y;
+				int gs = (cs * (bm.wx - 1) + 32) >> 6;
+				int gt = (ct * (bm.wy - 1) + 32) >> 6;
+				int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
+				int w11 = (fs * ft + 8) >> 4;
+				int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
+				int v0 = js + jt * bm.wx;
+				int idx[4] = { v0, v0 + 1, v0 + bm.wx, v0 + bm.wx + 1 };
+				int wt[4] = { w00, w01, w10, w11 };
+				int tw[2];
+				for (int p = 0; p < 2; p++)
+				{
+					int sum = 8;
+					for (int k = 0; k < 4; k++)
+					{
+						if (wt[k] && idx[k] < wcount) sum += w[p][idx[k]] * wt[k];
+					}
+					tw[p] = sum >> 4;
+				}
+				int part = parts == 1 ? 0 : select_partition(seed, x, y, 0, parts, small_block);
+				uint8_t *o = texels + 4 * (y * bx + x);
+				for (int k = 0; k < 4; k++)
+				{
+					int wk = (k == plane2) ? tw[1] : tw[0];
+					int c = (ep0[part][k] * (64 - wk) + ep1[part][k] * wk + 32) >> 6;
+					o[k] = (uint8_t)(c >> 8);
+				}
+			}
+		}
+		return 0;
+	}
+
+error:
+	fill_block(texels, T, 0xFF, 0, 0xFF, 0xFF);
+	return 1;
+}
+
+/* Decode a whole 2D image.  `blocks` holds ceil(w/bx)*ceil(h/by) blocks in raster order; out is
+ * tightly packed RGBA8.  Returns the number of error blocks. */
+EXPORT int astc_oracle_decode_image(const uint8_t *blocks, int bx, int by, int w, int h, int srgb, uint8_t *out)
+{
+	int nbx = (w + bx - 1) / bx, nby = (h + by - 1) / by;
+	int errors = 0;
+	uint8_t tex[12 * 12 * 4];
+	for (int j = 0; j < nby; j++)
+	{
+		for (int i = 0; i < nbx; i++)
+		{
+			errors += astc_oracle_decode_block(blocks + 16 * ((size_t)j * nbx + i), bx, by, srgb, tex);
+			for (int y = 0; y < by && j * by + y < h; y++)
+			{
+				for (int x = 0; x < bx && i * bx + x < w; x++)
+				{
+					memcpy(out + 4 * ((size_t)(j * by + y) * w + (i * bx + x)), tex + 4 * (y * bx + x), 4);
+				}
+			}
+		}
+	}
+	return errors;
+}

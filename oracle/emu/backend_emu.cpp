@@ -69,6 +69,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 			compress_block(c, out + idx * 16);
 		}
 		if (job.cancel_flag && *job.cancel_flag) break;
+		if (job.progress) job.progress(100.0f * (float)(by + 1) / (float)img.blocks_y);
 	}
 	if (job.kernel_ms) *job.kernel_ms = 0.0f;
 	return 0;

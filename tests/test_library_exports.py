@@ -1,0 +1,53 @@
+# SPDX-License-Identifier: Apache-2.0
+"""The shipped library: exports exactly the C ABI that include/*.h declares, loads on a box with no
+GPU, and refuses to create a compression context there instead of falling back to any CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(astcenc_[a-z0-9_]+)\s*\(", text))
+
+
+def test_exports_every_declared_symbol_and_nothing_else(product, A):
+    declared = _declared("astcenc.h") | _declared("astcenc_amd.h")
+    assert declared == set(A.EXPORTS) | set(A.EXPORTS_AMD)
+    handle = ctypes.CDLL(A.LIB_PRODUCT)
+    for sym in declared:
+        assert getattr(handle, sym) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", A.LIB_PRODUCT], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    extra = {s for s in exported if not s.startswith(("_init", "_fini", "__hip", "_Z"))} - declared
+    assert extra == set(), extra
+    assert not any(s.startswith("_Z") and "astcd" in s for s in exported), "internal C++ symbols leak from the library"
+
+
+def test_product_does_not_link_the_oracle(A):
+    out = subprocess.run(["ldd", A.LIB_PRODUCT], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "astcenc-none" not in out and "emu" not in out, out
+    strings = subprocess.run(["strings", "-n", "6", A.LIB_PRODUCT], capture_output=True, text=True).stdout if _have("strings") else ""
+    assert "libastcenc_emu" not in strings and "oracle/" not in strings
+
+
+def _have(tool):
+    return subprocess.run(["which", tool], capture_output=True).returncode == 0
+
+
+def test_no_device_means_no_context(product, A):
+    """Without a HIP device context_alloc must fail loudly (no CPU fallback exists in the product)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU; covered by the gpu tests")
+    err, cfg = product.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, 0)
+    assert err == A.SUCCESS                      # config_init is pure host arithmetic
+    err, ctx = product.context_alloc(cfg, 1)
+    assert err != A.SUCCESS and not ctx.value
+    assert product.error_string(err) is not None
