@@ -88,12 +88,44 @@ def cpu_reference_baseline(img, gpu_blocks, blocks_x):
             "blocks_compared_with_gpu": nb * nb, "blocks_mismatching_gpu": mismatch}
 
 
+def decoded_psnr(img, gpu_blocks):
+    """PSNR (dB, RGBA, reference definition astcenccli_error_metrics.cpp:240-346) of the GPU's blocks
+    decoded by the independent plain-C decoder in oracle/ (checker only, never timed)."""
+    path = os.path.join(ROOT, "oracle", "_build", "libastc_decode.so")
+    if not os.path.exists(path):
+        return None
+    dec = ctypes.CDLL(path)
+    dec.astc_oracle_decode_image.restype = ctypes.c_int
+    dec.astc_oracle_decode_image.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    h, w = img.shape[:2]
+    out = np.zeros((h, w, 4), dtype=np.uint8)
+    errors = dec.astc_oracle_decode_image(gpu_blocks.ctypes.data, BLOCK[0], BLOCK[1], w, h, 0, out.ctypes.data)
+    sq = 0.0
+    for y in range(0, h, 1024):             # chunked: keeps the float64 temporaries small
+        d = (img[y:y + 1024].astype(np.float64) - out[y:y + 1024].astype(np.float64)) / 255.0
+        sq += float((d * d).sum())
+    psnr = float("inf") if sq == 0 else 10.0 * float(np.log10(img.size / sq))
+    return {"psnr_db": round(psnr, 4), "error_blocks": int(errors), "decoder": "oracle/astc_decode.c (plain-C restatement)"}
+
+
+def measured_traffic():
+    """HBM bytes per launch from the newest committed PMC summary of this same workload
+    (profiles/*/traffic.json, written by tools/gpu_profile.sh); None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    t = json.load(open(files[-1]))
+    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-quality", action="store_true", help="skip decoding the output for PSNR")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,8 +186,9 @@ def main():
         kernel_s = sum(kms) / len(kms) / 1e3
         achieved = algo_bytes / kernel_s / 1e9
         gpu_blocks = d_out.cpu().numpy()
+        traffic, traffic_src = measured_traffic()
         out = {
-            "metric": "Mtexels/s, 8192x8192 RGBA8 LDR 6x6 -medium",
+            "metric": "Mtexels/s + PSNR-dB, 8192x8192 RGBA8 LDR 6x6 -medium",
             "value": round(value, 3), "unit": "Mtexels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -164,10 +197,13 @@ def main():
             "config": {"workload": "8192x8192 RGBA8 LDR, 6x6 block, -medium, one image per GPU (BASELINE configs[1])",
                        "blocks_per_image": nblocks, "block": "6x6", "preset": "medium", "sharding": "one image per rank, no collectives"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "astc_compress_blocks_kernel", "kernel_ms": round(kernel_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if world == 1 and not args.no_quality:
+            out["quality"] = decoded_psnr(img_host, gpu_blocks)
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_reference_baseline(img_host, gpu_blocks, blocks_x)
             if base:

@@ -1,9 +1,20 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counter CSVs per (kernel, counter) for the compression kernel."""
-import csv, glob, os, sys
+"""Sum rocprofv3 --pmc counter CSVs per counter for the compression kernel, and derive the HBM
+traffic per launch the way /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+FETCH_SIZE and WRITE_SIZE are in KiB and come from separate passes; on gfx950 FETCH_SIZE counts
+128-byte read requests as 64 bytes, so the read side is doubled.
+
+usage: summarize_pmc.py [--json traffic.json] DIR...
+"""
+import csv, glob, json, os, sys
 from collections import defaultdict
+
+args = sys.argv[1:]
+json_path = None
+if args and args[0] == "--json":
+    json_path, args = args[1], args[2:]
 tot = defaultdict(float); n = defaultdict(int)
-for d in sys.argv[1:]:
+for d in args:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
@@ -12,3 +23,13 @@ for d in sys.argv[1:]:
             tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 for c in sorted(tot):
     print("%-24s sum=%.6g over %d dispatch records (per dispatch %.6g)" % (c, tot[c], n[c], tot[c] / max(n[c], 1)))
+if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
+    rd = tot["FETCH_SIZE"] / n["FETCH_SIZE"] * 1024.0 * 2.0
+    wr = tot["WRITE_SIZE"] / n["WRITE_SIZE"] * 1024.0
+    print("HBM traffic per launch: read %.4g B (2 x FETCH_SIZE KiB), write %.4g B, total %.4g B" % (rd, wr, rd + wr))
+    if json_path:
+        json.dump({"kernel": "astc_compress_blocks_kernel", "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                   "hbm_bytes_per_launch": rd + wr,
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1; "
+                             "KiB -> bytes, FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B)"},
+                  open(json_path, "w"), indent=1)
