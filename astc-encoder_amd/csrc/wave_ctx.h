@@ -96,28 +96,37 @@ struct LdsLayout {
 	uint32_t ei_wes;     // f32 [2][Tp]    weight error scale per plane
 	uint32_t ptab;       // u8  [2][Tp]    staged partition record of the current trial
 	uint32_t candw;      // u8  [candidates][64]  quantized weights of the chosen candidates
-	uint32_t tsc;        // f32 scratch rows (tsc_stride floats apart)
-	uint32_t wsc;        // f32 [3][64]    per-weight scratch rows
 	// ---- phase-multiplexed region: {search | refine | partition search} never overlap in time ----
 	uint32_t dwi;        // f32 packed     search: ideal weights of every grid (DecimationMode::dwi_offset)
 	uint32_t lowhigh;    // f32 [slots][16] search: angular low/high per quant level
 	uint32_t modes;      // ModeRec [NBM]  search
-	uint32_t uni;        // search: angular batch [64][8] f32, then mode-score terms, then FmtScratch
+	uint32_t uni;        // search: infill rows, angular batch [64][8] f32, mode-score terms, then
+	                     //         5 texel rows of the encoding-choice errors, then the format tables
 	uint32_t dtab;       // refine: staged decimation tables of the candidate
 	uint32_t ctab;       // refine: u8 [2][512] staged colour quant rows
 	uint32_t qtab;       // refine: QuantXfer of the candidate's weight quant level
 	uint32_t rsc;        // refine: f32 [19][Tp] per-texel term rows of the endpoint re-fit
+	uint32_t tsc_r;      // refine: f32 scratch rows (tsc_stride floats apart)
+	uint32_t wsc;        // refine: f32 [3][64] per-weight scratch rows
 	uint32_t part;       // partition search scratch
+	uint32_t tsc_p;      // partition search: f32 [2][Tp] k-means rows
 	uint32_t uni_bytes;  // size of the `uni` region
 	uint32_t tsc_stride; // floats between tsc rows
 	uint32_t total;
 };
 
 /* Sizes in bytes of the variable scratch regions. */
-constexpr uint32_t FMT_SCRATCH_BYTES = 4 * 21 * 4 * 4      /* best_error */
-                                     + 4 * 21 * 4          /* format_of_choice */
-                                     + 21 * 13 * 4         /* combined error */
-                                     + 21 * 13 * 4;        /* combined formats */
+
+/* Endpoint-format tables of one trial (see FmtView, wave_format.h).  Only quant levels >= QUANT_6
+ * (17 of the 21) are ever read, and the combined tables are as wide as the partition-count limit
+ * needs: 7 / 10 / 13 integer-count columns for 2 / 3 / 4 partitions. */
+constexpr uint32_t FMT_QUANT_ROWS = 17;
+WV_FN uint32_t fmt_comb_cols(uint32_t partition_limit) { return partition_limit <= 1 ? 0u : partition_limit == 2 ? 7u : partition_limit == 3 ? 10u : 13u; }
+WV_FN uint32_t fmt_scratch_bytes(uint32_t partition_limit)
+{
+	uint32_t P = partition_limit < 1 ? 1u : partition_limit > 4 ? 4u : partition_limit;
+	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 4);
+}
 
 WV_FN uint32_t part_scratch_bytes(uint32_t max_partitionings, uint32_t max_index_limit)
 {
@@ -142,19 +151,17 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.ei_wes = take(2 * Tp * 4);
 	L.ptab = take(2 * Tp);
 	L.candw = take(cfg.tune_candidate_limit * 64);
-	// scratch rows: 5 texel-length rows (format search) or 12 rows of one weight's texel list (realign)
-	uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
 	L.tsc_stride = Tp;
-	uint32_t tsc_floats = 5 * Tp > 12 * rs ? 5 * Tp : 12 * rs;
-	L.tsc = take(tsc_floats * 4);
-	L.wsc = take(3 * 64 * 4);
 
 	const uint32_t begin = o;
 	// search phase
 	L.dwi = take(r.dwi_total_floats * 4);
 	L.lowhigh = take(r.lowhigh_slots * 16 * 4);
 	L.modes = take(nbm * sizeof(ModeRec));
-	L.uni_bytes = FMT_SCRATCH_BYTES > 64 * 8 * 4 ? FMT_SCRATCH_BYTES : 64 * 8 * 4;
+	L.uni_bytes = 64 * 8 * 4;                                     // angular batch
+	if (fmt_scratch_bytes(cfg.tune_partition_count_limit) > L.uni_bytes) L.uni_bytes = fmt_scratch_bytes(cfg.tune_partition_count_limit);
+	if (5 * Tp * 4 > L.uni_bytes) L.uni_bytes = 5 * Tp * 4;       // encoding-choice rows
+	L.uni_bytes = (L.uni_bytes + 15u) & ~15u;
 	L.uni = take(L.uni_bytes);
 	uint32_t end = o;
 	// refine phase
@@ -163,6 +170,13 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.ctab = take(2 * 512);
 	L.qtab = take(sizeof(QuantXfer));
 	L.rsc = take(19 * Tp * 4);
+	{
+		// 5 texel-length rows (weight expansion, difference terms) or 12 rows of one weight's texel list (realign)
+		uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
+		uint32_t tsc_floats = 5 * Tp > 12 * rs ? 5 * Tp : 12 * rs;
+		L.tsc_r = take(tsc_floats * 4);
+	}
+	L.wsc = take(3 * 64 * 4);
 	if (o > end) end = o;
 	// partition search phase
 	o = begin;
@@ -170,7 +184,11 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	if (cfg.tune_partition_index_limit[1] > lim) lim = cfg.tune_partition_index_limit[1];
 	if (cfg.tune_partition_index_limit[2] > lim) lim = cfg.tune_partition_index_limit[2];
 	L.part = take(part_scratch_bytes(r.max_partitionings, lim));
+	L.tsc_p = take(2 * Tp * 4);
 	if (o > end) end = o;
+#if defined(ASTC_LDS_PAD)
+	end += ASTC_LDS_PAD;   // occupancy experiments only
+#endif
 	L.total = end;
 }
 
@@ -198,8 +216,11 @@ struct Ctx {
 	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.uni); }
 	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L.uni); }
 	WV_FN ModeRec* modes() const { return reinterpret_cast<ModeRec*>(lds + L.modes); }
-	WV_FN float* tsc(int row) const { return reinterpret_cast<float*>(lds + L.tsc) + row * L.tsc_stride; }
-	WV_FN float* tsc_base() const { return reinterpret_cast<float*>(lds + L.tsc); }
+	// texel-length scratch rows; one set per phase because the phases' regions alias each other
+	WV_FN float* tsc_f(int row) const { return reinterpret_cast<float*>(lds + L.uni) + row * L.tsc_stride; }      // format search
+	WV_FN float* tsc_r(int row) const { return reinterpret_cast<float*>(lds + L.tsc_r) + row * L.tsc_stride; }    // refinement
+	WV_FN float* tsc_p(int row) const { return reinterpret_cast<float*>(lds + L.tsc_p) + row * L.tsc_stride; }    // partition search
+	WV_FN float* tsc_r_base() const { return reinterpret_cast<float*>(lds + L.tsc_r); }
 	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L.wsc) + row * 64; }
 	WV_FN uint8_t* fmt() const { return lds + L.uni; }
 	WV_FN uint8_t* part() const { return lds + L.part; }

@@ -48,13 +48,37 @@ WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
 #endif
 }
 
-struct FmtScratch {
-	float   best_error[4][21][4];
-	uint8_t format_of_choice[4][21][4];
-	float   comb_error[21][13];
-	uint8_t comb_format[21][13][4];
+/* Endpoint-format tables of one trial, laid out in the `uni` LDS region (fmt_scratch_bytes()):
+ *   best_error[P][17][4], format_of_choice[P][17][4]   per partition x quant level x integer count
+ *   comb_error[17][cols], comb_format[17][cols][4]       best combination over partitions
+ * Quant rows are indexed by (quant - QUANT_6): lower levels are never legal for colour endpoints
+ * (the reference fills them with ERROR_CALC_DEFAULT and never reads them back, ref :328-346). */
+struct FmtView {
+	float*   best_error_;
+	uint8_t* format_of_choice_;
+	float*   comb_error_;
+	uint8_t* comb_format_;
+	int      cols;
+
+	WV_FN float* best_error(int p, int quant) const { return best_error_ + (p * (int)FMT_QUANT_ROWS + (quant - QUANT_6)) * 4; }
+	WV_FN uint8_t* format_of_choice(int p, int quant) const { return format_of_choice_ + (p * (int)FMT_QUANT_ROWS + (quant - QUANT_6)) * 4; }
+	WV_FN float* comb_error(int quant) const { return comb_error_ + (quant - QUANT_6) * cols; }
+	WV_FN uint8_t* comb_format(int quant, int col) const { return comb_format_ + ((quant - QUANT_6) * cols + col) * 4; }
 };
-static_assert(sizeof(FmtScratch) == FMT_SCRATCH_BYTES, "format scratch size");
+
+WV_FN FmtView fmt_view(const Ctx& c)
+{
+	uint32_t P = c.cfg->tune_partition_count_limit;
+	P = P < 1 ? 1u : P > 4 ? 4u : P;
+	FmtView v;
+	uint8_t* base = c.fmt();
+	v.best_error_ = reinterpret_cast<float*>(base);
+	v.format_of_choice_ = base + P * FMT_QUANT_ROWS * 16;
+	v.cols = (int)fmt_comb_cols(P);
+	v.comb_error_ = reinterpret_cast<float*>(base + P * FMT_QUANT_ROWS * 20);
+	v.comb_format_ = base + P * FMT_QUANT_ROWS * 20 + FMT_QUANT_ROWS * (uint32_t)v.cols * 4;
+	return v;
+}
 
 WV_FN float blk_default_alpha(const BlkInfo& blk) { return blk.alpha_lns ? (float)0x7800 : (float)0xFFFF; }
 WV_FN bool blk_is_luminance(const BlkInfo& blk)
@@ -111,38 +135,38 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 		float r = c.data(0)[t], g = c.data(1)[t], b = c.data(2)[t], a = c.data(3)[t];
 
 		float alpha_diff = a - default_a;
-		c.tsc(0)[i] = alpha_diff * alpha_diff;
+		c.tsc_f(0)[i] = alpha_diff * alpha_diff;
 
 		float param = r * o[3] + g * o[4] + b * o[5];
 		float dist0 = (o[0] + param * o[3]) - r;
 		float dist1 = (o[1] + param * o[4]) - g;
 		float dist2 = (o[2] + param * o[5]) - b;
-		c.tsc(1)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+		c.tsc_f(1)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
 
 		param = r * o[6] + g * o[7] + b * o[8];
 		dist0 = (param * o[6]) - r;
 		dist1 = (param * o[7]) - g;
 		dist2 = (param * o[8]) - b;
-		c.tsc(2)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+		c.tsc_f(2)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
 
 		const float u = 0.577350258827209473f;
 		param = r * u + g * u + b * u;
 		dist0 = (o[9] + param * u) - r;
 		dist1 = (o[10] + param * u) - g;
 		dist2 = (o[11] + param * u) - b;
-		c.tsc(3)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+		c.tsc_f(3)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
 
 		dist0 = (param * u) - r;
 		dist1 = (param * u) - g;
 		dist2 = (param * u) - b;
-		c.tsc(4)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
+		c.tsc_f(4)[i] = dist0 * dist0 * ew0 + dist1 * dist1 * ew1 + dist2 * dist2 * ew2;
 	}
 	WV_SYNC();
 
 	WV_FOR(k, pc * 5)
 	{
 		int p = k / 5, which = k % 5;
-		tr.fbox[64 - 20 + k] = sum4(c.tsc(which) + pv.offset[p], pv.count[p]);
+		tr.fbox[64 - 20 + k] = sum4(c.tsc_f(which) + pv.offset[p], pv.count[p]);
 	}
 	WV_SYNC();
 
@@ -193,15 +217,15 @@ WV_FN float baseline_quant_error(int i /* quant - QUANT_6 */)
 
 /* One (partition, quant level) cell of the table. (ref: :315-665) */
 WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, int i,
-                                       const float* ep0p, const float* ep1p, FmtScratch& fs)
+                                       const float* ep0p, const float* ep1p, const FmtView& fs)
 {
 	const TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	bool encode_hdr_rgb = kHdr && blk.rgb_lns != 0;
 	bool encode_hdr_alpha = kHdr && blk.alpha_lns != 0;
 	int partition_size = pv.count[p];
-	float* best_error = fs.best_error[p][i];
-	uint8_t* fmt = fs.format_of_choice[p][i];
+	float* best_error = fs.best_error(p, i);
+	uint8_t* fmt = fs.format_of_choice(p, i);
 
 	f4 ep0 = load4(ep0p), ep1 = load4(ep1p);
 	f4 ew = load4(blk.cw);
@@ -363,10 +387,10 @@ WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, 
 }
 
 /* Combine the per-partition tables for one quant level (ref: :728-766, :842-891, :967-1027). */
-WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
+WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 {
 	const int ncols = pc == 2 ? 7 : pc == 3 ? 10 : 13;
-	for (int j = 0; j < ncols; j++) fs.comb_error[quant][j] = ERROR_CALC_DEFAULT;
+	for (int j = 0; j < ncols; j++) fs.comb_error(quant)[j] = ERROR_CALC_DEFAULT;
 	if (quant < QUANT_6) return;
 
 	for (int i = 0; i < 4; i++)
@@ -378,12 +402,12 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
 			if (pc == 2)
 			{
 				int intcnt = i + j;
-				float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j], 1e10f);
-				if (errorterm <= fs.comb_error[quant][intcnt])
+				float errorterm = f_min(fs.best_error(0, quant)[i] + fs.best_error(1, quant)[j], 1e10f);
+				if (errorterm <= fs.comb_error(quant)[intcnt])
 				{
-					fs.comb_error[quant][intcnt] = errorterm;
-					fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
-					fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
+					fs.comb_error(quant)[intcnt] = errorterm;
+					fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
+					fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
 				}
 				continue;
 			}
@@ -394,13 +418,13 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
 				if (pc == 3)
 				{
 					int intcnt = i + j + k;
-					float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j] + fs.best_error[2][quant][k], 1e10f);
-					if (errorterm <= fs.comb_error[quant][intcnt])
+					float errorterm = f_min(fs.best_error(0, quant)[i] + fs.best_error(1, quant)[j] + fs.best_error(2, quant)[k], 1e10f);
+					if (errorterm <= fs.comb_error(quant)[intcnt])
 					{
-						fs.comb_error[quant][intcnt] = errorterm;
-						fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
-						fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
-						fs.comb_format[quant][intcnt][2] = fs.format_of_choice[2][quant][k];
+						fs.comb_error(quant)[intcnt] = errorterm;
+						fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
+						fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
+						fs.comb_format(quant, intcnt)[2] = fs.format_of_choice(2, quant)[k];
 					}
 					continue;
 				}
@@ -409,14 +433,14 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
 					int low4 = i_min(l, low3), high4 = i_max(l, high3);
 					if ((high4 - low4) > 1) continue;
 					int intcnt = i + j + k + l;
-					float errorterm = f_min(fs.best_error[0][quant][i] + fs.best_error[1][quant][j] + fs.best_error[2][quant][k] + fs.best_error[3][quant][l], 1e10f);
-					if (errorterm <= fs.comb_error[quant][intcnt])
+					float errorterm = f_min(fs.best_error(0, quant)[i] + fs.best_error(1, quant)[j] + fs.best_error(2, quant)[k] + fs.best_error(3, quant)[l], 1e10f);
+					if (errorterm <= fs.comb_error(quant)[intcnt])
 					{
-						fs.comb_error[quant][intcnt] = errorterm;
-						fs.comb_format[quant][intcnt][0] = fs.format_of_choice[0][quant][i];
-						fs.comb_format[quant][intcnt][1] = fs.format_of_choice[1][quant][j];
-						fs.comb_format[quant][intcnt][2] = fs.format_of_choice[2][quant][k];
-						fs.comb_format[quant][intcnt][3] = fs.format_of_choice[3][quant][l];
+						fs.comb_error(quant)[intcnt] = errorterm;
+						fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
+						fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
+						fs.comb_format(quant, intcnt)[2] = fs.format_of_choice(2, quant)[k];
+						fs.comb_format(quant, intcnt)[3] = fs.format_of_choice(3, quant)[l];
 					}
 				}
 			}
@@ -426,7 +450,7 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, FmtScratch& fs)
 
 /* Best (quant level, formats) for one block mode's colour bit budget. (ref: :678-718, :780-832,
  * :905-957, :1041-1093) */
-WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch& fs, int bits_available, ModeRec& m)
+WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available, ModeRec& m)
 {
 	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.tab + c.root->off_quant_mode_table);
 	float best_integer_count_error = ERROR_CALC_DEFAULT;
@@ -438,7 +462,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch
 		{
 			int quant_level = qmt[integer_count * 128 + bits_available];
 			if (quant_level < QUANT_6) continue;
-			float e = fs.best_error[0][quant_level][integer_count - 1];
+			float e = fs.best_error(0, quant_level)[integer_count - 1];
 			if (e < best_integer_count_error)
 			{
 				best_integer_count_error = e;
@@ -449,7 +473,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch
 		m.quant_level = (uint8_t)ql;
 		m.quant_level_mod = (uint8_t)ql;
 		m.formats[0] = FMT_LUMINANCE;
-		if (ql >= QUANT_6) m.formats[0] = fs.format_of_choice[0][ql][best_integer_count];
+		if (ql >= QUANT_6) m.formats[0] = fs.format_of_choice(0, ql)[best_integer_count];
 		return best_integer_count_error;
 	}
 
@@ -461,7 +485,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch
 	{
 		int quant_level = qmt[integer_count * 128 + bits_available];
 		if (quant_level < QUANT_6) break;
-		float e = fs.comb_error[quant_level][integer_count - lo];
+		float e = fs.comb_error(quant_level)[integer_count - lo];
 		if (e < best_integer_count_error)
 		{
 			best_integer_count_error = e;
@@ -474,7 +498,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtScratch
 	m.quant_level_mod = (uint8_t)ql_mod;
 	for (int i = 0; i < pc; i++)
 	{
-		m.formats[i] = ql >= QUANT_6 ? fs.comb_format[ql][best_integer_count - lo][i] : (uint8_t)FMT_LUMINANCE;
+		m.formats[i] = ql >= QUANT_6 ? fs.comb_format(ql, best_integer_count - lo)[i] : (uint8_t)FMT_LUMINANCE;
 	}
 	return best_integer_count_error;
 }
@@ -494,21 +518,21 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 {
 	TrialInfo& tr = c.tr();
 	const int pc = pv.pcount;
-	FmtScratch& fs = *reinterpret_cast<FmtScratch*>(c.fmt());
+	const FmtView fs = fmt_view(c);
 	ModeRec* modes = c.modes();
 
 	compute_encoding_choice_errors(c, pv, ep0, ep1);
 
-	WV_FOR(k, pc * 21)
+	WV_FOR(k, pc * (int)FMT_QUANT_ROWS)
 	{
-		int p = k / 21, i = k % 21;
+		int p = k / (int)FMT_QUANT_ROWS, i = k % (int)FMT_QUANT_ROWS + QUANT_6;
 		color_error_for_quant_level(c, pv, p, i, ep0[p], ep1[p], fs);
 	}
 	WV_SYNC();
 
 	if (pc >= 2)
 	{
-		WV_FOR(q, 21) { combine_partitions_for_quant(pc, q, fs); }
+		WV_FOR(q, (int)FMT_QUANT_ROWS) { combine_partitions_for_quant(pc, q + QUANT_6, fs); }
 		WV_SYNC();
 	}
 

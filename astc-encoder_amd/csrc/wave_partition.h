@@ -74,8 +74,8 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
-	float* dist = c.tsc(0);
-	float* assign = c.tsc(1);          // partition of texel, as float
+	float* dist = c.tsc_p(0);
+	float* assign = c.tsc_p(1);          // partition of texel, as float
 	const f4 cw = load4(blk.cw);
 	float* centers = &tr.fbox[0];      // [4][4]
 

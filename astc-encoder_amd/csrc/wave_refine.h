@@ -93,7 +93,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T, pc = pv.pcount;
-	float* undec = c.tsc(0);
+	float* undec = c.tsc_r(0);
 	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec);
 
 	// pass 1: weighted partition colour sum -> scale direction (ref: :1198-1219)
@@ -265,8 +265,8 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
-	float* undec1 = c.tsc(0);
-	float* undec2 = c.tsc(1);
+	float* undec1 = c.tsc_r(0);
+	float* undec2 = c.tsc_r(1);
 	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec1);
 	expand_weights(c, di, c.wscb().weights + PLANE2_OFFSET, c.wsc(1), undec2);
 
@@ -469,8 +469,8 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	}
 	WV_SYNC();
 
-	float* term = c.tsc(2);
-	float* flag = c.tsc(3);
+	float* term = c.tsc_r(2);
+	float* flag = c.tsc_r(3);
 	WV_FOR(i, T)
 	{
 		// 1-plane multi-partition sums in partition order, the other two in texel order
@@ -587,7 +587,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 		if (!decimated)
 		{
-			float* moved = c.tsc(4);
+			float* moved = c.tsc_r(4);
 			WV_FOR(texel, T)
 			{
 				int uqw = uq[texel];
@@ -639,7 +639,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
 			float* uqf = c.wsc(2);
-			float* rt = c.tsc_base();
+			float* rt = c.tsc_r_base();
 			const int rs = ((int)c.root->max_weight_texel_rows + 3) & ~3;
 
 			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }

@@ -25,89 +25,8 @@ WV_FN float infill2(const float* wts, const uint8_t* tw, const float* tcf, int T
 	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]);
 }
 
-/* Ideal weights of plane `plane` on decimation grid `dm` -> out[0..W). */
-WV_FN void ideal_weights_for_decimation(const Ctx& c, int plane, int dm, float* out)
-{
-	const DecimationInfo& di = c.dec_info(dm);
-	const int T = di.texel_count, W = di.weight_count;
-	const float* eiw = c.ei_w(plane);
-	const float* eiwes = c.ei_wes(plane);
-
-	if (T == W)
-	{
-		WV_FOR(i, T) { out[i] = eiw[i]; }
-		WV_SYNC();
-		return;
-	}
-
-	const uint8_t* wtc = c.tab + di.off_weight_texel_count;
-	const uint8_t* wt = c.tab + di.off_weight_texels;
-	const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
-	const uint8_t* tw = c.tab + di.off_texel_weights;
-	const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
-	const float wes0 = eiwes[0];
-	float* infilled = c.tsc(0);
-
-	// initial guess: error-weighted average of the texels each weight touches (ref: :877-905)
-	WV_FOR(i, W)
-	{
-		float weight_weight = 1e-10f;
-		float initial_weight = 0.0f;
-		int cnt = wtc[i];
-		#pragma unroll 4
-		for (int j = 0; j < cnt; j++)
-		{
-			int texel = wt[j * W + i];
-			float weight = wc[j * W + i];
-			float wes = constant_wes ? wes0 : eiwes[texel];
-			float contrib_weight = weight * wes;
-			weight_weight += contrib_weight;
-			initial_weight += eiw[texel] * contrib_weight;
-		}
-		out[i] = initial_weight / weight_weight;
-	}
-	WV_SYNC();
-
-	// infill to texel resolution (ref: :910-926)
-	if (di.max_texel_weight_count <= 2)
-	{
-		WV_FOR(t, T) { infilled[t] = infill2(out, tw, tcf, T, t); }
-	}
-	else
-	{
-		WV_FOR(t, T) { infilled[t] = infill4(out, tw, tcf, T, t); }
-	}
-	WV_SYNC();
-
-	// one clamped gradient step (ref: :930-970)
-	WV_FOR(i, W)
-	{
-		float weight_val = out[i];
-		float error_change0 = 1e-10f;
-		float error_change1 = 0.0f;
-		int cnt = wtc[i];
-		#pragma unroll 4
-		for (int j = 0; j < cnt; j++)
-		{
-			int texel = wt[j * W + i];
-			float contrib_weight = wc[j * W + i];
-			float wes = constant_wes ? wes0 : eiwes[texel];
-			float scale = wes * contrib_weight;
-			float old_weight = infilled[texel];
-			float ideal_weight = eiw[texel];
-			error_change0 += contrib_weight * scale;
-			error_change1 += (old_weight - ideal_weight) * scale;
-		}
-		float step = (error_change1 * -16.0f) / error_change0;
-		step = v_clamp(-0.25f, 0.25f, step);
-		out[i] = weight_val + step;
-	}
-	WV_SYNC();
-}
-
 /* Ideal weights on ALL referenced grids of a trial in three lane-parallel sweeps instead of three
- * per grid (same arithmetic as ideal_weights_for_decimation above).
+ * per grid.
  *   nplanes        : 1 or 2 weight planes in this trial
  *   ref_mask       : quant levels allowed in this trial (grid is used if refprec & ref_mask)
  *   max_dm         : grids [0, max_dm) are considered
