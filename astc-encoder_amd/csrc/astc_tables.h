@@ -61,9 +61,12 @@ struct DecimationMode {
 	int8_t   maxprec_2planes;
 	uint16_t refprec_1plane;
 	uint16_t refprec_2planes;
-	// LDS slots of this grid's per-trial results (planes that the grid cannot encode get no slot)
-	uint16_t dwi_offset[2];      // float offset of the ideal weights of plane 0 / 1 in the packed dwi region
-	uint8_t  lowhigh_slot[2];    // 16-float slot of the angular low/high bounds of plane 0 / 1
+	// LDS slots of this grid's per-trial results.  1-plane and 2-plane trials never run at the same
+	// time, so each trial class has its own dense packing: slot 0 = the plane of a 1-plane trial,
+	// slots 1 / 2 = plane 0 / 1 of a 2-plane trial.  A grid the class cannot use gets a zero-length
+	// slot at the running offset (so [offset(dm0), offset(dm1)) is always the range of grids dm0..dm1-1).
+	uint16_t dwi_offset[3];      // float offset of the ideal weights in the packed dwi region
+	uint16_t lowhigh_offset[3];  // float offset of the angular (low, high) pairs, one per quant level 0..min(maxprec, 7)
 };
 
 // Bilinear-infill tables of one weight grid. (ref: struct decimation_info :347)
@@ -130,9 +133,9 @@ struct TableRoot {
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
-	uint32_t dwi_total_floats;                // size of the packed ideal-weight region
-	uint32_t off_dwi_owner;                   // u16[dwi_total_floats]: (decimation mode << 1) | plane owning each packed slot
-	uint32_t lowhigh_slots;                   // number of 16-float low/high slots
+	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]
+	uint32_t off_dwi_owner[2];                // u16[dwi_total_floats[class]]: (decimation mode << 1) | plane owning each packed slot
+	uint32_t lowhigh_floats[2];               // size of the packed low/high region per trial class
 	uint32_t max_partitionings;               // largest partitioning_count_selected[1..3]
 	uint32_t total_bytes;
 };

@@ -686,19 +686,31 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	}
 	if (bm_counts[0] == 0 || dms.empty()) return false;
 
-	// packed LDS slots for the per-trial ideal weights and angular bounds of each grid
-	uint32_t dwi_total = 0, lh_slots = 0, max_rows_unused = 0;
-	(void)max_rows_unused;
+	// packed LDS slots for the per-trial ideal weights and angular bounds of each grid, one dense
+	// packing per trial class (see DecimationMode)
+	uint32_t dwi_total[2] = { 0, 0 }, lh_total[2] = { 0, 0 };
 	for (size_t i = 0; i < dms.size(); i++)
 	{
 		uint32_t wc = dm_grid[i].first * dm_grid[i].second;
 		uint32_t wc4 = (wc + 3u) & ~3u;
-		dms[i].dwi_offset[0] = (uint16_t)dwi_total; dwi_total += wc4;
-		dms[i].lowhigh_slot[0] = (uint8_t)lh_slots++;
-		if (dms[i].maxprec_2planes >= 0)
+		// 1-plane trials
+		dms[i].dwi_offset[0] = (uint16_t)dwi_total[0];
+		dms[i].lowhigh_offset[0] = (uint16_t)lh_total[0];
+		if (dms[i].refprec_1plane != 0)
 		{
-			dms[i].dwi_offset[1] = (uint16_t)dwi_total; dwi_total += wc4;
-			dms[i].lowhigh_slot[1] = (uint8_t)lh_slots++;
+			dwi_total[0] += wc4;
+			lh_total[0] += 2u * (uint32_t)(std::min<int>(dms[i].maxprec_1plane, 7) + 1);
+		}
+		// 2-plane trials
+		for (int plane = 0; plane < 2; plane++)
+		{
+			dms[i].dwi_offset[1 + plane] = (uint16_t)dwi_total[1];
+			dms[i].lowhigh_offset[1 + plane] = (uint16_t)lh_total[1];
+			if (dms[i].refprec_2planes != 0)
+			{
+				dwi_total[1] += wc4;
+				lh_total[1] += 2u * (uint32_t)(std::min<int>(dms[i].maxprec_2planes, 7) + 1);
+			}
 		}
 	}
 
@@ -799,15 +811,19 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	}
 
 	// owner of every packed ideal-weight slot (lets one lane-parallel loop cover all grids)
-	uint32_t off_owner = blob.alloc(std::max<uint32_t>(dwi_total, 1) * sizeof(uint16_t));
+	uint32_t off_owner[2];
+	for (int cls = 0; cls < 2; cls++)
 	{
-		uint16_t* own = blob.at<uint16_t>(off_owner);
+		off_owner[cls] = blob.alloc(std::max<uint32_t>(dwi_total[cls], 1) * sizeof(uint16_t));
+		uint16_t* own = blob.at<uint16_t>(off_owner[cls]);
 		for (size_t i = 0; i < dms.size(); i++)
 		{
 			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
-			for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[0] + k] = (uint16_t)(i << 1);
-			if (dms[i].maxprec_2planes >= 0)
-				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[1] + k] = (uint16_t)((i << 1) | 1);
+			if (cls == 0 && dms[i].refprec_1plane != 0)
+				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[0] + k] = (uint16_t)(i << 1);
+			if (cls == 1 && dms[i].refprec_2planes != 0)
+				for (int plane = 0; plane < 2; plane++)
+					for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[1 + plane] + k] = (uint16_t)((i << 1) | (unsigned)plane);
 		}
 	}
 
@@ -875,9 +891,12 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		uint32_t mr = 0;
 		for (size_t i = 0; i < dms.size(); i++) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
 		r->max_weight_texel_rows = mr;
-		r->dwi_total_floats = dwi_total;
-		r->off_dwi_owner = off_owner;
-		r->lowhigh_slots = lh_slots;
+		for (int cls = 0; cls < 2; cls++)
+		{
+			r->dwi_total_floats[cls] = dwi_total[cls];
+			r->off_dwi_owner[cls] = off_owner[cls];
+			r->lowhigh_floats[cls] = lh_total[cls];
+		}
 		r->max_partitionings = std::max(pcounts[1], std::max(pcounts[2], pcounts[3]));
 	}
 	blob.alloc(0, 256);

@@ -31,7 +31,7 @@ WV_FN void mode_weight_bounds(const Ctx& c, const BlockMode& bm, int plane, floa
 {
 	if (bm.quant_mode <= MAX_ANGULAR_QUANT)
 	{
-		const float* lh = c.lowhigh(plane, bm.decimation_mode);
+		const float* lh = c.lowhigh(plane, bm.decimation_mode, bm.is_dual_plane != 0);
 		low = lh[bm.quant_mode * 2];
 		high = lh[bm.quant_mode * 2 + 1];
 	}
@@ -54,7 +54,7 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 	mode_weight_bounds(c, bm, plane, low, high);
 	QuantParams qp = quant_params(low, high, bm.quant_mode);
 	const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
-	const float* ideal = c.dwi(bm.decimation_mode, plane);
+	const float* ideal = c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0);
 	WV_FOR(i, di.weight_count)
 	{
 		float f;
@@ -73,7 +73,7 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
  * per mode run the reference's 4 interleaved accumulators over the terms in texel order. */
 WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
 {
-	ModeRec* modes = c.modes();
+	ModeRec* modes = c.modes(start);
 	const int T = c.T, Tp = c.Tp;
 	float* buf = c.uni_f();
 	const int chunk_modes = (int)(c.L.uni_bytes / 4) / Tp;
@@ -103,7 +103,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 					float low, high;
 					mode_weight_bounds(c, bm, plane, low, high);
 					QuantParams qp = quant_params(low, high, bm.quant_mode);
-					const float* ideal = c.dwi(bm.decimation_mode, plane);
+					const float* ideal = c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0);
 					float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 					float current;
 					if (taps == 1)
@@ -145,7 +145,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			const BlockMode& bm = c.block_mode(first + m);
 			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
 			const float* v = buf + m * Tp;
-			modes[first + m].qwt_error = valid ? (v[0] + v[2]) + (v[1] + v[3]) : 1e38f;
+			modes[first + m].error = valid ? (v[0] + v[2]) + (v[1] + v[3]) : 1e38f;
 		}
 		WV_SYNC();
 	}
@@ -395,8 +395,8 @@ WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_err
 			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
 			max_precision = i_min(max_precision, max_weight_quant);
 			AngSet a;
-			a.weights = c.dwi(dm, 0);
-			a.out = c.lowhigh(0, dm);
+			a.weights = c.dwi(dm, 0, false);
+			a.out = c.lowhigh(0, dm, false);
 			a.wcount = c.dec_info(dm).weight_count;
 			a.maxq = max_precision;
 			return a;
@@ -474,8 +474,8 @@ WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, 
 			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
 			max_precision = i_min(max_precision, max_weight_quant);
 			AngSet a;
-			a.weights = c.dwi(dm, plane);
-			a.out = c.lowhigh(plane, dm);
+			a.weights = c.dwi(dm, plane, true);
+			a.out = c.lowhigh(plane, dm, true);
 			a.wcount = c.dec_info(dm).weight_count;
 			a.maxq = max_precision;
 			return a;

@@ -77,8 +77,7 @@ struct TrialInfo {
 
 /* Per block mode record of one trial. */
 struct ModeRec {
-	float qwt_error;
-	float total_error;        // errors_of_best_combination
+	float error;              // weight quantization error, then (in place) + error of the best colour combination
 	uint8_t quant_level;
 	uint8_t quant_level_mod;
 	uint8_t formats[4];
@@ -155,9 +154,12 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 
 	const uint32_t begin = o;
 	// search phase
-	L.dwi = take(r.dwi_total_floats * 4);
-	L.lowhigh = take(r.lowhigh_slots * 16 * 4);
-	L.modes = take(nbm * sizeof(ModeRec));
+	// one trial is either 1-plane or 2-plane: size for the larger class
+	uint32_t nbm1 = r.block_mode_count_1plane_selected;
+	uint32_t nbm_max = nbm1 > nbm - nbm1 ? nbm1 : nbm - nbm1;
+	L.dwi = take((r.dwi_total_floats[0] > r.dwi_total_floats[1] ? r.dwi_total_floats[0] : r.dwi_total_floats[1]) * 4);
+	L.lowhigh = take((r.lowhigh_floats[0] > r.lowhigh_floats[1] ? r.lowhigh_floats[0] : r.lowhigh_floats[1]) * 4);
+	L.modes = take(nbm_max * sizeof(ModeRec));
 	L.uni_bytes = 64 * 8 * 4;                                     // angular batch
 	if (fmt_scratch_bytes(cfg.tune_partition_count_limit) > L.uni_bytes) L.uni_bytes = fmt_scratch_bytes(cfg.tune_partition_count_limit);
 	if (5 * Tp * 4 > L.uni_bytes) L.uni_bytes = 5 * Tp * 4;       // encoding-choice rows
@@ -211,11 +213,13 @@ struct Ctx {
 	WV_FN TrialInfo& tr() const { return *reinterpret_cast<TrialInfo*>(lds + L.trial); }
 	WV_FN float* ei_w(int plane) const { return reinterpret_cast<float*>(lds + L.ei_w) + plane * Tp; }
 	WV_FN float* ei_wes(int plane) const { return reinterpret_cast<float*>(lds + L.ei_wes) + plane * Tp; }
-	WV_FN float* dwi(int dm, int plane) const { return reinterpret_cast<float*>(lds + L.dwi) + dec_mode(dm).dwi_offset[plane]; }
-	WV_FN float* lowhigh(int plane, int dm) const { return reinterpret_cast<float*>(lds + L.lowhigh) + dec_mode(dm).lowhigh_slot[plane] * 16; }
+	// per-grid results of the current trial; `dual` = the trial has two weight planes
+	WV_FN float* dwi(int dm, int plane, bool dual) const { return reinterpret_cast<float*>(lds + L.dwi) + dec_mode(dm).dwi_offset[dual ? 1 + plane : 0]; }
+	WV_FN float* lowhigh(int plane, int dm, bool dual) const { return reinterpret_cast<float*>(lds + L.lowhigh) + dec_mode(dm).lowhigh_offset[dual ? 1 + plane : 0]; }
 	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.uni); }
 	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L.uni); }
-	WV_FN ModeRec* modes() const { return reinterpret_cast<ModeRec*>(lds + L.modes); }
+	// records of the block modes [first, ...) scored by the current trial; index with the packed mode index
+	WV_FN ModeRec* modes(int first) const { return reinterpret_cast<ModeRec*>(lds + L.modes) - first; }
 	// texel-length scratch rows; one set per phase because the phases' regions alias each other
 	WV_FN float* tsc_f(int row) const { return reinterpret_cast<float*>(lds + L.uni) + row * L.tsc_stride; }      // format search
 	WV_FN float* tsc_r(int row) const { return reinterpret_cast<float*>(lds + L.tsc_r) + row * L.tsc_stride; }    // refinement

@@ -519,7 +519,7 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	TrialInfo& tr = c.tr();
 	const int pc = pv.pcount;
 	const FmtView fs = fmt_view(c);
-	ModeRec* modes = c.modes();
+	ModeRec* modes = c.modes(start_block_mode);
 
 	compute_encoding_choice_errors(c, pv, ep0, ep1);
 
@@ -539,15 +539,15 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	WV_FOR(i, end_block_mode - start_block_mode)
 	{
 		ModeRec& m = modes[start_block_mode + i];
-		if (m.qwt_error >= ERROR_CALC_DEFAULT)
+		if (m.error >= ERROR_CALC_DEFAULT)
 		{
-			m.total_error = ERROR_CALC_DEFAULT;
+			m.error = ERROR_CALC_DEFAULT;
 		}
 		else
 		{
 			int bitcount = mode_bitcount(pc, c.block_mode(start_block_mode + i));
 			float error_of_best = best_combination_for_bitcount(c, pc, fs, bitcount, m);
-			m.total_error = error_of_best + m.qwt_error;
+			m.error = error_of_best + m.error;
 		}
 	}
 	WV_SYNC();
@@ -557,7 +557,7 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	int count = 0;
 	for (int n = 0; n < limit; n++)
 	{
-		int best = wave_argmin(c, start_block_mode, end_block_mode, [&](int i) { return modes[i].total_error; });
+		int best = wave_argmin(c, start_block_mode, end_block_mode, [&](int i) { return modes[i].error; });
 		if (best < 0) break;
 		WV_SYNC();
 		WV_ONE
@@ -566,7 +566,7 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 			tr.cand_quant[n] = modes[best].quant_level;
 			tr.cand_quant_mod[n] = modes[best].quant_level_mod;
 			for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = modes[best].formats[j];
-			modes[best].total_error = ERROR_CALC_DEFAULT;
+			modes[best].error = ERROR_CALC_DEFAULT;
 		}
 		WV_SYNC();
 		count++;

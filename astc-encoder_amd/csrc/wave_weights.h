@@ -35,7 +35,8 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 {
 	const TableRoot& r = *c.root;
 	const int T = c.T, Tp = c.Tp;
-	const uint16_t* owner = reinterpret_cast<const uint16_t*>(c.tab + r.off_dwi_owner);
+	const int cls = nplanes == 2 ? 1 : 0;          // trial class: selects the packing of the dwi region
+	const uint16_t* owner = reinterpret_cast<const uint16_t*>(c.tab + r.off_dwi_owner[cls]);
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L.dwi);
 	float* infilled = c.uni_f();
 	const int cap_sets = (int)(c.L.uni_bytes / 4) / Tp;
@@ -47,13 +48,13 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	};
 
 	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
-	WV_FOR(k, (int)r.dwi_total_floats)
+	WV_FOR(k, (int)r.dwi_total_floats[cls])
 	{
 		int dm = owner[k] >> 1, plane = owner[k] & 1;
 		if (!grid_used(dm, plane)) continue;
 		const DecimationInfo& di = c.dec_info(dm);
 		const int W = di.weight_count;
-		int i = k - c.dec_mode(dm).dwi_offset[plane];
+		int i = k - c.dec_mode(dm).dwi_offset[cls + plane];
 		if (i >= W) continue;
 		const float* eiw = c.ei_w(plane);
 		const float* eiwes = c.ei_wes(plane);
@@ -102,14 +103,14 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			if (di.texel_count == di.weight_count) continue;
 			const uint8_t* tw = c.tab + di.off_texel_weights;
 			const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-			const float* wts = dwi_base + c.dec_mode(dm).dwi_offset[plane];
+			const float* wts = dwi_base + c.dec_mode(dm).dwi_offset[cls + plane];
 			infilled[set * Tp + t] = di.max_texel_weight_count <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
 		}
 		WV_SYNC();
 
 		// sweep 3: one clamped gradient step (ref: :930-970)
-		const int k_begin = c.dec_mode(dm0).dwi_offset[0];
-		const int k_end = dm1 < (int)r.decimation_mode_count_selected ? (int)c.dec_mode(dm1).dwi_offset[0] : (int)r.dwi_total_floats;
+		const int k_begin = c.dec_mode(dm0).dwi_offset[cls];
+		const int k_end = dm1 < (int)r.decimation_mode_count_selected ? (int)c.dec_mode(dm1).dwi_offset[cls] : (int)r.dwi_total_floats[cls];
 		WV_FOR(kk, k_end - k_begin)
 		{
 			int k = k_begin + kk;
@@ -117,7 +118,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			if (!grid_used(dm, plane)) continue;
 			const DecimationInfo& di = c.dec_info(dm);
 			const int W = di.weight_count;
-			int i = k - c.dec_mode(dm).dwi_offset[plane];
+			int i = k - c.dec_mode(dm).dwi_offset[cls + plane];
 			if (i >= W || di.texel_count == W) continue;
 			const float* eiw = c.ei_w(plane);
 			const float* eiwes = c.ei_wes(plane);
