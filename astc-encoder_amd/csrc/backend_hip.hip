@@ -66,9 +66,9 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
-	enum { PS_COUNT = 16, PS_TOTAL = 14 };
-	HIP_TRY(hipMalloc(&b->d_prof, PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
-	HIP_TRY(hipMemset(b->d_prof, 0, PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
+	enum { PS_COUNT = 32, PS_TOTAL = 14 };
+	HIP_TRY(hipMalloc(&b->d_prof, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
+	HIP_TRY(hipMemset(b->d_prof, 0, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
 #endif
 	*status = 0;
 	return b;
@@ -168,15 +168,20 @@ int backend_compress(Backend* b, const CompressJob& job)
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
 #if defined(ASTC_PROFILE)
 	{
-		enum { PS_COUNT = 16, PS_TOTAL = 14 };
+		enum { PS_COUNT = 32, PS_TOTAL = 14 };
 		static const char* names[PS_COUNT] = { "load", "ideal", "decimate", "angular", "modes", "formats", "recompute", "pack", "diff",
-		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks" };
-		unsigned long long h[PS_COUNT];
+		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks",
+		                                        "  dec sweep1", "  dec infill", "  dec sweep3", "  ang phase1", "  ang phase2",
+		                                        "  mode terms", "  mode acc", "  mode quant", "  fmt eci", "  fmt table", "  fmt combine", "  fmt select",
+		                                        "  x0", "  x1", "  x2", "  x3" };
+		unsigned long long h[2 * PS_COUNT];
 		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
 		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);
-		fprintf(stderr, "stage cycles per block (lane-0 shader clock), %zu blocks:\n", nblocks);
-		for (int i = 0; i < PS_COUNT - 1; i++)
-			fprintf(stderr, "  %-18s %12.0f  %5.1f%%\n", names[i], (double)h[i] / (double)nblocks, 100.0 * (double)h[i] / (double)h[PS_TOTAL]);
+		fprintf(stderr, "stage cycles per block (lane-0 shader clock), %zu blocks:   [calls per block]\n", nblocks);
+		for (int i = 0; i < PS_COUNT; i++)
+			if (i != 15 && h[i])
+				fprintf(stderr, "  %-18s %12.0f  %5.1f%%   [%6.2f]\n", names[i], (double)h[i] / (double)nblocks, 100.0 * (double)h[i] / (double)h[PS_TOTAL],
+				        (double)h[PS_COUNT + i] / (double)nblocks);
 	}
 #endif
 	return 0;

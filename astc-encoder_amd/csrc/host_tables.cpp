@@ -875,6 +875,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	r->off_block_modes = off_bm;
 	r->off_decimation_modes = off_dm;
 	r->off_decimation_infos = off_di;
+	r->meta_bytes = (uint32_t)(off_di + dms.size() * sizeof(DecimationInfo)) - off_bm;
 	r->off_kmeans_texels = off_km;
 	r->off_color_unquant_to_uquant = off_cq;
 	r->off_color_uquant_to_pquant = off_cp;
@@ -891,6 +892,13 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		uint32_t mr = 0;
 		for (size_t i = 0; i < dms.size(); i++) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
 		r->max_weight_texel_rows = mr;
+		r->max_weights[0] = r->max_weights[1] = 1;
+		for (size_t i = 0; i < dms.size(); i++)
+		{
+			uint32_t wc = dm_grid[i].first * dm_grid[i].second;
+			if (dms[i].refprec_1plane != 0) r->max_weights[0] = std::max(r->max_weights[0], wc);
+			if (dms[i].refprec_2planes != 0) r->max_weights[1] = std::max(r->max_weights[1], wc);
+		}
 		for (int cls = 0; cls < 2; cls++)
 		{
 			r->dwi_total_floats[cls] = dwi_total[cls];

@@ -47,6 +47,9 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L,
 	c.prof = prof;
 
 	PROF_SCOPE(c, PS_TOTAL);
+#if defined(ASTC_META_LDS)
+	stage_words(lds + L.meta, tab + c.root->off_block_modes, (int)(c.root->meta_bytes / 4));
+#endif
 	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
 	compress_block(c, out + (size_t)b * 16);
 }

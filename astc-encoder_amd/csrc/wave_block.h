@@ -64,72 +64,154 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 	}
 }
 
+/* Per-mode records of one scoring chunk, built once by one lane per (mode, plane) so that the
+ * (mode, texel) sweep reads them with a single LDS access instead of chasing
+ * block mode -> decimation info -> table pointers through global memory in every lane. */
+struct ModeHdr { uint32_t tw_off, tcf_off; int32_t taps; int32_t valid; };
+struct ModeQ { float scale, scaled_low_bound, quant_level_m1, rscale, low_bound; int32_t steps_m1; uint32_t q2u_off; uint32_t dwi_off; };
+static_assert(sizeof(ModeHdr) + 2 * sizeof(ModeQ) == MODE_DESC_BYTES, "mode descriptor size");
+
+WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* quant_to_unquant, float ideal)
+{
+	// same arithmetic as quantize_weight() (ref: compute_quantized_weights_for_decimation :974)
+	float ix = ideal * q.scale - q.scaled_low_bound;
+	ix = v_clampzo(ix);
+	float ix1 = ix * q.quant_level_m1;
+	int weightl = (int)ix1;
+	int weighth = i_min(weightl + 1, q.steps_m1);
+	float ixl = (float)(int)quant_to_unquant[weightl];
+	float ixh = (float)(int)quant_to_unquant[weighth];
+	bool mask = (ixl + ixh) < (128.0f * ix);
+	ixl = mask ? ixh : ixl;
+	return ixl * q.rscale + q.low_bound;
+}
+
 /* Quantize-and-score every block mode in [start, end) (ref: compress_symbolic.cpp:438-485 / :806-860 with
  * compute_quantized_weights_for_decimation + compute_error_of_weight_set_{1plane,2planes}).
  *
  * The reference walks the modes one by one.  Here a chunk of modes is scored at once: one lane per
- * (mode, texel) quantizes the <= 4 grid weights that texel interpolates (same quantize_weight() on
- * the same inputs as a per-weight pass would use) and writes the texel's error term; then four lanes
- * per mode run the reference's 4 interleaved accumulators over the terms in texel order. */
+ * (mode, plane) prepares the mode's quantization parameters; one lane per (mode, texel) quantizes the
+ * <= 4 grid weights that texel interpolates (same arithmetic on the same inputs as a per-weight pass
+ * would use) and writes the texel's error term; then four lanes per mode run the reference's 4
+ * interleaved accumulators over the terms in texel order. */
 WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
 {
 	ModeRec* modes = c.modes(start);
 	const int T = c.T, Tp = c.Tp;
-	float* buf = c.uni_f();
-	const int chunk_modes = (int)(c.L.uni_bytes / 4) / Tp;
+	const int planes = dual ? 2 : 1;
+	const int chunk_modes = (int)(c.L.uni_bytes / (MODE_DESC_BYTES + (uint32_t)Tp * 4));
+	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L.uni);
+	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L.uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
+	float* buf = reinterpret_cast<float*>(c.lds + c.L.uni + (uint32_t)chunk_modes * MODE_DESC_BYTES);
+	const float* ldsf = reinterpret_cast<const float*>(c.lds);
 	const float* eiw0 = c.ei_w(0); const float* eiwes0 = c.ei_wes(0);
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
+	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;     // k / T == (k * t_inv) >> 24 for k < 2^24 / T
 
 	for (int first = start; first < end; first += chunk_modes)
 	{
 		const int nm = i_min(chunk_modes, end - first);
 
-		WV_FOR(k, nm * T)
+		{ PROF_SCOPE(c, PS_MODE3);
+		WV_FOR(k, nm * 2)
 		{
-			int m = k / T, t = k - m * T;
+			int m = k >> 1, plane = k & 1;
 			const BlockMode& bm = c.block_mode(first + m);
 			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
-			float term = 0.0f;
-			if (valid)
+			if (plane == 0)
 			{
 				const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-				const uint8_t* tw = c.tab + di.off_texel_weights;
-				const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-				const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
 				const int mtwc = di.max_texel_weight_count;
-				const int taps = mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1;
-				for (int plane = 0; plane <= (dual ? 1 : 0); plane++)
+				ModeHdr h;
+				h.tw_off = di.off_texel_weights;
+				h.tcf_off = di.off_texel_contribs_f;
+				h.taps = mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1;
+				h.valid = valid ? 1 : 0;
+				hdr[m] = h;
+			}
+			if (valid && plane < planes)
+			{
+				float low, high;
+				mode_weight_bounds(c, bm, plane, low, high);
+				QuantParams qp = quant_params(low, high, bm.quant_mode);
+				ModeQ q;
+				q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
+				q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
+				q.q2u_off = c.root->off_quant_xfer + (uint32_t)bm.quant_mode * (uint32_t)sizeof(QuantXfer);
+				q.dwi_off = (uint32_t)(c.dwi(bm.decimation_mode, plane, dual) - ldsf);
+				mq[m * 2 + plane] = q;
+			}
+		}
+		WV_SYNC(); }
+
+		{ PROF_SCOPE(c, PS_MODE1);
+		WV_FOR(k, nm * T)
+		{
+			int m = (int)(((uint32_t)k * t_inv) >> 24), t = k - m * T;
+			const ModeHdr h = hdr[m];
+			float term = 0.0f;
+			if (h.valid)
+			{
+				const uint8_t* tw = c.tab + h.tw_off;
+				const float* tcf = reinterpret_cast<const float*>(c.tab + h.tcf_off);
+				if (h.taps == 4)
 				{
-					float low, high;
-					mode_weight_bounds(c, bm, plane, low, high);
-					QuantParams qp = quant_params(low, high, bm.quant_mode);
-					const float* ideal = c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0);
-					float v[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-					float current;
-					if (taps == 1)
+					const int i0 = tw[t], i1 = tw[T + t], i2 = tw[2 * T + t], i3 = tw[3 * T + t];
+					const float c0 = tcf[t], c1 = tcf[T + t], c2 = tcf[2 * T + t], c3 = tcf[3 * T + t];
+					for (int plane = 0; plane < planes; plane++)
 					{
-						quantize_weight(qp, q2u, ideal[t], &current);
+						const ModeQ q = mq[m * 2 + plane];
+						const float* ideal = ldsf + q.dwi_off;
+						const uint8_t* q2u = c.tab + q.q2u_off;
+						const float w0 = ideal[i0], w1 = ideal[i1], w2 = ideal[i2], w3 = ideal[i3];
+						const float v0 = quantize_weight_q(q, q2u, w0) * c0;
+						const float v1 = quantize_weight_q(q, q2u, w1) * c1;
+						const float v2 = quantize_weight_q(q, q2u, w2) * c2;
+						const float v3 = quantize_weight_q(q, q2u, w3) * c3;
+						float current = (v0 + v1) + (v2 + v3);
+						float diff = current - (plane ? eiw1[t] : eiw0[t]);
+						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
+						term = plane ? term + e : e;
 					}
-					else
+				}
+				else if (h.taps == 2)
+				{
+					const int i0 = tw[t], i1 = tw[T + t];
+					const float c0 = tcf[t], c1 = tcf[T + t];
+					for (int plane = 0; plane < planes; plane++)
 					{
-						for (int j = 0; j < taps; j++)
-						{
-							float f;
-							quantize_weight(qp, q2u, ideal[tw[j * T + t]], &f);
-							v[j] = f * tcf[j * T + t];
-						}
-						current = taps == 4 ? (v[0] + v[1]) + (v[2] + v[3]) : (v[0] + v[1]);
+						const ModeQ q = mq[m * 2 + plane];
+						const float* ideal = ldsf + q.dwi_off;
+						const uint8_t* q2u = c.tab + q.q2u_off;
+						const float w0 = ideal[i0], w1 = ideal[i1];
+						const float v0 = quantize_weight_q(q, q2u, w0) * c0;
+						const float v1 = quantize_weight_q(q, q2u, w1) * c1;
+						float current = v0 + v1;
+						float diff = current - (plane ? eiw1[t] : eiw0[t]);
+						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
+						term = plane ? term + e : e;
 					}
-					float diff = current - (plane ? eiw1[t] : eiw0[t]);
-					float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
-					term = plane ? term + e : e;
+				}
+				else
+				{
+					for (int plane = 0; plane < planes; plane++)
+					{
+						const ModeQ q = mq[m * 2 + plane];
+						const float* ideal = ldsf + q.dwi_off;
+						const uint8_t* q2u = c.tab + q.q2u_off;
+						float current = quantize_weight_q(q, q2u, ideal[t]);
+						float diff = current - (plane ? eiw1[t] : eiw0[t]);
+						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
+						term = plane ? term + e : e;
+					}
 				}
 			}
 			buf[m * Tp + t] = term;
 		}
-		WV_SYNC();
+		WV_SYNC(); }
 
 		// 4 interleaved accumulators per mode, in place (lane l only touches indices = l mod 4)
+		{ PROF_SCOPE(c, PS_MODE2);
 		WV_FOR(k, nm * 4)
 		{
 			int m = k >> 2, l = k & 3;
@@ -138,14 +220,11 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			for (int i = l; i < T; i += 4) acc += v[i];
 			v[l] = acc;
 		}
-		WV_SYNC();
+		WV_SYNC(); }
 
 		WV_FOR(m, nm)
 		{
-			const BlockMode& bm = c.block_mode(first + m);
-			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
-			const float* v = buf + m * Tp;
-			modes[first + m].error = valid ? (v[0] + v[2]) + (v[1] + v[3]) : 1e38f;
+			modes[first + m].error = hdr[m].valid ? (buf[m * Tp] + buf[m * Tp + 2]) + (buf[m * Tp + 1] + buf[m * Tp + 3]) : 1e38f;
 		}
 		WV_SYNC();
 	}

@@ -95,6 +95,7 @@ struct LdsLayout {
 	uint32_t ei_wes;     // f32 [2][Tp]    weight error scale per plane
 	uint32_t ptab;       // u8  [2][Tp]    staged partition record of the current trial
 	uint32_t candw;      // u8  [candidates][64]  quantized weights of the chosen candidates
+	uint32_t meta;       // copy of the block mode / decimation mode / decimation info records (0 = not staged)
 	// ---- phase-multiplexed region: {search | refine | partition search} never overlap in time ----
 	uint32_t dwi;        // f32 packed     search: ideal weights of every grid (DecimationMode::dwi_offset)
 	uint32_t lowhigh;    // f32 [slots][16] search: angular low/high per quant level
@@ -115,6 +116,8 @@ struct LdsLayout {
 };
 
 /* Sizes in bytes of the variable scratch regions. */
+
+constexpr uint32_t MODE_DESC_BYTES = 16 + 2 * 32;   // ModeHdr + ModeQ[2], see score_block_modes (wave_block.h)
 
 /* Endpoint-format tables of one trial (see FmtView, wave_format.h).  Only quant levels >= QUANT_6
  * (17 of the 21) are ever read, and the combined tables are as wide as the partition-count limit
@@ -151,6 +154,10 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.ptab = take(2 * Tp);
 	L.candw = take(cfg.tune_candidate_limit * 64);
 	L.tsc_stride = Tp;
+	L.meta = 0;
+#if defined(ASTC_META_LDS)
+	L.meta = take(r.meta_bytes);
+#endif
 
 	const uint32_t begin = o;
 	// search phase
@@ -161,6 +168,11 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.lowhigh = take((r.lowhigh_floats[0] > r.lowhigh_floats[1] ? r.lowhigh_floats[0] : r.lowhigh_floats[1]) * 4);
 	L.modes = take(nbm_max * sizeof(ModeRec));
 	L.uni_bytes = 64 * 8 * 4;                                     // angular batch
+	{
+		// mode scoring: per-mode descriptors + texel terms of a chunk of block modes (score_block_modes)
+		uint32_t chunk = Tp <= 36 ? 16u : 8u;
+		if (chunk * (MODE_DESC_BYTES + Tp * 4) > L.uni_bytes) L.uni_bytes = chunk * (MODE_DESC_BYTES + Tp * 4);
+	}
 	if (fmt_scratch_bytes(cfg.tune_partition_count_limit) > L.uni_bytes) L.uni_bytes = fmt_scratch_bytes(cfg.tune_partition_count_limit);
 	if (5 * Tp * 4 > L.uni_bytes) L.uni_bytes = 5 * Tp * 4;       // encoding-choice rows
 	L.uni_bytes = (L.uni_bytes + 15u) & ~15u;
@@ -232,9 +244,15 @@ struct Ctx {
 	WV_FN uint8_t* candw(int n) const { return lds + L.candw + n * 64; }
 
 	// table accessors
+#if defined(ASTC_META_LDS)
+	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(lds + L.meta)[i]; }
+	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(lds + L.meta + (root->off_decimation_modes - root->off_block_modes))[i]; }
+	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(lds + L.meta + (root->off_decimation_infos - root->off_block_modes))[i]; }
+#else
 	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }
 	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(tab + root->off_decimation_modes)[i]; }
 	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(tab + root->off_decimation_infos)[i]; }
+#endif
 	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
 	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
 };
@@ -242,12 +260,16 @@ struct Ctx {
 /* Stage timers for profiling builds (-DASTC_PROFILE): lane 0 accumulates shader-clock cycles per
  * stage into c.prof[].  Compiled out otherwise. */
 enum { PS_LOAD, PS_IDEAL, PS_DECIMATE, PS_ANGULAR, PS_MODES, PS_FORMATS, PS_RECOMPUTE, PS_PACK, PS_DIFF, PS_REALIGN,
-       PS_KMEANS, PS_PSCORE, PS_PHYSICAL, PS_STATS, PS_TOTAL, PS_BLOCKS, PS_COUNT };
+       PS_KMEANS, PS_PSCORE, PS_PHYSICAL, PS_STATS, PS_TOTAL, PS_BLOCKS,
+       // fine-grained sub-stage slots (names in backend_hip.hip)
+       PS_DEC1, PS_DEC2, PS_DEC3, PS_ANG1, PS_ANG2, PS_MODE1, PS_MODE2, PS_MODE3, PS_FMT1, PS_FMT2, PS_FMT3, PS_FMT4,
+       PS_X0, PS_X1, PS_X2, PS_X3,
+       PS_COUNT };   // slots [PS_COUNT, 2 * PS_COUNT) count how often each scope was entered
 #if defined(ASTC_PROFILE) && WV_DEVICE
 struct ProfScope {
 	unsigned long long* p; unsigned long long t0;
 	__device__ ProfScope(unsigned long long* prof, int id) : p(prof ? prof + id : nullptr), t0(__builtin_amdgcn_s_memtime()) {}
-	__device__ ~ProfScope() { if (p && threadIdx.x == 0) atomicAdd(p, __builtin_amdgcn_s_memtime() - t0); }
+	__device__ ~ProfScope() { if (p && threadIdx.x == 0) { atomicAdd(p, __builtin_amdgcn_s_memtime() - t0); atomicAdd(p + PS_COUNT, 1ull); } }
 };
 #define PROF_SCOPE(c, id) ProfScope prof_scope_##id((c).prof, id)
 #else

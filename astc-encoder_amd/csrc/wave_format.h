@@ -521,21 +521,24 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	const FmtView fs = fmt_view(c);
 	ModeRec* modes = c.modes(start_block_mode);
 
-	compute_encoding_choice_errors(c, pv, ep0, ep1);
+	{ PROF_SCOPE(c, PS_FMT1); compute_encoding_choice_errors(c, pv, ep0, ep1); }
 
+	{ PROF_SCOPE(c, PS_FMT2);
 	WV_FOR(k, pc * (int)FMT_QUANT_ROWS)
 	{
 		int p = k / (int)FMT_QUANT_ROWS, i = k % (int)FMT_QUANT_ROWS + QUANT_6;
 		color_error_for_quant_level(c, pv, p, i, ep0[p], ep1[p], fs);
 	}
-	WV_SYNC();
+	WV_SYNC(); }
 
 	if (pc >= 2)
 	{
+		PROF_SCOPE(c, PS_FMT3);
 		WV_FOR(q, (int)FMT_QUANT_ROWS) { combine_partitions_for_quant(pc, q + QUANT_6, fs); }
 		WV_SYNC();
 	}
 
+	PROF_SCOPE(c, PS_FMT4);
 	WV_FOR(i, end_block_mode - start_block_mode)
 	{
 		ModeRec& m = modes[start_block_mode + i];

@@ -48,6 +48,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	};
 
 	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
+	{ PROF_SCOPE(c, PS_DEC1);
 	WV_FOR(k, (int)r.dwi_total_floats[cls])
 	{
 		int dm = owner[k] >> 1, plane = owner[k] & 1;
@@ -82,7 +83,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		}
 		dwi_base[k] = initial_weight / weight_weight;
 	}
-	WV_SYNC();
+	WV_SYNC(); }
 
 	// sweeps 2+3 over chunks of grids whose infill fits the scratch region
 	int dm0 = 0;
@@ -94,6 +95,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		const int nsets = (dm1 - dm0) * nplanes;
 
 		// sweep 2: infill to texel resolution (ref: :910-926)
+		{ PROF_SCOPE(c, PS_DEC2);
 		WV_FOR(k, nsets * T)
 		{
 			int set = k / T, t = k - set * T;
@@ -106,9 +108,10 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const float* wts = dwi_base + c.dec_mode(dm).dwi_offset[cls + plane];
 			infilled[set * Tp + t] = di.max_texel_weight_count <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
 		}
-		WV_SYNC();
+		WV_SYNC(); }
 
 		// sweep 3: one clamped gradient step (ref: :930-970)
+		PROF_SCOPE(c, PS_DEC3);
 		const int k_begin = c.dec_mode(dm0).dwi_offset[cls];
 		const int k_end = dm1 < (int)r.decimation_mode_count_selected ? (int)c.dec_mode(dm1).dwi_offset[cls] : (int)r.dwi_total_floats[cls];
 		WV_FOR(kk, k_end - k_begin)
@@ -198,6 +201,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			s1++;
 		}
 
+		{ PROF_SCOPE(c, PS_ANG1);
 		WV_FOR(k, pairs)
 		{
 			// locate (set, step) of pair k
@@ -262,7 +266,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			o[3] = errval * errscale;
 			o[4] = cut_low * errscale;
 			o[5] = cut_high * errscale;
-		}
+		} }
 		// slot table for phase 2
 		WV_ONE
 		{
@@ -276,6 +280,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		WV_SYNC();
 
 		// phase 2: (set, quant) lanes (ref: weight_align.cpp:285-354)
+		PROF_SCOPE(c, PS_ANG2);
 		WV_FOR(k, (s1 - s0) * 8)
 		{
 			int s = s0 + (k >> 3), qi = k & 7;
