@@ -133,6 +133,8 @@ struct TableRoot {
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
+	uint32_t off_device_config;               // DeviceConfig of the owning context (appended to the blob by the backend)
+	uint32_t off_lds_layout;                  // LdsLayout for that config (likewise)
 	uint32_t meta_bytes;                      // block modes + decimation modes + decimation infos are contiguous: [off_block_modes, +meta_bytes)
 	uint32_t max_weights[2];                  // largest weight count per plane among the grids of [1-plane, 2-plane] trials
 	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]

@@ -36,9 +36,8 @@ const char* backend_name();
 /* One kernel launch over blocks [first, first + count) of an image.  The kernel exists in two
  * builds of the same source (kernel_ldr.hip / kernel_hdr.hip). */
 struct KernelLaunch {
-	const uint8_t* d_tab;            // table blob in HBM
-	const TableRoot* root;           // host copy of the blob's root record
-	DeviceConfig cfg;
+	const uint8_t* d_tab;            // table blob in HBM (with the context's DeviceConfig and LdsLayout appended)
+	uint32_t lds_bytes;              // dynamic LDS per workgroup
 	ImageDesc img;
 	uint8_t* d_out;
 	uint32_t first, count;
@@ -47,9 +46,10 @@ struct KernelLaunch {
 };
 
 /* Return 0 on success, a hipError_t value otherwise. `prepare` sets the dynamic-LDS attribute and
- * reports the per-workgroup LDS bytes. */
-int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes);
-int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes);
+ * reports the per-workgroup LDS bytes and the LdsLayout record (<= 256 bytes) that the backend
+ * appends to the device copy of the table blob together with the DeviceConfig. */
+int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
+int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
 int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
 

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace astcd {
 
@@ -52,7 +53,10 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	b->tab_bytes = blob_bytes;
 	memcpy(&b->root, blob, sizeof(TableRoot));
 	b->hdr = cfg.profile >= 2;
-	int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes) : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes);
+	uint8_t layout[256];
+	uint32_t layout_bytes = 0;
+	int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes)
+	                 : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes);
 
 	if (prc != 0 || b->lds_bytes > 160 * 1024)
 	{
@@ -60,8 +64,21 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		delete b; *status = 2; return nullptr;
 	}
 
-	HIP_TRY(hipMalloc(&b->d_tab, blob_bytes), { delete b; *status = 1; return nullptr; });
-	HIP_TRY(hipMemcpy(b->d_tab, blob, blob_bytes, hipMemcpyHostToDevice), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
+	// device copy of the blob = tables + this context's DeviceConfig + LdsLayout, located through the root record
+	std::vector<uint8_t> full(blob, blob + blob_bytes);
+	full.resize((full.size() + 255) & ~(size_t)255);
+	const uint32_t off_cfg = (uint32_t)full.size();
+	full.resize(full.size() + ((sizeof(DeviceConfig) + 255) & ~(size_t)255));
+	memcpy(full.data() + off_cfg, &b->cfg, sizeof(DeviceConfig));
+	const uint32_t off_layout = (uint32_t)full.size();
+	full.resize(full.size() + 256);
+	memcpy(full.data() + off_layout, layout, layout_bytes);
+	reinterpret_cast<TableRoot*>(full.data())->off_device_config = off_cfg;
+	reinterpret_cast<TableRoot*>(full.data())->off_lds_layout = off_layout;
+	memcpy(&b->root, full.data(), sizeof(TableRoot));
+	b->tab_bytes = full.size();
+	HIP_TRY(hipMalloc(&b->d_tab, full.size()), { delete b; *status = 1; return nullptr; });
+	HIP_TRY(hipMemcpy(b->d_tab, full.data(), full.size(), hipMemcpyHostToDevice), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
 	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
@@ -148,7 +165,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		if (job.cancel_flag && *job.cancel_flag) break;
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
 		KernelLaunch k;
-		k.d_tab = b->d_tab; k.root = &b->root; k.cfg = b->cfg; k.img = img; k.d_out = d_out;
+		k.d_tab = b->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
 		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = b->d_prof;
 		int lrc = b->hdr ? astc_kernel_launch_hdr(k) : astc_kernel_launch_ldr(k);
 		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }

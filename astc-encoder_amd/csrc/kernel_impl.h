@@ -8,6 +8,7 @@
 #include "backend.h"
 #include "wave_block.h"
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #ifndef ASTC_WAVES_PER_EU
 #define ASTC_WAVES_PER_EU 3
@@ -27,10 +28,10 @@ __device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
 }
 
 __global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
-ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L, ImageDesc img,
+ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
                  uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* lds = astc_lds;
 
 	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
 	uint32_t by = b / img.blocks_x;
@@ -39,36 +40,43 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, DeviceConfig cfg, LdsLayout L,
 	Ctx c;
 	c.tab = tab;
 	c.root = reinterpret_cast<const TableRoot*>(tab);
-	c.cfg = &cfg;
+	c.cfg = reinterpret_cast<const DeviceConfig*>(tab + c.root->off_device_config);
 	c.lds = lds;
-	c.L = L;
+	c.L = reinterpret_cast<const LdsLayout*>(tab + c.root->off_lds_layout);
 	c.T = c.root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.prof = prof;
 
+	// header for the out-of-line stage functions (ctx_make)
+	WV_ONE
+	{
+		LdsHeader* h = reinterpret_cast<LdsHeader*>(lds);
+		h->tab = tab;
+		h->prof = prof;
+	}
+	WV_SYNC();
+
 	PROF_SCOPE(c, PS_TOTAL);
-#if defined(ASTC_META_LDS)
-	stage_words(lds + L.meta, tab + c.root->off_block_modes, (int)(c.root->meta_bytes / 4));
-#endif
 	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
 	compress_block(c, out + (size_t)b * 16);
 }
 
-int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes)
+int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes)
 {
 	LdsLayout L;
 	make_lds_layout(root, cfg, L);
 	*lds_bytes = L.total;
+	static_assert(sizeof(LdsLayout) <= 256, "layout record grew past the space the backend reserves");
+	memcpy(layout_out, &L, sizeof(L));
+	*layout_bytes = (uint32_t)sizeof(L);
 	return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(ASTC_KERNEL_NAME),
 	                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
 }
 
 int ASTC_LAUNCH_NAME(const KernelLaunch& k)
 {
-	LdsLayout L;
-	make_lds_layout(*k.root, k.cfg, L);
-	hipLaunchKernelGGL(ASTC_KERNEL_NAME, dim3(k.count), dim3(64), L.total, static_cast<hipStream_t>(k.stream),
-	                   k.d_tab, k.cfg, L, k.img, k.d_out, k.first, k.count, k.d_prof);
+	hipLaunchKernelGGL(ASTC_KERNEL_NAME, dim3(k.count), dim3(64), k.lds_bytes, static_cast<hipStream_t>(k.stream),
+	                   k.d_tab, k.img, k.d_out, k.first, k.count, k.d_prof);
 	return (int)hipGetLastError();
 }
 

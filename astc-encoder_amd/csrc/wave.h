@@ -39,6 +39,7 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 	#define WV_DEVICE 1
 	#define WV_FN __host__ __device__ inline
+	#define WV_OUT __host__ __device__ __attribute__((noinline)) inline
 	#define WV_LANE ((int)threadIdx.x)
 	// A workgroup is exactly one wavefront, and a wavefront's LDS instructions execute in issue
 	// order, so a cross-lane hand-off through LDS needs no s_barrier and no s_waitcnt: it only needs
@@ -56,8 +57,10 @@
 	#define WV_DEVICE 0
 	#if defined(__HIPCC__)
 		#define WV_FN __host__ __device__ inline
+		#define WV_OUT __host__ __device__ __attribute__((noinline)) inline
 	#else
 		#define WV_FN inline
+		#define WV_OUT __attribute__((noinline)) inline
 	#endif
 	#define WV_SYNC() ((void)0)
 	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)

@@ -99,10 +99,10 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	ModeRec* modes = c.modes(start);
 	const int T = c.T, Tp = c.Tp;
 	const int planes = dual ? 2 : 1;
-	const int chunk_modes = (int)(c.L.uni_bytes / (MODE_DESC_BYTES + (uint32_t)Tp * 4));
-	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L.uni);
-	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L.uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
-	float* buf = reinterpret_cast<float*>(c.lds + c.L.uni + (uint32_t)chunk_modes * MODE_DESC_BYTES);
+	const int chunk_modes = (int)(c.L->uni_bytes / (MODE_DESC_BYTES + (uint32_t)Tp * 4));
+	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);
+	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
+	float* buf = reinterpret_cast<float*>(c.lds + c.L->uni + (uint32_t)chunk_modes * MODE_DESC_BYTES);
 	const float* ldsf = reinterpret_cast<const float*>(c.lds);
 	const float* eiw0 = c.ei_w(0); const float* eiwes0 = c.ei_wes(0);
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
@@ -230,6 +230,63 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	}
 }
 
+// Out-of-line pieces of the refinement loop (see the note on stage functions below): each one
+// rebuilds the views it needs from LDS.
+WV_OUT void refine_recompute(bool dual, int partition_count, int partition_packed, int decimation_mode, int plane2_component)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	decimation_mode = wv_uniform(decimation_mode); plane2_component = wv_uniform(plane2_component);
+	const DecView di = dec_view_lds(c, decimation_mode);
+	PROF_SCOPE(c, PS_RECOMPUTE);
+	// (the single-partition case is by far the most frequent: give it its own specialised copy)
+	if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
+	else if (partition_count == 1) recompute_ideal_colors_1plane(c, part_view_lds(c, 1, 0), di);
+	else recompute_ideal_colors_1plane(c, part_view_lds(c, partition_count, partition_packed), di);
+}
+
+/* Pack the working endpoints of every partition, one lane per partition (ref: :542-555, :925-931).
+ * Formats go to fmt_out[], values to values_out[][8]. */
+WV_OUT void refine_pack(int partition_count, int candidate, int quant_level, bool to_scratch)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); candidate = wv_uniform(candidate);
+	quant_level = wv_uniform(quant_level); to_scratch = wv_uniform(to_scratch);
+	TrialInfo& tr = c.tr();
+	Scb& workscb = c.wscb();
+	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8] scratch copy for the matched-format retry
+	uint8_t* fmts = colorvals + 32;                                   // [4]
+	PROF_SCOPE(c, PS_PACK);
+	WV_FOR(j, partition_count)
+	{
+		uint8_t* vals = to_scratch ? colorvals + j * 8 : workscb.color_values[j];
+		uint8_t f = (uint8_t)pack_color_endpoints(
+		    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
+		    tr.cand_formats[candidate][j], vals, quant_level);
+		if (to_scratch) fmts[j] = f; else workscb.color_formats[j] = f;
+	}
+	WV_SYNC();
+}
+
+WV_OUT float refine_difference(int partition_count, int partition_packed, int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
+	PROF_SCOPE(c, PS_DIFF);
+	if (partition_count == 1) return compute_symbolic_block_difference(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode));
+	return compute_symbolic_block_difference(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode));
+}
+
+WV_OUT bool refine_realign(int partition_count, int partition_packed, int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
+	const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
+	PROF_SCOPE(c, PS_REALIGN);
+	if (partition_count == 1) return realign_weights(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode), qat);
+	return realign_weights(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode), qat);
+}
+
 /* Shared tail of both trials: refine the chosen candidates. Returns best error seen in this trial. */
 WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_count, int partition_packed,
                               int plane2_component, float tune_errorval_threshold)
@@ -265,8 +322,8 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 		// stage what the refinement loop reads in serial, latency-bound code into LDS
 		const DecView di = dec_view_staged(c, qw_bm.decimation_mode);
-		stage_words(c.lds + c.L.qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
-		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L.qtab);
+		stage_words(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
+		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
 		stage_color_rows(c, color_quant_level, color_quant_level_mod);
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
@@ -288,19 +345,10 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
-			{ PROF_SCOPE(c, PS_RECOMPUTE);
-			if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
-			else recompute_ideal_colors_1plane(c, pv, di); }
+			refine_recompute(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component);
 
 			// pack endpoints, one lane per partition (ref: :542-555, :925-931)
-			PROF_SCOPE(c, PS_PACK);
-			WV_FOR(j, partition_count)
-			{
-				workscb.color_formats[j] = (uint8_t)pack_color_endpoints(
-				    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
-				    tr.cand_formats[i][j], workscb.color_values[j], color_quant_level);
-			}
-			WV_SYNC();
+			refine_pack(partition_count, i, color_quant_level, false);
 
 			int formats_matched = 0;
 			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
@@ -312,13 +360,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 					// retry at the higher quant level that matched formats allow (ref: :561-598)
 					uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8]
 					uint8_t* fmts = colorvals + 32;                                   // [4]
-					WV_FOR(j, partition_count)
-					{
-						fmts[j] = (uint8_t)pack_color_endpoints(
-						    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
-						    tr.cand_formats[i][j], colorvals + j * 8, color_quant_level_mod);
-					}
-					WV_SYNC();
+					refine_pack(partition_count, i, color_quant_level_mod, true);
 					bool all_same_mod = true;
 					for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
 					if (all_same_mod)
@@ -346,7 +388,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			if (l == 0)
 			{
 				float errorval;
-				{ PROF_SCOPE(c, PS_DIFF); errorval = compute_symbolic_block_difference(c, pv, di); }
+				errorval = wv_uniform(refine_difference(partition_count, partition_packed, qw_bm.decimation_mode));
 				if (errorval == -ERROR_CALC_DEFAULT)
 				{
 					errorval = -errorval;
@@ -379,10 +421,10 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 			WV_SYNC();
 			bool adjustments;
-			{ PROF_SCOPE(c, PS_REALIGN); adjustments = realign_weights(c, pv, di, qat); }
+			adjustments = wv_uniform(refine_realign(partition_count, partition_packed, qw_bm.decimation_mode));
 
 			float errorval;
-			{ PROF_SCOPE(c, PS_DIFF); errorval = compute_symbolic_block_difference(c, pv, di); }
+			errorval = wv_uniform(refine_difference(partition_count, partition_packed, qw_bm.decimation_mode));
 			if (errorval == -ERROR_CALC_DEFAULT)
 			{
 				errorval = -errorval;
@@ -424,163 +466,200 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 	return best_errorval_in_mode;
 }
 
-/* (ref: compress_symbolic_block_for_partition_1plane :353) */
+// ---------------------------------------------------------------------------------------------
+// Out-of-line stages.  Every stage of a trial is its own (non-inlined) function that rebuilds the
+// wave context from LDS (ctx_make) and takes only uniform scalars.  The register allocator then
+// works on one stage at a time: the hot inner loops no longer carry (and spill/reload around) the
+// live state of the whole search, and each stage exists once in the kernel instead of once per
+// call site.
+// ---------------------------------------------------------------------------------------------
+
+WV_OUT void stage_ideal(bool dual, int partition_count, int partition_packed, int plane2_component)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count);
+	partition_packed = wv_uniform(partition_packed); plane2_component = wv_uniform(plane2_component);
+	PROF_SCOPE(c, PS_IDEAL);
+	if (partition_count == 1)
+	{
+		PartView pv = part_view_staged(c, 1, 0);
+		if (dual) ideal_colors_and_weights_2planes(c, pv, plane2_component);
+		else ideal_colors_and_weights_1plane(c, pv);
+	}
+	else
+	{
+		PartView pv = part_view_staged(c, partition_count, partition_packed);
+		ideal_colors_and_weights_1plane(c, pv);
+	}
+}
+
+WV_OUT void stage_decimate(int nplanes, int ref_mask, int max_decimation_modes)
+{
+	const Ctx c = ctx_make();
+	nplanes = wv_uniform(nplanes); ref_mask = wv_uniform(ref_mask); max_decimation_modes = wv_uniform(max_decimation_modes);
+	PROF_SCOPE(c, PS_DECIMATE);
+	ideal_weights_all_grids(c, nplanes, (uint16_t)ref_mask, max_decimation_modes);
+}
+
+/* Weight cut-offs, the list of grids of this trial and their angular bounds
+ * (ref: compress_symbolic.cpp:409-418 / :765-785; weight_align.cpp:358-426). */
+WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, int max_decimation_modes, int ref_mask_i, int max_weight_quant)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); plane2_component = wv_uniform(plane2_component);
+	max_decimation_modes = wv_uniform(max_decimation_modes); max_weight_quant = wv_uniform(max_weight_quant);
+	const uint16_t ref_mask = (uint16_t)wv_uniform(ref_mask_i);
+	TrialInfo& tr = c.tr();
+
+	WV_ONE
+	{
+		if (!dual)
+		{
+			f4 min_ep = splat4(10.0f);
+			for (int i = 0; i < partition_count; i++)
+			{
+				f4 e0 = load4(tr.ep0[0][i]), e1 = load4(tr.ep1[0][i]);
+				f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
+				for (int k = 0; k < 4; k++)
+				{
+					float v = lane(ep, k);
+					if (v > 0.5f && v < lane(min_ep, k)) set_lane(min_ep, k, v);
+				}
+			}
+			tr.min_wt_cutoff[0] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+		}
+		else
+		{
+			float cut[2];
+			for (int plane = 0; plane < 2; plane++)
+			{
+				f4 e0 = load4(tr.ep0[plane][0]), e1 = load4(tr.ep1[plane][0]);
+				f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
+				f4 min_ep = splat4(10.0f);
+				for (int k = 0; k < 4; k++)
+				{
+					float v = lane(ep, k);
+					if (v > 0.5f && v < 10.0f) set_lane(min_ep, k, v);
+				}
+				// plane 0 ignores the separated component, plane 1 only looks at it
+				for (int k = 0; k < 4; k++)
+				{
+					bool is_p2 = k == plane2_component;
+					if (plane == 0 ? is_p2 : !is_p2) set_lane(min_ep, k, ERROR_CALC_DEFAULT);
+				}
+				cut[plane] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+			}
+			tr.min_wt_cutoff[0] = cut[0];
+			tr.min_wt_cutoff[1] = cut[1];
+		}
+
+		int n = 0;
+		for (int i = 0; i < max_decimation_modes; i++)
+		{
+			const DecimationMode& m = c.dec_mode(i);
+			if ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) tr.dm_list[n++] = (uint8_t)i;
+		}
+		tr.dm_count = n;
+	}
+	WV_SYNC();
+
+	auto get_set = [&](int s) {
+		int plane = dual ? (s & 1) : 0;
+		int dm = tr.dm_list[dual ? (s >> 1) : s];
+		const DecimationMode& m = c.dec_mode(dm);
+		int max_precision = dual ? m.maxprec_2planes : m.maxprec_1plane;
+		max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
+		max_precision = i_min(max_precision, max_weight_quant);
+		AngSet a;
+		a.weights = c.dwi(dm, plane, dual);
+		a.out = c.lowhigh(plane, dm, dual);
+		a.wcount = c.dec_info(dm).weight_count;
+		a.maxq = max_precision;
+		return a;
+	};
+	PROF_SCOPE(c, PS_ANGULAR);
+	angular_endpoints(c, tr.dm_count * (dual ? 2 : 1), get_set);
+}
+
+WV_OUT void stage_modes(int partition_count, int start, int end, int max_weight_quant, bool dual)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
+	max_weight_quant = wv_uniform(max_weight_quant); dual = wv_uniform(dual);
+	PROF_SCOPE(c, PS_MODES);
+	score_block_modes(c, partition_count, start, end, max_weight_quant, dual);
+}
+
+WV_OUT void stage_formats(bool dual, int partition_count, int partition_packed, int plane2_component, int start, int end)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component); start = wv_uniform(start); end = wv_uniform(end);
+	TrialInfo& tr = c.tr();
+	const PartView pv = part_view_lds(c, partition_count, partition_packed);
+	if (dual)
+	{
+		// merged endpoints (ref: merge_endpoints :37) are what the format search sees
+		WV_FOR(ch, 4)
+		{
+			int plane = ch == plane2_component ? 1 : 0;
+			tr.rgbs[1][ch] = tr.ep0[plane][0][ch];   // staging rows (rgbs[1..2] are unused with 1 partition)
+			tr.rgbs[2][ch] = tr.ep1[plane][0][ch];
+		}
+		WV_SYNC();
+	}
+	PROF_SCOPE(c, PS_FORMATS);
+	if (partition_count == 1)
+		compute_ideal_endpoint_formats(c, part_view_lds(c, 1, 0), dual ? &tr.rgbs[1] : tr.ep0[0], dual ? &tr.rgbs[2] : tr.ep1[0], start, end);
+	else
+		compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], start, end);
+}
+
+WV_OUT float stage_refine(int partition_count, int partition_packed, int plane2_component, float tune_errorval_threshold)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component); tune_errorval_threshold = wv_uniform(tune_errorval_threshold);
+	const PartView pv = part_view_lds(c, partition_count, partition_packed);
+	return refine_candidates(c, pv, partition_count, partition_packed, plane2_component, tune_errorval_threshold);
+}
+
+/* One trial of the search (ref: compress_symbolic_block_for_partition_1plane :353, _2planes :715). */
+WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune_errorval_threshold,
+                           int partition_count, int partition_packed, int plane2_component, int quant_limit)
+{
+	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
+	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
+	const int ref_mask = (int)((1u << (max_weight_quant + 1)) - 1);
+	int mode_start, mode_end;
+	if (dual)
+	{
+		mode_start = (int)c.root->block_mode_count_1plane_selected;
+		mode_end = (int)c.root->block_mode_count_1plane_2plane_selected;
+	}
+	else
+	{
+		mode_start = 0;
+		mode_end = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
+	}
+
+	stage_ideal(dual, partition_count, partition_packed, plane2_component);
+	stage_decimate(dual ? 2 : 1, ref_mask, max_decimation_modes);
+	stage_angular(dual, partition_count, plane2_component, max_decimation_modes, ref_mask, max_weight_quant);
+	stage_modes(partition_count, mode_start, mode_end, max_weight_quant, dual);
+	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end);
+	return wv_uniform(stage_refine(partition_count, partition_packed, dual ? plane2_component : -1, tune_errorval_threshold));
+}
+
 WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_errorval_threshold,
                                   int partition_count, int partition_packed, int quant_limit)
 {
-	TrialInfo& tr = c.tr();
-	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
-	PartView pv = part_view_staged(c, partition_count, partition_packed);
-
-	{ PROF_SCOPE(c, PS_IDEAL); ideal_colors_and_weights_1plane(c, pv); }
-
-	// ideal weights on every referenced decimation grid (ref: :388-405)
-	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
-	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
-	{
-		PROF_SCOPE(c, PS_DECIMATE);
-		ideal_weights_all_grids(c, 1, ref_mask, max_decimation_modes);
-	}
-
-	// (ref: :409-418)
-	WV_ONE
-	{
-		f4 min_ep = splat4(10.0f);
-		for (int i = 0; i < partition_count; i++)
-		{
-			f4 e0 = load4(tr.ep0[0][i]), e1 = load4(tr.ep1[0][i]);
-			f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
-			for (int k = 0; k < 4; k++)
-			{
-				float v = lane(ep, k);
-				if (v > 0.5f && v < lane(min_ep, k)) set_lane(min_ep, k, v);
-			}
-		}
-		tr.min_wt_cutoff[0] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
-	}
-
-	// angular bounds (ref: compute_angular_endpoints_1plane, weight_align.cpp:358-399)
-	WV_ONE
-	{
-		int n = 0;
-		for (int i = 0; i < max_decimation_modes; i++) if (c.dec_mode(i).refprec_1plane & ref_mask) tr.dm_list[n++] = (uint8_t)i;
-		tr.dm_count = n;
-	}
-	WV_SYNC();
-	{
-		auto get_set = [&](int s) {
-			int dm = tr.dm_list[s];
-			int max_precision = c.dec_mode(dm).maxprec_1plane;
-			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
-			max_precision = i_min(max_precision, max_weight_quant);
-			AngSet a;
-			a.weights = c.dwi(dm, 0, false);
-			a.out = c.lowhigh(0, dm, false);
-			a.wcount = c.dec_info(dm).weight_count;
-			a.maxq = max_precision;
-			return a;
-		};
-		PROF_SCOPE(c, PS_ANGULAR);
-		angular_endpoints(c, tr.dm_count, get_set);
-	}
-
-	// quantize + score every block mode (ref: :438-485)
-	const int max_block_modes = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
-	{
-		PROF_SCOPE(c, PS_MODES);
-		score_block_modes(c, partition_count, 0, max_block_modes, max_weight_quant, false);
-	}
-
-	{ PROF_SCOPE(c, PS_FORMATS); compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], 0, max_block_modes); }
-
-	return refine_candidates(c, pv, partition_count, partition_packed, -1, tune_errorval_threshold);
+	return compress_trial(c, false, only_always, tune_errorval_threshold, partition_count, partition_packed, -1, quant_limit);
 }
 
-/* (ref: compress_symbolic_block_for_partition_2planes :715) */
 WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, int plane2_component, int quant_limit)
 {
-	TrialInfo& tr = c.tr();
-	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
-	PartView pv = part_view_staged(c, 1, 0);
-
-	{ PROF_SCOPE(c, PS_IDEAL); ideal_colors_and_weights_2planes(c, pv, plane2_component); }
-
-	const int ndm = (int)c.root->decimation_mode_count_selected;
-	const uint16_t ref_mask = (uint16_t)((1u << (max_weight_quant + 1)) - 1);
-	{
-		PROF_SCOPE(c, PS_DECIMATE);
-		ideal_weights_all_grids(c, 2, ref_mask, ndm);
-	}
-
-	// (ref: :765-785)
-	WV_ONE
-	{
-		float cut[2];
-		for (int plane = 0; plane < 2; plane++)
-		{
-			f4 e0 = load4(tr.ep0[plane][0]), e1 = load4(tr.ep1[plane][0]);
-			f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
-			f4 min_ep = splat4(10.0f);
-			for (int k = 0; k < 4; k++)
-			{
-				float v = lane(ep, k);
-				if (v > 0.5f && v < 10.0f) set_lane(min_ep, k, v);
-			}
-			// plane 0 ignores the separated component, plane 1 only looks at it
-			for (int k = 0; k < 4; k++)
-			{
-				bool is_p2 = k == plane2_component;
-				if (plane == 0 ? is_p2 : !is_p2) set_lane(min_ep, k, ERROR_CALC_DEFAULT);
-			}
-			cut[plane] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
-		}
-		tr.min_wt_cutoff[0] = cut[0];
-		tr.min_wt_cutoff[1] = cut[1];
-	}
-
-	WV_ONE
-	{
-		int n = 0;
-		for (int i = 0; i < ndm; i++) if (c.dec_mode(i).refprec_2planes & ref_mask) tr.dm_list[n++] = (uint8_t)i;
-		tr.dm_count = n;
-	}
-	WV_SYNC();
-	{
-		auto get_set = [&](int s) {
-			int plane = s & 1;
-			int dm = tr.dm_list[s >> 1];
-			int max_precision = c.dec_mode(dm).maxprec_2planes;
-			max_precision = i_min(max_precision, MAX_ANGULAR_QUANT);
-			max_precision = i_min(max_precision, max_weight_quant);
-			AngSet a;
-			a.weights = c.dwi(dm, plane, true);
-			a.out = c.lowhigh(plane, dm, true);
-			a.wcount = c.dec_info(dm).weight_count;
-			a.maxq = max_precision;
-			return a;
-		};
-		PROF_SCOPE(c, PS_ANGULAR);
-		angular_endpoints(c, tr.dm_count * 2, get_set);
-	}
-
-	const int start_2plane = (int)c.root->block_mode_count_1plane_selected;
-	const int end_2plane = (int)c.root->block_mode_count_1plane_2plane_selected;
-	{
-		PROF_SCOPE(c, PS_MODES);
-		score_block_modes(c, 1, start_2plane, end_2plane, max_weight_quant, true);
-	}
-
-	// merged endpoints (ref: merge_endpoints :37) -> wep0/wep1 used as the format-search input
-	WV_FOR(ch, 4)
-	{
-		int plane = ch == plane2_component ? 1 : 0;
-		tr.rgbs[1][ch] = tr.ep0[plane][0][ch];   // staging rows (rgbs[1..2] are unused with 1 partition)
-		tr.rgbs[2][ch] = tr.ep1[plane][0][ch];
-	}
-	WV_SYNC();
-	{ PROF_SCOPE(c, PS_FORMATS); compute_ideal_endpoint_formats(c, pv, &tr.rgbs[1], &tr.rgbs[2], start_2plane, end_2plane); }
-
-	return refine_candidates(c, pv, 1, 0, plane2_component, tune_errorval_threshold);
+	return compress_trial(c, true, false, tune_errorval_threshold, 1, 0, plane2_component, quant_limit);
 }
 
 /* (ref: prepare_block_statistics :1047) */

@@ -84,7 +84,14 @@ struct ModeRec {
 	uint8_t pad[2];
 };
 
+/* First bytes of every workgroup's LDS: what an out-of-line stage function needs to rebuild its Ctx. */
+struct LdsHeader {
+	const uint8_t* tab;
+	unsigned long long* prof;
+};
+
 struct LdsLayout {
+	uint32_t hdr;        // LdsHeader (offset 0)
 	// ---- block / trial lifetime ----
 	uint32_t data;       // f32 [4][Tp]
 	uint32_t blk;        // BlkInfo
@@ -144,6 +151,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	uint32_t nbm = r.block_mode_count_1plane_2plane_selected;
 	uint32_t o = 0;
 	auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
+	L.hdr = take(sizeof(LdsHeader));
 	L.data = take(4 * Tp * 4);
 	L.blk = take(sizeof(BlkInfo));
 	L.scb = take(sizeof(Scb));
@@ -212,42 +220,42 @@ struct Ctx {
 	const TableRoot* root;
 	const DeviceConfig* cfg;
 	uint8_t* lds;
-	LdsLayout L;
+	const LdsLayout* L;          // in the table blob (constant memory): fields are scalar loads
 	int T;                       // texels per block
 	int Tp;                      // T rounded up to 4
 	unsigned long long* prof;    // stage cycle counters (profiling builds only), else null
 
 	// typed views
-	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L.data) + c * Tp; }
-	WV_FN BlkInfo& blk() const { return *reinterpret_cast<BlkInfo*>(lds + L.blk); }
-	WV_FN Scb& scb() const { return *reinterpret_cast<Scb*>(lds + L.scb); }
-	WV_FN Scb& wscb() const { return *reinterpret_cast<Scb*>(lds + L.wscb); }
-	WV_FN TrialInfo& tr() const { return *reinterpret_cast<TrialInfo*>(lds + L.trial); }
-	WV_FN float* ei_w(int plane) const { return reinterpret_cast<float*>(lds + L.ei_w) + plane * Tp; }
-	WV_FN float* ei_wes(int plane) const { return reinterpret_cast<float*>(lds + L.ei_wes) + plane * Tp; }
+	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L->data) + c * Tp; }
+	WV_FN BlkInfo& blk() const { return *reinterpret_cast<BlkInfo*>(lds + L->blk); }
+	WV_FN Scb& scb() const { return *reinterpret_cast<Scb*>(lds + L->scb); }
+	WV_FN Scb& wscb() const { return *reinterpret_cast<Scb*>(lds + L->wscb); }
+	WV_FN TrialInfo& tr() const { return *reinterpret_cast<TrialInfo*>(lds + L->trial); }
+	WV_FN float* ei_w(int plane) const { return reinterpret_cast<float*>(lds + L->ei_w) + plane * Tp; }
+	WV_FN float* ei_wes(int plane) const { return reinterpret_cast<float*>(lds + L->ei_wes) + plane * Tp; }
 	// per-grid results of the current trial; `dual` = the trial has two weight planes
-	WV_FN float* dwi(int dm, int plane, bool dual) const { return reinterpret_cast<float*>(lds + L.dwi) + dec_mode(dm).dwi_offset[dual ? 1 + plane : 0]; }
-	WV_FN float* lowhigh(int plane, int dm, bool dual) const { return reinterpret_cast<float*>(lds + L.lowhigh) + dec_mode(dm).lowhigh_offset[dual ? 1 + plane : 0]; }
-	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L.uni); }
-	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L.uni); }
+	WV_FN float* dwi(int dm, int plane, bool dual) const { return reinterpret_cast<float*>(lds + L->dwi) + dec_mode(dm).dwi_offset[dual ? 1 + plane : 0]; }
+	WV_FN float* lowhigh(int plane, int dm, bool dual) const { return reinterpret_cast<float*>(lds + L->lowhigh) + dec_mode(dm).lowhigh_offset[dual ? 1 + plane : 0]; }
+	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L->uni); }
+	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L->uni); }
 	// records of the block modes [first, ...) scored by the current trial; index with the packed mode index
-	WV_FN ModeRec* modes(int first) const { return reinterpret_cast<ModeRec*>(lds + L.modes) - first; }
+	WV_FN ModeRec* modes(int first) const { return reinterpret_cast<ModeRec*>(lds + L->modes) - first; }
 	// texel-length scratch rows; one set per phase because the phases' regions alias each other
-	WV_FN float* tsc_f(int row) const { return reinterpret_cast<float*>(lds + L.uni) + row * L.tsc_stride; }      // format search
-	WV_FN float* tsc_r(int row) const { return reinterpret_cast<float*>(lds + L.tsc_r) + row * L.tsc_stride; }    // refinement
-	WV_FN float* tsc_p(int row) const { return reinterpret_cast<float*>(lds + L.tsc_p) + row * L.tsc_stride; }    // partition search
-	WV_FN float* tsc_r_base() const { return reinterpret_cast<float*>(lds + L.tsc_r); }
-	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L.wsc) + row * 64; }
-	WV_FN uint8_t* fmt() const { return lds + L.uni; }
-	WV_FN uint8_t* part() const { return lds + L.part; }
-	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L.rsc) + row * Tp; }
-	WV_FN uint8_t* candw(int n) const { return lds + L.candw + n * 64; }
+	WV_FN float* tsc_f(int row) const { return reinterpret_cast<float*>(lds + L->uni) + row * L->tsc_stride; }      // format search
+	WV_FN float* tsc_r(int row) const { return reinterpret_cast<float*>(lds + L->tsc_r) + row * L->tsc_stride; }    // refinement
+	WV_FN float* tsc_p(int row) const { return reinterpret_cast<float*>(lds + L->tsc_p) + row * L->tsc_stride; }    // partition search
+	WV_FN float* tsc_r_base() const { return reinterpret_cast<float*>(lds + L->tsc_r); }
+	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L->wsc) + row * 64; }
+	WV_FN uint8_t* fmt() const { return lds + L->uni; }
+	WV_FN uint8_t* part() const { return lds + L->part; }
+	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L->rsc) + row * Tp; }
+	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
 #if defined(ASTC_META_LDS)
-	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(lds + L.meta)[i]; }
-	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(lds + L.meta + (root->off_decimation_modes - root->off_block_modes))[i]; }
-	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(lds + L.meta + (root->off_decimation_infos - root->off_block_modes))[i]; }
+	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(lds + L->meta)[i]; }
+	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(lds + L->meta + (root->off_decimation_modes - root->off_block_modes))[i]; }
+	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(lds + L->meta + (root->off_decimation_infos - root->off_block_modes))[i]; }
 #else
 	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }
 	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(tab + root->off_decimation_modes)[i]; }
@@ -256,6 +264,49 @@ struct Ctx {
 	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
 	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
 };
+
+/* Rebuild the wave's context inside an out-of-line stage function.  On the device everything comes
+ * from the LDS header and the table blob, so stage functions need no context argument (arguments of
+ * non-kernel functions travel in VGPRs and would make every table address look lane-variant). */
+#if defined(__HIPCC__)
+extern __shared__ __attribute__((aligned(16))) uint8_t astc_lds[];
+#endif
+#if WV_DEVICE
+WV_FN uint32_t wv_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+WV_FN int wv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+WV_FN bool wv_uniform(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
+WV_FN float wv_uniform(float v) { return int_as_float(__builtin_amdgcn_readfirstlane(float_as_int(v))); }
+WV_FN uint64_t wv_uniform(uint64_t v)
+{
+	uint32_t lo = wv_uniform((uint32_t)v), hi = wv_uniform((uint32_t)(v >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
+WV_FN Ctx ctx_make()
+{
+	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(astc_lds);
+	Ctx c;
+	// A pointer rebuilt from integers would be a generic (flat) pointer to the compiler: go through
+	// explicit global-address-space pointers so that table reads stay s_load / global_load.
+	typedef const __attribute__((address_space(1))) uint8_t* global_bytes;
+	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
+	c.tab = (const uint8_t*)(global_bytes)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->tab));
+	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
+	c.root = reinterpret_cast<const TableRoot*>(c.tab);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab + c.root->off_device_config);
+	c.L = reinterpret_cast<const LdsLayout*>(c.tab + c.root->off_lds_layout);
+	c.lds = astc_lds;
+	c.T = c.root->texel_count;
+	c.Tp = (c.T + 3) & ~3;
+	return c;
+}
+#else
+WV_FN uint32_t wv_uniform(uint32_t v) { return v; }
+WV_FN int wv_uniform(int v) { return v; }
+WV_FN bool wv_uniform(bool v) { return v; }
+WV_FN float wv_uniform(float v) { return v; }
+extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block
+WV_FN Ctx ctx_make() { return *g_wave_ctx; }
+#endif
 
 /* Stage timers for profiling builds (-DASTC_PROFILE): lane 0 accumulates shader-clock cycles per
  * stage into c.prof[].  Compiled out otherwise. */
@@ -319,10 +370,20 @@ WV_FN void stage_words(uint8_t* lds_dst, const uint8_t* src, int words)
 WV_FN PartView part_view_staged(const Ctx& c, int pcount, int packed)
 {
 	PartView v = part_view(c, pcount, packed);
-	uint8_t* dst = c.lds + c.L.ptab;
+	uint8_t* dst = c.lds + c.L->ptab;
 	// of_texel[T] and sorted[T] are adjacent in the record; record stride is a multiple of 4
 	const uint8_t* src = reinterpret_cast<const uint8_t*>(v.h) + sizeof(PartitionHeader);
 	stage_words(dst, src, (2 * c.T + 3) / 4);
+	v.of_texel = dst;
+	v.sorted = dst + c.T;
+	return v;
+}
+
+/* The same view without copying: for stage functions that run after part_view_staged() did. */
+WV_FN PartView part_view_lds(const Ctx& c, int pcount, int packed)
+{
+	PartView v = part_view(c, pcount, packed);
+	const uint8_t* dst = c.lds + c.L->ptab;
 	v.of_texel = dst;
 	v.sorted = dst + c.T;
 	return v;
@@ -364,9 +425,15 @@ WV_FN DecView dec_view_global(const Ctx& c, int dm)
 WV_FN DecView dec_view_staged(const Ctx& c, int dm)
 {
 	const DecimationInfo& di = c.dec_info(dm);
-	uint8_t* dst = c.lds + c.L.dtab;
+	uint8_t* dst = c.lds + c.L->dtab;
 	stage_words(dst, c.tab + di.off_texel_weights, (int)((di.table_bytes + 3) / 4));
 	return dec_view_at(di, dst);
+}
+
+/* The staged view again, without copying (after dec_view_staged() of the same mode). */
+WV_FN DecView dec_view_lds(const Ctx& c, int dm)
+{
+	return dec_view_at(c.dec_info(dm), c.lds + c.L->dtab);
 }
 
 } } // namespace astcd::ASTC_VARIANT

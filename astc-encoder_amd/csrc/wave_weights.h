@@ -37,9 +37,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const int T = c.T, Tp = c.Tp;
 	const int cls = nplanes == 2 ? 1 : 0;          // trial class: selects the packing of the dwi region
 	const uint16_t* owner = reinterpret_cast<const uint16_t*>(c.tab + r.off_dwi_owner[cls]);
-	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L.dwi);
+	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
 	float* infilled = c.uni_f();
-	const int cap_sets = (int)(c.L.uni_bytes / 4) / Tp;
+	const int cap_sets = (int)(c.L->uni_bytes / 4) / Tp;
 
 	auto grid_used = [&](int dm, int plane) {
 		const DecimationMode& m = c.dec_mode(dm);

@@ -14,9 +14,12 @@
 
 namespace astcd {
 
+inline namespace ASTC_VARIANT { thread_local const Ctx* g_wave_ctx = nullptr; }
+
 struct Backend {
-	std::vector<uint8_t> blob;
+	std::vector<uint8_t> blob;      // tables + DeviceConfig + LdsLayout, like the device copy
 	DeviceConfig cfg;
+	LdsLayout layout;
 };
 
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
@@ -24,6 +27,16 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	Backend* b = new Backend;
 	b->blob.assign(blob, blob + blob_bytes);
 	b->cfg = cfg;
+	make_lds_layout(*reinterpret_cast<const TableRoot*>(blob), cfg, b->layout);
+	b->blob.resize((b->blob.size() + 255) & ~(size_t)255);
+	const uint32_t off_cfg = (uint32_t)b->blob.size();
+	b->blob.resize(b->blob.size() + 256 + sizeof(DeviceConfig));
+	memcpy(b->blob.data() + off_cfg, &cfg, sizeof(cfg));
+	const uint32_t off_layout = (uint32_t)((b->blob.size() + 15) & ~(size_t)15);
+	b->blob.resize(off_layout + sizeof(LdsLayout));
+	memcpy(b->blob.data() + off_layout, &b->layout, sizeof(LdsLayout));
+	reinterpret_cast<TableRoot*>(b->blob.data())->off_device_config = off_cfg;
+	reinterpret_cast<TableRoot*>(b->blob.data())->off_lds_layout = off_layout;
 	*status = 0;
 	return b;
 }
@@ -37,13 +50,14 @@ int backend_compress(Backend* b, const CompressJob& job)
 	Ctx c;
 	c.tab = b->blob.data();
 	c.root = root;
-	c.cfg = &b->cfg;
-	make_lds_layout(*root, b->cfg, c.L);
-	std::vector<uint8_t> lds(c.L.total + 64, 0xCD);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(b->blob.data() + root->off_device_config);
+	c.L = reinterpret_cast<const LdsLayout*>(b->blob.data() + root->off_lds_layout);
+	std::vector<uint8_t> lds(c.L->total + 64, 0xCD);
 	c.lds = lds.data();
 	c.T = root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.prof = nullptr;
+	g_wave_ctx = &c;
 
 	ImageDesc img;
 	img.data = job.host_data ? job.host_data : job.device_data;
