@@ -11,7 +11,7 @@
 #include <cstring>
 
 #ifndef ASTC_WAVES_PER_EU
-#define ASTC_WAVES_PER_EU 3
+#define ASTC_WAVES_PER_EU 4
 #endif
 
 namespace astcd {

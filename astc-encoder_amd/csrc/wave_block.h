@@ -324,7 +324,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		const DecView di = dec_view_staged(c, qw_bm.decimation_mode);
 		stage_words(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
 		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
-		stage_color_rows(c, color_quant_level, color_quant_level_mod);
+		stage_color_rows(c, color_quant_level);
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
 		// recomputed here instead of being stored for every block mode

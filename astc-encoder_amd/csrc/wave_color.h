@@ -19,19 +19,19 @@ WV_FN ColorTabs color_tabs(const Ctx& c, int quant_level)
 	ColorTabs t;
 	const TrialInfo& tr = c.tr();
 	if (quant_level == tr.staged_color_quant[0]) t.unq_to_uq = c.lds + c.L->ctab;
-	else if (quant_level == tr.staged_color_quant[1]) t.unq_to_uq = c.lds + c.L->ctab + 512;
 	else t.unq_to_uq = c.tab + c.root->off_color_unquant_to_uquant + (quant_level - QUANT_6) * 512;
 	return t;
 }
 
-WV_FN void stage_color_rows(const Ctx& c, int q0, int q1)
+/* Stage the rows of the candidate's colour quant level (the rarely used "matched formats" retry at
+ * the next level reads the table in global memory). */
+WV_FN void stage_color_rows(const Ctx& c, int q0)
 {
 	TrialInfo& tr = c.tr();
 	const uint32_t* s0 = reinterpret_cast<const uint32_t*>(c.tab + c.root->off_color_unquant_to_uquant + (q0 - QUANT_6) * 512);
-	const uint32_t* s1 = reinterpret_cast<const uint32_t*>(c.tab + c.root->off_color_unquant_to_uquant + (q1 - QUANT_6) * 512);
 	uint32_t* d = reinterpret_cast<uint32_t*>(c.lds + c.L->ctab);
-	WV_FOR(i, 256) { d[i] = i < 128 ? s0[i] : s1[i - 128]; }
-	WV_ONE { tr.staged_color_quant[0] = q0; tr.staged_color_quant[1] = q1; }
+	WV_FOR(i, 128) { d[i] = s0[i]; }
+	WV_ONE { tr.staged_color_quant[0] = q0; tr.staged_color_quant[1] = -1; }
 	WV_SYNC();
 }
 

@@ -110,11 +110,11 @@ struct LdsLayout {
 	uint32_t uni;        // search: infill rows, angular batch [64][8] f32, mode-score terms, then
 	                     //         5 texel rows of the encoding-choice errors, then the format tables
 	uint32_t dtab;       // refine: staged decimation tables of the candidate
-	uint32_t ctab;       // refine: u8 [2][512] staged colour quant rows
+	uint32_t ctab;       // refine: u8 [512] staged colour quant rows of the candidate's quant level
 	uint32_t qtab;       // refine: QuantXfer of the candidate's weight quant level
 	uint32_t rsc;        // refine: f32 [19][Tp] per-texel term rows of the endpoint re-fit
-	uint32_t tsc_r;      // refine: f32 scratch rows (tsc_stride floats apart)
-	uint32_t wsc;        // refine: f32 [3][64] per-weight scratch rows
+	uint32_t tsc_r;      // refine: f32 [2][Tp] weights expanded to texel resolution
+	uint32_t wsc;        // refine: f32 [2][64] per-weight scratch rows
 	uint32_t part;       // partition search scratch
 	uint32_t tsc_p;      // partition search: f32 [2][Tp] k-means rows
 	uint32_t uni_bytes;  // size of the `uni` region
@@ -154,8 +154,8 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.hdr = take(sizeof(LdsHeader));
 	L.data = take(4 * Tp * 4);
 	L.blk = take(sizeof(BlkInfo));
-	L.scb = take(sizeof(Scb));
-	L.wscb = take(sizeof(Scb));
+	L.scb = take(2 * sizeof(Scb));                               // best + working symbolic block, back to back
+	L.wscb = L.scb + (uint32_t)sizeof(Scb);
 	L.trial = take(sizeof(TrialInfo));
 	L.ei_w = take(2 * Tp * 4);
 	L.ei_wes = take(2 * Tp * 4);
@@ -178,7 +178,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.uni_bytes = 64 * 8 * 4;                                     // angular batch
 	{
 		// mode scoring: per-mode descriptors + texel terms of a chunk of block modes (score_block_modes)
-		uint32_t chunk = Tp <= 36 ? 16u : 8u;
+		uint32_t chunk = 8u;
 		if (chunk * (MODE_DESC_BYTES + Tp * 4) > L.uni_bytes) L.uni_bytes = chunk * (MODE_DESC_BYTES + Tp * 4);
 	}
 	if (fmt_scratch_bytes(cfg.tune_partition_count_limit) > L.uni_bytes) L.uni_bytes = fmt_scratch_bytes(cfg.tune_partition_count_limit);
@@ -189,16 +189,18 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	// refine phase
 	o = begin;
 	L.dtab = take(r.max_decimation_table_bytes);
-	L.ctab = take(2 * 512);
+	L.ctab = take(512);
 	L.qtab = take(sizeof(QuantXfer));
 	L.rsc = take(19 * Tp * 4);
 	{
-		// 5 texel-length rows (weight expansion, difference terms) or 12 rows of one weight's texel list (realign)
+		// the re-fit rows double as scratch of the difference / realign steps; realign needs 2 + 12 rows of
+		// one weight's texel list
 		uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
-		uint32_t tsc_floats = 5 * Tp > 12 * rs ? 5 * Tp : 12 * rs;
-		L.tsc_r = take(tsc_floats * 4);
+		uint32_t need = 2 * Tp + 12 * rs;
+		if (need > 19 * Tp) { o = L.rsc; take(need * 4); }
 	}
-	L.wsc = take(3 * 64 * 4);
+	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
+	L.wsc = take(2 * 64 * 4);
 	if (o > end) end = o;
 	// partition search phase
 	o = begin;
@@ -244,7 +246,6 @@ struct Ctx {
 	WV_FN float* tsc_f(int row) const { return reinterpret_cast<float*>(lds + L->uni) + row * L->tsc_stride; }      // format search
 	WV_FN float* tsc_r(int row) const { return reinterpret_cast<float*>(lds + L->tsc_r) + row * L->tsc_stride; }    // refinement
 	WV_FN float* tsc_p(int row) const { return reinterpret_cast<float*>(lds + L->tsc_p) + row * L->tsc_stride; }    // partition search
-	WV_FN float* tsc_r_base() const { return reinterpret_cast<float*>(lds + L->tsc_r); }
 	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L->wsc) + row * 64; }
 	WV_FN uint8_t* fmt() const { return lds + L->uni; }
 	WV_FN uint8_t* part() const { return lds + L->part; }

@@ -469,8 +469,8 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	}
 	WV_SYNC();
 
-	float* term = c.tsc_r(2);
-	float* flag = c.tsc_r(3);
+	float* term = c.rsc(0);        // (the endpoint re-fit rows are free between re-fits)
+	float* flag = c.rsc(1);
 	WV_FOR(i, T)
 	{
 		// 1-plane multi-partition sums in partition order, the other two in texel order
@@ -587,7 +587,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 		if (!decimated)
 		{
-			float* moved = c.tsc_r(4);
+			float* moved = c.rsc(0);
 			WV_FOR(texel, T)
 			{
 				int uqw = uq[texel];
@@ -638,8 +638,8 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const float* tcw = di.tcw;
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
-			float* uqf = c.wsc(2);
-			float* rt = c.tsc_r_base();
+			float* uqf = c.rsc(1);
+			float* rt = c.rsc(2);          // 12 rows of `rs` floats
 			const int rs = ((int)c.root->max_weight_texel_rows + 3) & ~3;
 
 			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }
