@@ -71,15 +71,34 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		float weight_weight = 1e-10f;
 		float initial_weight = 0.0f;
 		int cnt = (c.tab + di.off_weight_texel_count)[i];
-		#pragma unroll 4
-		for (int j = 0; j < cnt; j++)
+		// groups of 8 taps: all table loads of a group are issued together, then all gathers, then the
+		// (strictly ordered) accumulation -- one memory round trip per level instead of one per tap
+		for (int j0 = 0; j0 < cnt; j0 += 8)
 		{
-			int texel = wt[j * W + i];
-			float weight = wc[j * W + i];
-			float wes = constant_wes ? wes0 : eiwes[texel];
-			float contrib_weight = weight * wes;
-			weight_weight += contrib_weight;
-			initial_weight += eiw[texel] * contrib_weight;
+			int tx[8]; float wv[8], iw[8], es[8];
+			#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				int j = j0 + u < cnt ? j0 + u : 0;
+				tx[u] = wt[j * W + i];
+				wv[u] = wc[j * W + i];
+			}
+			#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				iw[u] = eiw[tx[u]];
+				es[u] = constant_wes ? wes0 : eiwes[tx[u]];
+			}
+			#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				if (j0 + u < cnt)
+				{
+					float contrib_weight = wv[u] * es[u];
+					weight_weight += contrib_weight;
+					initial_weight += iw[u] * contrib_weight;
+				}
+			}
 		}
 		dwi_base[k] = initial_weight / weight_weight;
 	}
@@ -134,17 +153,33 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			float error_change0 = 1e-10f;
 			float error_change1 = 0.0f;
 			int cnt = (c.tab + di.off_weight_texel_count)[i];
-			#pragma unroll 4
-			for (int j = 0; j < cnt; j++)
+			for (int j0 = 0; j0 < cnt; j0 += 8)
 			{
-				int texel = wt[j * W + i];
-				float contrib_weight = wc[j * W + i];
-				float wes = constant_wes ? wes0 : eiwes[texel];
-				float scale = wes * contrib_weight;
-				float old_weight = inf[texel];
-				float ideal_weight = eiw[texel];
-				error_change0 += contrib_weight * scale;
-				error_change1 += (old_weight - ideal_weight) * scale;
+				int tx[8]; float wv[8], iw[8], es[8], ow[8];
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					int j = j0 + u < cnt ? j0 + u : 0;
+					tx[u] = wt[j * W + i];
+					wv[u] = wc[j * W + i];
+				}
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					iw[u] = eiw[tx[u]];
+					ow[u] = inf[tx[u]];
+					es[u] = constant_wes ? wes0 : eiwes[tx[u]];
+				}
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					if (j0 + u < cnt)
+					{
+						float scale = es[u] * wv[u];
+						error_change0 += wv[u] * scale;
+						error_change1 += (ow[u] - iw[u]) * scale;
+					}
+				}
 			}
 			float step = (error_change1 * -16.0f) / error_change0;
 			step = v_clamp(-0.25f, 0.25f, step);
@@ -222,16 +257,31 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
 			float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
-			#pragma unroll 4
-			for (int j = 0; j < W; j++)
+			// groups of 8 weights: LDS reads, then all table loads, then the ordered accumulation
+			for (int j0 = 0; j0 < W; j0 += 8)
 			{
-				float wj = wv[j];
-				float sample = v_clampzo(wj) * (SINCOS_STEPS - 1.0f);
-				int isample = (int)(sample + 0.5f);
-				anglesum_x += cos_table[isample * ANGULAR_STEPS + sp];
-				anglesum_y += sin_table[isample * ANGULAR_STEPS + sp];
-				min_weight = wj < min_weight ? wj : min_weight;
-				max_weight = wj > max_weight ? wj : max_weight;
+				float wj[8], cs[8], sn[8];
+				#pragma unroll
+				for (int u = 0; u < 8; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					float sample = v_clampzo(wj[u]) * (SINCOS_STEPS - 1.0f);
+					int isample = (int)(sample + 0.5f);
+					cs[u] = cos_table[isample * ANGULAR_STEPS + sp];
+					sn[u] = sin_table[isample * ANGULAR_STEPS + sp];
+				}
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					if (j0 + u < W)
+					{
+						anglesum_x += cs[u];
+						anglesum_y += sn[u];
+						min_weight = wj[u] < min_weight ? wj[u] : min_weight;
+						max_weight = wj[u] > max_weight ? wj[u] : max_weight;
+					}
+				}
 			}
 			float angle = ref_atan2(anglesum_y, anglesum_x);
 			angle = angle == angle ? angle : 0.0f;
@@ -242,15 +292,24 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			float errval = 0.0f, cut_low = 0.0f, cut_high = 0.0f;
 			float minidx = f_round(min_weight * rcp_stepsize - offset);
 			float maxidx = f_round(max_weight * rcp_stepsize - offset);
-			#pragma unroll 4
-			for (int j = 0; j < W; j++)
+			for (int j0 = 0; j0 < W; j0 += 8)
 			{
-				float sval = wv[j] * rcp_stepsize - offset;
-				float svalrte = f_round(sval);
-				float diff = sval - svalrte;
-				errval += diff * diff;
-				if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
-				if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+				float wj[8];
+				#pragma unroll
+				for (int u = 0; u < 8; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
+				#pragma unroll
+				for (int u = 0; u < 8; u++)
+				{
+					if (j0 + u < W)
+					{
+						float sval = wj[u] * rcp_stepsize - offset;
+						float svalrte = f_round(sval);
+						float diff = sval - svalrte;
+						errval += diff * diff;
+						if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
+						if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+					}
+				}
 			}
 			int max_quant_steps = steps;
 			int span = (int)(maxidx - minidx + 1.0f);
