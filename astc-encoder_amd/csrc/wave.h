@@ -63,7 +63,13 @@
 		#define WV_OUT __attribute__((noinline)) inline
 	#endif
 	#define WV_SYNC() ((void)0)
+	#if defined(ASTC_EMU_REVERSE_LANES)
+	// debugging aid: run the lanes of every WV_FOR in reverse order; any output change means a loop
+	// body depends on another lane's writes without a WV_SYNC() in between
+	#define WV_FOR(i, n) for (int i = (int)(n) - 1; i >= 0; i--)
+	#else
 	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)
+	#endif
 	#define WV_ONE if (true)
 #endif
 

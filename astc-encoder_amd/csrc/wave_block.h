@@ -736,6 +736,13 @@ WV_FN float prepare_block_statistics(const Ctx& c)
 	return lowest_correlation;
 }
 
+WV_OUT float stage_block_statistics()
+{
+	const Ctx c = ctx_make();
+	PROF_SCOPE(c, PS_STATS);
+	return prepare_block_statistics(c);
+}
+
 /* Compress the block currently loaded in LDS and write 16 bytes to pcb. (ref: compress_block :1162) */
 WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 {
@@ -815,7 +822,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	if (!done)
 	{
 		float lowest_correl;
-		{ PROF_SCOPE(c, PS_STATS); lowest_correl = prepare_block_statistics(c); }
+		lowest_correl = wv_uniform(stage_block_statistics());
 		bool block_skip_two_plane = lowest_correl > cfg.tune_2plane_early_out_limit_correlation;
 		for (int i = 3; i >= 0 && !done; i--)
 		{
@@ -841,6 +848,8 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			requested_trials = i_min(requested_trials, requested_indices);
 
 			int actual_trials;
+			// (kept inline: as an out-of-line stage this search produced different candidates on hardware;
+			// not understood yet)
 			{ PROF_SCOPE(c, PS_KMEANS); actual_trials = find_best_partition_candidates(c, partition_count, requested_indices, requested_trials); }
 			// copy out of the scratch region: the trials below reuse it
 			int partition_indices[MAX_PARTITIONING_CANDIDATES];

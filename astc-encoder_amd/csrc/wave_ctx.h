@@ -117,6 +117,8 @@ struct LdsLayout {
 	uint32_t wsc;        // refine: f32 [2][64] per-weight scratch rows
 	uint32_t part;       // partition search scratch
 	uint32_t tsc_p;      // partition search: f32 [2][Tp] k-means rows
+	uint32_t part_tabs;  // partition search: staged records (header + texel lists) of the candidates being scored
+	uint32_t part_chunk; // candidates per staging pass
 	uint32_t uni_bytes;  // size of the `uni` region
 	uint32_t tsc_stride; // floats between tsc rows
 	uint32_t total;
@@ -209,6 +211,16 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	if (cfg.tune_partition_index_limit[2] > lim) lim = cfg.tune_partition_index_limit[2];
 	L.part = take(part_scratch_bytes(r.max_partitionings, lim));
 	L.tsc_p = take(2 * Tp * 4);
+	{
+		// as many candidate records as fit without growing the block's LDS (at least 8, at most one per lane)
+		uint32_t rec = (uint32_t)(sizeof(PartitionHeader) + 2 * r.texel_count + 3u) & ~3u;
+		uint32_t room = end > o ? (end - o) / rec : 0;
+		uint32_t chunk = room < 8 ? 8 : room;
+		if (chunk > 64) chunk = 64;
+		if (chunk > lim) chunk = lim < 1 ? 1 : lim;
+		L.part_chunk = chunk;
+		L.part_tabs = take(chunk * rec);
+	}
 	if (o > end) end = o;
 #if defined(ASTC_LDS_PAD)
 	end += ASTC_LDS_PAD;   // occupancy experiments only

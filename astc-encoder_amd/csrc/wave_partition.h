@@ -249,18 +249,51 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	return count;
 }
 
-/* Line-fit error of one candidate partitioning, all work on one lane.
+/* Line-fit error of one candidate partitioning, all work on one lane; `pv` points at the candidate's
+ * record staged in LDS (a lane per candidate reading its own record from global memory would touch
+ * a different cache line per lane on every access).
  * (ref: compute_avgs_and_dirs_{4_comp,3_comp_rgb} + compute_error_squared_{rgba,rgb} + :660-670 / :726-738) */
-WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha, float weight_imprecision_estim, float& uncor_out, float& samec_out)
+WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool uses_alpha, float weight_imprecision_estim, float& uncor_out, float& samec_out)
 {
 	const BlkInfo& blk = c.blk();
-	const int T = c.T;
+	const int T = c.T, Tp = c.Tp;
 	const int n = uses_alpha ? 4 : 3;
-	PartView pv = part_view(c, pc, packed);
 
-	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385)
+	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385).
+	// One pass over the texels feeds the accumulators of every (partition, channel); lanes past T read
+	// the zero padding of the texel rows, which adds +0.0 like the reference's masked tail lanes.
 	float avg[4][4];
 	{
+		float acc[3][4][4];
+		#pragma unroll
+		for (int p = 0; p < 3; p++)
+			#pragma unroll
+			for (int ch = 0; ch < 4; ch++)
+				#pragma unroll
+				for (int l = 0; l < 4; l++) acc[p][ch][l] = 0.0f;
+
+		const uint32_t* ot4 = reinterpret_cast<const uint32_t*>(pv.of_texel);
+		for (int i = 0; i < Tp; i += 4)
+		{
+			const uint32_t ot = ot4[i >> 2];
+			#pragma unroll
+			for (int ch = 0; ch < 4; ch++)
+			{
+				if (ch >= n) break;
+				const float* d = c.data(ch) + i;
+				const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+				#pragma unroll
+				for (int p = 0; p < 3; p++)
+				{
+					if (p >= pc - 1) break;
+					acc[p][ch][0] = acc[p][ch][0] + ((int)(ot & 0xFF) == p ? d0 : 0.0f);
+					acc[p][ch][1] = acc[p][ch][1] + ((int)((ot >> 8) & 0xFF) == p ? d1 : 0.0f);
+					acc[p][ch][2] = acc[p][ch][2] + ((int)((ot >> 16) & 0xFF) == p ? d2 : 0.0f);
+					acc[p][ch][3] = acc[p][ch][3] + ((int)(ot >> 24) == p ? d3 : 0.0f);
+				}
+			}
+		}
+
 		float rest[4];
 		#pragma unroll
 		for (int ch = 0; ch < 4; ch++) rest[ch] = blk.data_mean[ch] * (float)T;
@@ -272,20 +305,7 @@ WV_FN void score_partitioning(const Ctx& c, int pc, int packed, bool uses_alpha,
 			for (int ch = 0; ch < 4; ch++)
 			{
 				if (ch >= n) break;
-				const float* d = c.data(ch);
-				float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-				int i = 0;
-				for (; i + 3 < T; i += 4)
-				{
-					a0 = a0 + (pv.of_texel[i] == p ? d[i] : 0.0f);
-					a1 = a1 + (pv.of_texel[i + 1] == p ? d[i + 1] : 0.0f);
-					a2 = a2 + (pv.of_texel[i + 2] == p ? d[i + 2] : 0.0f);
-					a3 = a3 + (pv.of_texel[i + 3] == p ? d[i + 3] : 0.0f);
-				}
-				if (i < T) a0 = a0 + (pv.of_texel[i] == p ? d[i] : 0.0f);
-				if (i + 1 < T) a1 = a1 + (pv.of_texel[i + 1] == p ? d[i + 1] : 0.0f);
-				if (i + 2 < T) a2 = a2 + (pv.of_texel[i + 2] == p ? d[i + 2] : 0.0f);
-				float total = hadd4(a0, a1, a2, a3);
+				float total = hadd4(acc[p][ch][0], acc[p][ch][1], acc[p][ch][2], acc[p][ch][3]);
 				rest[ch] = rest[ch] - total;
 				avg[p][ch] = total / (float)pv.count[p];
 			}
@@ -465,14 +485,38 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	bool uses_alpha = !(blk.data_min[3] == blk.data_max[3]);
 
 	{ PROF_SCOPE(c, PS_PSCORE);
-	WV_FOR(i, partition_search_limit)
+	const int rec_words = (int)(((uint32_t)sizeof(PartitionHeader) + 2u * (uint32_t)T + 3u) >> 2);
+	const int chunk = (int)c.L->part_chunk;
+	uint32_t* staged = reinterpret_cast<uint32_t*>(c.lds + c.L->part_tabs);
+	for (int first = 0; first < partition_search_limit; first += chunk)
 	{
-		float ue, se;
-		score_partitioning(c, pc, ps.ordering()[i], uses_alpha, weight_imprecision_estim, ue, se);
-		ps.uncor_err()[i] = ue;
-		ps.samec_err()[i] = se;
+		const int nn = i_min(chunk, partition_search_limit - first);
+		// stage the records of candidates [first, first + nn) (coalesced word copies)
+		WV_FOR(k, nn * rec_words)
+		{
+			int sl = k / rec_words, w = k - sl * rec_words;
+			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.part_rec(pc, ps.ordering()[first + sl]));
+			staged[k] = src[w];
+		}
+		WV_SYNC();
+		WV_FOR(i, nn)
+		{
+			const uint8_t* rec = reinterpret_cast<const uint8_t*>(staged + i * rec_words);
+			PartView pv;
+			pv.h = reinterpret_cast<const PartitionHeader*>(rec);
+			pv.of_texel = rec + sizeof(PartitionHeader);
+			pv.sorted = pv.of_texel + T;
+			pv.pcount = pc;
+			int o = 0;
+			for (int q = 0; q < 4; q++) { pv.offset[q] = o; pv.count[q] = pv.h->texel_count[q]; o += pv.count[q]; }
+			float ue, se;
+			score_partitioning(c, pc, pv, uses_alpha, weight_imprecision_estim, ue, se);
+			ps.uncor_err()[first + i] = ue;
+			ps.samec_err()[first + i] = se;
+		}
+		WV_SYNC();
 	}
-	WV_SYNC(); }
+	}
 
 	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
 	WV_ONE
