@@ -195,10 +195,10 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.qtab = take(sizeof(QuantXfer));
 	L.rsc = take(19 * Tp * 4);
 	{
-		// the re-fit rows double as scratch of the difference / realign steps; realign needs 2 + 12 rows of
+		// the re-fit rows double as scratch of the difference / realign steps; realign needs 3 texel rows + 12 rows of
 		// one weight's texel list
 		uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
-		uint32_t need = 2 * Tp + 12 * rs;
+		uint32_t need = 3 * Tp + 12 * rs;
 		if (need > 19 * Tp) { o = L.rsc; take(need * 4); }
 	}
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1

@@ -638,36 +638,56 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const float* tcw = di.tcw;
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
-			float* uqf = c.rsc(1);
-			float* rt = c.rsc(2);          // 12 rows of `rs` floats
 			const int rs = ((int)c.root->max_weight_texel_rows + 3) & ~3;
+			uint32_t* pn = reinterpret_cast<uint32_t*>(c.rsc(0));   // prev/next quant values of each weight's current value
+			float* uqf = c.rsc(1);
+			float* rt = c.rsc(2);                                    // 12 rows of `rs` floats
+			float* wb = rt + 12 * rs;                                // [T] current weights infilled to texel resolution
 
-			WV_FOR(i, W) { uqf[i] = (float)uq[i]; }
+			WV_FOR(i, W)
+			{
+				int u = uq[i];
+				uqf[i] = (float)u;
+				pn[i] = qat.prev_next_values[u];
+			}
 			WV_SYNC();
+			// The reference re-infills a texel's weight every time it looks at it; the value only changes
+			// when one of its grid weights moves, so it is kept here and refreshed on moves.
+			WV_FOR(t, T) { wb[t] = infill4(uqf, tw, tcf, T, t); }
+			WV_SYNC();
+
+			// with one partition the endpoint base / step are the same for every texel
+			const bool one_partition = pc == 1;
+			const f4 color_offset_1 = load4(&tr.fbox[4]);
+			const f4 color_base_1 = load4(&tr.fbox[0]);
 
 			for (int we = 0; we < W; we++)
 			{
 				int uqw = uq[we];
-				uint32_t prev_and_next = qat.prev_next_values[uqw];
-				float uqw_base = uqf[we];
+				uint32_t prev_and_next = pn[we];
+				int n = wtc[we];
+				float uqw_base = (float)uqw;
 				float uqw_down = (float)(prev_and_next & 0xFF);
 				float uqw_up = (float)((prev_and_next >> 8) & 0xFF);
 				float uqw_diff_down = uqw_down - uqw_base;
 				float uqw_diff_up = uqw_up - uqw_base;
-				int n = wtc[we];
 
-				// per-texel squared differences for base / down / up, 4 channels each -> tsc(0..11)
+				// per-texel squared differences for base / down / up, 4 channels each -> rt rows 0..11
 				WV_FOR(te, n)
 				{
 					int texel = wt[te * W + we];
 					float tw_base = tcw[te * W + we];
-					float weight_base = infill4(uqf, tw, tcf, T, texel);
+					float weight_base = wb[texel];
 					float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
 					float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
 
-					int p = pv.of_texel[texel];
-					f4 color_offset = load4(&tr.fbox[p * 8 + 4]);
-					f4 color_base = load4(&tr.fbox[p * 8]);
+					f4 color_offset = color_offset_1, color_base = color_base_1;
+					if (!one_partition)
+					{
+						int p = pv.of_texel[texel];
+						color_offset = load4(&tr.fbox[p * 8 + 4]);
+						color_base = load4(&tr.fbox[p * 8]);
+					}
 					f4 color = color_base + color_offset * weight_base;
 					f4 orig_color = mk4(c.data(0)[texel], c.data(1)[texel], c.data(2)[texel], c.data(3)[texel]);
 					f4 color_diff = color - orig_color;
@@ -693,15 +713,19 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				float error_down = hadd_s(load4(&tr.fbox[68]) * error_weight);
 				float error_up = hadd_s(load4(&tr.fbox[72]) * error_weight);
 
-				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64))
+				float new_value = -1.0f;
+				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = uqw_up;
+				else if ((error_down < error_base) && (uqw > 0)) new_value = uqw_down;
+				if (new_value >= 0.0f)
 				{
-					WV_ONE { uqf[we] = uqw_up; uq[we] = (uint8_t)uqw_up; }
+					WV_ONE { uqf[we] = new_value; uq[we] = (uint8_t)new_value; }
 					adjustments = true;
-				}
-				else if ((error_down < error_base) && (uqw > 0))
-				{
-					WV_ONE { uqf[we] = uqw_down; uq[we] = (uint8_t)uqw_down; }
-					adjustments = true;
+					WV_SYNC();
+					WV_FOR(te, n)
+					{
+						int texel = wt[te * W + we];
+						wb[texel] = infill4(uqf, tw, tcf, T, texel);
+					}
 				}
 				WV_SYNC();
 			}
