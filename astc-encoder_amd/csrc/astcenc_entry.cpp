@@ -232,6 +232,8 @@ struct astcenc_context {
 	std::condition_variable cv;
 	enum { IDLE, RUNNING, DONE } state;
 	astcenc_error result;
+	int dstate;                       // same protocol for decompress (ref: manage_decompress)
+	astcenc_error dresult;
 	volatile int cancel_flag;
 };
 
@@ -388,6 +390,7 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 	ctx->host_tables = nullptr;
 	ctx->backend = nullptr;
 	ctx->state = astcenc_context::IDLE;
+	ctx->dstate = astcenc_context::IDLE;
 	ctx->result = ASTCENC_SUCCESS;
 	ctx->cancel_flag = 0;
 
@@ -437,7 +440,7 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 		else ctx->config.tune_db_limit = 0.0f;
 	}
 
-	if (compress)
+	// decompress-only contexts need the device too (the decode kernel), so the backend always exists
 	{
 		DeviceConfig dc;
 		memset(&dc, 0, sizeof(dc));
@@ -605,12 +608,11 @@ astcenc_error astcenc_compress_cancel(astcenc_context* ctx)
 	return ASTCENC_SUCCESS;
 }
 
-/* Decode side is outside this round's hot-path scope: argument checks follow the
- * reference (astcenc_entry.cpp:1287-1330), then NOT_IMPLEMENTED. */
+/* (ref: astcenc_decompress_image, astcenc_entry.cpp:1274-1390).  Blocks go to the device, one wavefront
+ * decodes each block straight into the output image, the image comes back. */
 astcenc_error astcenc_decompress_image(astcenc_context* ctx, const uint8_t* data, size_t data_len,
                                        astcenc_image* image_outp, const astcenc_swizzle* swizzle, unsigned int thread_index)
 {
-	(void)data;
 	if (thread_index >= ctx->thread_count) return ASTCENC_ERR_BAD_PARAM;
 	if (!swz_ok(swizzle->r, true) || !swz_ok(swizzle->g, true) || !swz_ok(swizzle->b, true) || !swz_ok(swizzle->a, true))
 	{
@@ -627,12 +629,40 @@ astcenc_error astcenc_decompress_image(astcenc_context* ctx, const uint8_t* data
 	mul_safe(block_count, 16, overflow);
 	if (overflow || block_count == 0) return ASTCENC_ERR_BAD_PARAM;
 	if (data_len < block_count * 16) return ASTCENC_ERR_OUT_OF_MEM;
-	return ASTCENC_ERR_NOT_IMPLEMENTED;
+	if (image_outp->dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;       // 3D: DESIGN.md section 8
+
+	DecompressJob job;
+	memset(&job, 0, sizeof(job));
+	job.host_blocks = data;
+	job.block_bytes = block_count * 16;
+	job.host_image = image_outp->data[0];
+	job.dim_x = image_outp->dim_x;
+	job.dim_y = image_outp->dim_y;
+	job.data_type = (uint32_t)image_outp->data_type;
+	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
+
+	// every caller thread arrives here; the first drives the device, the others wait for it
+	std::unique_lock<std::mutex> lk(ctx->lock);
+	if (ctx->thread_count == 1) ctx->dstate = astcenc_context::IDLE;
+	if (ctx->dstate == astcenc_context::IDLE)
+	{
+		ctx->dstate = astcenc_context::RUNNING;
+		lk.unlock();
+		int rc = backend_decompress(ctx->backend, job);
+		lk.lock();
+		ctx->dresult = rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+		ctx->dstate = astcenc_context::DONE;
+		ctx->cv.notify_all();
+		return ctx->dresult;
+	}
+	while (ctx->dstate == astcenc_context::RUNNING) ctx->cv.wait(lk);
+	return ctx->dresult;
 }
 
 astcenc_error astcenc_decompress_reset(astcenc_context* ctx)
 {
-	(void)ctx;
+	std::unique_lock<std::mutex> lk(ctx->lock);
+	ctx->dstate = astcenc_context::IDLE;
 	return ASTCENC_SUCCESS;
 }
 

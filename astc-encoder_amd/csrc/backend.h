@@ -26,10 +26,20 @@ struct CompressJob {
 	void (*progress)(float);   // optional
 };
 
+struct DecompressJob {
+	const uint8_t* host_blocks;   // 16 bytes per block, raster block order
+	size_t   block_bytes;
+	void*    host_image;          // tightly packed RGBA rows (one 2D slice) of data_type, host memory
+	uint32_t dim_x, dim_y;
+	uint32_t data_type;           // astcenc_type
+	uint32_t swz[4];
+};
+
 /* status: 0 ok, 1 out of memory, 2 no usable device / launch failure */
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status);
 void backend_destroy(Backend* b);
 int backend_compress(Backend* b, const CompressJob& job);
+int backend_decompress(Backend* b, const DecompressJob& job);
 const char* backend_name();
 
 
@@ -52,5 +62,15 @@ int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint
 int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
 int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
+
+/* Decompression kernel launch (kernel_decode.hip). */
+struct DecodeLaunch {
+	const uint8_t* d_blocks;
+	void* d_image;
+	uint32_t dim_x, dim_y, data_type, swz[4];
+	uint32_t block_x, block_y, profile;
+	void* stream;
+};
+int astc_decode_launch(const DecodeLaunch& d);
 
 } // namespace astcd

@@ -190,7 +190,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks",
 		                                        "  dec sweep1", "  dec infill", "  dec sweep3", "  ang phase1", "  ang phase2",
 		                                        "  mode terms", "  mode acc", "  mode quant", "  fmt eci", "  fmt table", "  fmt combine", "  fmt select",
-		                                        "  x0", "  x1", "  x2", "  x3" };
+		                                        "  cand staging", "  physical", "  x2", "  x3" };
 		unsigned long long h[2 * PS_COUNT];
 		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
 		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);
@@ -201,6 +201,44 @@ int backend_compress(Backend* b, const CompressJob& job)
 				        (double)h[PS_COUNT + i] / (double)nblocks);
 	}
 #endif
+	return 0;
+}
+
+int backend_decompress(Backend* b, const DecompressJob& job)
+{
+	HIP_TRY(hipSetDevice(b->device), return 2);
+	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
+	const size_t image_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+
+	// the staging buffers of the compress path are reused the other way round
+	if (b->image_cap < image_bytes)
+	{
+		if (b->d_image) hipFree(b->d_image);
+		b->d_image = nullptr; b->image_cap = 0;
+		HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
+		b->image_cap = image_bytes;
+	}
+	if (b->out_cap < job.block_bytes)
+	{
+		if (b->d_out) hipFree(b->d_out);
+		b->d_out = nullptr; b->out_cap = 0;
+		HIP_TRY(hipMalloc(&b->d_out, job.block_bytes), return 1);
+		b->out_cap = job.block_bytes;
+	}
+	HIP_TRY(hipMemcpyAsync(b->d_out, job.host_blocks, job.block_bytes, hipMemcpyHostToDevice, b->stream), return 2);
+
+	DecodeLaunch d;
+	d.d_blocks = b->d_out;
+	d.d_image = b->d_image;
+	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
+	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y;
+	d.profile = b->cfg.profile;
+	d.stream = b->stream;
+	int lrc = astc_decode_launch(d);
+	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
+	HIP_TRY(hipMemcpyAsync(job.host_image, b->d_image, image_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
+	HIP_TRY(hipStreamSynchronize(b->stream), return 2);
 	return 0;
 }
 

@@ -321,10 +321,15 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		const int color_quant_level_mod = tr.cand_quant_mod[i];
 
 		// stage what the refinement loop reads in serial, latency-bound code into LDS
-		const DecView di = dec_view_staged(c, qw_bm.decimation_mode);
-		stage_words(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
+		{
+			PROF_SCOPE(c, PS_X0);
+			const DecimationInfo& dinfo = c.dec_info(qw_bm.decimation_mode);
+			stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
+			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
+			stage_color_rows(c, color_quant_level);      // ends with a sync
+		}
+		const DecView di = dec_view_lds(c, qw_bm.decimation_mode);
 		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
-		stage_color_rows(c, color_quant_level);
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
 		// recomputed here instead of being stored for every block mode
@@ -908,6 +913,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 				scb.constant_color[k] = (int)(v + 0.5f);
 			}
 		}
+		PROF_SCOPE(c, PS_X1);
 		symbolic_to_physical(c, scb, pcb);
 	}
 }

@@ -29,8 +29,7 @@ WV_FN void stage_color_rows(const Ctx& c, int q0)
 {
 	TrialInfo& tr = c.tr();
 	const uint32_t* s0 = reinterpret_cast<const uint32_t*>(c.tab + c.root->off_color_unquant_to_uquant + (q0 - QUANT_6) * 512);
-	uint32_t* d = reinterpret_cast<uint32_t*>(c.lds + c.L->ctab);
-	WV_FOR(i, 128) { d[i] = s0[i]; }
+	stage_words_nosync(c.lds + c.L->ctab, reinterpret_cast<const uint8_t*>(s0), 128);
 	WV_ONE { tr.staged_color_quant[0] = q0; tr.staged_color_quant[1] = -1; }
 	WV_SYNC();
 }

@@ -370,11 +370,35 @@ WV_FN PartView part_view(const Ctx& c, int pcount, int packed)
 
 
 /* Copy `words` 32-bit words global -> LDS with all lanes (coalesced), then sync. */
-WV_FN void stage_words(uint8_t* lds_dst, const uint8_t* src, int words)
+WV_FN void stage_words_nosync(uint8_t* lds_dst, const uint8_t* src, int words)
 {
 	const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
 	uint32_t* d = reinterpret_cast<uint32_t*>(lds_dst);
-	WV_FOR(i, words) { d[i] = s[i]; }
+#if WV_DEVICE
+	// 8 loads in flight per lane before the first store: one memory round trip per 512 words
+	for (int base = 0; base < words; base += 512)
+	{
+		uint32_t v[8];
+		#pragma unroll
+		for (int u = 0; u < 8; u++)
+		{
+			int i = base + u * 64 + WV_LANE;
+			v[u] = s[i < words ? i : 0];
+		}
+		#pragma unroll
+		for (int u = 0; u < 8; u++)
+		{
+			int i = base + u * 64 + WV_LANE;
+			if (i < words) d[i] = v[u];
+		}
+	}
+#else
+	for (int i = 0; i < words; i++) d[i] = s[i];
+#endif
+}
+WV_FN void stage_words(uint8_t* lds_dst, const uint8_t* src, int words)
+{
+	stage_words_nosync(lds_dst, src, words);
 	WV_SYNC();
 }
 

@@ -1,0 +1,634 @@
+// SPDX-License-Identifier: Apache-2.0
+// Block decoder: 128-bit physical block -> texels of the output image.
+//   ref: physical_to_symbolic        Source/astcenc_symbolic_physical.cpp:291-556
+//        decode_ise                  Source/astcenc_integer_sequence.cpp:651-739
+//        decompress_symbolic_block   Source/astcenc_decompress_symbolic.cpp:170-308
+//        unpack_weights / lerp_color_int / decode_texel       :37-155
+//        store_image_block           Source/astcenc_image.cpp:345-573
+//
+// One wavefront decodes one block.  Unlike the reference (and unlike the encoder) nothing here reads
+// a table: the decoder must accept every legal block mode and partitioning, not just the ones a
+// compression preset selects, so grid weights are infilled with the format's arithmetic rule, BISE
+// symbols are unpacked per element straight from the bit stream, and texels are assigned to
+// partitions with the hash function.  Lanes own weights / colour values while unpacking and texels
+// while interpolating.
+#pragma once
+#include "wave_color.h"
+#include "wave_load.h"
+#include "wave_pack.h"
+
+namespace astcd { inline namespace ASTC_VARIANT {
+
+struct DecodeImage {
+	void*    data;            // tightly packed RGBA rows of data_type
+	uint32_t dim_x, dim_y;
+	uint32_t data_type;       // astcenc_type
+	uint32_t swz[4];          // astcenc_swz per output channel
+	uint32_t blocks_x, blocks_y;
+	uint32_t block_x, block_y;
+	uint32_t profile;         // astcenc_profile
+};
+
+/* Per-wave scratch (LDS). */
+struct DecodeScratch {
+	uint8_t weights[2][64];   // unquantized grid weights per plane, 0..64
+	uint8_t colors[32];       // unquantized colour values, 0..255
+	int     ep[4][8];         // endpoint0.rgba, endpoint1.rgba per partition (16-bit domain)
+	int     lns[4][2];        // rgb / alpha are LNS encoded, per partition
+};
+
+/* 128-bit block held as four dwords, bit 0 = LSB of byte 0. */
+struct Bits128 { uint32_t w[4]; };
+
+WV_FN uint32_t bits_get(const Bits128& b, int off, int n)
+{
+	// n <= 16, may run past bit 127 (reads zeros there, like the reference's padded buffer)
+	if (n <= 0 || off >= 128) return 0u;
+	int word = off >> 5, sh = off & 31;
+	uint64_t lo = b.w[word];
+	uint64_t hi = word + 1 < 4 ? b.w[word + 1] : 0u;
+	uint64_t v = (lo | (hi << 32)) >> sh;
+	return (uint32_t)v & ((1u << n) - 1u);
+}
+
+WV_FN uint32_t rev32(uint32_t v)
+{
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+	return (v >> 16) | (v << 16);
+}
+
+/* The weight stream is stored from the top of the block downwards: bit i of it is bit 127 - i. */
+WV_FN Bits128 bits_reversed(const Bits128& b)
+{
+	Bits128 r;
+	r.w[0] = rev32(b.w[3]); r.w[1] = rev32(b.w[2]); r.w[2] = rev32(b.w[1]); r.w[3] = rev32(b.w[0]);
+	return r;
+}
+
+/* Five trits of a packed 8-bit group -> the one at `pos`. */
+WV_FN int trit_of(uint32_t t8, int pos)
+{
+	int t[5];
+	uint32_t cbits;
+	if (((t8 >> 2) & 7u) == 7u)
+	{
+		cbits = (((t8 >> 5) & 7u) << 2) | (t8 & 3u);
+		t[4] = 2; t[3] = 2;
+	}
+	else
+	{
+		cbits = t8 & 0x1Fu;
+		if (((t8 >> 5) & 3u) == 3u) { t[4] = 2; t[3] = (int)((t8 >> 7) & 1u); }
+		else { t[4] = (int)((t8 >> 7) & 1u); t[3] = (int)((t8 >> 5) & 3u); }
+	}
+	if ((cbits & 3u) == 3u)
+	{
+		t[2] = 2; t[1] = (int)((cbits >> 4) & 1u);
+		uint32_t c3 = (cbits >> 3) & 1u, c2 = (cbits >> 2) & 1u;
+		t[0] = (int)((c3 << 1) | (c2 & ~c3 & 1u));
+	}
+	else if (((cbits >> 2) & 3u) == 3u)
+	{
+		t[2] = 2; t[1] = 2; t[0] = (int)(cbits & 3u);
+	}
+	else
+	{
+		t[2] = (int)((cbits >> 4) & 1u); t[1] = (int)((cbits >> 2) & 3u);
+		uint32_t c1 = (cbits >> 1) & 1u, c0 = cbits & 1u;
+		t[0] = (int)((c1 << 1) | (c0 & ~c1 & 1u));
+	}
+	int r = t[0];
+	r = pos == 1 ? t[1] : r; r = pos == 2 ? t[2] : r; r = pos == 3 ? t[3] : r; r = pos == 4 ? t[4] : r;
+	return r;
+}
+
+/* Three quints of a packed 7-bit group -> the one at `pos`. */
+WV_FN int quint_of(uint32_t q7, int pos)
+{
+	int q[3];
+	if (((q7 >> 1) & 3u) == 3u && ((q7 >> 5) & 3u) == 0u)
+	{
+		uint32_t n0 = ~q7 & 1u;
+		q[2] = (int)(((q7 & 1u) << 2) | ((((q7 >> 4) & 1u) & n0) << 1) | (((q7 >> 3) & 1u) & n0));
+		q[1] = 4; q[0] = 4;
+	}
+	else
+	{
+		uint32_t cbits;
+		if (((q7 >> 1) & 3u) == 3u)
+		{
+			q[2] = 4;
+			cbits = (((q7 >> 3) & 3u) << 3) | ((~(q7 >> 5) & 3u) << 1) | (q7 & 1u);
+		}
+		else
+		{
+			q[2] = (int)((q7 >> 5) & 3u);
+			cbits = q7 & 0x1Fu;
+		}
+		if ((cbits & 7u) == 5u) { q[1] = 4; q[0] = (int)((cbits >> 3) & 3u); }
+		else { q[1] = (int)((cbits >> 3) & 3u); q[0] = (int)(cbits & 7u); }
+	}
+	int r = q[0];
+	r = pos == 1 ? q[1] : r; r = pos == 2 ? q[2] : r;
+	return r;
+}
+
+/* Symbol `index` of a BISE sequence of `count` symbols at `offset`:  (trit or quint) << bits | low bits.
+ * (ref: decode_ise, per element instead of streaming) */
+WV_FN int ise_symbol(const Bits128& b, int offset, int quant, int count, int index)
+{
+	const Btq q = btq_of(quant);
+	const int bits = q.bits;
+	if (q.trits)
+	{
+		const int tb[5] = { 2, 2, 1, 2, 1 };
+		const int group = index / 5, pos = index - group * 5;
+		int at = offset + group * (5 * bits + 8);
+		const int in_group = i_min(5, count - group * 5);
+		uint32_t t8 = 0, low = 0;
+		int shift = 0;
+		for (int k = 0; k < 5; k++)
+		{
+			if (k < in_group)
+			{
+				uint32_t m = bits_get(b, at, bits);
+				at += bits;
+				t8 |= bits_get(b, at, tb[k]) << shift;
+				at += tb[k];
+				low = k == pos ? m : low;
+			}
+			shift += tb[k];
+		}
+		return (trit_of(t8, pos) << bits) | (int)low;
+	}
+	if (q.quints)
+	{
+		const int qb[3] = { 3, 2, 2 };
+		const int group = index / 3, pos = index - group * 3;
+		int at = offset + group * (3 * bits + 7);
+		const int in_group = i_min(3, count - group * 3);
+		uint32_t q7 = 0, low = 0;
+		int shift = 0;
+		for (int k = 0; k < 3; k++)
+		{
+			if (k < in_group)
+			{
+				uint32_t m = bits_get(b, at, bits);
+				at += bits;
+				q7 |= bits_get(b, at, qb[k]) << shift;
+				at += qb[k];
+				low = k == pos ? m : low;
+			}
+			shift += qb[k];
+		}
+		return (quint_of(q7, pos) << bits) | (int)low;
+	}
+	return (int)bits_get(b, offset + index * bits, bits);
+}
+
+/* BISE weight symbol -> 0..64 (format rule "weight unquantization"). */
+WV_FN int unquant_weight_symbol(int v, int quant)
+{
+	const Btq q = btq_of(quant);
+	const int bits = q.bits;
+	int r;
+	if (!q.trits && !q.quints)
+	{
+		// replicate the pattern into 6 bits
+		r = 0;
+		int have = 0;
+		for (int k = 0; k < 6 && have < 6; k++) { r = (r << bits) | v; have += bits; }
+		r >>= (have - 6);
+	}
+	else if (bits == 0)
+	{
+		r = q.trits ? (v == 0 ? 0 : v == 1 ? 32 : 63) : (v == 0 ? 0 : v == 1 ? 16 : v == 2 ? 32 : v == 3 ? 47 : 63);
+	}
+	else
+	{
+		const int d = v >> bits;
+		const int m = v & ((1 << bits) - 1);
+		const int a = m & 1, b = (m >> 1) & 1, cc = (m >> 2) & 1;
+		const int A = a ? 0x7F : 0;
+		int B, C;
+		if (q.trits)
+		{
+			if (bits == 1) { C = 50; B = 0; }
+			else if (bits == 2) { C = 23; B = (b << 6) | (b << 2) | b; }
+			else { C = 11; B = (cc << 6) | (b << 5) | (cc << 1) | b; }
+		}
+		else
+		{
+			if (bits == 1) { C = 28; B = 0; }
+			else { C = 13; B = (b << 6) | (b << 1); }
+		}
+		int t = d * C + B;
+		t ^= A;
+		r = (A & 0x20) | (t >> 2);
+	}
+	return r > 32 ? r + 1 : r;
+}
+
+/* BISE colour symbol -> 0..255 (format rule "endpoint unquantization"). */
+WV_FN int unquant_color_symbol(int v, int quant)
+{
+	const Btq q = btq_of(quant);
+	const int bits = q.bits;
+	if (!q.trits && !q.quints)
+	{
+		int r = 0, have = 0;
+		for (int k = 0; k < 8 && have < 8; k++) { r = (r << bits) | v; have += bits; }
+		return r >> (have - 8);
+	}
+	const int dd = v >> bits;
+	const int m = v & ((1 << bits) - 1);
+	const int a = m & 1, b = (m >> 1) & 1, c = (m >> 2) & 1, d = (m >> 3) & 1, e = (m >> 4) & 1, f = (m >> 5) & 1;
+	const int A = a ? 0x1FF : 0;
+	int B = 0, C = 0;
+	if (q.trits)
+	{
+		if (bits == 1) { C = 204; }
+		else if (bits == 2) { C = 93; B = (b << 8) | (b << 4) | (b << 2) | (b << 1); }
+		else if (bits == 3) { C = 44; B = (c << 8) | (b << 7) | (c << 3) | (b << 2) | (c << 1) | b; }
+		else if (bits == 4) { C = 22; B = (d << 8) | (c << 7) | (b << 6) | (d << 2) | (c << 1) | b; }
+		else if (bits == 5) { C = 11; B = (e << 8) | (d << 7) | (c << 6) | (b << 5) | (e << 1) | d; }
+		else { C = 5; B = (f << 8) | (e << 7) | (d << 6) | (c << 5) | (b << 4) | f; }
+	}
+	else
+	{
+		if (bits == 1) { C = 113; }
+		else if (bits == 2) { C = 54; B = (b << 8) | (b << 3) | (b << 2); }
+		else if (bits == 3) { C = 26; B = (c << 8) | (b << 7) | (c << 2) | (b << 1) | c; }
+		else if (bits == 4) { C = 13; B = (d << 8) | (c << 7) | (b << 6) | (d << 1) | c; }
+		else { C = 6; B = (e << 8) | (d << 7) | (c << 6) | (b << 5) | e; }
+	}
+	int t = dd * C + B;
+	t ^= A;
+	return (A & 0x80) | (t >> 2);
+}
+
+/* 2D block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.
+ * (ref: decode_block_mode_2d, astcenc_block_sizes.cpp:37-160 + the checks in construct_block_size_descriptor_2d) */
+WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int& wx, int& wy, bool& dual, int& wquant)
+{
+	int r, h, d, w = 0, ht = 0;
+	if (mode & 3u)
+	{
+		r = (int)(((mode >> 4) & 1u) | ((mode & 3u) << 1));
+		const int a = (int)((mode >> 5) & 3u);
+		int b = (int)((mode >> 7) & 3u);
+		const int sel = (int)((mode >> 2) & 3u);
+		if (sel == 0) { w = b + 4; ht = a + 2; }
+		else if (sel == 1) { w = b + 8; ht = a + 2; }
+		else if (sel == 2) { w = a + 2; ht = b + 8; }
+		else
+		{
+			b &= 1;
+			if (mode & 0x100u) { w = b + 2; ht = a + 2; }
+			else { w = a + 2; ht = b + 6; }
+		}
+		d = (int)((mode >> 10) & 1u); h = (int)((mode >> 9) & 1u);
+	}
+	else
+	{
+		if ((mode & 0xFu) == 0u) return false;
+		r = (int)(((mode >> 4) & 1u) | (((mode >> 2) & 3u) << 1));
+		const int a = (int)((mode >> 5) & 3u);
+		const int b = (int)((mode >> 9) & 3u);
+		d = (int)((mode >> 10) & 1u); h = (int)((mode >> 9) & 1u);
+		const int sel = (int)((mode >> 7) & 3u);
+		if (sel == 0) { w = 12; ht = a + 2; }
+		else if (sel == 1) { w = a + 2; ht = 12; }
+		else if (sel == 2) { w = a + 6; ht = b + 6; d = 0; h = 0; }
+		else
+		{
+			if (a == 0) { w = 6; ht = 10; }
+			else if (a == 1) { w = 10; ht = 6; }
+			else return false;
+		}
+	}
+	if (r < 2) return false;
+	wquant = (r - 2) + 6 * h;
+	wx = w; wy = ht; dual = d != 0;
+	if (w > block_x || ht > block_y) return false;
+	const int count = w * ht * (d ? 2 : 1);
+	if (count > 64) return false;
+	const int wbits = (int)ise_bitcount((unsigned)count, wquant);
+	return wbits >= 24 && wbits <= 96;
+}
+
+/* (ref: select_partition / hash52, astcenc_partition_tables.cpp:66-245) */
+WV_FN int partition_of_texel(int seed, int x, int y, int partition_count, bool small_block)
+{
+	if (small_block) { x <<= 1; y <<= 1; }
+	seed += (partition_count - 1) * 1024;
+	uint32_t rnum = (uint32_t)seed;
+	rnum ^= rnum >> 15; rnum -= rnum << 17; rnum += rnum << 7; rnum += rnum << 4;
+	rnum ^= rnum >> 5; rnum += rnum << 16; rnum ^= rnum >> 7; rnum ^= rnum >> 3;
+	rnum ^= rnum << 6; rnum ^= rnum >> 17;
+
+	uint32_t s1 = rnum & 0xF, s2 = (rnum >> 4) & 0xF, s3 = (rnum >> 8) & 0xF, s4 = (rnum >> 12) & 0xF;
+	uint32_t s5 = (rnum >> 16) & 0xF, s6 = (rnum >> 20) & 0xF, s7 = (rnum >> 24) & 0xF, s8 = (rnum >> 28) & 0xF;
+	s1 *= s1; s2 *= s2; s3 *= s3; s4 *= s4; s5 *= s5; s6 *= s6; s7 *= s7; s8 *= s8;
+
+	int sh1, sh2;
+	if (seed & 1) { sh1 = (seed & 2) ? 4 : 5; sh2 = partition_count == 3 ? 6 : 5; }
+	else { sh1 = partition_count == 3 ? 6 : 5; sh2 = (seed & 2) ? 4 : 5; }
+	s1 >>= sh1; s2 >>= sh2; s3 >>= sh1; s4 >>= sh2; s5 >>= sh1; s6 >>= sh2; s7 >>= sh1; s8 >>= sh2;
+
+	int a = (int)(s1 * (uint32_t)x + s2 * (uint32_t)y + (rnum >> 14));
+	int b = (int)(s3 * (uint32_t)x + s4 * (uint32_t)y + (rnum >> 10));
+	int c = (int)(s5 * (uint32_t)x + s6 * (uint32_t)y + (rnum >> 6));
+	int d = (int)(s7 * (uint32_t)x + s8 * (uint32_t)y + (rnum >> 2));
+	a &= 0x3F; b &= 0x3F; c &= 0x3F; d &= 0x3F;
+	if (partition_count <= 3) d = 0;
+	if (partition_count <= 2) c = 0;
+	if (a >= b && a >= c && a >= d) return 0;
+	if (b >= c && b >= d) return 1;
+	if (c >= d) return 2;
+	return 3;
+}
+
+/* (ref: unorm16_to_sf16, astcenc_vecmathlib.h:503) */
+WV_FN int unorm16_to_sf16(int p)
+{
+	if (p == 0xFFFF) return 0x3C00;
+	if (p < 4) return p << 8;
+	int lz = 0;
+	while (!((p << lz) & 0x8000)) lz++;          // leading zeros within 16 bits
+	int v = (p << (lz + 1)) & 0xFFFF;
+	v >>= 6;
+	return v | ((14 - lz) << 10);
+}
+
+/* Write one decoded texel (floats) through the swizzle.  (ref: store_image_block :345-573) */
+WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, float r, float g, float b, float a)
+{
+	float src[7];
+	src[0] = r; src[1] = g; src[2] = b; src[3] = a; src[4] = 0.0f; src[5] = 1.0f;
+	{
+		float xn = (r * 2.0f) - 1.0f;
+		float yn = (a * 2.0f) - 1.0f;
+		float zn = 1.0f - xn * xn - yn * yn;
+		if (zn < 0.0f) zn = 0.0f;
+		src[6] = (f_sqrt(zn) * 0.5f) + 0.5f;
+	}
+	const size_t at = ((size_t)y * img.dim_x + x) * 4;
+	if (img.data_type == 0)
+	{
+		uint8_t* o = static_cast<uint8_t*>(img.data) + at;
+		if (r != r)
+		{
+			o[0] = 0xFF; o[1] = 0x00; o[2] = 0xFF; o[3] = 0xFF;      // error colour
+			return;
+		}
+		for (int k = 0; k < 4; k++)
+		{
+			uint32_t sw = img.swz[k];
+			int v;
+			if (sw == 4) v = 0;
+			else if (sw == 5) v = 255;
+			else
+			{
+				float f = src[sw];
+				if (sw == 6) f = f < 1.0f ? f : 1.0f;                    // min(z, 1), z is never negative
+				else f = v_clampzo(f);
+				v = (int)(f * 255.0f + 0.5f);
+			}
+			o[k] = (uint8_t)v;
+		}
+	}
+	else if (img.data_type == 1)
+	{
+		uint16_t* o = static_cast<uint16_t*>(img.data) + at;
+		for (int k = 0; k < 4; k++) o[k] = float_to_half(src[img.swz[k]]);
+	}
+	else
+	{
+		float* o = static_cast<float*>(img.data) + at;
+		for (int k = 0; k < 4; k++) o[k] = src[img.swz[k]];
+	}
+}
+
+/* Decode block (bx, by) of the stream into the image.  All 64 lanes call this. */
+WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx, uint32_t by, DecodeScratch& s)
+{
+	const int block_x = (int)img.block_x, block_y = (int)img.block_y;
+	const int T = block_x * block_y;
+	const int profile = (int)img.profile;
+	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
+	const float error_nan = int_as_float((int)0xFFFFE000u);
+
+	Bits128 blk;
+	{
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(pcb);
+		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
+	}
+	const uint32_t mode = bits_get(blk, 0, 11);
+
+	// ---- what kind of block ----
+	bool error = false, constant = false;
+	float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+	int wx = 0, wy = 0, wquant = 0;
+	bool dual = false;
+
+	if ((mode & 0x1FFu) == 0x1FCu)
+	{
+		// void extent (ref: symbolic_physical.cpp:302-370, decompress_symbolic.cpp:204-255)
+		constant = true;
+		const uint32_t ls = bits_get(blk, 12, 13), hs = bits_get(blk, 25, 13), lt = bits_get(blk, 38, 13), ht = bits_get(blk, 51, 13);
+		const bool all_ones = ls == 0x1FFFu && hs == 0x1FFFu && lt == 0x1FFFu && ht == 0x1FFFu;
+		if (bits_get(blk, 10, 2) != 3u || ((ls >= hs || lt >= ht) && !all_ones)) error = true;
+		int cc[4];
+		for (int k = 0; k < 4; k++) cc[k] = (int)bits_get(blk, 64 + 16 * k, 16);
+		if (!error)
+		{
+			if (mode & 0x200u)
+			{
+				// FP16 constant colour: legal in the HDR profiles only
+				if (profile == 2 || profile == 3)
+				{
+					cr = half_to_float((uint16_t)cc[0]); cg = half_to_float((uint16_t)cc[1]);
+					cb = half_to_float((uint16_t)cc[2]); ca = half_to_float((uint16_t)cc[3]);
+				}
+				else error = true;
+			}
+			else
+			{
+				for (int k = 0; k < 4; k++)
+				{
+					int v = u8_out ? (cc[k] >> 8) * 257 : cc[k];
+					float f = half_to_float((uint16_t)unorm16_to_sf16(v));
+					if (k == 0) cr = f; else if (k == 1) cg = f; else if (k == 2) cb = f; else ca = f;
+				}
+			}
+		}
+	}
+	else if (!decode_block_mode(mode, block_x, block_y, wx, wy, dual, wquant))
+	{
+		error = true;
+	}
+
+	int parts = 1, seed = 0, plane2 = -1;
+	if (!error && !constant)
+	{
+		const int wcount = wx * wy;
+		const int real_wcount = dual ? 2 * wcount : wcount;
+		const int wbits = (int)ise_bitcount((unsigned)real_wcount, wquant);
+		parts = (int)bits_get(blk, 11, 2) + 1;
+		if (dual && parts == 4) error = true;
+
+		int fmt[4] = { 0, 0, 0, 0 };
+		int below = 128 - wbits;
+		int color_start = 17;
+		if (parts == 1)
+		{
+			fmt[0] = (int)bits_get(blk, 13, 4);
+		}
+		else
+		{
+			seed = (int)bits_get(blk, 13, 10);
+			color_start = 29;
+			const uint32_t cem = bits_get(blk, 23, 6);
+			if ((cem & 3u) == 0u)
+			{
+				for (int i = 0; i < 4; i++) fmt[i] = (int)((cem >> 2) & 0xFu);
+			}
+			else
+			{
+				const int extra = 3 * parts - 4;
+				below -= extra;
+				const uint32_t enc = cem | (bits_get(blk, below, extra) << 6);
+				const int base = (int)(enc & 3u) - 1;
+				for (int i = 0; i < 4; i++)
+				{
+					const int cls = base + (int)((enc >> (2 + i)) & 1u);
+					const int low = (int)((enc >> (2 + parts + 2 * i)) & 3u);
+					fmt[i] = i < parts ? cls * 4 + low : 0;
+				}
+			}
+		}
+		if (dual)
+		{
+			below -= 2;
+			plane2 = (int)bits_get(blk, below, 2);
+		}
+
+		int nvals = 0;
+		for (int i = 0; i < 4; i++) nvals += i < parts ? 2 * (fmt[i] >> 2) + 2 : 0;
+		if (nvals > 18) error = true;
+
+		// the colour stream uses the highest quant level whose BISE size fits the bits left
+		int cbits = below - color_start;
+		if (cbits < 0) cbits = 0;
+		int cquant = -1;
+		for (int q = 20; q >= 0; q--)
+		{
+			if (cquant < 0 && (int)ise_bitcount((unsigned)nvals, q) <= cbits) cquant = q;
+		}
+		if (cquant < QUANT_6) error = true;
+
+		if (!error)
+		{
+			const Bits128 rev = bits_reversed(blk);
+			WV_FOR(i, real_wcount)
+			{
+				int sym = ise_symbol(rev, 0, wquant, real_wcount, i);
+				int w = unquant_weight_symbol(sym, wquant);
+				if (dual) s.weights[i & 1][i >> 1] = (uint8_t)w;
+				else s.weights[0][i] = (uint8_t)w;
+			}
+			WV_FOR(i, nvals)
+			{
+				int sym = ise_symbol(blk, color_start, cquant, nvals, i);
+				s.colors[i] = (uint8_t)unquant_color_symbol(sym, cquant);
+			}
+			WV_SYNC();
+			WV_FOR(p, parts)
+			{
+				int first = 0;
+				for (int i = 0; i < 4; i++) first += i < p ? 2 * (fmt[i] >> 2) + 2 : 0;
+				const int f = p == 0 ? fmt[0] : p == 1 ? fmt[1] : p == 2 ? fmt[2] : fmt[3];
+				uint8_t in[8];
+				const int n = 2 * (f >> 2) + 2;
+				for (int j = 0; j < 8; j++) in[j] = j < n ? s.colors[first + j] : 0;
+				i4 e0, e1;
+				unpack_color_endpoints(profile, f, in, e0, e1);
+				int* o = s.ep[p];
+				o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+				o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+				// which lanes hold LNS codes (ref: color_unquantize.cpp:854-1022)
+				const bool hdr_fmt = f == 2 || f == 3 || f == 7 || f == 11 || f == 14 || f == 15;
+				const bool hdr_profile = profile == 2 || profile == 3;
+				const bool alpha_default = f == 2 || f == 3 || f == 7 || f == 11;
+				s.lns[p][0] = (hdr_fmt && hdr_profile) ? 1 : 0;
+				s.lns[p][1] = (hdr_profile && (f == 15 || (alpha_default && profile == 3))) ? 1 : 0;
+			}
+			WV_SYNC();
+		}
+	}
+
+	// ---- texels ----
+	const bool small_block = T < 31;
+	const int ds = !constant && !error ? (1024 + block_x / 2) / (block_x - 1) : 0;
+	const int dt = !constant && !error ? (1024 + block_y / 2) / (block_y - 1) : 0;
+	WV_FOR(t, T)
+	{
+		const int ty = t / block_x, tx = t - ty * block_x;
+		const uint32_t xi = bx * (uint32_t)block_x + (uint32_t)tx;
+		const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
+		if (xi >= img.dim_x || yi >= img.dim_y) continue;
+
+		float r, g, b, a;
+		if (error)
+		{
+			r = g = b = a = error_nan;
+		}
+		else if (constant)
+		{
+			r = cr; g = cg; b = cb; a = ca;
+		}
+		else
+		{
+			// grid weights -> this texel (format rule "weight infill"; ref: unpack_weights :89)
+			const int cs = ds * tx, ct = dt * ty;
+			const int gs = (cs * (wx - 1) + 32) >> 6;
+			const int gt = (ct * (wy - 1) + 32) >> 6;
+			const int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
+			const int w11 = (fs * ft + 8) >> 4;
+			const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
+			const int v0 = js + jt * wx;
+			const int wcount = wx * wy;
+			int wp[2];
+			for (int pl = 0; pl < 2; pl++)
+			{
+				const uint8_t* gw = s.weights[pl];
+				int sum = 8;
+				sum += w00 ? gw[v0] * w00 : 0;
+				sum += (w01 && v0 + 1 < wcount) ? gw[v0 + 1] * w01 : 0;
+				sum += (w10 && v0 + wx < wcount) ? gw[v0 + wx] * w10 : 0;
+				sum += (w11 && v0 + wx + 1 < wcount) ? gw[v0 + wx + 1] * w11 : 0;
+				wp[pl] = sum >> 4;
+			}
+			const int p = parts == 1 ? 0 : partition_of_texel(seed, tx, ty, parts, small_block);
+			const int* e = s.ep[p];
+			float out[4];
+			for (int k = 0; k < 4; k++)
+			{
+				const int wk = (dual && k == plane2) ? wp[1] : wp[0];
+				int cval = (e[k] * (64 - wk) + e[4 + k] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
+				if (u8_out) cval = (cval >> 8) * 257;
+				const bool lns = s.lns[p][k == 3 ? 1 : 0] != 0;
+				const int h = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);   // (ref: decode_texel :66)
+				out[k] = half_to_float((uint16_t)h);
+			}
+			r = out[0]; g = out[1]; b = out[2]; a = out[3];
+		}
+		store_texel(img, xi, yi, r, g, b, a);
+	}
+}
+
+} } // namespace astcd::ASTC_VARIANT

@@ -7,6 +7,7 @@
 // oracle/emu/_build/libastcenc_emu.so and is never part of the product library.
 #include "backend.h"
 #include "wave_block.h"
+#include "wave_decode.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -86,6 +87,26 @@ int backend_compress(Backend* b, const CompressJob& job)
 		if (job.progress) job.progress(100.0f * (float)(by + 1) / (float)img.blocks_y);
 	}
 	if (job.kernel_ms) *job.kernel_ms = 0.0f;
+	return 0;
+}
+
+int backend_decompress(Backend* b, const DecompressJob& job)
+{
+	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data());
+	DecodeImage img;
+	img.data = job.host_image;
+	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
+	img.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
+	img.block_x = root->dim_x; img.block_y = root->dim_y;
+	img.blocks_x = (job.dim_x + root->dim_x - 1) / root->dim_x;
+	img.blocks_y = (job.dim_y + root->dim_y - 1) / root->dim_y;
+	img.profile = b->cfg.profile;
+	DecodeScratch scratch;
+	memset(&scratch, 0xCD, sizeof(scratch));
+	for (uint32_t by = 0; by < img.blocks_y; by++)
+		for (uint32_t bx = 0; bx < img.blocks_x; bx++)
+			decode_block(img, job.host_blocks + ((size_t)by * img.blocks_x + bx) * 16, bx, by, scratch);
 	return 0;
 }
 

@@ -1,0 +1,144 @@
+# SPDX-License-Identifier: Apache-2.0
+"""astcenc_decompress_image of the drop-in library against the reference decoder, byte for byte
+(LDR / sRGB / HDR profiles, U8 / F16 / F32 outputs, swizzles, illegal encodings).  Runs on the scalar
+CPU build of the decoder source here and on the HIP kernel with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import images
+
+LIBS = [pytest.param("emu", id="emu"), pytest.param("product", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=LIBS)
+def lib(request):
+    return request.getfixturevalue(request.param)
+
+
+def decode(L, A, data, w, h, block, profile=None, out_type=np.uint8, swizzle=None):
+    profile = A.PRF_LDR if profile is None else profile
+    err, cfg = L.config_init(profile, block[0], block[1], 1, A.PRE_MEDIUM, A.FLG_DECOMPRESS_ONLY)
+    assert err == 0
+    err, ctx = L.context_alloc(cfg, 1)
+    assert err == 0, L.error_string(err)
+    try:
+        out = np.zeros((h, w, 4), dtype=out_type)
+        dtype = {np.dtype(np.uint8): A.TYPE_U8, np.dtype(np.float16): A.TYPE_F16, np.dtype(np.float32): A.TYPE_F32}[out.dtype]
+        slices = (C.c_void_p * 1)(out.ctypes.data)
+        img = A.Image(w, h, 1, dtype, slices)
+        swz = A.Swizzle(*(swizzle or A.SWZ_RGBA))
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        err = L.lib.astcenc_decompress_image(ctx, data.ctypes.data, data.nbytes, C.byref(img), C.byref(swz), 0)
+        assert err == 0, L.error_string(err)
+        return out
+    finally:
+        L.context_free(ctx)
+
+
+def same(a, b):
+    """Bit equality (NaN payloads included)."""
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+FOOTPRINTS = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8), (10, 10), (12, 10), (12, 12)]
+
+
+@pytest.mark.parametrize("block", FOOTPRINTS)
+def test_decode_ldr_matches_reference(lib, ref, A, block):
+    w, h = block[0] * 5 + 2, block[1] * 4 + 3
+    for name, quality in (("noisy", 60.0), ("two_colour", 98.0), ("flat", 10.0)):
+        data = ref.compress(images.ALL[name](w, h), block, quality)
+        for out_type in (np.uint8, np.float16, np.float32):
+            want = decode(ref, A, data, w, h, block, out_type=out_type)
+            got = decode(lib, A, data, w, h, block, out_type=out_type)
+            assert same(want, got), (name, out_type, np.argwhere(want != got)[:3])
+
+
+def test_decode_srgb_and_swizzles(lib, ref, A):
+    block, (w, h) = (6, 6), (40, 31)
+    data = ref.compress(images.noisy(w, h, 4), block, 60.0, profile=A.PRF_LDR_SRGB)
+    for out_type in (np.uint8, np.float16, np.float32):
+        assert same(decode(ref, A, data, w, h, block, A.PRF_LDR_SRGB, out_type), decode(lib, A, data, w, h, block, A.PRF_LDR_SRGB, out_type))
+    data = ref.compress(images.noisy(w, h, 5), block, 60.0)
+    for swz in [(A.SWZ_B, A.SWZ_G, A.SWZ_R, A.SWZ_A), (A.SWZ_R, A.SWZ_A, A.SWZ_Z, A.SWZ_1), (A.SWZ_0, A.SWZ_1, A.SWZ_G, A.SWZ_G)]:
+        for out_type in (np.uint8, np.float16, np.float32):
+            want = decode(ref, A, data, w, h, block, out_type=out_type, swizzle=swz)
+            got = decode(lib, A, data, w, h, block, out_type=out_type, swizzle=swz)
+            assert same(want, got), (swz, out_type)
+
+
+@pytest.mark.parametrize("profile_name", ["PRF_HDR", "PRF_HDR_RGB_LDR_A"])
+def test_decode_hdr_matches_reference(lib, ref, A, profile_name):
+    profile = getattr(A, profile_name)
+    block, (w, h) = (6, 6), (50, 45)
+    for im in images.hdr_variants(w, h).values():
+        data = ref.compress(im.astype(np.float16), block, 60.0, profile=profile)
+        for out_type in (np.float16, np.float32, np.uint8):
+            want = decode(ref, A, data, w, h, block, profile, out_type)
+            got = decode(lib, A, data, w, h, block, profile, out_type)
+            assert same(want, got), (profile_name, out_type, np.argwhere(want != got)[:3])
+
+
+@pytest.mark.parametrize("block", [(4, 4), (6, 6), (8, 5), (12, 12)])
+@pytest.mark.parametrize("profile_name", ["PRF_LDR", "PRF_HDR"])
+def test_decode_random_bit_patterns(lib, ref, A, block, profile_name):
+    """Reserved modes, illegal void extents, HDR endpoint formats, over-long colour streams."""
+    profile = getattr(A, profile_name)
+    rng = np.random.default_rng(99 + block[0] + block[1])
+    nbx, nby = 48, 32
+    data = rng.integers(0, 256, size=nbx * nby * 16, dtype=np.uint8)
+    blocks = data.reshape(-1, 16)
+    blocks[::7, 0] = 0xFC
+    blocks[::7, 1] |= 0x01
+    blocks[::14, 1] = 0xFD
+    blocks[::14, 2:8] = 0xFF
+    blocks[::28, 1] = 0xFF
+    blocks[1::5, 1] &= 0xE7
+    w, h = nbx * block[0], nby * block[1]
+    for out_type in (np.uint8, np.float16, np.float32):
+        want = decode(ref, A, data, w, h, block, profile, out_type)
+        got = decode(lib, A, data, w, h, block, profile, out_type)
+        if not same(want, got):
+            diff = np.argwhere((want.view(np.uint8) != got.view(np.uint8)).reshape(h, w, -1).any(axis=2))
+            y, x = diff[0]
+            bi = (y // block[1]) * nbx + x // block[0]
+            raise AssertionError("%s: first differing texel (y=%d, x=%d) block %s: want %s got %s" %
+                                 (out_type.__name__, y, x, blocks[bi].tobytes().hex(), want[y, x], got[y, x]))
+
+
+def test_decode_matches_independent_oracle_decoder(lib, ref, A):
+    """The plain-C oracle decoder (oracle/astc_decode.c) agrees too: three implementations, one answer."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "oracle", "_build", "libastc_decode.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle decoder not built")
+    dec = C.CDLL(path)
+    dec.astc_oracle_decode_image.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    for block in ((5, 5), (6, 6), (10, 8)):
+        w, h = block[0] * 6 + 1, block[1] * 5 + 2
+        data = ref.compress(images.noisy(w, h, 8), block, 60.0)
+        out = np.zeros((h, w, 4), dtype=np.uint8)
+        dec.astc_oracle_decode_image(data.ctypes.data, block[0], block[1], w, h, 0, out.ctypes.data)
+        assert same(out, decode(lib, A, data, w, h, block))
+
+
+def test_decode_argument_errors(lib, A):
+    err, cfg = lib.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, A.FLG_DECOMPRESS_ONLY)
+    err, ctx = lib.context_alloc(cfg, 1)
+    assert err == 0
+    out = np.zeros((12, 12, 4), dtype=np.uint8)
+    slices = (C.c_void_p * 1)(out.ctypes.data)
+    img = A.Image(12, 12, 1, A.TYPE_U8, slices)
+    data = np.zeros(64, dtype=np.uint8)
+    swz = A.Swizzle(*A.SWZ_RGBA)
+    f = lib.lib.astcenc_decompress_image
+    assert f(ctx, data.ctypes.data, 63, C.byref(img), C.byref(swz), 0) == A.ERR_OUT_OF_MEM
+    assert f(ctx, data.ctypes.data, 64, C.byref(img), C.byref(swz), 1) == A.ERR_BAD_PARAM
+    bad = A.Swizzle(A.SWZ_R, A.SWZ_G, 9, A.SWZ_A)
+    assert f(ctx, data.ctypes.data, 64, C.byref(img), C.byref(bad), 0) == A.ERR_BAD_SWIZZLE
+    assert f(ctx, data.ctypes.data, 64, C.byref(img), C.byref(swz), 0) == A.SUCCESS
+    assert lib.lib.astcenc_decompress_reset(ctx) == A.SUCCESS
+    lib.context_free(ctx)
