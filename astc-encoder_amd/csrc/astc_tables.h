@@ -78,7 +78,8 @@ struct DecimationInfo {
 	uint8_t  weight_x;
 	uint8_t  weight_y;
 	uint8_t  max_weight_texel_count;     // rows in the per-weight arrays
-	uint8_t  pad[2];
+	uint8_t  realign_levels;             // number of groups in the realign schedule below
+	uint8_t  realign_slots;              // most weights per group for this grid (lanes: slots * rows rounded to 4 <= 64)
 	uint32_t off_texel_weights;          // u8  [4][T]   ref: texel_weights_tr
 	uint32_t off_texel_contribs_int;     // u8  [4][T]   ref: texel_weight_contribs_int_tr
 	uint32_t off_texel_contribs_f;       // f32 [4][T]   ref: texel_weight_contribs_float_tr
@@ -86,7 +87,12 @@ struct DecimationInfo {
 	uint32_t off_weight_texels;          // u8  [rows][W] ref: weight_texels_tr
 	uint32_t off_weight_contribs;        // f32 [rows][W] ref: weights_texel_contribs_tr
 	uint32_t off_texel_contrib_for_weight; // f32 [rows][W] ref: texel_contrib_for_weight
-	uint32_t table_bytes;                // the seven arrays are contiguous from off_texel_weights
+	// Realign schedule: the weights in processing order, cut into groups of weights that share no
+	// texel (so a group can be evaluated at once) while every pair of weights that does share a texel
+	// keeps its index order across groups -- equivalent to the reference's one-by-one sweep.
+	uint32_t off_realign_order;          // u8 [W]      weight indices
+	uint32_t off_realign_counts;         // u8 [W]      weights per group, realign_levels entries used
+	uint32_t table_bytes;                // all nine arrays are contiguous from off_texel_weights
 };
 
 // One partitioning; fixed-stride record followed by two u8[T] arrays:
@@ -136,6 +142,7 @@ struct TableRoot {
 	uint32_t off_device_config;               // DeviceConfig of the owning context (appended to the blob by the backend)
 	uint32_t off_lds_layout;                  // LdsLayout for that config (likewise)
 	uint32_t meta_bytes;                      // block modes + decimation modes + decimation infos are contiguous: [off_block_modes, +meta_bytes)
+	uint32_t realign_rt_floats;               // LDS floats the realign term rows need: max over grids of slots * 12 * rows4
 	uint32_t max_weights[2];                  // largest weight count per plane among the grids of [1-plane, 2-plane] trials
 	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]
 	uint32_t off_dwi_owner[2];                // u16[dwi_total_floats[class]]: (decimation mode << 1) | plane owning each packed slot

@@ -172,6 +172,8 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	uint32_t o_wt  = blob.alloc(rows * W, 4);
 	uint32_t o_wc  = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_tcw = blob.alloc(rows * W * sizeof(float), 4);
+	uint32_t o_ro  = blob.alloc(W, 4);          // realign schedule, filled by build_realign_schedules()
+	uint32_t o_rc  = blob.alloc(W, 4);
 
 	uint8_t* p_tw = blob.at<uint8_t>(o_tw);
 	uint8_t* p_tci = blob.at<uint8_t>(o_tci);
@@ -236,7 +238,44 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	di->off_weight_texels = o_wt;
 	di->off_weight_contribs = o_wc;
 	di->off_texel_contrib_for_weight = o_tcw;
-	di->table_bytes = (uint32_t)(o_tcw + rows * W * sizeof(float) - o_tw);
+	di->off_realign_order = o_ro;
+	di->off_realign_counts = o_rc;
+	di->realign_levels = 0;
+	di->table_bytes = (uint32_t)(o_rc + ((W + 3u) & ~3u) - o_tw);
+}
+
+/* Realign schedule of one decimation grid (see DecimationInfo): greedy levelling in index order.
+ * level[w] = first level above every earlier weight that shares a texel with w, and with room left. */
+static void build_realign_schedule(Blob& blob, uint32_t di_off, unsigned int max_slots)
+{
+	DecimationInfo* di = blob.at<DecimationInfo>(di_off);
+	const unsigned int W = di->weight_count, T = di->texel_count, rows = di->max_weight_texel_count;
+	const uint8_t* wtc = blob.at<uint8_t>(di->off_weight_texel_count);
+	const uint8_t* wt = blob.at<uint8_t>(di->off_weight_texels);
+	std::vector<int> level(W, 0), fill;
+	std::vector<int> texel_level(T, -1);          // highest level of any earlier weight touching the texel
+	(void)rows;
+	for (unsigned int w = 0; w < W; w++)
+	{
+		int need = 0;
+		for (unsigned int j = 0; j < wtc[w]; j++) need = std::max(need, texel_level[wt[j * W + w]] + 1);
+		int L = need;
+		while ((int)fill.size() <= L) fill.push_back(0);
+		while (fill[L] >= (int)max_slots) { L++; if ((int)fill.size() <= L) fill.push_back(0); }
+		level[w] = L;
+		fill[L]++;
+		for (unsigned int j = 0; j < wtc[w]; j++) texel_level[wt[j * W + w]] = std::max(texel_level[wt[j * W + w]], L);
+	}
+	uint8_t* order = blob.at<uint8_t>(di->off_realign_order);
+	uint8_t* counts = blob.at<uint8_t>(di->off_realign_counts);
+	unsigned int pos = 0, nlev = 0;
+	for (size_t L = 0; L < fill.size(); L++)
+	{
+		if (fill[L] == 0) continue;
+		for (unsigned int w = 0; w < W; w++) if (level[w] == (int)L) order[pos++] = (uint8_t)w;
+		counts[nlev++] = (uint8_t)fill[L];
+	}
+	blob.at<DecimationInfo>(di_off)->realign_levels = (uint8_t)nlev;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -892,6 +931,23 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		uint32_t mr = 0;
 		for (size_t i = 0; i < dms.size(); i++) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
 		r->max_weight_texel_rows = mr;
+		{
+			// weights per realign group, per grid: one lane per (weight, texel row) and 12 LDS rows of
+			// that many floats per weight, inside the 16 texel-length rows the refit scratch has to spare
+			uint32_t Tp = ((uint32_t)T + 3u) & ~3u;
+			uint32_t rt_floats = 0;
+			for (size_t i = 0; i < dms.size(); i++)
+			{
+				uint32_t di_off = (uint32_t)(off_di + i * sizeof(DecimationInfo));
+				uint32_t rs = ((uint32_t)blob.at<DecimationInfo>(di_off)->max_weight_texel_count + 3u) & ~3u;
+				uint32_t slots = std::min<uint32_t>(std::min(64u / rs, (16u * Tp) / (12u * rs)), 4u);
+				if (slots < 1) slots = 1;
+				blob.at<DecimationInfo>(di_off)->realign_slots = (uint8_t)slots;
+				rt_floats = std::max(rt_floats, slots * 12u * rs);
+				build_realign_schedule(blob, di_off, slots);
+			}
+			r->realign_rt_floats = rt_floats;
+		}
 		r->max_weights[0] = r->max_weights[1] = 1;
 		for (size_t i = 0; i < dms.size(); i++)
 		{

@@ -197,8 +197,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	{
 		// the re-fit rows double as scratch of the difference / realign steps; realign needs 3 texel rows + 12 rows of
 		// one weight's texel list
-		uint32_t rs = (r.max_weight_texel_rows + 3u) & ~3u;
-		uint32_t need = 3 * Tp + 12 * rs;
+		uint32_t need = 3 * Tp + r.realign_rt_floats;
 		if (need > 19 * Tp) { o = L.rsc; take(need * 4); }
 	}
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
@@ -436,6 +435,9 @@ struct DecView {
 	const uint8_t* wt;     // [rows][W]
 	const float*   wc;     // [rows][W]
 	const float*   tcw;    // [rows][W]
+	const uint8_t* ro;     // [W]  realign schedule: weights in processing order
+	const uint8_t* rc;     // [levels] weights per group
+	int levels;
 };
 
 WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* address of the texel_weights array */)
@@ -450,6 +452,9 @@ WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* addre
 	v.wt = base + (di.off_weight_texels - di.off_texel_weights);
 	v.wc = reinterpret_cast<const float*>(base + (di.off_weight_contribs - di.off_texel_weights));
 	v.tcw = reinterpret_cast<const float*>(base + (di.off_texel_contrib_for_weight - di.off_texel_weights));
+	v.ro = base + (di.off_realign_order - di.off_texel_weights);
+	v.rc = base + (di.off_realign_counts - di.off_texel_weights);
+	v.levels = di.realign_levels;
 	return v;
 }
 

@@ -638,11 +638,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const float* tcw = di.tcw;
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
-			const int rs = ((int)c.root->max_weight_texel_rows + 3) & ~3;
+			const int rs = (di.rows + 3) & ~3;                       // row stride of the term rows for this grid
 			uint32_t* pn = reinterpret_cast<uint32_t*>(c.rsc(0));   // prev/next quant values of each weight's current value
 			float* uqf = c.rsc(1);
-			float* rt = c.rsc(2);                                    // 12 rows of `rs` floats
-			float* wb = rt + 12 * rs;                                // [T] current weights infilled to texel resolution
+			float* rt = c.rsc(2);                                    // [slots of this grid][12] rows of `rs` floats
+			float* wb = rt + (int)c.root->realign_rt_floats;         // [T] current weights infilled to texel resolution
 
 			WV_FOR(i, W)
 			{
@@ -661,20 +661,31 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const f4 color_offset_1 = load4(&tr.fbox[4]);
 			const f4 color_base_1 = load4(&tr.fbox[0]);
 
-			for (int we = 0; we < W; we++)
+			// The reference visits the weights one by one; a weight's decision only depends on earlier
+			// weights that share a texel with it, so the host-built schedule (DecimationInfo) groups
+			// weights that touch disjoint texels and a whole group is evaluated at once: one lane per
+			// (weight of the group, texel row of that weight).
+			const uint8_t* order = di.ro;
+			const uint8_t* group_count = di.rc;
+			float* sums = &tr.fbox[64];                 // [slot][12]
+			int* moved_to = &tr.ibox[40];               // [slot] new quantized value or -1
+			int pos = 0;
+			for (int lv = 0; lv < di.levels; lv++)
 			{
-				int uqw = uq[we];
-				uint32_t prev_and_next = pn[we];
-				int n = wtc[we];
-				float uqw_base = (float)uqw;
-				float uqw_down = (float)(prev_and_next & 0xFF);
-				float uqw_up = (float)((prev_and_next >> 8) & 0xFF);
-				float uqw_diff_down = uqw_down - uqw_base;
-				float uqw_diff_up = uqw_up - uqw_base;
+				const int gn = group_count[lv];
 
-				// per-texel squared differences for base / down / up, 4 channels each -> rt rows 0..11
-				WV_FOR(te, n)
+				// per-texel squared differences for base / down / up, 4 channels each -> rt[slot][12][rs]
+				WV_FOR(k, gn * rs)
 				{
+					const int slot = k / rs, te = k - slot * rs;
+					const int we = order[pos + slot];
+					if (te >= (int)wtc[we]) continue;
+					const int uqw = uq[we];
+					const uint32_t prev_and_next = pn[we];
+					const float uqw_base = (float)uqw;
+					const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+					const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+
 					int texel = wt[te * W + we];
 					float tw_base = tcw[te * W + we];
 					float weight_base = wb[texel];
@@ -694,40 +705,57 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					f4 color_down_diff = color_diff + color_offset * weight_down;
 					f4 color_up_diff = color_diff + color_offset * weight_up;
 					f4 b = color_diff * color_diff, d = color_down_diff * color_down_diff, u = color_up_diff * color_up_diff;
-					float* o = rt + te;
+					float* o = rt + slot * 12 * rs + te;
 					o[0] = b.x; o[rs] = b.y; o[2 * rs] = b.z; o[3 * rs] = b.w;
 					o[4 * rs] = d.x; o[5 * rs] = d.y; o[6 * rs] = d.z; o[7 * rs] = d.w;
 					o[8 * rs] = u.x; o[9 * rs] = u.y; o[10 * rs] = u.z; o[11 * rs] = u.w;
 				}
 				WV_SYNC();
-				WV_FOR(k, 12)
+				WV_FOR(k, gn * 12)
 				{
-					const float* v = rt + k * rs;
+					const int slot = k / 12;
+					const int n = wtc[order[pos + slot]];
+					const float* v = rt + k * rs;             // == rt + slot * 12 * rs + (k % 12) * rs
 					float acc = 0.0f;
 					for (int te = 0; te < n; te++) acc += v[te];
-					tr.fbox[64 + k] = acc;
+					sums[k] = acc;
 				}
 				WV_SYNC();
-
-				float error_base = hadd_s(load4(&tr.fbox[64]) * error_weight);
-				float error_down = hadd_s(load4(&tr.fbox[68]) * error_weight);
-				float error_up = hadd_s(load4(&tr.fbox[72]) * error_weight);
-
-				float new_value = -1.0f;
-				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = uqw_up;
-				else if ((error_down < error_base) && (uqw > 0)) new_value = uqw_down;
-				if (new_value >= 0.0f)
+				WV_FOR(slot, gn)
 				{
-					WV_ONE { uqf[we] = new_value; uq[we] = (uint8_t)new_value; }
-					adjustments = true;
-					WV_SYNC();
-					WV_FOR(te, n)
+					const int we = order[pos + slot];
+					const int uqw = uq[we];
+					const uint32_t prev_and_next = pn[we];
+					float error_base = hadd_s(load4(&sums[slot * 12]) * error_weight);
+					float error_down = hadd_s(load4(&sums[slot * 12 + 4]) * error_weight);
+					float error_up = hadd_s(load4(&sums[slot * 12 + 8]) * error_weight);
+					int new_value = -1;
+					if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+					else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+					moved_to[slot] = new_value;
+					if (new_value >= 0)
 					{
+						uqf[we] = (float)new_value;
+						uq[we] = (uint8_t)new_value;
+					}
+				}
+				WV_SYNC();
+				bool any_moved = false;
+				for (int slot = 0; slot < gn; slot++) any_moved = any_moved || moved_to[slot] >= 0;
+				if (any_moved)
+				{
+					adjustments = true;
+					WV_FOR(k, gn * rs)
+					{
+						const int slot = k / rs, te = k - slot * rs;
+						const int we = order[pos + slot];
+						if (moved_to[slot] < 0 || te >= (int)wtc[we]) continue;
 						int texel = wt[te * W + we];
 						wb[texel] = infill4(uqf, tw, tcf, T, texel);
 					}
 				}
 				WV_SYNC();
+				pos += gn;
 			}
 		}
 	}
