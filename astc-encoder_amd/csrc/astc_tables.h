@@ -69,6 +69,31 @@ struct DecimationMode {
 	uint16_t lowhigh_offset[3];  // float offset of the angular (low, high) pairs, one per quant level 0..min(maxprec, 7)
 };
 
+// Everything the decimation sweeps need about one packed ideal-weight slot (TableRoot::off_dwi_slots):
+// one 16-byte load per lane instead of walking owner -> decimation mode -> decimation info.
+struct DwiSlot {
+	uint32_t wt_off;        // blob offset of weight_texels[0][i]   (tap j at + j * weight_count)
+	uint32_t wc_off;        // blob offset of weight_contribs[0][i] (tap j at + j * weight_count floats)
+	uint16_t refprec;       // quant levels (bit mask) of the block modes using this grid in this trial class
+	uint8_t  weight_count;
+	uint8_t  taps;          // texels this weight touches; 0 for the padding slots past weight_count
+	uint8_t  direct;        // grid == texels: the ideal weight is copied
+	uint8_t  dm;            // decimation mode
+	uint8_t  plane;
+	uint8_t  index;         // weight index in the grid
+};
+
+// The same for the texel-resolution infill of one (grid, plane) of a trial class (TableRoot::off_infill_sets).
+struct InfillSet {
+	uint32_t tw_off;        // blob offset of texel_weights
+	uint32_t tcf_off;       // blob offset of texel_contribs_f
+	uint16_t dwi_offset;    // float offset of the grid's ideal weights in the packed region
+	uint16_t refprec;
+	uint8_t  taps;          // 1, 2 or 4 weights per texel
+	uint8_t  direct;
+	uint8_t  pad[2];
+};
+
 // Bilinear-infill tables of one weight grid. (ref: struct decimation_info :347)
 // Arrays are [row][T] or [row][W] with row stride = texel_count / weight_count.
 struct DecimationInfo {
@@ -146,6 +171,8 @@ struct TableRoot {
 	uint32_t max_weights[2];                  // largest weight count per plane among the grids of [1-plane, 2-plane] trials
 	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]
 	uint32_t off_dwi_owner[2];                // u16[dwi_total_floats[class]]: (decimation mode << 1) | plane owning each packed slot
+	uint32_t off_dwi_slots[2];                // DwiSlot[dwi_total_floats[class]]
+	uint32_t off_infill_sets[2];              // InfillSet[decimation modes][planes of the class]
 	uint32_t lowhigh_floats[2];               // size of the packed low/high region per trial class
 	uint32_t max_partitionings;               // largest partitioning_count_selected[1..3]
 	uint32_t total_bytes;

@@ -866,6 +866,46 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		}
 	}
 
+	// per-slot / per-set records of the decimation sweeps (see DwiSlot, InfillSet)
+	uint32_t off_slots[2], off_isets[2];
+	for (int cls = 0; cls < 2; cls++)
+	{
+		const int planes = cls + 1;
+		off_slots[cls] = blob.alloc(std::max<uint32_t>(dwi_total[cls], 1) * sizeof(DwiSlot));
+		off_isets[cls] = blob.alloc(dms.size() * planes * sizeof(InfillSet));
+		for (size_t i = 0; i < dms.size(); i++)
+		{
+			const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)));
+			const uint16_t refprec = cls == 0 ? dms[i].refprec_1plane : dms[i].refprec_2planes;
+			const uint32_t wc4 = ((uint32_t)di.weight_count + 3u) & ~3u;
+			for (int plane = 0; plane < planes; plane++)
+			{
+				InfillSet* is = blob.at<InfillSet>((uint32_t)(off_isets[cls] + (i * planes + plane) * sizeof(InfillSet)));
+				is->tw_off = di.off_texel_weights;
+				is->tcf_off = di.off_texel_contribs_f;
+				is->dwi_offset = dms[i].dwi_offset[cls + plane];
+				is->refprec = refprec;
+				is->taps = (uint8_t)(di.max_texel_weight_count > 2 ? 4 : di.max_texel_weight_count > 1 ? 2 : 1);
+				is->direct = di.texel_count == di.weight_count;
+				if (refprec == 0) continue;
+				const uint8_t* wtc = blob.at<uint8_t>(di.off_weight_texel_count);
+				for (uint32_t k = 0; k < wc4; k++)
+				{
+					DwiSlot* sl = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + (dms[i].dwi_offset[cls + plane] + k) * sizeof(DwiSlot)));
+					sl->wt_off = di.off_weight_texels + k;
+					sl->wc_off = di.off_weight_contribs + k * (uint32_t)sizeof(float);
+					sl->refprec = refprec;
+					sl->weight_count = di.weight_count;
+					sl->taps = k < di.weight_count ? wtc[k] : 0;
+					sl->direct = di.texel_count == di.weight_count;
+					sl->dm = (uint8_t)i;
+					sl->plane = (uint8_t)plane;
+					sl->index = (uint8_t)k;
+				}
+			}
+		}
+	}
+
 	// ---- static tables ----
 	uint32_t off_cq = blob.alloc(17 * 512);
 	uint32_t off_cp = blob.alloc(17 * 256);
@@ -959,6 +999,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		{
 			r->dwi_total_floats[cls] = dwi_total[cls];
 			r->off_dwi_owner[cls] = off_owner[cls];
+			r->off_dwi_slots[cls] = off_slots[cls];
+			r->off_infill_sets[cls] = off_isets[cls];
 			r->lowhigh_floats[cls] = lh_total[cls];
 		}
 		r->max_partitionings = std::max(pcounts[1], std::max(pcounts[2], pcounts[3]));

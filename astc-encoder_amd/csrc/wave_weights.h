@@ -36,41 +36,36 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const TableRoot& r = *c.root;
 	const int T = c.T, Tp = c.Tp;
 	const int cls = nplanes == 2 ? 1 : 0;          // trial class: selects the packing of the dwi region
-	const uint16_t* owner = reinterpret_cast<const uint16_t*>(c.tab + r.off_dwi_owner[cls]);
+	const DwiSlot* slots = reinterpret_cast<const DwiSlot*>(c.tab + r.off_dwi_slots[cls]);
+	const InfillSet* isets = reinterpret_cast<const InfillSet*>(c.tab + r.off_infill_sets[cls]);
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
 	float* infilled = c.uni_f();
 	const int cap_sets = (int)(c.L->uni_bytes / 4) / Tp;
-
-	auto grid_used = [&](int dm, int plane) {
-		const DecimationMode& m = c.dec_mode(dm);
-		if (dm >= max_dm || plane >= nplanes) return false;
-		return ((nplanes == 2 ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
-	};
+	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;      // k / T == (k * t_inv) >> 24
 
 	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
 	{ PROF_SCOPE(c, PS_DEC1);
 	WV_FOR(k, (int)r.dwi_total_floats[cls])
 	{
-		int dm = owner[k] >> 1, plane = owner[k] & 1;
-		if (!grid_used(dm, plane)) continue;
-		const DecimationInfo& di = c.dec_info(dm);
-		const int W = di.weight_count;
-		int i = k - c.dec_mode(dm).dwi_offset[cls + plane];
-		if (i >= W) continue;
+		const DwiSlot sl = slots[k];
+		if (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
+		const int plane = sl.plane;
+		const int W = sl.weight_count;
+		const int i = sl.index;
 		const float* eiw = c.ei_w(plane);
 		const float* eiwes = c.ei_wes(plane);
-		if (di.texel_count == W)
+		if (sl.direct)
 		{
 			dwi_base[k] = eiw[i];
 			continue;
 		}
-		const uint8_t* wt = c.tab + di.off_weight_texels;
-		const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
+		const uint8_t* wt = c.tab + sl.wt_off - i;
+		const float* wc = reinterpret_cast<const float*>(c.tab + sl.wc_off) - i;
 		const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 		const float wes0 = eiwes[0];
 		float weight_weight = 1e-10f;
 		float initial_weight = 0.0f;
-		int cnt = (c.tab + di.off_weight_texel_count)[i];
+		int cnt = sl.taps;
 		// groups of 8 taps: all table loads of a group are issued together, then all gathers, then the
 		// (strictly ordered) accumulation -- one memory round trip per level instead of one per tap
 		for (int j0 = 0; j0 < cnt; j0 += 8)
@@ -117,15 +112,13 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		{ PROF_SCOPE(c, PS_DEC2);
 		WV_FOR(k, nsets * T)
 		{
-			int set = k / T, t = k - set * T;
-			int dm = dm0 + set / nplanes, plane = set % nplanes;
-			if (!grid_used(dm, plane)) continue;
-			const DecimationInfo& di = c.dec_info(dm);
-			if (di.texel_count == di.weight_count) continue;
-			const uint8_t* tw = c.tab + di.off_texel_weights;
-			const float* tcf = reinterpret_cast<const float*>(c.tab + di.off_texel_contribs_f);
-			const float* wts = dwi_base + c.dec_mode(dm).dwi_offset[cls + plane];
-			infilled[set * Tp + t] = di.max_texel_weight_count <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
+			int set = (int)(((uint32_t)k * t_inv) >> 24), t = k - set * T;
+			const InfillSet is = isets[dm0 * nplanes + set];
+			if (is.direct || !(is.refprec & ref_mask)) continue;
+			const uint8_t* tw = c.tab + is.tw_off;
+			const float* tcf = reinterpret_cast<const float*>(c.tab + is.tcf_off);
+			const float* wts = dwi_base + is.dwi_offset;
+			infilled[set * Tp + t] = is.taps <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
 		}
 		WV_SYNC(); }
 
@@ -136,23 +129,22 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		WV_FOR(kk, k_end - k_begin)
 		{
 			int k = k_begin + kk;
-			int dm = owner[k] >> 1, plane = owner[k] & 1;
-			if (!grid_used(dm, plane)) continue;
-			const DecimationInfo& di = c.dec_info(dm);
-			const int W = di.weight_count;
-			int i = k - c.dec_mode(dm).dwi_offset[cls + plane];
-			if (i >= W || di.texel_count == W) continue;
+			const DwiSlot sl = slots[k];
+			if (sl.taps == 0 || sl.direct || !(sl.refprec & ref_mask)) continue;
+			const int dm = sl.dm, plane = sl.plane;
+			const int W = sl.weight_count;
+			const int i = sl.index;
 			const float* eiw = c.ei_w(plane);
 			const float* eiwes = c.ei_wes(plane);
-			const uint8_t* wt = c.tab + di.off_weight_texels;
-			const float* wc = reinterpret_cast<const float*>(c.tab + di.off_weight_contribs);
+			const uint8_t* wt = c.tab + sl.wt_off - i;
+			const float* wc = reinterpret_cast<const float*>(c.tab + sl.wc_off) - i;
 			const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 			const float wes0 = eiwes[0];
 			const float* inf = infilled + ((dm - dm0) * nplanes + plane) * Tp;
 			float weight_val = dwi_base[k];
 			float error_change0 = 1e-10f;
 			float error_change1 = 0.0f;
-			int cnt = (c.tab + di.off_weight_texel_count)[i];
+			int cnt = sl.taps;
 			for (int j0 = 0; j0 < cnt; j0 += 8)
 			{
 				int tx[8]; float wv[8], iw[8], es[8], ow[8];
