@@ -232,28 +232,29 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 
 // Out-of-line pieces of the refinement loop (see the note on stage functions below): each one
 // rebuilds the views it needs from LDS.
-WV_OUT void refine_recompute(bool dual, int partition_count, int partition_packed, int decimation_mode, int plane2_component)
+/* One refinement step's front half: least-squares endpoints for the current weights, then pack them
+ * (one lane per partition; ref: :542-555, :925-931).  With to_scratch the re-fit is skipped and the
+ * formats / values go to the retry buffer of the matched-format case instead of the working block. */
+WV_OUT void refine_recompute_pack(bool dual, int partition_count, int partition_packed, int decimation_mode, int plane2_component,
+                                  int candidate, int quant_level, bool to_scratch)
 {
 	const Ctx c = ctx_make();
 	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
 	decimation_mode = wv_uniform(decimation_mode); plane2_component = wv_uniform(plane2_component);
-	const DecView di = dec_view_lds(c, decimation_mode);
-	PROF_SCOPE(c, PS_RECOMPUTE);
-	// (the single-partition case is by far the most frequent: give it its own specialised copy)
-	if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
-	else if (partition_count == 1) recompute_ideal_colors_1plane(c, part_view_lds(c, 1, 0), di);
-	else recompute_ideal_colors_1plane(c, part_view_lds(c, partition_count, partition_packed), di);
-}
-
-/* Pack the working endpoints of every partition, one lane per partition (ref: :542-555, :925-931).
- * Formats go to fmt_out[], values to values_out[][8]. */
-WV_OUT void refine_pack(int partition_count, int candidate, int quant_level, bool to_scratch)
-{
-	const Ctx c = ctx_make();
-	partition_count = wv_uniform(partition_count); candidate = wv_uniform(candidate);
-	quant_level = wv_uniform(quant_level); to_scratch = wv_uniform(to_scratch);
+	candidate = wv_uniform(candidate); quant_level = wv_uniform(quant_level); to_scratch = wv_uniform(to_scratch);
 	TrialInfo& tr = c.tr();
 	Scb& workscb = c.wscb();
+
+	if (!to_scratch)
+	{
+		const DecView di = dec_view_lds(c, decimation_mode);
+		PROF_SCOPE(c, PS_RECOMPUTE);
+		// (the single-partition case is by far the most frequent: give it its own specialised copy)
+		if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
+		else if (partition_count == 1) recompute_ideal_colors_1plane(c, part_view_lds(c, 1, 0), di);
+		else recompute_ideal_colors_1plane(c, part_view_lds(c, partition_count, partition_packed), di);
+	}
+
 	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8] scratch copy for the matched-format retry
 	uint8_t* fmts = colorvals + 32;                                   // [4]
 	PROF_SCOPE(c, PS_PACK);
@@ -350,10 +351,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
-			refine_recompute(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component);
-
-			// pack endpoints, one lane per partition (ref: :542-555, :925-931)
-			refine_pack(partition_count, i, color_quant_level, false);
+			refine_recompute_pack(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component, i, color_quant_level, false);
 
 			int formats_matched = 0;
 			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
@@ -365,7 +363,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 					// retry at the higher quant level that matched formats allow (ref: :561-598)
 					uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8]
 					uint8_t* fmts = colorvals + 32;                                   // [4]
-					refine_pack(partition_count, i, color_quant_level_mod, true);
+					refine_recompute_pack(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component, i, color_quant_level_mod, true);
 					bool all_same_mod = true;
 					for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
 					if (all_same_mod)

@@ -344,9 +344,12 @@ struct PartView {
 	const PartitionHeader* h;
 	const uint8_t* of_texel;    // [T]
 	const uint8_t* sorted;      // [T]  texels grouped by partition
-	int offset[4];              // start of each partition's run in sorted[]
-	int count[4];
+	uint32_t offsets;           // start of each partition's run in sorted[], one byte per partition
+	uint32_t counts;            // texels per partition, one byte per partition
 	int pcount;
+	// (packed bytes instead of int[4] arrays: a run-time partition index would put arrays in scratch)
+	WV_FN int off(int p) const { return (int)((offsets >> (8 * p)) & 0xFFu); }
+	WV_FN int cnt(int p) const { return (int)((counts >> (8 * p)) & 0xFFu); }
 };
 
 WV_FN PartView part_view(const Ctx& c, int pcount, int packed)
@@ -357,12 +360,14 @@ WV_FN PartView part_view(const Ctx& c, int pcount, int packed)
 	v.of_texel = rec + sizeof(PartitionHeader);
 	v.sorted = v.of_texel + c.T;
 	v.pcount = pcount;
-	int o = 0;
+	uint32_t o = 0;
+	v.offsets = 0; v.counts = 0;
 	for (int i = 0; i < 4; i++)
 	{
-		v.offset[i] = o;
-		v.count[i] = v.h->texel_count[i];
-		o += v.count[i];
+		uint32_t n = v.h->texel_count[i];
+		v.offsets |= o << (8 * i);
+		v.counts |= n << (8 * i);
+		o += n;
 	}
 	return v;
 }

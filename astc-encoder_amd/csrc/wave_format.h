@@ -166,7 +166,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 	WV_FOR(k, pc * 5)
 	{
 		int p = k / 5, which = k % 5;
-		tr.fbox[64 - 20 + k] = sum4(c.tsc_f(which) + pv.offset[p], pv.count[p]);
+		tr.fbox[64 - 20 + k] = sum4(c.tsc_f(which) + pv.off(p), pv.cnt(p));
 	}
 	WV_SYNC();
 
@@ -223,7 +223,7 @@ WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, 
 	const BlkInfo& blk = c.blk();
 	bool encode_hdr_rgb = kHdr && blk.rgb_lns != 0;
 	bool encode_hdr_alpha = kHdr && blk.alpha_lns != 0;
-	int partition_size = pv.count[p];
+	int partition_size = pv.cnt(p);
 	float* best_error = fs.best_error(p, i);
 	uint8_t* fmt = fs.format_of_choice(p, i);
 

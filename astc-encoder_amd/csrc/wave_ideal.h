@@ -58,9 +58,9 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 					const float* a = &tr.fbox[(p * n + j) * 4];
 					float total = hadd4(a[0], a[1], a[2], a[3]);
 					rest = rest - total;
-					tr.pm_avg[p][j] = total / (float)pv.count[p];
+					tr.pm_avg[p][j] = total / (float)pv.cnt(p);
 				}
-				tr.pm_avg[pc - 1][j] = rest / (float)pv.count[pc - 1];
+				tr.pm_avg[pc - 1][j] = rest / (float)pv.cnt(pc - 1);
 			}
 			else
 			{
@@ -77,9 +77,9 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 		const float* dj = c.data(cs.comps[j]);
 		const float* dw = c.data(cs.comps[which]);
 		float avg_j = tr.pm_avg[p][j], avg_w = tr.pm_avg[p][which];
-		const uint8_t* tix = pv.sorted + pv.offset[p];
+		const uint8_t* tix = pv.sorted + pv.off(p);
 		float sum = 0.0f;
-		for (int i = 0; i < pv.count[p]; i++)
+		for (int i = 0; i < pv.cnt(p); i++)
 		{
 			int t = tix[i];
 			float dat_w = dw[t] - avg_w;
@@ -124,8 +124,8 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 	WV_FOR(p, pc)
 	{
 		float lowvalue = 1e10f, highvalue = -1e10f;
-		const uint8_t* tix = pv.sorted + pv.offset[p];
-		for (int j = 0; j < pv.count[p]; j++)
+		const uint8_t* tix = pv.sorted + pv.off(p);
+		for (int j = 0; j < pv.cnt(p); j++)
 		{
 			float value = d[tix[j]];
 			lowvalue = f_min(value, lowvalue);
@@ -213,8 +213,8 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	WV_FOR(p, pc)
 	{
 		float lowparam = 1e10f, highparam = -1e10f;
-		const uint8_t* tix = pv.sorted + pv.offset[p];
-		for (int j = 0; j < pv.count[p]; j++)
+		const uint8_t* tix = pv.sorted + pv.off(p);
+		for (int j = 0; j < pv.cnt(p); j++)
 		{
 			float param = w[tix[j]];
 			lowparam = f_min(param, lowparam);

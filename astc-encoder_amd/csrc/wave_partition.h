@@ -307,7 +307,7 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 				if (ch >= n) break;
 				float total = hadd4(acc[p][ch][0], acc[p][ch][1], acc[p][ch][2], acc[p][ch][3]);
 				rest[ch] = rest[ch] - total;
-				avg[p][ch] = total / (float)pv.count[p];
+				avg[p][ch] = total / (float)pv.cnt(p);
 			}
 			if (n == 3) avg[p][3] = 0.0f;
 		}
@@ -316,7 +316,7 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		{
 			if (p != pc - 1) continue;
 			#pragma unroll
-			for (int ch = 0; ch < 4; ch++) avg[p][ch] = ch < n ? rest[ch] / (float)pv.count[p] : 0.0f;
+			for (int ch = 0; ch < 4; ch++) avg[p][ch] = ch < n ? rest[ch] / (float)pv.cnt(p) : 0.0f;
 		}
 	}
 
@@ -330,8 +330,8 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 	for (int p = 0; p < 4; p++)
 	{
 		if (p >= pc) break;
-		const uint8_t* tix = pv.sorted + pv.offset[p];
-		const int cnt = pv.count[p];
+		const uint8_t* tix = pv.sorted + pv.off(p);
+		const int cnt = pv.cnt(p);
 		f4 average = load4(avg[p]);
 
 		// dominant direction (ref: :409-454)
@@ -417,7 +417,7 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 	for (int p = 0; p < 4; p++)
 	{
 		if (p >= pc) break;
-		float tpp = (float)pv.count[p];
+		float tpp = (float)pv.cnt(p);
 		f4 error_weights = splat4(tpp * weight_imprecision_estim);
 		f4 uncor_vector = uncor_b[p] * line_len[p];
 		f4 samec_vector = samec_b[p] * line_len[p];
@@ -507,8 +507,16 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 			pv.of_texel = rec + sizeof(PartitionHeader);
 			pv.sorted = pv.of_texel + T;
 			pv.pcount = pc;
-			int o = 0;
-			for (int q = 0; q < 4; q++) { pv.offset[q] = o; pv.count[q] = pv.h->texel_count[q]; o += pv.count[q]; }
+			{
+				uint32_t o = 0;
+				pv.offsets = 0; pv.counts = 0;
+				for (int q = 0; q < 4; q++)
+				{
+					uint32_t n = pv.h->texel_count[q];
+					pv.offsets |= o << (8 * q); pv.counts |= n << (8 * q);
+					o += n;
+				}
+			}
 			float ue, se;
 			score_partitioning(c, pc, pv, uses_alpha, weight_imprecision_estim, ue, se);
 			ps.uncor_err()[first + i] = ue;

@@ -103,9 +103,9 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 		{
 			int p = k >> 2, ch = k & 3;
 			const float* d = c.data(ch);
-			const uint8_t* tix = pv.sorted + pv.offset[p];
+			const uint8_t* tix = pv.sorted + pv.off(p);
 			float s = 0.0f;
-			for (int j = 0; j < pv.count[p]; j++) s += d[tix[j]];
+			for (int j = 0; j < pv.cnt(p); j++) s += d[tix[j]];
 			tr.fbox[96 + k] = s;
 		}
 	}
@@ -117,7 +117,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	WV_FOR(p, pc)
 	{
 		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * load4(blk.cw);
-		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.count[p], splat4(1e-17f));
+		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.cnt(p), splat4(1e-17f));
 		f4 scale_dir = normalize4(xyz0(rgba_sum / rgba_weight_sum));
 		store4(&tr.fbox[112 + p * 4], scale_dir);
 	}
@@ -152,8 +152,8 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	WV_FOR(k, pc * 15)
 	{
 		int p = k / 15, r = k % 15;
-		const float* v = c.rsc(r) + pv.offset[p];
-		const int n = pv.count[p];
+		const float* v = c.rsc(r) + pv.off(p);
+		const int n = pv.cnt(p);
 		// one branch-free loop for all chains: running sum, min and max of the row
 		float acc = r == 0 ? 1e-17f : 0.0f;   // row 0 doubles as weight_weight_sum (starts at 1e-17)
 		float mn = r == 0 ? 1.0f : 1e10f;
@@ -183,7 +183,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 		float scale_vec0 = s[16], scale_vec1 = s[17];
 		f4 color_weight = load4(blk.cw);
 		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
-		f4 rgba_weight_sum = v4_max(color_weight * (float)pv.count[p], splat4(1e-17f));
+		f4 rgba_weight_sum = v4_max(color_weight * (float)pv.cnt(p), splat4(1e-17f));
 
 		f4 left_sum = splat4(left_sum_s) * color_weight;
 		f4 middle_sum = splat4(middle_sum_s) * color_weight;

@@ -199,7 +199,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": "astc_compress_blocks_kernel", "kernel_ms": round(kernel_s * 1e3, 3),
+                         "kernel": "astcd::astc_compress_blocks_ldr", "kernel_ms": round(kernel_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_quality:

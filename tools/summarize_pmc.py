@@ -28,7 +28,7 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     wr = tot["WRITE_SIZE"] / n["WRITE_SIZE"] * 1024.0
     print("HBM traffic per launch: read %.4g B (2 x FETCH_SIZE KiB), write %.4g B, total %.4g B" % (rd, wr, rd + wr))
     if json_path:
-        json.dump({"kernel": "astc_compress_blocks_kernel", "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+        json.dump({"kernel": "astcd::astc_compress_blocks_ldr", "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                    "hbm_bytes_per_launch": rd + wr,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1; "
                              "KiB -> bytes, FETCH_SIZE doubled (gfx950 counts 128 B requests as 64 B)"},
