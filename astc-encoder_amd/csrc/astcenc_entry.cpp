@@ -17,6 +17,12 @@
 #include "backend.h"
 #include "host_tables.h"
 
+// sequential (host) build of the block decoder source, for astcenc_get_block_info
+#define ASTC_VARIANT v_host
+#define ASTC_ENABLE_HDR 1
+#include "wave_decode.h"
+namespace block_info_host = astcd::v_host;
+
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -666,10 +672,16 @@ astcenc_error astcenc_decompress_reset(astcenc_context* ctx)
 	return ASTCENC_SUCCESS;
 }
 
+/* (ref: astcenc_get_block_info, astcenc_entry.cpp:1401-1517).  A single block is described on the host by
+ * the same decoder source the decompression kernel is built from (wave_decode.h, plain sequential build). */
 astcenc_error astcenc_get_block_info(astcenc_context* ctx, const uint8_t data[16], astcenc_block_info* info)
 {
-	(void)ctx; (void)data; (void)info;
-	return ASTCENC_ERR_NOT_IMPLEMENTED;
+	memset(info, 0, sizeof(*info));
+	info->profile = ctx->config.profile;
+	block_info_host::DecodeScratch scratch;
+	memset(&scratch, 0, sizeof(scratch));
+	block_info_host::describe_block(data, (int)ctx->config.block_x, (int)ctx->config.block_y, (int)ctx->config.profile, info, scratch);
+	return ASTCENC_SUCCESS;
 }
 
 const char* astcenc_get_error_string(astcenc_error status)

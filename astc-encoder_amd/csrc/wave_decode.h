@@ -413,6 +413,174 @@ WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, float r, 
 	}
 }
 
+/* Everything the header of a block says (ref: physical_to_symbolic :291-556 up to the ISE decode). */
+struct BlockHeader {
+	bool error, constant, constant_f16;
+	int  const_color[4];      // void-extent colour, raw 16-bit fields
+	int  wx, wy, wquant;      // weight grid and its quant level
+	bool dual;
+	int  parts, seed, plane2;
+	int  fmt[4];              // colour endpoint mode per partition
+	int  nvals, cquant, color_start;
+};
+
+WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_y)
+{
+	BlockHeader h;
+	h.error = false; h.constant = false; h.constant_f16 = false;
+	h.wx = 0; h.wy = 0; h.wquant = 0; h.dual = false;
+	h.parts = 1; h.seed = 0; h.plane2 = -1;
+	h.nvals = 0; h.cquant = 0; h.color_start = 17;
+	for (int k = 0; k < 4; k++) { h.const_color[k] = 0; h.fmt[k] = 0; }
+
+	const uint32_t mode = bits_get(blk, 0, 11);
+	if ((mode & 0x1FFu) == 0x1FCu)
+	{
+		// void extent (ref: :302-370): reserved bits set, coordinates all ones or properly ordered
+		h.constant = true;
+		h.constant_f16 = (mode & 0x200u) != 0;
+		const uint32_t ls = bits_get(blk, 12, 13), hs = bits_get(blk, 25, 13), lt = bits_get(blk, 38, 13), ht = bits_get(blk, 51, 13);
+		const bool all_ones = ls == 0x1FFFu && hs == 0x1FFFu && lt == 0x1FFFu && ht == 0x1FFFu;
+		if (bits_get(blk, 10, 2) != 3u || ((ls >= hs || lt >= ht) && !all_ones)) h.error = true;
+		for (int k = 0; k < 4; k++) h.const_color[k] = (int)bits_get(blk, 64 + 16 * k, 16);
+		return h;
+	}
+	if (!decode_block_mode(mode, block_x, block_y, h.wx, h.wy, h.dual, h.wquant))
+	{
+		h.error = true;
+		return h;
+	}
+
+	const int wcount = h.wx * h.wy;
+	const int real_wcount = h.dual ? 2 * wcount : wcount;
+	const int wbits = (int)ise_bitcount((unsigned)real_wcount, h.wquant);
+	h.parts = (int)bits_get(blk, 11, 2) + 1;
+	if (h.dual && h.parts == 4) h.error = true;
+
+	int below = 128 - wbits;
+	if (h.parts == 1)
+	{
+		h.fmt[0] = (int)bits_get(blk, 13, 4);
+	}
+	else
+	{
+		h.seed = (int)bits_get(blk, 13, 10);
+		h.color_start = 29;
+		const uint32_t cem = bits_get(blk, 23, 6);
+		if ((cem & 3u) == 0u)
+		{
+			for (int i = 0; i < 4; i++) h.fmt[i] = (int)((cem >> 2) & 0xFu);
+		}
+		else
+		{
+			const int extra = 3 * h.parts - 4;
+			below -= extra;
+			const uint32_t enc = cem | (bits_get(blk, below, extra) << 6);
+			const int base = (int)(enc & 3u) - 1;
+			for (int i = 0; i < 4; i++)
+			{
+				const int cls = base + (int)((enc >> (2 + i)) & 1u);
+				const int low = (int)((enc >> (2 + h.parts + 2 * i)) & 3u);
+				h.fmt[i] = i < h.parts ? cls * 4 + low : 0;
+			}
+		}
+	}
+	if (h.dual)
+	{
+		below -= 2;
+		h.plane2 = (int)bits_get(blk, below, 2);
+	}
+
+	for (int i = 0; i < 4; i++) h.nvals += i < h.parts ? 2 * (h.fmt[i] >> 2) + 2 : 0;
+	if (h.nvals > 18) h.error = true;
+
+	// the colour stream uses the highest quant level whose BISE size fits the bits left
+	int cbits = below - h.color_start;
+	if (cbits < 0) cbits = 0;
+	h.cquant = -1;
+	for (int q = 20; q >= 0; q--)
+	{
+		if (h.cquant < 0 && (int)ise_bitcount((unsigned)h.nvals, q) <= cbits) h.cquant = q;
+	}
+	if (h.cquant < QUANT_6) h.error = true;
+	return h;
+}
+
+/* Which endpoint lanes hold LNS codes (ref: color_unquantize.cpp:854-1022). */
+WV_FN void endpoint_lns_flags(int profile, int f, bool& rgb_lns, bool& alpha_lns)
+{
+	const bool hdr_fmt = f == 2 || f == 3 || f == 7 || f == 11 || f == 14 || f == 15;
+	const bool hdr_profile = profile == 2 || profile == 3;
+	const bool alpha_default = f == 2 || f == 3 || f == 7 || f == 11;
+	rgb_lns = hdr_fmt && hdr_profile;
+	alpha_lns = hdr_profile && (f == 15 || (alpha_default && profile == 3));
+}
+
+/* Weights of one texel from the grid (format rule "weight infill"; ref: unpack_weights :89). */
+WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int block_x, int block_y, int tx, int ty, int wp[2])
+{
+	const int ds = (1024 + block_x / 2) / (block_x - 1);
+	const int dt = (1024 + block_y / 2) / (block_y - 1);
+	const int cs = ds * tx, ct = dt * ty;
+	const int gs = (cs * (h.wx - 1) + 32) >> 6;
+	const int gt = (ct * (h.wy - 1) + 32) >> 6;
+	const int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
+	const int w11 = (fs * ft + 8) >> 4;
+	const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
+	const int v0 = js + jt * h.wx;
+	const int wcount = h.wx * h.wy;
+	for (int pl = 0; pl < 2; pl++)
+	{
+		const uint8_t* g = gw[pl];
+		int sum = 8;
+		sum += w00 ? g[v0] * w00 : 0;
+		sum += (w01 && v0 + 1 < wcount) ? g[v0 + 1] * w01 : 0;
+		sum += (w10 && v0 + h.wx < wcount) ? g[v0 + h.wx] * w10 : 0;
+		sum += (w11 && v0 + h.wx + 1 < wcount) ? g[v0 + h.wx + 1] * w11 : 0;
+		wp[pl] = sum >> 4;
+	}
+}
+
+/* Unpack weights, colour values and endpoints of a non-constant, legal block into the scratch. */
+WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int profile, DecodeScratch& s)
+{
+	const int wcount = h.wx * h.wy;
+	const int real_wcount = h.dual ? 2 * wcount : wcount;
+	const Bits128 rev = bits_reversed(blk);
+	WV_FOR(i, real_wcount)
+	{
+		int sym = ise_symbol(rev, 0, h.wquant, real_wcount, i);
+		int w = unquant_weight_symbol(sym, h.wquant);
+		if (h.dual) s.weights[i & 1][i >> 1] = (uint8_t)w;
+		else s.weights[0][i] = (uint8_t)w;
+	}
+	WV_FOR(i, h.nvals)
+	{
+		int sym = ise_symbol(blk, h.color_start, h.cquant, h.nvals, i);
+		s.colors[i] = (uint8_t)unquant_color_symbol(sym, h.cquant);
+	}
+	WV_SYNC();
+	WV_FOR(p, h.parts)
+	{
+		int first = 0;
+		for (int i = 0; i < 4; i++) first += i < p ? 2 * (h.fmt[i] >> 2) + 2 : 0;
+		const int f = p == 0 ? h.fmt[0] : p == 1 ? h.fmt[1] : p == 2 ? h.fmt[2] : h.fmt[3];
+		uint8_t in[8];
+		const int n = 2 * (f >> 2) + 2;
+		for (int j = 0; j < 8; j++) in[j] = j < n ? s.colors[first + j] : 0;
+		i4 e0, e1;
+		unpack_color_endpoints(profile, f, in, e0, e1);
+		int* o = s.ep[p];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+		bool rgb_lns, alpha_lns;
+		endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
+		s.lns[p][0] = rgb_lns ? 1 : 0;
+		s.lns[p][1] = alpha_lns ? 1 : 0;
+	}
+	WV_SYNC();
+}
+
 /* Decode block (bx, by) of the stream into the image.  All 64 lanes call this. */
 WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx, uint32_t by, DecodeScratch& s)
 {
@@ -427,154 +595,37 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(pcb);
 		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
 	}
-	const uint32_t mode = bits_get(blk, 0, 11);
+	const BlockHeader h = parse_block_header(blk, block_x, block_y);
+	bool error = h.error;
 
-	// ---- what kind of block ----
-	bool error = false, constant = false;
+	// constant colour (ref: decompress_symbolic.cpp:204-255)
 	float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
-	int wx = 0, wy = 0, wquant = 0;
-	bool dual = false;
-
-	if ((mode & 0x1FFu) == 0x1FCu)
+	if (h.constant && !error)
 	{
-		// void extent (ref: symbolic_physical.cpp:302-370, decompress_symbolic.cpp:204-255)
-		constant = true;
-		const uint32_t ls = bits_get(blk, 12, 13), hs = bits_get(blk, 25, 13), lt = bits_get(blk, 38, 13), ht = bits_get(blk, 51, 13);
-		const bool all_ones = ls == 0x1FFFu && hs == 0x1FFFu && lt == 0x1FFFu && ht == 0x1FFFu;
-		if (bits_get(blk, 10, 2) != 3u || ((ls >= hs || lt >= ht) && !all_ones)) error = true;
-		int cc[4];
-		for (int k = 0; k < 4; k++) cc[k] = (int)bits_get(blk, 64 + 16 * k, 16);
-		if (!error)
+		if (h.constant_f16)
 		{
-			if (mode & 0x200u)
+			// FP16 constant colour: legal in the HDR profiles only
+			if (profile == 2 || profile == 3)
 			{
-				// FP16 constant colour: legal in the HDR profiles only
-				if (profile == 2 || profile == 3)
-				{
-					cr = half_to_float((uint16_t)cc[0]); cg = half_to_float((uint16_t)cc[1]);
-					cb = half_to_float((uint16_t)cc[2]); ca = half_to_float((uint16_t)cc[3]);
-				}
-				else error = true;
+				cr = half_to_float((uint16_t)h.const_color[0]); cg = half_to_float((uint16_t)h.const_color[1]);
+				cb = half_to_float((uint16_t)h.const_color[2]); ca = half_to_float((uint16_t)h.const_color[3]);
 			}
-			else
-			{
-				for (int k = 0; k < 4; k++)
-				{
-					int v = u8_out ? (cc[k] >> 8) * 257 : cc[k];
-					float f = half_to_float((uint16_t)unorm16_to_sf16(v));
-					if (k == 0) cr = f; else if (k == 1) cg = f; else if (k == 2) cb = f; else ca = f;
-				}
-			}
-		}
-	}
-	else if (!decode_block_mode(mode, block_x, block_y, wx, wy, dual, wquant))
-	{
-		error = true;
-	}
-
-	int parts = 1, seed = 0, plane2 = -1;
-	if (!error && !constant)
-	{
-		const int wcount = wx * wy;
-		const int real_wcount = dual ? 2 * wcount : wcount;
-		const int wbits = (int)ise_bitcount((unsigned)real_wcount, wquant);
-		parts = (int)bits_get(blk, 11, 2) + 1;
-		if (dual && parts == 4) error = true;
-
-		int fmt[4] = { 0, 0, 0, 0 };
-		int below = 128 - wbits;
-		int color_start = 17;
-		if (parts == 1)
-		{
-			fmt[0] = (int)bits_get(blk, 13, 4);
+			else error = true;
 		}
 		else
 		{
-			seed = (int)bits_get(blk, 13, 10);
-			color_start = 29;
-			const uint32_t cem = bits_get(blk, 23, 6);
-			if ((cem & 3u) == 0u)
+			for (int k = 0; k < 4; k++)
 			{
-				for (int i = 0; i < 4; i++) fmt[i] = (int)((cem >> 2) & 0xFu);
+				int v = u8_out ? (h.const_color[k] >> 8) * 257 : h.const_color[k];
+				float f = half_to_float((uint16_t)unorm16_to_sf16(v));
+				if (k == 0) cr = f; else if (k == 1) cg = f; else if (k == 2) cb = f; else ca = f;
 			}
-			else
-			{
-				const int extra = 3 * parts - 4;
-				below -= extra;
-				const uint32_t enc = cem | (bits_get(blk, below, extra) << 6);
-				const int base = (int)(enc & 3u) - 1;
-				for (int i = 0; i < 4; i++)
-				{
-					const int cls = base + (int)((enc >> (2 + i)) & 1u);
-					const int low = (int)((enc >> (2 + parts + 2 * i)) & 3u);
-					fmt[i] = i < parts ? cls * 4 + low : 0;
-				}
-			}
-		}
-		if (dual)
-		{
-			below -= 2;
-			plane2 = (int)bits_get(blk, below, 2);
-		}
-
-		int nvals = 0;
-		for (int i = 0; i < 4; i++) nvals += i < parts ? 2 * (fmt[i] >> 2) + 2 : 0;
-		if (nvals > 18) error = true;
-
-		// the colour stream uses the highest quant level whose BISE size fits the bits left
-		int cbits = below - color_start;
-		if (cbits < 0) cbits = 0;
-		int cquant = -1;
-		for (int q = 20; q >= 0; q--)
-		{
-			if (cquant < 0 && (int)ise_bitcount((unsigned)nvals, q) <= cbits) cquant = q;
-		}
-		if (cquant < QUANT_6) error = true;
-
-		if (!error)
-		{
-			const Bits128 rev = bits_reversed(blk);
-			WV_FOR(i, real_wcount)
-			{
-				int sym = ise_symbol(rev, 0, wquant, real_wcount, i);
-				int w = unquant_weight_symbol(sym, wquant);
-				if (dual) s.weights[i & 1][i >> 1] = (uint8_t)w;
-				else s.weights[0][i] = (uint8_t)w;
-			}
-			WV_FOR(i, nvals)
-			{
-				int sym = ise_symbol(blk, color_start, cquant, nvals, i);
-				s.colors[i] = (uint8_t)unquant_color_symbol(sym, cquant);
-			}
-			WV_SYNC();
-			WV_FOR(p, parts)
-			{
-				int first = 0;
-				for (int i = 0; i < 4; i++) first += i < p ? 2 * (fmt[i] >> 2) + 2 : 0;
-				const int f = p == 0 ? fmt[0] : p == 1 ? fmt[1] : p == 2 ? fmt[2] : fmt[3];
-				uint8_t in[8];
-				const int n = 2 * (f >> 2) + 2;
-				for (int j = 0; j < 8; j++) in[j] = j < n ? s.colors[first + j] : 0;
-				i4 e0, e1;
-				unpack_color_endpoints(profile, f, in, e0, e1);
-				int* o = s.ep[p];
-				o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
-				o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
-				// which lanes hold LNS codes (ref: color_unquantize.cpp:854-1022)
-				const bool hdr_fmt = f == 2 || f == 3 || f == 7 || f == 11 || f == 14 || f == 15;
-				const bool hdr_profile = profile == 2 || profile == 3;
-				const bool alpha_default = f == 2 || f == 3 || f == 7 || f == 11;
-				s.lns[p][0] = (hdr_fmt && hdr_profile) ? 1 : 0;
-				s.lns[p][1] = (hdr_profile && (f == 15 || (alpha_default && profile == 3))) ? 1 : 0;
-			}
-			WV_SYNC();
 		}
 	}
+	if (!error && !h.constant) unpack_block_payload(blk, h, profile, s);
 
 	// ---- texels ----
 	const bool small_block = T < 31;
-	const int ds = !constant && !error ? (1024 + block_x / 2) / (block_x - 1) : 0;
-	const int dt = !constant && !error ? (1024 + block_y / 2) / (block_y - 1) : 0;
 	WV_FOR(t, T)
 	{
 		const int ty = t / block_x, tx = t - ty * block_x;
@@ -587,47 +638,81 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 		{
 			r = g = b = a = error_nan;
 		}
-		else if (constant)
+		else if (h.constant)
 		{
 			r = cr; g = cg; b = cb; a = ca;
 		}
 		else
 		{
-			// grid weights -> this texel (format rule "weight infill"; ref: unpack_weights :89)
-			const int cs = ds * tx, ct = dt * ty;
-			const int gs = (cs * (wx - 1) + 32) >> 6;
-			const int gt = (ct * (wy - 1) + 32) >> 6;
-			const int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
-			const int w11 = (fs * ft + 8) >> 4;
-			const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
-			const int v0 = js + jt * wx;
-			const int wcount = wx * wy;
 			int wp[2];
-			for (int pl = 0; pl < 2; pl++)
-			{
-				const uint8_t* gw = s.weights[pl];
-				int sum = 8;
-				sum += w00 ? gw[v0] * w00 : 0;
-				sum += (w01 && v0 + 1 < wcount) ? gw[v0 + 1] * w01 : 0;
-				sum += (w10 && v0 + wx < wcount) ? gw[v0 + wx] * w10 : 0;
-				sum += (w11 && v0 + wx + 1 < wcount) ? gw[v0 + wx + 1] * w11 : 0;
-				wp[pl] = sum >> 4;
-			}
-			const int p = parts == 1 ? 0 : partition_of_texel(seed, tx, ty, parts, small_block);
+			infill_texel_weights(h, s.weights, block_x, block_y, tx, ty, wp);
+			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, h.parts, small_block);
 			const int* e = s.ep[p];
 			float out[4];
 			for (int k = 0; k < 4; k++)
 			{
-				const int wk = (dual && k == plane2) ? wp[1] : wp[0];
+				const int wk = (h.dual && k == h.plane2) ? wp[1] : wp[0];
 				int cval = (e[k] * (64 - wk) + e[4 + k] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
 				if (u8_out) cval = (cval >> 8) * 257;
 				const bool lns = s.lns[p][k == 3 ? 1 : 0] != 0;
-				const int h = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);   // (ref: decode_texel :66)
-				out[k] = half_to_float((uint16_t)h);
+				const int hf = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
+				out[k] = half_to_float((uint16_t)hf);
 			}
 			r = out[0]; g = out[1]; b = out[2]; a = out[3];
 		}
 		store_texel(img, xi, yi, r, g, b, a);
+	}
+}
+
+/* astcenc_get_block_info for one block, as plain sequential code (runs on the host).
+ * (ref: astcenc_get_block_info, astcenc_entry.cpp:1401-1517)  `info` is a struct astcenc_block_info. */
+template <typename BlockInfo>
+WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int profile, BlockInfo* info, DecodeScratch& s)
+{
+	const int T = block_x * block_y;
+	Bits128 blk;
+	for (int k = 0; k < 4; k++) blk.w[k] = (uint32_t)pcb[4 * k] | ((uint32_t)pcb[4 * k + 1] << 8) | ((uint32_t)pcb[4 * k + 2] << 16) | ((uint32_t)pcb[4 * k + 3] << 24);
+	const BlockHeader h = parse_block_header(blk, block_x, block_y);
+
+	info->block_x = (unsigned)block_x; info->block_y = (unsigned)block_y; info->block_z = 1;
+	info->texel_count = (unsigned)T;
+	info->is_error_block = h.error;
+	if (h.error) return;
+	info->is_constant_block = h.constant;
+	if (h.constant) return;
+
+	unpack_block_payload(blk, h, profile, s);
+	info->weight_x = (unsigned)h.wx; info->weight_y = (unsigned)h.wy; info->weight_z = 1;
+	info->is_dual_plane_block = h.dual;
+	info->partition_count = (unsigned)h.parts;
+	info->partition_index = (unsigned)h.seed;
+	info->dual_plane_component = (unsigned)h.plane2;          // -1 (all ones) for single-plane blocks, as the reference
+	info->color_level_count = quant_level_count(h.cquant);
+	info->weight_level_count = quant_level_count(h.wquant);
+	for (int p = 0; p < h.parts; p++)
+	{
+		info->color_endpoint_modes[p] = (unsigned)h.fmt[p];
+		const bool rgb_lns = s.lns[p][0] != 0, alpha_lns = s.lns[p][1] != 0;
+		info->is_hdr_block = info->is_hdr_block || rgb_lns || alpha_lns;
+		for (int j = 0; j < 2; j++)
+		{
+			for (int k = 0; k < 4; k++)
+			{
+				const int v = s.ep[p][j * 4 + k];
+				const bool lns = k == 3 ? alpha_lns : rgb_lns;
+				info->color_endpoints[p][j][k] = half_to_float((uint16_t)(lns ? lns_to_sf16(v) : unorm16_to_sf16(v)));
+			}
+		}
+	}
+	const bool small_block = T < 31;
+	for (int t = 0; t < T; t++)
+	{
+		const int ty = t / block_x, tx = t - ty * block_x;
+		int wp[2];
+		infill_texel_weights(h, s.weights, block_x, block_y, tx, ty, wp);
+		info->weight_values_plane1[t] = (float)wp[0] * (1.0f / 16.0f);
+		if (h.dual) info->weight_values_plane2[t] = (float)wp[1] * (1.0f / 16.0f);
+		info->partition_assignment[t] = (uint8_t)(h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, h.parts, small_block));
 	}
 }
 

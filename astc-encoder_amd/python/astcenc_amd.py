@@ -77,6 +77,17 @@ class Swizzle(C.Structure):
     _fields_ = [("r", C.c_int), ("g", C.c_int), ("b", C.c_int), ("a", C.c_int)]
 
 
+class BlockInfo(C.Structure):
+    """struct astcenc_block_info (ref: astcenc.h:637-704)."""
+    _fields_ = [("profile", C.c_int), ("block_x", C.c_uint), ("block_y", C.c_uint), ("block_z", C.c_uint), ("texel_count", C.c_uint),
+                ("is_error_block", C.c_bool), ("is_constant_block", C.c_bool), ("is_hdr_block", C.c_bool), ("is_dual_plane_block", C.c_bool),
+                ("partition_count", C.c_uint), ("partition_index", C.c_uint), ("dual_plane_component", C.c_uint),
+                ("color_endpoint_modes", C.c_uint * 4), ("color_level_count", C.c_uint), ("weight_level_count", C.c_uint),
+                ("weight_x", C.c_uint), ("weight_y", C.c_uint), ("weight_z", C.c_uint),
+                ("color_endpoints", ((C.c_float * 4) * 2) * 4), ("weight_values_plane1", C.c_float * 216),
+                ("weight_values_plane2", C.c_float * 216), ("partition_assignment", C.c_uint8 * 216)]
+
+
 SWZ_RGBA = (SWZ_R, SWZ_G, SWZ_B, SWZ_A)
 
 EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_image", "astcenc_compress_reset",
@@ -116,6 +127,8 @@ class Library:
         L.astcenc_decompress_reset.restype = C.c_int
         L.astcenc_context_free.argtypes = [C.c_void_p]
         L.astcenc_context_free.restype = None
+        L.astcenc_get_block_info.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BlockInfo)]
+        L.astcenc_get_block_info.restype = C.c_int
         L.astcenc_get_error_string.argtypes = [C.c_int]
         L.astcenc_get_error_string.restype = C.c_char_p
         self.has_amd = hasattr(L, "astcenc_amd_compress_image_device")
@@ -179,7 +192,7 @@ class Library:
             self.context_free(ctx)
 
     def decompress(self, data, width, height, block=(6, 6), profile=PRF_LDR, out_type=np.uint8):
-        """Decode blocks back to [H, W, 4] (reference library only; used for PSNR)."""
+        """Decode blocks back to [H, W, 4] through astcenc_decompress_image of whichever library this is."""
         err, cfg = self.config_init(profile, block[0], block[1], 1, PRE_MEDIUM, FLG_DECOMPRESS_ONLY)
         if err:
             raise AstcError(err, "astcenc_config_init")

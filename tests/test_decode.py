@@ -142,3 +142,46 @@ def test_decode_argument_errors(lib, A):
     assert f(ctx, data.ctypes.data, 64, C.byref(img), C.byref(swz), 0) == A.SUCCESS
     assert lib.lib.astcenc_decompress_reset(ctx) == A.SUCCESS
     lib.context_free(ctx)
+
+
+@pytest.mark.parametrize("profile_name,block", [("PRF_LDR", (6, 6)), ("PRF_LDR", (8, 5)), ("PRF_LDR", (12, 12)), ("PRF_HDR", (6, 6)), ("PRF_HDR_RGB_LDR_A", (5, 5))])
+def test_get_block_info_matches_reference(lib, ref, A, profile_name, block):
+    """astcenc_get_block_info byte for byte (the whole struct) on encoder output and on random patterns."""
+    profile = getattr(A, profile_name)
+    w, h = block[0] * 6, block[1] * 5
+    if profile == A.PRF_LDR:
+        data = ref.compress(images.two_colour(w, h), block, 98.0)
+    else:
+        data = ref.compress(images.hdr_f16(w, h), block, 60.0, profile=profile)
+    rng = np.random.default_rng(5)
+    rnd = rng.integers(0, 256, size=16 * 400, dtype=np.uint8)
+    rnd.reshape(-1, 16)[::6, 0] = 0xFC
+    rnd.reshape(-1, 16)[::6, 1] |= 1
+    rnd.reshape(-1, 16)[::12, 1] = 0xFD
+    rnd.reshape(-1, 16)[::12, 2:8] = 0xFF
+    blocks = np.concatenate([data.reshape(-1, 16), rnd.reshape(-1, 16)])
+
+    def ctx_of(L):
+        err, cfg = L.config_init(profile, block[0], block[1], 1, A.PRE_MEDIUM, 0)
+        assert err == 0
+        err, ctx = L.context_alloc(cfg, 1)
+        assert err == 0, L.error_string(err)
+        return ctx
+
+    c_ref, c_lib = ctx_of(ref), ctx_of(lib)
+    try:
+        seen = {"error": 0, "constant": 0, "dual": 0, "multi": 0}
+        for i, b in enumerate(blocks):
+            b = np.ascontiguousarray(b)
+            want, got = A.BlockInfo(), A.BlockInfo()
+            assert ref.lib.astcenc_get_block_info(c_ref, b.ctypes.data, C.byref(want)) == 0
+            assert lib.lib.astcenc_get_block_info(c_lib, b.ctypes.data, C.byref(got)) == 0
+            assert bytes(want) == bytes(got), "block %d %s" % (i, b.tobytes().hex())
+            seen["error"] += want.is_error_block
+            seen["constant"] += want.is_constant_block
+            seen["dual"] += want.is_dual_plane_block
+            seen["multi"] += want.partition_count > 1
+        assert all(v > 0 for v in seen.values()), seen
+    finally:
+        ref.context_free(c_ref)
+        lib.context_free(c_lib)
