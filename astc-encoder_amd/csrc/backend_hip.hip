@@ -190,7 +190,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks",
 		                                        "  dec sweep1", "  dec infill", "  dec sweep3", "  ang phase1", "  ang phase2",
 		                                        "  mode terms", "  mode acc", "  mode quant", "  fmt eci", "  fmt table", "  fmt combine", "  fmt select",
-		                                        "  cand staging", "  physical", "  x2", "  x3" };
+		                                        "  cand staging", "  physical", "  refine (all)", "  trial (all)" };
 		unsigned long long h[2 * PS_COUNT];
 		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
 		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);

@@ -624,6 +624,7 @@ WV_OUT float stage_refine(int partition_count, int partition_packed, int plane2_
 	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
 	plane2_component = wv_uniform(plane2_component); tune_errorval_threshold = wv_uniform(tune_errorval_threshold);
 	const PartView pv = part_view_lds(c, partition_count, partition_packed);
+	PROF_SCOPE(c, PS_X2);
 	return refine_candidates(c, pv, partition_count, partition_packed, plane2_component, tune_errorval_threshold);
 }
 
@@ -631,6 +632,7 @@ WV_OUT float stage_refine(int partition_count, int partition_packed, int plane2_
 WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune_errorval_threshold,
                            int partition_count, int partition_packed, int plane2_component, int quant_limit)
 {
+	PROF_SCOPE(c, PS_X3);
 	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
 	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
 	const int ref_mask = (int)((1u << (max_weight_quant + 1)) - 1);
