@@ -73,6 +73,23 @@
 	#define WV_ONE if (true)
 #endif
 
+/* A small array with one element per lane index 0..127, written from WV_FOR bodies (element i by
+ * the lane that runs iteration i) and read back with a wave-uniform index.  On the device it is two
+ * VGPRs and a v_readlane, i.e. no memory at all; on the CPU it is an array. */
+struct LaneArray128 {
+#if WV_DEVICE
+	int v0, v1;
+	WV_FN void clear() { v0 = 0; v1 = 0; }
+	WV_FN void set(int i, int value) { if (i < 64) v0 = value; else v1 = value; }
+	WV_FN int get(int i) const { return i < 64 ? __builtin_amdgcn_readlane(v0, i) : __builtin_amdgcn_readlane(v1, i - 64); }
+#else
+	int v[128];
+	WV_FN void clear() { for (int i = 0; i < 128; i++) v[i] = 0; }
+	WV_FN void set(int i, int value) { v[i] = value; }
+	WV_FN int get(int i) const { return v[i]; }
+#endif
+};
+
 // Cold, bulky routines (HDR endpoint coders) are kept out of line so that they do not inflate the
 // register pressure and code size of the LDR hot path.
 #if defined(__HIPCC__)

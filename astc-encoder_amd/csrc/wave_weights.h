@@ -214,6 +214,13 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 	const float* sin_table = reinterpret_cast<const float*>(c.tab + c.root->off_sin_table);
 	const float* cos_table = reinterpret_cast<const float*>(c.tab + c.root->off_cos_table);
 
+	// steps of every set, one per lane: the batching below then needs no memory access per set
+	LaneArray128 steps_of;
+	steps_of.clear();
+	WV_FOR(s, nsets) { steps_of.set(s, steps_for_quant_level(get_set(s).maxq)); }
+	uint8_t* pair_set = reinterpret_cast<uint8_t*>(&tr.ibox[32]);      // [64] batch-local set of each (set, step) pair
+	uint8_t* set_steps = reinterpret_cast<uint8_t*>(&tr.ibox[48]);     // [32] steps of each set of the batch
+
 	int s0 = 0;
 	while (s0 < nsets)
 	{
@@ -221,27 +228,29 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		int s1 = s0, pairs = 0;
 		while (s1 < nsets && s1 - s0 < 32)
 		{
-			AngSet a = get_set(s1);
-			int steps = steps_for_quant_level(a.maxq);
+			int steps = steps_of.get(s1);
 			if (pairs + steps > 64) break;
+			WV_ONE { tr.ibox[s1 - s0] = pairs; set_steps[s1 - s0] = (uint8_t)steps; }
 			pairs += steps;
 			s1++;
 		}
+		WV_SYNC();
+		WV_FOR(sl, s1 - s0)
+		{
+			const int base = tr.ibox[sl], steps = set_steps[sl];
+			for (int j = 0; j < steps; j++) pair_set[base + j] = (uint8_t)sl;
+		}
+		WV_SYNC();
 
 		{ PROF_SCOPE(c, PS_ANG1);
 		WV_FOR(k, pairs)
 		{
-			// locate (set, step) of pair k
-			int s = s0, base = 0;
-			AngSet a = get_set(s);
-			int steps = steps_for_quant_level(a.maxq);
-			while (k >= base + steps)
-			{
-				base += steps;
-				s++;
-				a = get_set(s);
-				steps = steps_for_quant_level(a.maxq);
-			}
+			// (set, step) of pair k
+			const int sl = pair_set[k];
+			const int s = s0 + sl;
+			const int base = tr.ibox[sl];
+			const AngSet a = get_set(s);
+			const int steps = steps_for_quant_level(a.maxq);
 			int sp = k - base;
 			const int W = a.wcount;
 			const float* wv = a.weights;
@@ -318,18 +327,6 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			o[4] = cut_low * errscale;
 			o[5] = cut_high * errscale;
 		} }
-		// slot table for phase 2
-		WV_ONE
-		{
-			int base = 0;
-			for (int s = s0; s < s1; s++)
-			{
-				tr.ibox[s - s0] = base;
-				base += steps_for_quant_level(get_set(s).maxq);
-			}
-		}
-		WV_SYNC();
-
 		// phase 2: (set, quant) lanes (ref: weight_align.cpp:285-354)
 		PROF_SCOPE(c, PS_ANG2);
 		WV_FOR(k, (s1 - s0) * 8)
