@@ -556,6 +556,28 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 			tr.min_wt_cutoff[1] = cut[1];
 		}
 
+	}
+	// list of the grids this trial uses, in index order
+#if WV_DEVICE
+	{
+		int n = 0;
+		for (int base = 0; base < max_decimation_modes; base += 64)
+		{
+			const int i = base + WV_LANE;
+			bool used = false;
+			if (i < max_decimation_modes)
+			{
+				const DecimationMode& m = c.dec_mode(i);
+				used = ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
+			}
+			const unsigned long long mask = __ballot(used);
+			if (used) tr.dm_list[n + __popcll(mask & ((1ull << WV_LANE) - 1ull))] = (uint8_t)i;
+			n += __popcll(mask);
+		}
+		WV_ONE { tr.dm_count = n; }
+	}
+#else
+	{
 		int n = 0;
 		for (int i = 0; i < max_decimation_modes; i++)
 		{
@@ -564,6 +586,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		}
 		tr.dm_count = n;
 	}
+#endif
 	WV_SYNC();
 
 	auto get_set = [&](int s) {
