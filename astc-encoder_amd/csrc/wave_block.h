@@ -299,15 +299,17 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 	const int T = c.T;
 
 	float best_errorval_in_mode = ERROR_CALC_DEFAULT;
-	float best_errorval_in_scb = scb.errorval;
-	const int candidate_count = tr.cand_count;
+	// (values read from LDS look lane-variant to the compiler; wv_uniform() puts them in SGPRs so that the
+	//  control flow and the table addressing below run on the scalar unit)
+	float best_errorval_in_scb = wv_uniform(scb.errorval);
+	const int candidate_count = wv_uniform(tr.cand_count);
 
 	// The quantized weights of the chosen candidates are produced now (the reference keeps them
 	// for every block mode, compress_symbolic.cpp:469-478); after this the search-phase LDS
 	// (ideal weights, angular bounds, mode records) is dead and the refine-phase tables reuse it.
 	for (int i = 0; i < candidate_count; i++)
 	{
-		const BlockMode& bm = c.block_mode(tr.cand_block_mode[i]);
+		const BlockMode& bm = c.block_mode(wv_uniform(tr.cand_block_mode[i]));
 		quantize_mode_weights(c, bm, 0, nullptr, c.candw(i));
 		if (dual) quantize_mode_weights(c, bm, 1, nullptr, c.candw(i) + PLANE2_OFFSET);
 	}
@@ -316,21 +318,20 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 	for (int i = 0; i < candidate_count; i++)
 	{
-		const int bm_packed_index = tr.cand_block_mode[i];
+		const int bm_packed_index = wv_uniform(tr.cand_block_mode[i]);
 		const BlockMode& qw_bm = c.block_mode(bm_packed_index);
-		const int color_quant_level = tr.cand_quant[i];
-		const int color_quant_level_mod = tr.cand_quant_mod[i];
+		const int color_quant_level = wv_uniform(tr.cand_quant[i]);
+		const int color_quant_level_mod = wv_uniform(tr.cand_quant_mod[i]);
+		const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
 
 		// stage what the refinement loop reads in serial, latency-bound code into LDS
 		{
 			PROF_SCOPE(c, PS_X0);
-			const DecimationInfo& dinfo = c.dec_info(qw_bm.decimation_mode);
+			const DecimationInfo& dinfo = c.dec_info(cand_dm);
 			stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
-			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(qw_bm.quant_mode)), (int)(sizeof(QuantXfer) / 4));
+			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(wv_uniform((int)qw_bm.quant_mode))), (int)(sizeof(QuantXfer) / 4));
 			stage_color_rows(c, color_quant_level);      // ends with a sync
 		}
-		const DecView di = dec_view_lds(c, qw_bm.decimation_mode);
-		const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
 		// recomputed here instead of being stored for every block mode
@@ -351,7 +352,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
-			refine_recompute_pack(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component, i, color_quant_level, false);
+			refine_recompute_pack(dual, partition_count, partition_packed, cand_dm, plane2_component, i, color_quant_level, false);
 
 			int formats_matched = 0;
 			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
@@ -363,7 +364,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 					// retry at the higher quant level that matched formats allow (ref: :561-598)
 					uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8]
 					uint8_t* fmts = colorvals + 32;                                   // [4]
-					refine_recompute_pack(dual, partition_count, partition_packed, qw_bm.decimation_mode, plane2_component, i, color_quant_level_mod, true);
+					refine_recompute_pack(dual, partition_count, partition_packed, cand_dm, plane2_component, i, color_quant_level_mod, true);
 					bool all_same_mod = true;
 					for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
 					if (all_same_mod)
@@ -391,7 +392,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			if (l == 0)
 			{
 				float errorval;
-				errorval = wv_uniform(refine_difference(partition_count, partition_packed, qw_bm.decimation_mode));
+				errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
 				if (errorval == -ERROR_CALC_DEFAULT)
 				{
 					errorval = -errorval;
@@ -424,10 +425,10 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 			WV_SYNC();
 			bool adjustments;
-			adjustments = wv_uniform(refine_realign(partition_count, partition_packed, qw_bm.decimation_mode));
+			adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
 			float errorval;
-			errorval = wv_uniform(refine_difference(partition_count, partition_packed, qw_bm.decimation_mode));
+			errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
 			if (errorval == -ERROR_CALC_DEFAULT)
 			{
 				errorval = -errorval;

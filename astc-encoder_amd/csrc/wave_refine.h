@@ -445,18 +445,18 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
-	if (scb.block_type == SYM_BTYPE_ERROR) return ERROR_CALC_DEFAULT;
+	if (wv_uniform((int)scb.block_type) == SYM_BTYPE_ERROR) return ERROR_CALC_DEFAULT;
 
-	const BlockMode& bm = c.block_mode(scb.block_mode);
+	const BlockMode& bm = c.block_mode(wv_uniform((int)scb.block_mode));
 	const uint8_t* tw = di.tw;
 	const uint8_t* tci = di.tci;
-	const bool dual = bm.is_dual_plane != 0;
-	const int pc = scb.partition_count;
+	const bool dual = wv_uniform((int)bm.is_dual_plane) != 0;
+	const int pc = wv_uniform((int)scb.partition_count);
 	const int profile = c.cfg->profile;
 	const bool u8 = (c.cfg->flags & (1u << 1)) || profile == 0;
 	const bool rgbm = (c.cfg->flags & (1u << 6)) != 0;
 	const bool fast_1p = !dual && pc == 1 && !rgbm;
-	const int p2c = scb.plane2_component;
+	const int p2c = wv_uniform((int)scb.plane2_component);
 
 	// endpoints per partition -> ibox[p*8 ..]
 	WV_FOR(p, pc)
@@ -548,11 +548,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
-	const BlockMode& bm = c.block_mode(scb.block_mode);
+	const BlockMode& bm = c.block_mode(wv_uniform((int)scb.block_mode));
 	const int W = di.W;
-	const int pc = scb.partition_count;
-	const int max_plane = bm.is_dual_plane;
-	const int p2c = scb.plane2_component;
+	const int pc = wv_uniform((int)scb.partition_count);
+	const int max_plane = wv_uniform((int)bm.is_dual_plane);
+	const int p2c = wv_uniform((int)scb.plane2_component);
 	const bool decimated = W != T;
 
 	WV_FOR(p, pc)
