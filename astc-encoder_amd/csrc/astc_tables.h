@@ -138,6 +138,12 @@ struct QuantXfer {
 	uint16_t pad;
 };
 
+// The device copy of the blob is preceded by two 256-byte records of the owning context, so that a
+// kernel or stage function that knows the blob pointer reaches them without a dependent load:
+//   blob - CTX_LAYOUT_BACK : LdsLayout      blob - CTX_CONFIG_BACK : DeviceConfig
+constexpr uint32_t CTX_CONFIG_BACK = 256;
+constexpr uint32_t CTX_LAYOUT_BACK = 512;
+
 // Root record at blob offset 0.
 struct TableRoot {
 	uint8_t  dim_x, dim_y, texel_count, pad0;
@@ -164,8 +170,6 @@ struct TableRoot {
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
-	uint32_t off_device_config;               // DeviceConfig of the owning context (appended to the blob by the backend)
-	uint32_t off_lds_layout;                  // LdsLayout for that config (likewise)
 	uint32_t meta_bytes;                      // block modes + decimation modes + decimation infos are contiguous: [off_block_modes, +meta_bytes)
 	uint32_t realign_rt_floats;               // LDS floats the realign term rows need: max over grids of slots * 12 * rows4
 	uint32_t max_weights[2];                  // largest weight count per plane among the grids of [1-plane, 2-plane] trials

@@ -17,7 +17,8 @@ namespace astcd {
 
 struct Backend {
 	int device;
-	uint8_t* d_tab;
+	uint8_t* d_base;              // device allocation: context records, then the table blob
+	uint8_t* d_tab;               // the blob inside it
 	size_t tab_bytes;
 	DeviceConfig cfg;
 	uint32_t lds_bytes;
@@ -64,22 +65,17 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		delete b; *status = 2; return nullptr;
 	}
 
-	// device copy of the blob = tables + this context's DeviceConfig + LdsLayout, located through the root record
-	std::vector<uint8_t> full(blob, blob + blob_bytes);
-	full.resize((full.size() + 255) & ~(size_t)255);
-	const uint32_t off_cfg = (uint32_t)full.size();
-	full.resize(full.size() + ((sizeof(DeviceConfig) + 255) & ~(size_t)255));
-	memcpy(full.data() + off_cfg, &b->cfg, sizeof(DeviceConfig));
-	const uint32_t off_layout = (uint32_t)full.size();
-	full.resize(full.size() + 256);
-	memcpy(full.data() + off_layout, layout, layout_bytes);
-	reinterpret_cast<TableRoot*>(full.data())->off_device_config = off_cfg;
-	reinterpret_cast<TableRoot*>(full.data())->off_lds_layout = off_layout;
-	memcpy(&b->root, full.data(), sizeof(TableRoot));
+	// device allocation = [LdsLayout, 256 B][DeviceConfig, 256 B][table blob]; kernels get the blob pointer
+	std::vector<uint8_t> full(CTX_LAYOUT_BACK + blob_bytes, 0);
+	memcpy(full.data(), layout, layout_bytes);
+	static_assert(sizeof(DeviceConfig) <= 256, "DeviceConfig outgrew its slot");
+	memcpy(full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
+	memcpy(full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
 	b->tab_bytes = full.size();
-	HIP_TRY(hipMalloc(&b->d_tab, full.size()), { delete b; *status = 1; return nullptr; });
-	HIP_TRY(hipMemcpy(b->d_tab, full.data(), full.size(), hipMemcpyHostToDevice), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
-	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_tab); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipMalloc(&b->d_base, full.size()), { delete b; *status = 1; return nullptr; });
+	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { hipFree(b->d_base); delete b; *status = 2; return nullptr; });
+	b->d_tab = b->d_base + CTX_LAYOUT_BACK;
+	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_base); delete b; *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
@@ -100,7 +96,7 @@ void backend_destroy(Backend* b)
 	hipEventDestroy(b->ev0);
 	hipEventDestroy(b->ev1);
 	hipStreamDestroy(b->stream);
-	hipFree(b->d_tab);
+	hipFree(b->d_base);
 	delete b;
 }
 

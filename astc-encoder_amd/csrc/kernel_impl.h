@@ -40,9 +40,9 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	Ctx c;
 	c.tab = tab;
 	c.root = reinterpret_cast<const TableRoot*>(tab);
-	c.cfg = reinterpret_cast<const DeviceConfig*>(tab + c.root->off_device_config);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(tab - CTX_CONFIG_BACK);
 	c.lds = lds;
-	c.L = reinterpret_cast<const LdsLayout*>(tab + c.root->off_lds_layout);
+	c.L = reinterpret_cast<const LdsLayout*>(tab - CTX_LAYOUT_BACK);
 	c.T = c.root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.prof = prof;

@@ -304,8 +304,8 @@ WV_FN Ctx ctx_make()
 	c.tab = (const uint8_t*)(global_bytes)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->tab));
 	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
 	c.root = reinterpret_cast<const TableRoot*>(c.tab);
-	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab + c.root->off_device_config);
-	c.L = reinterpret_cast<const LdsLayout*>(c.tab + c.root->off_lds_layout);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
+	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
 	c.lds = astc_lds;
 	c.T = c.root->texel_count;
 	c.Tp = (c.T + 3) & ~3;

@@ -26,18 +26,13 @@ struct Backend {
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
 {
 	Backend* b = new Backend;
-	b->blob.assign(blob, blob + blob_bytes);
 	b->cfg = cfg;
 	make_lds_layout(*reinterpret_cast<const TableRoot*>(blob), cfg, b->layout);
-	b->blob.resize((b->blob.size() + 255) & ~(size_t)255);
-	const uint32_t off_cfg = (uint32_t)b->blob.size();
-	b->blob.resize(b->blob.size() + 256 + sizeof(DeviceConfig));
-	memcpy(b->blob.data() + off_cfg, &cfg, sizeof(cfg));
-	const uint32_t off_layout = (uint32_t)((b->blob.size() + 15) & ~(size_t)15);
-	b->blob.resize(off_layout + sizeof(LdsLayout));
-	memcpy(b->blob.data() + off_layout, &b->layout, sizeof(LdsLayout));
-	reinterpret_cast<TableRoot*>(b->blob.data())->off_device_config = off_cfg;
-	reinterpret_cast<TableRoot*>(b->blob.data())->off_lds_layout = off_layout;
+	// same arrangement as the device copy: [LdsLayout][DeviceConfig][table blob]
+	b->blob.assign(CTX_LAYOUT_BACK + blob_bytes, 0);
+	memcpy(b->blob.data(), &b->layout, sizeof(LdsLayout));
+	memcpy(b->blob.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &cfg, sizeof(cfg));
+	memcpy(b->blob.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
 	*status = 0;
 	return b;
 }
@@ -47,12 +42,12 @@ const char* backend_name() { return "emu:cpu"; }
 
 int backend_compress(Backend* b, const CompressJob& job)
 {
-	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data());
+	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data() + CTX_LAYOUT_BACK);
 	Ctx c;
-	c.tab = b->blob.data();
+	c.tab = b->blob.data() + CTX_LAYOUT_BACK;
 	c.root = root;
-	c.cfg = reinterpret_cast<const DeviceConfig*>(b->blob.data() + root->off_device_config);
-	c.L = reinterpret_cast<const LdsLayout*>(b->blob.data() + root->off_lds_layout);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
+	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
 	std::vector<uint8_t> lds(c.L->total + 64, 0xCD);
 	c.lds = lds.data();
 	c.T = root->texel_count;
@@ -92,7 +87,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 
 int backend_decompress(Backend* b, const DecompressJob& job)
 {
-	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data());
+	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data() + CTX_LAYOUT_BACK);
 	DecodeImage img;
 	img.data = job.host_image;
 	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
