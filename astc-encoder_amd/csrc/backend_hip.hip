@@ -79,7 +79,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
-	enum { PS_COUNT = 32, PS_TOTAL = 14 };
+	enum { PS_COUNT = 40, PS_TOTAL = 14 };
 	HIP_TRY(hipMalloc(&b->d_prof, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
 	HIP_TRY(hipMemset(b->d_prof, 0, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
 #endif
@@ -181,12 +181,13 @@ int backend_compress(Backend* b, const CompressJob& job)
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
 #if defined(ASTC_PROFILE)
 	{
-		enum { PS_COUNT = 32, PS_TOTAL = 14 };
+		enum { PS_COUNT = 40, PS_TOTAL = 14 };
 		static const char* names[PS_COUNT] = { "load", "ideal", "decimate", "angular", "modes", "formats", "recompute", "pack", "diff",
 		                                        "realign", "kmeans+partsearch", "  partscore", "physical", "stats", "TOTAL", "blocks",
 		                                        "  dec sweep1", "  dec infill", "  dec sweep3", "  ang phase1", "  ang phase2",
 		                                        "  mode terms", "  mode acc", "  mode quant", "  fmt eci", "  fmt table", "  fmt combine", "  fmt select",
-		                                        "  cand staging", "  physical", "  refine (all)", "  trial (all)" };
+		                                        "  cand staging", "  physical", "  refine (all)", "  trial (all)",
+		                                        "  y0 cand quantize", "  y1 cand setup", "  y2 after pack", "  y3 accept/copy", "  y4", "  y5", "  y6", "  y7" };
 		unsigned long long h[2 * PS_COUNT];
 		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
 		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);

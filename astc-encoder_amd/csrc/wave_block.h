@@ -71,16 +71,18 @@ struct ModeHdr { uint32_t tw_off, tcf_off; int32_t taps; int32_t valid; };
 struct ModeQ { float scale, scaled_low_bound, quant_level_m1, rscale, low_bound; int32_t steps_m1; uint32_t q2u_off; uint32_t dwi_off; };
 static_assert(sizeof(ModeHdr) + 2 * sizeof(ModeQ) == MODE_DESC_BYTES, "mode descriptor size");
 
-WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* quant_to_unquant, float ideal)
+WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* tab, float ideal)
 {
+	// table reads as uniform base + 32-bit lane offset (one address register, no 64-bit pointer math)
+	const uint32_t q2u = q.q2u_off;
 	// same arithmetic as quantize_weight() (ref: compute_quantized_weights_for_decimation :974)
 	float ix = ideal * q.scale - q.scaled_low_bound;
 	ix = v_clampzo(ix);
 	float ix1 = ix * q.quant_level_m1;
 	int weightl = (int)ix1;
 	int weighth = i_min(weightl + 1, q.steps_m1);
-	float ixl = (float)(int)quant_to_unquant[weightl];
-	float ixh = (float)(int)quant_to_unquant[weighth];
+	float ixl = (float)(int)tab[q2u + (uint32_t)weightl];
+	float ixh = (float)(int)tab[q2u + (uint32_t)weighth];
 	bool mask = (ixl + ixh) < (128.0f * ix);
 	ixl = mask ? ixh : ixl;
 	return ixl * q.rscale + q.low_bound;
@@ -152,22 +154,23 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			float term = 0.0f;
 			if (h.valid)
 			{
-				const uint8_t* tw = c.tab + h.tw_off;
-				const float* tcf = reinterpret_cast<const float*>(c.tab + h.tcf_off);
+				const uint8_t* tab = c.tab;
+				const float* tabf = reinterpret_cast<const float*>(c.tab);
+				const uint32_t tw = h.tw_off + (uint32_t)t, tcf = (h.tcf_off >> 2) + (uint32_t)t;
+				const uint32_t uT = (uint32_t)T;
 				if (h.taps == 4)
 				{
-					const int i0 = tw[t], i1 = tw[T + t], i2 = tw[2 * T + t], i3 = tw[3 * T + t];
-					const float c0 = tcf[t], c1 = tcf[T + t], c2 = tcf[2 * T + t], c3 = tcf[3 * T + t];
+					const int i0 = tab[tw], i1 = tab[tw + uT], i2 = tab[tw + 2 * uT], i3 = tab[tw + 3 * uT];
+					const float c0 = tabf[tcf], c1 = tabf[tcf + uT], c2 = tabf[tcf + 2 * uT], c3 = tabf[tcf + 3 * uT];
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
 						const float* ideal = ldsf + q.dwi_off;
-						const uint8_t* q2u = c.tab + q.q2u_off;
 						const float w0 = ideal[i0], w1 = ideal[i1], w2 = ideal[i2], w3 = ideal[i3];
-						const float v0 = quantize_weight_q(q, q2u, w0) * c0;
-						const float v1 = quantize_weight_q(q, q2u, w1) * c1;
-						const float v2 = quantize_weight_q(q, q2u, w2) * c2;
-						const float v3 = quantize_weight_q(q, q2u, w3) * c3;
+						const float v0 = quantize_weight_q(q, tab, w0) * c0;
+						const float v1 = quantize_weight_q(q, tab, w1) * c1;
+						const float v2 = quantize_weight_q(q, tab, w2) * c2;
+						const float v3 = quantize_weight_q(q, tab, w3) * c3;
 						float current = (v0 + v1) + (v2 + v3);
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
@@ -176,16 +179,15 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				}
 				else if (h.taps == 2)
 				{
-					const int i0 = tw[t], i1 = tw[T + t];
-					const float c0 = tcf[t], c1 = tcf[T + t];
+					const int i0 = tab[tw], i1 = tab[tw + uT];
+					const float c0 = tabf[tcf], c1 = tabf[tcf + uT];
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
 						const float* ideal = ldsf + q.dwi_off;
-						const uint8_t* q2u = c.tab + q.q2u_off;
 						const float w0 = ideal[i0], w1 = ideal[i1];
-						const float v0 = quantize_weight_q(q, q2u, w0) * c0;
-						const float v1 = quantize_weight_q(q, q2u, w1) * c1;
+						const float v0 = quantize_weight_q(q, tab, w0) * c0;
+						const float v1 = quantize_weight_q(q, tab, w1) * c1;
 						float current = v0 + v1;
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
@@ -198,8 +200,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 					{
 						const ModeQ q = mq[m * 2 + plane];
 						const float* ideal = ldsf + q.dwi_off;
-						const uint8_t* q2u = c.tab + q.q2u_off;
-						float current = quantize_weight_q(q, q2u, ideal[t]);
+						float current = quantize_weight_q(q, tab, ideal[t]);
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
 						term = plane ? term + e : e;
@@ -307,13 +308,23 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 	// The quantized weights of the chosen candidates are produced now (the reference keeps them
 	// for every block mode, compress_symbolic.cpp:469-478); after this the search-phase LDS
 	// (ideal weights, angular bounds, mode records) is dead and the refine-phase tables reuse it.
-	for (int i = 0; i < candidate_count; i++)
+	{ PROF_SCOPE(c, PS_Y0);
+	// one lane per (candidate, plane, weight): a single dependent chain instead of one per candidate
+	const int plane_shift = dual ? 7 : 6;
+	WV_FOR(k, candidate_count << plane_shift)
 	{
-		const BlockMode& bm = c.block_mode(wv_uniform(tr.cand_block_mode[i]));
-		quantize_mode_weights(c, bm, 0, nullptr, c.candw(i));
-		if (dual) quantize_mode_weights(c, bm, 1, nullptr, c.candw(i) + PLANE2_OFFSET);
+		const int ci = k >> plane_shift, plane = (k >> 6) & (dual ? 1 : 0), i = k & 63;
+		const BlockMode& bm = c.block_mode(tr.cand_block_mode[ci]);
+		if (i >= (int)c.dec_info(bm.decimation_mode).weight_count) continue;
+		float low, high;
+		mode_weight_bounds(c, bm, plane, low, high);
+		QuantParams qp = quant_params(low, high, bm.quant_mode);
+		const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
+		float f;
+		int w = quantize_weight(qp, q2u, c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0)[i], &f);
+		c.candw(ci)[plane * PLANE2_OFFSET + i] = (uint8_t)w;
 	}
-	WV_SYNC();
+	WV_SYNC(); }
 	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
 
 	for (int i = 0; i < candidate_count; i++)
@@ -335,6 +346,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 
 		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
 		// recomputed here instead of being stored for every block mode
+		{ PROF_SCOPE(c, PS_Y1);
 		WV_FOR(k, partition_count * 4)
 		{
 			int p = k >> 2, ch = k & 3;
@@ -347,7 +359,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
 			WV_FOR(k, 16) { dst[k] = src[k]; }
 		}
-		WV_SYNC();
+		WV_SYNC(); }
 
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
@@ -355,6 +367,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 			refine_recompute_pack(dual, partition_count, partition_packed, cand_dm, plane2_component, i, color_quant_level, false);
 
 			int formats_matched = 0;
+			{ PROF_SCOPE(c, PS_Y2);
 			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
 			{
 				bool all_same = true;
@@ -387,7 +400,7 @@ WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_co
 				workscb.block_mode = (uint16_t)bm_packed_index;
 				workscb.block_type = SYM_BTYPE_NONCONST;
 			}
-			WV_SYNC();
+			WV_SYNC(); }
 
 			if (l == 0)
 			{

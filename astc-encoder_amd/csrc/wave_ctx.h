@@ -327,6 +327,7 @@ enum { PS_LOAD, PS_IDEAL, PS_DECIMATE, PS_ANGULAR, PS_MODES, PS_FORMATS, PS_RECO
        // fine-grained sub-stage slots (names in backend_hip.hip)
        PS_DEC1, PS_DEC2, PS_DEC3, PS_ANG1, PS_ANG2, PS_MODE1, PS_MODE2, PS_MODE3, PS_FMT1, PS_FMT2, PS_FMT3, PS_FMT4,
        PS_X0, PS_X1, PS_X2, PS_X3,
+       PS_Y0, PS_Y1, PS_Y2, PS_Y3, PS_Y4, PS_Y5, PS_Y6, PS_Y7,
        PS_COUNT };   // slots [PS_COUNT, 2 * PS_COUNT) count how often each scope was entered
 #if defined(ASTC_PROFILE) && WV_DEVICE
 struct ProfScope {

@@ -25,6 +25,22 @@ WV_FN float infill2(const float* wts, const uint8_t* tw, const float* tcf, int T
 	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]);
 }
 
+/* The same with the tables addressed as uniform base + 32-bit offset (tw_off in bytes, tcf_off in floats):
+ * the address of every load is one VGPR next to a scalar base instead of a 64-bit per-lane pointer. */
+WV_FN float infill4_at(const float* wts, const uint8_t* tab, uint32_t tw_off, uint32_t tcf_off, uint32_t T, uint32_t t)
+{
+	const float* tabf = reinterpret_cast<const float*>(tab);
+	const uint32_t a = tw_off + t, b = tcf_off + t;
+	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]) +
+	       (wts[tab[a + 2 * T]] * tabf[b + 2 * T] + wts[tab[a + 3 * T]] * tabf[b + 3 * T]);
+}
+WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, uint32_t tcf_off, uint32_t T, uint32_t t)
+{
+	const float* tabf = reinterpret_cast<const float*>(tab);
+	const uint32_t a = tw_off + t, b = tcf_off + t;
+	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]);
+}
+
 /* Ideal weights on ALL referenced grids of a trial in three lane-parallel sweeps instead of three
  * per grid.
  *   nplanes        : 1 or 2 weight planes in this trial
@@ -59,8 +75,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			dwi_base[k] = eiw[i];
 			continue;
 		}
-		const uint8_t* wt = c.tab + sl.wt_off - i;
-		const float* wc = reinterpret_cast<const float*>(c.tab + sl.wc_off) - i;
+		const uint8_t* tab = c.tab;
+		const float* tabf = reinterpret_cast<const float*>(c.tab);
+		const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)W;
 		const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 		const float wes0 = eiwes[0];
 		float weight_weight = 1e-10f;
@@ -74,9 +91,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			#pragma unroll
 			for (int u = 0; u < 8; u++)
 			{
-				int j = j0 + u < cnt ? j0 + u : 0;
-				tx[u] = wt[j * W + i];
-				wv[u] = wc[j * W + i];
+				uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
+				tx[u] = tab[wt + j * uW];
+				wv[u] = tabf[wc + j * uW];
 			}
 			#pragma unroll
 			for (int u = 0; u < 8; u++)
@@ -115,10 +132,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			int set = (int)(((uint32_t)k * t_inv) >> 24), t = k - set * T;
 			const InfillSet is = isets[dm0 * nplanes + set];
 			if (is.direct || !(is.refprec & ref_mask)) continue;
-			const uint8_t* tw = c.tab + is.tw_off;
-			const float* tcf = reinterpret_cast<const float*>(c.tab + is.tcf_off);
 			const float* wts = dwi_base + is.dwi_offset;
-			infilled[set * Tp + t] = is.taps <= 2 ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
+			infilled[set * Tp + t] = is.taps <= 2 ? infill2_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t)
+			                                      : infill4_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t);
 		}
 		WV_SYNC(); }
 
@@ -133,11 +149,11 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			if (sl.taps == 0 || sl.direct || !(sl.refprec & ref_mask)) continue;
 			const int dm = sl.dm, plane = sl.plane;
 			const int W = sl.weight_count;
-			const int i = sl.index;
 			const float* eiw = c.ei_w(plane);
 			const float* eiwes = c.ei_wes(plane);
-			const uint8_t* wt = c.tab + sl.wt_off - i;
-			const float* wc = reinterpret_cast<const float*>(c.tab + sl.wc_off) - i;
+			const uint8_t* tab = c.tab;
+			const float* tabf = reinterpret_cast<const float*>(c.tab);
+			const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)W;
 			const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 			const float wes0 = eiwes[0];
 			const float* inf = infilled + ((dm - dm0) * nplanes + plane) * Tp;
@@ -151,9 +167,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
 				{
-					int j = j0 + u < cnt ? j0 + u : 0;
-					tx[u] = wt[j * W + i];
-					wv[u] = wc[j * W + i];
+					uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
+					tx[u] = tab[wt + j * uW];
+					wv[u] = tabf[wc + j * uW];
 				}
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
@@ -269,8 +285,9 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				{
 					float sample = v_clampzo(wj[u]) * (SINCOS_STEPS - 1.0f);
 					int isample = (int)(sample + 0.5f);
-					cs[u] = cos_table[isample * ANGULAR_STEPS + sp];
-					sn[u] = sin_table[isample * ANGULAR_STEPS + sp];
+					const uint32_t at = (uint32_t)isample * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
+					cs[u] = cos_table[at];
+					sn[u] = sin_table[at];
 				}
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
