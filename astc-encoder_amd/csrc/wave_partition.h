@@ -228,6 +228,55 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	WV_SYNC();
 
 	// ---- stable counting sort (ref: :412-446) ----
+#if WV_DEVICE
+	{
+		// Lane b owns bin b.  Elements are taken 64 at a time; within a chunk the distinct mismatch
+		// values are peeled off one by one with ballots, which gives every element its rank among the
+		// equal-valued elements before it (stability) without any memory traffic.
+		const int lane = WV_LANE;
+		const unsigned long long lt_mask = (1ull << lane) - 1ull;
+		const uint8_t* mm = ps.mismatch();
+		uint16_t* ord = ps.ordering();
+		int hist = 0;
+		for (int first = 0; first < count; first += 64)
+		{
+			const int i = first + lane;
+			const int m = i < count ? (int)mm[i] : -1;
+			unsigned long long todo = __ballot(m >= 0);
+			while (todo)
+			{
+				const int v = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
+				const unsigned long long same = __ballot(m == v);
+				if (lane == v) hist += __popcll(same);
+				todo &= ~same;
+			}
+		}
+		// exclusive prefix over the bins (integer adds: any order is exact)
+		int base = hist;
+		for (int d = 1; d < 64; d <<= 1)
+		{
+			int up = __shfl_up(base, d);
+			if (lane >= d) base += up;
+		}
+		base -= hist;
+		for (int first = 0; first < count; first += 64)
+		{
+			const int i = first + lane;
+			const int m = i < count ? (int)mm[i] : -1;
+			unsigned long long todo = __ballot(m >= 0);
+			while (todo)
+			{
+				const int v = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
+				const unsigned long long same = __ballot(m == v);
+				const int start = __builtin_amdgcn_readlane(base, v);
+				if (m == v) ord[start + __popcll(same & lt_mask)] = (uint16_t)i;
+				if (lane == v) base += __popcll(same);
+				todo &= ~same;
+			}
+		}
+		(void)texels_to_process;
+	}
+#else
 	WV_ONE
 	{
 		for (int i = 0; i < 64; i++) ps.mscount[i] = 0;
@@ -245,6 +294,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 			ps.ordering()[idx] = (uint16_t)i;
 		}
 	}
+#endif
 	WV_SYNC();
 	return count;
 }
