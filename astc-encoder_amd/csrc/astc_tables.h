@@ -208,6 +208,8 @@ struct ImageDesc {
 	uint32_t swz[4];       // astcenc_swz per output channel
 	uint32_t blocks_x, blocks_y;
 	uint32_t use_fast_load; // ref: astcenc_entry.cpp:946
+	const float* alpha_avg; // per-texel alpha averages of the a_scale_radius pre-pass, or null
+	uint32_t a_scale_radius;
 };
 
 } // namespace astcd

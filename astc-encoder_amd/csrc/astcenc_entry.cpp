@@ -414,7 +414,7 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 	// Scope of this library: 2D footprints, no alpha-scale RDO pre-pass.
 	bool is_hdr = config.profile == ASTCENC_PRF_HDR || config.profile == ASTCENC_PRF_HDR_RGB_LDR_A;
 	bool compress = !(config.flags & ASTCENC_FLG_DECOMPRESS_ONLY);
-	if (config.block_z > 1 || (compress && config.a_scale_radius != 0))
+	if (config.block_z > 1 || (compress && config.a_scale_radius > ALPHA_MAX_RADIUS_HOST))
 	{
 		delete ctx;
 		return ASTCENC_ERR_NOT_IMPLEMENTED;
@@ -563,6 +563,7 @@ astcenc_error astcenc_compress_image(astcenc_context* ctx, astcenc_image* imagep
 	job.data_type = (uint32_t)image.data_type;
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.host_out = data_out;
+	job.a_scale_radius = ctx->config.a_scale_radius;
 	return run_job(ctx, job);
 }
 
@@ -585,6 +586,7 @@ astcenc_error astcenc_amd_compress_image_device(astcenc_context* ctx, const void
 	job.device_out = static_cast<uint8_t*>(device_out);
 	job.stream = hip_stream;
 	job.kernel_ms = kernel_ms;
+	job.a_scale_radius = ctx->config.a_scale_radius;
 
 	std::unique_lock<std::mutex> lk(ctx->lock);
 	lk.unlock();

@@ -22,6 +22,7 @@ struct CompressJob {
 	uint8_t* device_out;       // HBM destination when host_out is null
 	void*    stream;           // hipStream_t for the device-resident path (null = backend's own)
 	float*   kernel_ms;        // optional: elapsed kernel time measured with HIP events
+	uint32_t a_scale_radius;   // != 0: alpha-average pre-pass, fully transparent neighbourhoods encode as constant zero
 	volatile int* cancel_flag; // polled between chunks
 	void (*progress)(float);   // optional
 };
@@ -62,6 +63,16 @@ int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint
 int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
 int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
+
+/* Alpha-average pre-pass launch (kernel_alpha.hip); radius <= ALPHA_MAX_RADIUS_HOST. */
+constexpr uint32_t ALPHA_MAX_RADIUS_HOST = 8;
+struct AlphaLaunch {
+	const void* d_image;
+	float* d_averages;
+	uint32_t dim_x, dim_y, data_type, swz_a, radius;
+	void* stream;
+};
+int astc_alpha_launch(const AlphaLaunch& a);
 
 /* Decompression kernel launch (kernel_decode.hip). */
 struct DecodeLaunch {

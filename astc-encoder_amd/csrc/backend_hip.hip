@@ -29,6 +29,7 @@ struct Backend {
 	// staging for the host-pointer API
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
+	float* d_alpha; size_t alpha_cap;   // alpha averages of the a_scale_radius pre-pass
 	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds)
 };
 
@@ -93,6 +94,7 @@ void backend_destroy(Backend* b)
 	hipSetDevice(b->device);
 	if (b->d_image) hipFree(b->d_image);
 	if (b->d_out) hipFree(b->d_out);
+	if (b->d_alpha) hipFree(b->d_alpha);
 	hipEventDestroy(b->ev0);
 	hipEventDestroy(b->ev1);
 	hipStreamDestroy(b->stream);
@@ -151,6 +153,26 @@ int backend_compress(Backend* b, const CompressJob& job)
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
 	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;   // ref: astcenc_entry.cpp:946
+	img.alpha_avg = nullptr;
+	img.a_scale_radius = job.a_scale_radius;
+	if (job.a_scale_radius != 0)
+	{
+		const size_t need = (size_t)job.dim_x * job.dim_y * sizeof(float);
+		if (b->alpha_cap < need)
+		{
+			if (b->d_alpha) hipFree(b->d_alpha);
+			b->d_alpha = nullptr; b->alpha_cap = 0;
+			HIP_TRY(hipMalloc(&b->d_alpha, need), return 1);
+			b->alpha_cap = need;
+		}
+		AlphaLaunch a;
+		a.d_image = d_image; a.d_averages = b->d_alpha;
+		a.dim_x = job.dim_x; a.dim_y = job.dim_y; a.data_type = job.data_type;
+		a.swz_a = job.swz[3]; a.radius = job.a_scale_radius; a.stream = stream;
+		int arc = astc_alpha_launch(a);
+		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
+		img.alpha_avg = b->d_alpha;
+	}
 
 	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is
 	// still tens of thousands of workgroups, far more than the 256 CUs need to stay full.

@@ -57,7 +57,11 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	WV_SYNC();
 
 	PROF_SCOPE(c, PS_TOTAL);
-	{ PROF_SCOPE(c, PS_LOAD); load_block(c, img, bx, by); }
+	{
+		PROF_SCOPE(c, PS_LOAD);
+		if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
+		else load_block(c, img, bx, by);
+	}
 	compress_block(c, out + (size_t)b * 16);
 }
 

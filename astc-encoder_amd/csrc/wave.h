@@ -73,6 +73,16 @@
 	#define WV_ONE if (true)
 #endif
 
+/* True on every lane if `flag` is true on any lane (flags are set inside WV_FOR bodies). */
+WV_FN bool wv_any(bool flag)
+{
+#if WV_DEVICE
+	return __ballot(flag) != 0ull;
+#else
+	return flag;
+#endif
+}
+
 /* A small array with one element per lane index 0..127, written from WV_FOR bodies (element i by
  * the lane that runs iteration i) and read back with a wave-uniform index.  On the device it is two
  * VGPRs and a v_readlane, i.e. no memory at all; on the CPU it is an array. */

@@ -184,4 +184,42 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 	}
 }
 
+/* Alpha-scale test of one block (ref: astcenc_entry.cpp:974-1007): is any texel of the block within
+ * reach of non-transparent content?  If not the block is encoded as constant zero without being read. */
+WV_FN bool block_has_visible_alpha(const Ctx& c, const ImageDesc& img, unsigned int bx, unsigned int by)
+{
+	const int dim_x = c.root->dim_x, dim_y = c.root->dim_y;
+	const unsigned int r = img.a_scale_radius;
+	const float footprint = (float)((size_t)(dim_x + 2 * (r - 1)) * (size_t)(dim_y + 2 * (r - 1)));
+	const float threshold = 0.9f / (255.0f * footprint);
+	bool seen = false;
+	WV_FOR(t, c.T)
+	{
+		unsigned int ty = (unsigned)t / (unsigned)dim_x;
+		unsigned int tx = (unsigned)t - ty * (unsigned)dim_x;
+		unsigned int xi = bx * (unsigned)dim_x + tx, yi = by * (unsigned)dim_y + ty;
+		if (xi < img.dim_x && yi < img.dim_y && img.alpha_avg[(size_t)yi * img.dim_x + xi] > threshold) seen = true;
+	}
+	return wv_any(seen);
+}
+
+/* The image_block of a skipped block: everything zero, so compress_block() emits the constant block
+ * (ref: astcenc_entry.cpp:1027-1034). */
+WV_FN void load_transparent_block(const Ctx& c)
+{
+	BlkInfo& blk = c.blk();
+	WV_ONE
+	{
+		for (int k = 0; k < 4; k++)
+		{
+			blk.origin[k] = 0.0f; blk.data_min[k] = 0.0f; blk.data_mean[k] = 0.0f; blk.data_max[k] = 0.0f;
+			blk.cw[k] = c.cfg->cw[k];
+		}
+		blk.grayscale = 1;
+		blk.rgb_lns = 0;
+		blk.alpha_lns = 0;
+	}
+	WV_SYNC();
+}
+
 } } // namespace astcd::ASTC_VARIANT

@@ -8,6 +8,7 @@
 #include "backend.h"
 #include "wave_block.h"
 #include "wave_decode.h"
+#include "wave_alpha.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,23 @@ int backend_compress(Backend* b, const CompressJob& job)
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
 	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;
+	img.alpha_avg = nullptr;
+	img.a_scale_radius = job.a_scale_radius;
+	std::vector<float> averages;
+	if (job.a_scale_radius != 0)
+	{
+		averages.assign((size_t)job.dim_x * job.dim_y, 0.0f);
+		AlphaJob aj;
+		aj.image = img.data; aj.averages = averages.data();
+		aj.dim_x = job.dim_x; aj.dim_y = job.dim_y; aj.data_type = job.data_type;
+		aj.swz_a = job.swz[3]; aj.radius = job.a_scale_radius;
+		const uint32_t pad = ALPHA_TILE + 2 * job.a_scale_radius + 1;
+		std::vector<float> buf((size_t)pad * pad);
+		for (uint32_t ty = 0; ty < (job.dim_y + ALPHA_TILE - 1) / ALPHA_TILE; ty++)
+			for (uint32_t tx = 0; tx < (job.dim_x + ALPHA_TILE - 1) / ALPHA_TILE; tx++)
+				alpha_average_tile(aj, tx, ty, buf.data());
+		img.alpha_avg = averages.data();
+	}
 
 	uint8_t* out = job.host_out ? job.host_out : job.device_out;
 	const char* only = getenv("ASTC_EMU_ONLY_BLOCK");
@@ -75,7 +93,8 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			size_t idx = (size_t)by * img.blocks_x + bx;
 			if (only_idx >= 0 && (long)idx != only_idx) continue;
-			load_block(c, img, bx, by);
+			if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
+			else load_block(c, img, bx, by);
 			compress_block(c, out + idx * 16);
 		}
 		if (job.cancel_flag && *job.cancel_flag) break;
