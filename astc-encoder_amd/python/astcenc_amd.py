@@ -285,3 +285,35 @@ def compress_shard(lib, ctx, pixels, block, rank, world, out=None):
     if out is not None:
         out[offset: offset + part.size] = part
     return offset, part
+
+
+# ---- .astc container (ref: Docs/FileFormat.md, astcenccli_image_load_store.cpp: 16-byte header) ----
+
+ASTC_MAGIC = bytes([0x13, 0xAB, 0xA1, 0x5C])
+
+
+def write_astc(path, blocks, width, height, block, depth=1):
+    """Write a block stream as an .astc file: magic, block dims (3 x u8), image dims (3 x 24-bit LE), data."""
+    def u24(v):
+        return bytes([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF])
+    bz = block[2] if len(block) > 2 else 1
+    header = ASTC_MAGIC + bytes([block[0], block[1], bz]) + u24(width) + u24(height) + u24(depth)
+    data = np.ascontiguousarray(blocks, dtype=np.uint8).tobytes()
+    with open(path, "wb") as f:
+        f.write(header + data)
+
+
+def read_astc(path):
+    """-> (blocks uint8[n*16], width, height, depth, (bx, by, bz)); raises ValueError on a malformed file
+    (bad magic, zero dimensions, truncated payload), like the reference loader."""
+    raw = open(path, "rb").read()
+    if len(raw) < 16 or raw[:4] != ASTC_MAGIC:
+        raise ValueError("not an .astc file")
+    bx, by, bz = raw[4], raw[5], raw[6]
+    dims = [raw[7 + 3 * i] | (raw[8 + 3 * i] << 8) | (raw[9 + 3 * i] << 16) for i in range(3)]
+    if 0 in (bx, by, bz) or 0 in dims:
+        raise ValueError("zero dimension in .astc header")
+    n = ((dims[0] + bx - 1) // bx) * ((dims[1] + by - 1) // by) * ((dims[2] + bz - 1) // bz)
+    if len(raw) - 16 < n * 16:
+        raise ValueError("truncated .astc payload")
+    return np.frombuffer(raw, dtype=np.uint8, count=n * 16, offset=16).copy(), dims[0], dims[1], dims[2], (bx, by, bz)
