@@ -170,7 +170,6 @@ struct TableRoot {
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
-	uint32_t meta_bytes;                      // block modes + decimation modes + decimation infos are contiguous: [off_block_modes, +meta_bytes)
 	uint32_t realign_rt_floats;               // LDS floats the realign term rows need: max over grids of slots * 12 * rows4
 	uint32_t max_weights[2];                  // largest weight count per plane among the grids of [1-plane, 2-plane] trials
 	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]

@@ -74,9 +74,9 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
 	b->tab_bytes = full.size();
 	HIP_TRY(hipMalloc(&b->d_base, full.size()), { delete b; *status = 1; return nullptr; });
-	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { hipFree(b->d_base); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
 	b->d_tab = b->d_base + CTX_LAYOUT_BACK;
-	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { hipFree(b->d_base); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
@@ -91,14 +91,14 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 void backend_destroy(Backend* b)
 {
 	if (!b) return;
-	hipSetDevice(b->device);
-	if (b->d_image) hipFree(b->d_image);
-	if (b->d_out) hipFree(b->d_out);
-	if (b->d_alpha) hipFree(b->d_alpha);
-	hipEventDestroy(b->ev0);
-	hipEventDestroy(b->ev1);
-	hipStreamDestroy(b->stream);
-	hipFree(b->d_base);
+	(void)hipSetDevice(b->device);
+	if (b->d_image) (void)hipFree(b->d_image);
+	if (b->d_out) (void)hipFree(b->d_out);
+	if (b->d_alpha) (void)hipFree(b->d_alpha);
+	(void)hipEventDestroy(b->ev0);
+	(void)hipEventDestroy(b->ev1);
+	(void)hipStreamDestroy(b->stream);
+	(void)hipFree(b->d_base);
 	delete b;
 }
 
@@ -123,7 +123,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	{
 		if (b->image_cap < image_bytes)
 		{
-			if (b->d_image) hipFree(b->d_image);
+			if (b->d_image) (void)hipFree(b->d_image);
 			b->d_image = nullptr; b->image_cap = 0;
 			HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
 			b->image_cap = image_bytes;
@@ -135,7 +135,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	{
 		if (b->out_cap < out_bytes)
 		{
-			if (b->d_out) hipFree(b->d_out);
+			if (b->d_out) (void)hipFree(b->d_out);
 			b->d_out = nullptr; b->out_cap = 0;
 			HIP_TRY(hipMalloc(&b->d_out, out_bytes), return 1);
 			b->out_cap = out_bytes;
@@ -160,7 +160,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		const size_t need = (size_t)job.dim_x * job.dim_y * sizeof(float);
 		if (b->alpha_cap < need)
 		{
-			if (b->d_alpha) hipFree(b->d_alpha);
+			if (b->d_alpha) (void)hipFree(b->d_alpha);
 			b->d_alpha = nullptr; b->alpha_cap = 0;
 			HIP_TRY(hipMalloc(&b->d_alpha, need), return 1);
 			b->alpha_cap = need;
@@ -232,14 +232,14 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	// the staging buffers of the compress path are reused the other way round
 	if (b->image_cap < image_bytes)
 	{
-		if (b->d_image) hipFree(b->d_image);
+		if (b->d_image) (void)hipFree(b->d_image);
 		b->d_image = nullptr; b->image_cap = 0;
 		HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
 		b->image_cap = image_bytes;
 	}
 	if (b->out_cap < job.block_bytes)
 	{
-		if (b->d_out) hipFree(b->d_out);
+		if (b->d_out) (void)hipFree(b->d_out);
 		b->d_out = nullptr; b->out_cap = 0;
 		HIP_TRY(hipMalloc(&b->d_out, job.block_bytes), return 1);
 		b->out_cap = job.block_bytes;

@@ -954,7 +954,6 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	r->off_block_modes = off_bm;
 	r->off_decimation_modes = off_dm;
 	r->off_decimation_infos = off_di;
-	r->meta_bytes = (uint32_t)(off_di + dms.size() * sizeof(DecimationInfo)) - off_bm;
 	r->off_kmeans_texels = off_km;
 	r->off_color_unquant_to_uquant = off_cq;
 	r->off_color_uquant_to_pquant = off_cp;

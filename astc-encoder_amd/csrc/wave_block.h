@@ -290,7 +290,7 @@ WV_OUT bool refine_realign(int partition_count, int partition_packed, int decima
 }
 
 /* Shared tail of both trials: refine the chosen candidates. Returns best error seen in this trial. */
-WV_FN float refine_candidates(const Ctx& c, const PartView& pv, int partition_count, int partition_packed,
+WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_packed,
                               int plane2_component, float tune_errorval_threshold)
 {
 	TrialInfo& tr = c.tr();
@@ -660,9 +660,8 @@ WV_OUT float stage_refine(int partition_count, int partition_packed, int plane2_
 	const Ctx c = ctx_make();
 	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
 	plane2_component = wv_uniform(plane2_component); tune_errorval_threshold = wv_uniform(tune_errorval_threshold);
-	const PartView pv = part_view_lds(c, partition_count, partition_packed);
 	PROF_SCOPE(c, PS_X2);
-	return refine_candidates(c, pv, partition_count, partition_packed, plane2_component, tune_errorval_threshold);
+	return refine_candidates(c, partition_count, partition_packed, plane2_component, tune_errorval_threshold);
 }
 
 /* One trial of the search (ref: compress_symbolic_block_for_partition_1plane :353, _2planes :715). */

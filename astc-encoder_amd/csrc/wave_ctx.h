@@ -102,7 +102,6 @@ struct LdsLayout {
 	uint32_t ei_wes;     // f32 [2][Tp]    weight error scale per plane
 	uint32_t ptab;       // u8  [2][Tp]    staged partition record of the current trial
 	uint32_t candw;      // u8  [candidates][64]  quantized weights of the chosen candidates
-	uint32_t meta;       // copy of the block mode / decimation mode / decimation info records (0 = not staged)
 	// ---- phase-multiplexed region: {search | refine | partition search} never overlap in time ----
 	uint32_t dwi;        // f32 packed     search: ideal weights of every grid (DecimationMode::dwi_offset)
 	uint32_t lowhigh;    // f32 [slots][16] search: angular low/high per quant level
@@ -164,10 +163,6 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.ptab = take(2 * Tp);
 	L.candw = take(cfg.tune_candidate_limit * 64);
 	L.tsc_stride = Tp;
-	L.meta = 0;
-#if defined(ASTC_META_LDS)
-	L.meta = take(r.meta_bytes);
-#endif
 
 	const uint32_t begin = o;
 	// search phase
@@ -264,15 +259,9 @@ struct Ctx {
 	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
-#if defined(ASTC_META_LDS)
-	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(lds + L->meta)[i]; }
-	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(lds + L->meta + (root->off_decimation_modes - root->off_block_modes))[i]; }
-	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(lds + L->meta + (root->off_decimation_infos - root->off_block_modes))[i]; }
-#else
 	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }
 	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(tab + root->off_decimation_modes)[i]; }
 	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(tab + root->off_decimation_infos)[i]; }
-#endif
 	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
 	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
 };
