@@ -777,7 +777,6 @@ WV_FN float prepare_block_statistics(const Ctx& c)
 	return lowest_correlation;
 }
 
-#if defined(ASTC_DBG_OUTLINE_PSEARCH)
 WV_OUT int stage_partition_search(int partition_count, int requested_indices, int requested_trials)
 {
 	const Ctx c = ctx_make();
@@ -785,7 +784,6 @@ WV_OUT int stage_partition_search(int partition_count, int requested_indices, in
 	PROF_SCOPE(c, PS_KMEANS);
 	return find_best_partition_candidates(c, partition_count, requested_indices, requested_trials);
 }
-#endif
 
 WV_OUT float stage_block_statistics()
 {
@@ -899,13 +897,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			requested_trials = i_min(requested_trials, requested_indices);
 
 			int actual_trials;
-			// (kept inline: as an out-of-line stage this search produced different candidates on hardware;
-			// not understood yet)
-#if defined(ASTC_DBG_OUTLINE_PSEARCH)
 			actual_trials = wv_uniform(stage_partition_search(partition_count, requested_indices, requested_trials));
-#else
-			{ PROF_SCOPE(c, PS_KMEANS); actual_trials = find_best_partition_candidates(c, partition_count, requested_indices, requested_trials); }
-#endif
 			// copy out of the scratch region: the trials below reuse it
 			int partition_indices[MAX_PARTITIONING_CANDIDATES];
 			{

@@ -579,8 +579,12 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
 	WV_ONE
 	{
-		float uncor_best_errors[MAX_PARTITIONING_CANDIDATES], samec_best_errors[MAX_PARTITIONING_CANDIDATES];
-		int uncor_best_partitions[MAX_PARTITIONING_CANDIDATES], samec_best_partitions[MAX_PARTITIONING_CANDIDATES];
+		// the four top-N lists live in the (now idle) counting-sort bins rather than in private arrays
+		static_assert(sizeof(ps.mscount) >= 4 * MAX_PARTITIONING_CANDIDATES * 4, "top-N lists do not fit the sort bins");
+		float* uncor_best_errors = reinterpret_cast<float*>(ps.mscount);
+		float* samec_best_errors = uncor_best_errors + MAX_PARTITIONING_CANDIDATES;
+		int* uncor_best_partitions = reinterpret_cast<int*>(samec_best_errors + MAX_PARTITIONING_CANDIDATES);
+		int* samec_best_partitions = uncor_best_partitions + MAX_PARTITIONING_CANDIDATES;
 		for (int i = 0; i < MAX_PARTITIONING_CANDIDATES; i++)
 		{
 			uncor_best_errors[i] = ERROR_CALC_DEFAULT; samec_best_errors[i] = ERROR_CALC_DEFAULT;
