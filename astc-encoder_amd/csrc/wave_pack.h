@@ -114,7 +114,12 @@ WV_FN int bitrev8(int p)
 /* Write the physical block for `scb` into pcb[16].  Call from ONE lane. */
 WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 {
-	uint8_t pcb[18];
+	// byte buffers in LDS (the search regions are idle by now): run-time indexed private arrays would
+	// live in scratch memory
+	uint8_t* pcb = c.lds + c.L->uni;            // [18] (+2 pad)
+	uint8_t* weightbuf = pcb + 20;              // [18] (+2 pad)
+	uint8_t* weights = pcb + 40;                // [64]
+	uint8_t* values_to_encode = pcb + 104;      // [32]
 	for (int i = 0; i < 18; i++) pcb[i] = 0;
 
 	if (scb.block_type == SYM_BTYPE_CONST_U16 || scb.block_type == SYM_BTYPE_CONST_F16)
@@ -144,8 +149,6 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 	int real_weight_count = is_dual_plane ? 2 * weight_count : weight_count;
 	int bits_for_weights = (int)ise_bitcount((unsigned)real_weight_count, wq);
 
-	uint8_t weights[64];
-	uint8_t weightbuf[18];
 	for (int i = 0; i < 18; i++) weightbuf[i] = 0;
 
 	for (int i = 0; i < weight_count; i++)
@@ -234,7 +237,6 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 		pk_write_bits((unsigned)scb.plane2_component, 2, (unsigned)(below_weights_pos - 2), pcb);
 	}
 
-	uint8_t values_to_encode[32];
 	int valuecount = 0;
 	const uint8_t* pack_table = c.tab + c.root->off_color_uquant_to_pquant + (scb.quant_mode - QUANT_6) * 256;
 	for (unsigned int i = 0; i < partition_count; i++)

@@ -179,18 +179,25 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		// empty-cluster repair, strictly sequential (ref: :184-198)
 		WV_ONE
 		{
-			int cnt[4] = { 0, 0, 0, 0 };
-			for (int i = 0; i < T; i++) cnt[(int)assign[i]]++;
+			// texels per cluster, in four scalars (a run-time indexed private array would live in scratch)
+			int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+			for (int i = 0; i < T; i++)
+			{
+				int a = (int)assign[i];
+				c0 += a == 0; c1 += a == 1; c2 += a == 2; c3 += a == 3;
+			}
 			bool problem_case;
 			do
 			{
 				problem_case = false;
 				for (int i = 0; i < pc; i++)
 				{
-					if (cnt[i] == 0)
+					int ci = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
+					if (ci == 0)
 					{
-						cnt[(int)assign[i]]--;
-						cnt[i]++;
+						int a = (int)assign[i];
+						c0 -= a == 0; c1 -= a == 1; c2 -= a == 2; c3 -= a == 3;
+						c0 += i == 0; c1 += i == 1; c2 += i == 2; c3 += i == 3;
 						assign[i] = (float)i;
 						problem_case = true;
 					}
