@@ -67,7 +67,7 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 /* Per-mode records of one scoring chunk, built once by one lane per (mode, plane) so that the
  * (mode, texel) sweep reads them with a single LDS access instead of chasing
  * block mode -> decimation info -> table pointers through global memory in every lane. */
-struct ModeHdr { uint32_t tw_off, tcf_off; int32_t taps; int32_t valid; };
+struct ModeHdr { uint32_t tw_off, tcf_off; int32_t taps; int32_t mode; };   // mode = packed block mode index
 struct ModeQ { float scale, scaled_low_bound, quant_level_m1, rscale, low_bound; int32_t steps_m1; uint32_t q2u_off; uint32_t dwi_off; };
 static_assert(sizeof(ModeHdr) + 2 * sizeof(ModeQ) == MODE_DESC_BYTES, "mode descriptor size");
 
@@ -110,16 +110,45 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
 	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;     // k / T == (k * t_inv) >> 24 for k < 2^24 / T
 
-	for (int first = start; first < end; first += chunk_modes)
+	// Windows of 64 block modes.  Only the modes that are legal under this trial's weight quant limit
+	// (less than half of them, typically, once trial A has set the limit) are scored: their window
+	// positions are compacted through a validity bit mask into chunks of descriptor slots.
+	for (int base = start; base < end; base += 64)
 	{
-		const int nm = i_min(chunk_modes, end - first);
+	const int nwin = i_min(64, end - base);
+	unsigned long long vmask = 0;
+#if WV_DEVICE
+	{
+		bool ok = false;
+		if (WV_LANE < nwin)
+		{
+			const BlockMode& bm = c.block_mode(base + WV_LANE);
+			ok = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
+		}
+		vmask = __ballot(ok);
+	}
+#else
+	for (int i = 0; i < nwin; i++)
+	{
+		const BlockMode& bm = c.block_mode(base + i);
+		if (bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0)) vmask |= 1ull << i;
+	}
+#endif
+	const int nvalid = popcount64(vmask);
+	WV_FOR(i, nwin) { if (!((vmask >> i) & 1ull)) modes[base + i].error = 1e38f; }
+
+	for (int first = 0; first < nvalid; first += chunk_modes)
+	{
+		const int nm = i_min(chunk_modes, nvalid - first);
 
 		{ PROF_SCOPE(c, PS_MODE3);
-		WV_FOR(k, nm * 2)
+		WV_FOR(k, nwin * 2)
 		{
-			int m = k >> 1, plane = k & 1;
-			const BlockMode& bm = c.block_mode(first + m);
-			bool valid = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
+			const int i = k >> 1, plane = k & 1;
+			if (!((vmask >> i) & 1ull) || plane >= planes) continue;
+			const int m = popcount64(vmask & ((1ull << i) - 1ull)) - first;       // descriptor slot of window mode i
+			if (m < 0 || m >= nm) continue;
+			const BlockMode& bm = c.block_mode(base + i);
 			if (plane == 0)
 			{
 				const DecimationInfo& di = c.dec_info(bm.decimation_mode);
@@ -128,21 +157,18 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				h.tw_off = di.off_texel_weights;
 				h.tcf_off = di.off_texel_contribs_f;
 				h.taps = mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1;
-				h.valid = valid ? 1 : 0;
+				h.mode = base + i;
 				hdr[m] = h;
 			}
-			if (valid && plane < planes)
-			{
-				float low, high;
-				mode_weight_bounds(c, bm, plane, low, high);
-				QuantParams qp = quant_params(low, high, bm.quant_mode);
-				ModeQ q;
-				q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
-				q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
-				q.q2u_off = c.root->off_quant_xfer + (uint32_t)bm.quant_mode * (uint32_t)sizeof(QuantXfer);
-				q.dwi_off = (uint32_t)(c.dwi(bm.decimation_mode, plane, dual) - ldsf);
-				mq[m * 2 + plane] = q;
-			}
+			float low, high;
+			mode_weight_bounds(c, bm, plane, low, high);
+			QuantParams qp = quant_params(low, high, bm.quant_mode);
+			ModeQ q;
+			q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
+			q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
+			q.q2u_off = c.root->off_quant_xfer + (uint32_t)bm.quant_mode * (uint32_t)sizeof(QuantXfer);
+			q.dwi_off = (uint32_t)(c.dwi(bm.decimation_mode, plane, dual) - ldsf);
+			mq[m * 2 + plane] = q;
 		}
 		WV_SYNC(); }
 
@@ -152,7 +178,6 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			int m = (int)(((uint32_t)k * t_inv) >> 24), t = k - m * T;
 			const ModeHdr h = hdr[m];
 			float term = 0.0f;
-			if (h.valid)
 			{
 				const uint8_t* tab = c.tab;
 				const float* tabf = reinterpret_cast<const float*>(c.tab);
@@ -225,9 +250,10 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 
 		WV_FOR(m, nm)
 		{
-			modes[first + m].error = hdr[m].valid ? (buf[m * Tp] + buf[m * Tp + 2]) + (buf[m * Tp + 1] + buf[m * Tp + 3]) : 1e38f;
+			modes[hdr[m].mode].error = (buf[m * Tp] + buf[m * Tp + 2]) + (buf[m * Tp + 1] + buf[m * Tp + 3]);
 		}
 		WV_SYNC();
+	}
 	}
 }
 
