@@ -63,8 +63,8 @@ struct DecimationMode {
 	uint16_t refprec_2planes;
 	// LDS slots of this grid's per-trial results.  1-plane and 2-plane trials never run at the same
 	// time, so each trial class has its own dense packing: slot 0 = the plane of a 1-plane trial,
-	// slots 1 / 2 = plane 0 / 1 of a 2-plane trial.  A grid the class cannot use gets a zero-length
-	// slot at the running offset (so [offset(dm0), offset(dm1)) is always the range of grids dm0..dm1-1).
+	// slots 1 / 2 = plane 0 / 1 of a 2-plane trial.  Within a class the grids are packed by ascending
+	// lowest quant level of their block modes (TableRoot::dwi_used_sets); grids the class cannot use have no slot.
 	uint16_t dwi_offset[3];      // float offset of the ideal weights in the packed dwi region
 	uint16_t lowhigh_offset[3];  // float offset of the angular (low, high) pairs, one per quant level 0..min(maxprec, 7)
 };
@@ -77,9 +77,9 @@ struct DwiSlot {
 	uint16_t refprec;       // quant levels (bit mask) of the block modes using this grid in this trial class
 	uint8_t  weight_count;
 	uint8_t  taps;          // texels this weight touches; 0 for the padding slots past weight_count
-	uint8_t  direct;        // grid == texels: the ideal weight is copied
+	uint8_t  flags;         // bit 0: grid == texels, the ideal weight is copied; bit 1: weight plane
 	uint8_t  dm;            // decimation mode
-	uint8_t  plane;
+	uint8_t  set;           // index of the (grid, plane) set in packing order (InfillSet index)
 	uint8_t  index;         // weight index in the grid
 };
 
@@ -91,7 +91,8 @@ struct InfillSet {
 	uint16_t refprec;
 	uint8_t  taps;          // 1, 2 or 4 weights per texel
 	uint8_t  direct;
-	uint8_t  pad[2];
+	uint8_t  dm;
+	uint8_t  plane;
 };
 
 // Bilinear-infill tables of one weight grid. (ref: struct decimation_info :347)
@@ -175,7 +176,9 @@ struct TableRoot {
 	uint32_t dwi_total_floats[2];             // size of the packed ideal-weight region, [1-plane trials, 2-plane trials]
 	uint32_t off_dwi_owner[2];                // u16[dwi_total_floats[class]]: (decimation mode << 1) | plane owning each packed slot
 	uint32_t off_dwi_slots[2];                // DwiSlot[dwi_total_floats[class]]
-	uint32_t off_infill_sets[2];              // InfillSet[decimation modes][planes of the class]
+	uint32_t off_infill_sets[2];              // InfillSet[dwi_sets[class]] in packing order
+	uint32_t dwi_sets[2];                     // (grid, plane) sets per class; packed by ascending lowest usable quant level,
+	uint32_t dwi_used_sets[2][12];            // so the sets a trial with weight quant limit q uses are the first [class][q]
 	uint32_t lowhigh_floats[2];               // size of the packed low/high region per trial class
 	uint32_t max_partitionings;               // largest partitioning_count_selected[1..3]
 	uint32_t total_bytes;

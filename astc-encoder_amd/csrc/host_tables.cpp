@@ -726,29 +726,31 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	if (bm_counts[0] == 0 || dms.empty()) return false;
 
 	// packed LDS slots for the per-trial ideal weights and angular bounds of each grid, one dense
-	// packing per trial class (see DecimationMode)
+	// packing per trial class (see DecimationMode).  Grids are packed by ascending lowest quant level
+	// of the block modes that use them, so that a trial limited to quant level q touches a prefix.
 	uint32_t dwi_total[2] = { 0, 0 }, lh_total[2] = { 0, 0 };
-	for (size_t i = 0; i < dms.size(); i++)
+	std::vector<uint32_t> pack_order[2];          // decimation modes of each class in packing order
+	auto lowest_bit = [](uint16_t v) { int b = 0; while (!((v >> b) & 1)) b++; return b; };
+	for (int cls = 0; cls < 2; cls++)
 	{
-		uint32_t wc = dm_grid[i].first * dm_grid[i].second;
-		uint32_t wc4 = (wc + 3u) & ~3u;
-		// 1-plane trials
-		dms[i].dwi_offset[0] = (uint16_t)dwi_total[0];
-		dms[i].lowhigh_offset[0] = (uint16_t)lh_total[0];
-		if (dms[i].refprec_1plane != 0)
+		for (size_t i = 0; i < dms.size(); i++)
 		{
-			dwi_total[0] += wc4;
-			lh_total[0] += 2u * (uint32_t)(std::min<int>(dms[i].maxprec_1plane, 7) + 1);
+			if ((cls == 0 ? dms[i].refprec_1plane : dms[i].refprec_2planes) != 0) pack_order[cls].push_back((uint32_t)i);
+			for (int plane = 0; plane <= cls; plane++) { dms[i].dwi_offset[cls + plane] = 0; dms[i].lowhigh_offset[cls + plane] = 0; }
 		}
-		// 2-plane trials
-		for (int plane = 0; plane < 2; plane++)
+		std::stable_sort(pack_order[cls].begin(), pack_order[cls].end(), [&](uint32_t a, uint32_t b) {
+			return lowest_bit(cls == 0 ? dms[a].refprec_1plane : dms[a].refprec_2planes) < lowest_bit(cls == 0 ? dms[b].refprec_1plane : dms[b].refprec_2planes);
+		});
+		for (uint32_t i : pack_order[cls])
 		{
-			dms[i].dwi_offset[1 + plane] = (uint16_t)dwi_total[1];
-			dms[i].lowhigh_offset[1 + plane] = (uint16_t)lh_total[1];
-			if (dms[i].refprec_2planes != 0)
+			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
+			int maxprec = cls == 0 ? dms[i].maxprec_1plane : dms[i].maxprec_2planes;
+			for (int plane = 0; plane <= cls; plane++)
 			{
-				dwi_total[1] += wc4;
-				lh_total[1] += 2u * (uint32_t)(std::min<int>(dms[i].maxprec_2planes, 7) + 1);
+				dms[i].dwi_offset[cls + plane] = (uint16_t)dwi_total[cls];
+				dms[i].lowhigh_offset[cls + plane] = (uint16_t)lh_total[cls];
+				dwi_total[cls] += wc4;
+				lh_total[cls] += 2u * (uint32_t)(std::min<int>(maxprec, 7) + 1);
 			}
 		}
 	}
@@ -849,46 +851,48 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		}
 	}
 
-	// owner of every packed ideal-weight slot (lets one lane-parallel loop cover all grids)
+	// owner of every packed ideal-weight slot
 	uint32_t off_owner[2];
 	for (int cls = 0; cls < 2; cls++)
 	{
 		off_owner[cls] = blob.alloc(std::max<uint32_t>(dwi_total[cls], 1) * sizeof(uint16_t));
 		uint16_t* own = blob.at<uint16_t>(off_owner[cls]);
-		for (size_t i = 0; i < dms.size(); i++)
+		for (uint32_t i : pack_order[cls])
 		{
 			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
-			if (cls == 0 && dms[i].refprec_1plane != 0)
-				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[0] + k] = (uint16_t)(i << 1);
-			if (cls == 1 && dms[i].refprec_2planes != 0)
-				for (int plane = 0; plane < 2; plane++)
-					for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[1 + plane] + k] = (uint16_t)((i << 1) | (unsigned)plane);
+			for (int plane = 0; plane <= cls; plane++)
+				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[cls + plane] + k] = (uint16_t)((i << 1) | (unsigned)plane);
 		}
 	}
 
-	// per-slot / per-set records of the decimation sweeps (see DwiSlot, InfillSet)
-	uint32_t off_slots[2], off_isets[2];
+	// per-slot / per-set records of the decimation sweeps (see DwiSlot, InfillSet), in packing order
+	uint32_t off_slots[2], off_isets[2], n_sets[2], used_sets[2][12];
 	for (int cls = 0; cls < 2; cls++)
 	{
 		const int planes = cls + 1;
+		n_sets[cls] = (uint32_t)pack_order[cls].size() * planes;
 		off_slots[cls] = blob.alloc(std::max<uint32_t>(dwi_total[cls], 1) * sizeof(DwiSlot));
-		off_isets[cls] = blob.alloc(dms.size() * planes * sizeof(InfillSet));
-		for (size_t i = 0; i < dms.size(); i++)
+		off_isets[cls] = blob.alloc(std::max<uint32_t>(n_sets[cls], 1) * sizeof(InfillSet));
+		for (int q = 0; q < 12; q++) used_sets[cls][q] = 0;
+		uint32_t set = 0;
+		for (uint32_t i : pack_order[cls])
 		{
 			const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)));
 			const uint16_t refprec = cls == 0 ? dms[i].refprec_1plane : dms[i].refprec_2planes;
 			const uint32_t wc4 = ((uint32_t)di.weight_count + 3u) & ~3u;
-			for (int plane = 0; plane < planes; plane++)
+			const uint8_t* wtc = blob.at<uint8_t>(di.off_weight_texel_count);
+			for (int q = lowest_bit(refprec); q < 12; q++) used_sets[cls][q] += planes;
+			for (int plane = 0; plane < planes; plane++, set++)
 			{
-				InfillSet* is = blob.at<InfillSet>((uint32_t)(off_isets[cls] + (i * planes + plane) * sizeof(InfillSet)));
+				InfillSet* is = blob.at<InfillSet>((uint32_t)(off_isets[cls] + set * sizeof(InfillSet)));
 				is->tw_off = di.off_texel_weights;
 				is->tcf_off = di.off_texel_contribs_f;
 				is->dwi_offset = dms[i].dwi_offset[cls + plane];
 				is->refprec = refprec;
 				is->taps = (uint8_t)(di.max_texel_weight_count > 2 ? 4 : di.max_texel_weight_count > 1 ? 2 : 1);
 				is->direct = di.texel_count == di.weight_count;
-				if (refprec == 0) continue;
-				const uint8_t* wtc = blob.at<uint8_t>(di.off_weight_texel_count);
+				is->dm = (uint8_t)i;
+				is->plane = (uint8_t)plane;
 				for (uint32_t k = 0; k < wc4; k++)
 				{
 					DwiSlot* sl = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + (dms[i].dwi_offset[cls + plane] + k) * sizeof(DwiSlot)));
@@ -897,9 +901,9 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 					sl->refprec = refprec;
 					sl->weight_count = di.weight_count;
 					sl->taps = k < di.weight_count ? wtc[k] : 0;
-					sl->direct = di.texel_count == di.weight_count;
+					sl->flags = (uint8_t)((di.texel_count == di.weight_count ? 1 : 0) | (plane << 1));
 					sl->dm = (uint8_t)i;
-					sl->plane = (uint8_t)plane;
+					sl->set = (uint8_t)set;
 					sl->index = (uint8_t)k;
 				}
 			}
@@ -1000,6 +1004,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 			r->off_dwi_owner[cls] = off_owner[cls];
 			r->off_dwi_slots[cls] = off_slots[cls];
 			r->off_infill_sets[cls] = off_isets[cls];
+			r->dwi_sets[cls] = n_sets[cls];
+			for (int q = 0; q < 12; q++) r->dwi_used_sets[cls][q] = used_sets[cls][q];
 			r->lowhigh_floats[cls] = lh_total[cls];
 		}
 		r->max_partitionings = std::max(pcounts[1], std::max(pcounts[2], pcounts[3]));

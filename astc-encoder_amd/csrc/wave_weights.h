@@ -57,20 +57,27 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
 	float* infilled = c.uni_f();
 	const int cap_sets = (int)(c.L->uni_bytes / 4) / Tp;
+	// Sets are packed by ascending lowest quant level, so the sets this trial can use are a prefix
+	// (the single-grid "always" pass of trial A is the exception and simply filters by grid index).
+	const int nsets_all = (int)r.dwi_sets[cls];
+	int quant_limit = 0;
+	while (quant_limit < 11 && (ref_mask >> (quant_limit + 1))) quant_limit++;
+	const int nsets_used = max_dm < (int)r.decimation_mode_count_selected ? nsets_all : (int)r.dwi_used_sets[cls][quant_limit];
+	const int slots_end = nsets_used < nsets_all ? (int)isets[nsets_used].dwi_offset : (int)r.dwi_total_floats[cls];
 	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;      // k / T == (k * t_inv) >> 24
 
 	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
 	{ PROF_SCOPE(c, PS_DEC1);
-	WV_FOR(k, (int)r.dwi_total_floats[cls])
+	WV_FOR(k, slots_end)
 	{
 		const DwiSlot sl = slots[k];
 		if (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
-		const int plane = sl.plane;
+		const int plane = (sl.flags >> 1) & 1;
 		const int W = sl.weight_count;
 		const int i = sl.index;
 		const float* eiw = c.ei_w(plane);
 		const float* eiwes = c.ei_wes(plane);
-		if (sl.direct)
+		if (sl.flags & 1)
 		{
 			dwi_base[k] = eiw[i];
 			continue;
@@ -116,22 +123,21 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	}
 	WV_SYNC(); }
 
-	// sweeps 2+3 over chunks of grids whose infill fits the scratch region
-	int dm0 = 0;
-	while (dm0 < max_dm)
+	// sweeps 2+3 over chunks of (grid, plane) sets whose infill fits the scratch region
+	int p0 = 0;
+	while (p0 < nsets_used)
 	{
-		// chunk [dm0, dm1): sets are numbered (dm - dm0) * nplanes + plane
-		int dm1 = dm0 + cap_sets / nplanes;
-		if (dm1 > max_dm) dm1 = max_dm;
-		const int nsets = (dm1 - dm0) * nplanes;
+		int p1 = p0 + cap_sets;
+		if (p1 > nsets_used) p1 = nsets_used;
+		const int nsets = p1 - p0;
 
 		// sweep 2: infill to texel resolution (ref: :910-926)
 		{ PROF_SCOPE(c, PS_DEC2);
 		WV_FOR(k, nsets * T)
 		{
 			int set = (int)(((uint32_t)k * t_inv) >> 24), t = k - set * T;
-			const InfillSet is = isets[dm0 * nplanes + set];
-			if (is.direct || !(is.refprec & ref_mask)) continue;
+			const InfillSet is = isets[p0 + set];
+			if (is.direct || (int)is.dm >= max_dm || !(is.refprec & ref_mask)) continue;
 			const float* wts = dwi_base + is.dwi_offset;
 			infilled[set * Tp + t] = is.taps <= 2 ? infill2_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t)
 			                                      : infill4_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t);
@@ -140,14 +146,14 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 
 		// sweep 3: one clamped gradient step (ref: :930-970)
 		PROF_SCOPE(c, PS_DEC3);
-		const int k_begin = c.dec_mode(dm0).dwi_offset[cls];
-		const int k_end = dm1 < (int)r.decimation_mode_count_selected ? (int)c.dec_mode(dm1).dwi_offset[cls] : (int)r.dwi_total_floats[cls];
+		const int k_begin = (int)isets[p0].dwi_offset;
+		const int k_end = p1 < nsets_all ? (int)isets[p1].dwi_offset : (int)r.dwi_total_floats[cls];
 		WV_FOR(kk, k_end - k_begin)
 		{
 			int k = k_begin + kk;
 			const DwiSlot sl = slots[k];
-			if (sl.taps == 0 || sl.direct || !(sl.refprec & ref_mask)) continue;
-			const int dm = sl.dm, plane = sl.plane;
+			if (sl.taps == 0 || (sl.flags & 1) || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
+			const int plane = (sl.flags >> 1) & 1;
 			const int W = sl.weight_count;
 			const float* eiw = c.ei_w(plane);
 			const float* eiwes = c.ei_wes(plane);
@@ -156,7 +162,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)W;
 			const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 			const float wes0 = eiwes[0];
-			const float* inf = infilled + ((dm - dm0) * nplanes + plane) * Tp;
+			const float* inf = infilled + ((int)sl.set - p0) * Tp;
 			float weight_val = dwi_base[k];
 			float error_change0 = 1e-10f;
 			float error_change1 = 0.0f;
@@ -194,7 +200,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			dwi_base[k] = weight_val + step;
 		}
 		WV_SYNC();
-		dm0 = dm1;
+		p0 = p1;
 	}
 }
 
