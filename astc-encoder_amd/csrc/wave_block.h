@@ -335,24 +335,47 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 	// for every block mode, compress_symbolic.cpp:469-478); after this the search-phase LDS
 	// (ideal weights, angular bounds, mode records) is dead and the refine-phase tables reuse it.
 	{ PROF_SCOPE(c, PS_Y0);
-	// one lane per (candidate, plane, weight): a single dependent chain instead of one per candidate
-	const int plane_shift = dual ? 7 : 6;
+	// quantization parameters of each (candidate, plane) once, then one lane per (candidate, plane, weight)
+	const int plane_shift = dual ? 1 : 0;
+	ModeQ* cq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni);          // [candidate][plane]; the scoring scratch is idle now
+	const float* ldsf = reinterpret_cast<const float*>(c.lds);
 	WV_FOR(k, candidate_count << plane_shift)
 	{
-		const int ci = k >> plane_shift, plane = (k >> 6) & (dual ? 1 : 0), i = k & 63;
+		const int ci = k >> plane_shift, plane = k & plane_shift;
 		const BlockMode& bm = c.block_mode(tr.cand_block_mode[ci]);
-		if (i >= (int)c.dec_info(bm.decimation_mode).weight_count) continue;
 		float low, high;
 		mode_weight_bounds(c, bm, plane, low, high);
 		QuantParams qp = quant_params(low, high, bm.quant_mode);
-		const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
-		float f;
-		int w = quantize_weight(qp, q2u, c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0)[i], &f);
-		c.candw(ci)[plane * PLANE2_OFFSET + i] = (uint8_t)w;
+		ModeQ q;
+		q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
+		q.rscale = (float)c.dec_info(bm.decimation_mode).weight_count;   // (field reused: weight count of the grid)
+		q.low_bound = 0.0f; q.steps_m1 = qp.steps_m1;
+		q.q2u_off = c.root->off_quant_xfer + (uint32_t)bm.quant_mode * (uint32_t)sizeof(QuantXfer);
+		q.dwi_off = (uint32_t)(c.dwi(bm.decimation_mode, plane, dual) - ldsf);
+		cq[k] = q;
+	}
+	WV_SYNC();
+	WV_FOR(k, candidate_count << (plane_shift + 6))
+	{
+		const int cp = k >> 6, i = k & 63;
+		const ModeQ q = cq[cp];
+		if (i >= (int)q.rscale) continue;
+		// (ref: compute_quantized_weights_for_decimation :974, integer output)
+		const float ideal = (ldsf + q.dwi_off)[i];
+		float ix = ideal * q.scale - q.scaled_low_bound;
+		ix = v_clampzo(ix);
+		const float ix1 = ix * q.quant_level_m1;
+		const int weightl = (int)ix1;
+		const int weighth = i_min(weightl + 1, q.steps_m1);
+		const int ixli = c.tab[q.q2u_off + (uint32_t)weightl];
+		const int ixhi = c.tab[q.q2u_off + (uint32_t)weighth];
+		const bool mask = ((float)ixli + (float)ixhi) < (128.0f * ix);
+		c.candw(cp >> plane_shift)[(cp & plane_shift) * PLANE2_OFFSET + i] = (uint8_t)(mask ? ixhi : ixli);
 	}
 	WV_SYNC(); }
 	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
 
+	int staged_dm = -1, staged_wq = -1;                 // what the candidate tables in LDS currently hold
 	for (int i = 0; i < candidate_count; i++)
 	{
 		const int bm_packed_index = wv_uniform(tr.cand_block_mode[i]);
@@ -364,9 +387,18 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 		// stage what the refinement loop reads in serial, latency-bound code into LDS
 		{
 			PROF_SCOPE(c, PS_X0);
-			const DecimationInfo& dinfo = c.dec_info(cand_dm);
-			stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
-			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(wv_uniform((int)qw_bm.quant_mode))), (int)(sizeof(QuantXfer) / 4));
+			const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
+			if (cand_dm != staged_dm)
+			{
+				const DecimationInfo& dinfo = c.dec_info(cand_dm);
+				stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
+				staged_dm = cand_dm;
+			}
+			if (cand_wq != staged_wq)
+			{
+				stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(cand_wq)), (int)(sizeof(QuantXfer) / 4));
+				staged_wq = cand_wq;
+			}
 			stage_color_rows(c, color_quant_level);      // ends with a sync
 		}
 
