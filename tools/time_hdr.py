@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Time BASELINE configs[3]: 4096x4096 RGBA16F, HDR profile, 6x6 -medium (device-resident)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import astcenc_amd as A, images
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lib = A.Library(A.LIB_PRODUCT)
+err, cfg = lib.config_init(A.PRF_HDR, 6, 6, 1, A.PRE_MEDIUM, 0); assert err == 0
+err, ctx = lib.context_alloc(cfg, 1); assert err == 0, err
+img_h = images.hdr_f16(size, size)
+img = torch.from_numpy(img_h.view(np.uint16).astype(np.int16)).cuda()
+nb = ((size + 5) // 6) ** 2
+out = torch.zeros(nb * 16, dtype=torch.uint8, device="cuda")
+swz = A.Swizzle(*A.SWZ_RGBA); ms = ctypes.c_float(); best = 1e9
+for i in range(3):
+    e = lib.lib.astcenc_amd_compress_image_device(ctx, img.data_ptr(), size, size, A.TYPE_F16, ctypes.byref(swz), out.data_ptr(), out.numel(), torch.cuda.current_stream().cuda_stream, ctypes.byref(ms))
+    assert e == 0
+    if i: best = min(best, ms.value)
+print("HDR %dx%d RGBA16F 6x6 medium: kernel %.2f ms -> %.2f Mtexels/s" % (size, size, best, size * size / best / 1e3))
+# cross-check a crop against the reference
+if os.path.exists(A.LIB_REF_AVX2):
+    ref = A.Library(A.LIB_REF_AVX2)
+    crop = np.ascontiguousarray(img_h[:240, :240])
+    want = ref.compress(crop, (6, 6), A.PRE_MEDIUM, profile=A.PRF_HDR).reshape(-1, 16)
+    bx = (size + 5) // 6
+    got = out.cpu().numpy().reshape(-1, 16)
+    rows = np.concatenate([got[r * bx: r * bx + 40] for r in range(40)])
+    print("crop cross-check: %d of %d blocks differ" % (int((rows != want).any(axis=1).sum()), want.shape[0]))
