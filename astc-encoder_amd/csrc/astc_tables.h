@@ -11,7 +11,7 @@
 
 namespace astcd {
 
-constexpr int MAX_TEXELS       = 144;  // largest 2D footprint (12x12); 3D blocks are out of scope
+constexpr int MAX_TEXELS       = 216;  // largest footprint (6x6x6)        ref: BLOCK_MAX_TEXELS astcenc_internal.h:68
 constexpr int MAX_WEIGHTS      = 64;   // ref: BLOCK_MAX_WEIGHTS           astcenc_internal.h:88
 constexpr int PLANE2_OFFSET    = 32;   // ref: WEIGHTS_PLANE2_OFFSET       astcenc_internal.h:109
 constexpr int MAX_PARTITIONS   = 4;    // ref: BLOCK_MAX_PARTITIONS        astcenc_internal.h:79
@@ -147,7 +147,7 @@ constexpr uint32_t CTX_LAYOUT_BACK = 512;
 
 // Root record at blob offset 0.
 struct TableRoot {
-	uint8_t  dim_x, dim_y, texel_count, pad0;
+	uint8_t  dim_x, dim_y, texel_count, dim_z;
 	uint32_t block_mode_count_1plane_always;
 	uint32_t block_mode_count_1plane_selected;
 	uint32_t block_mode_count_1plane_2plane_selected;
@@ -204,7 +204,7 @@ struct DeviceConfig {
 
 // One image (or image slice) handed to the kernel.
 struct ImageDesc {
-	const void* data;      // device pointer, tightly packed RGBA rows
+	const void* data;      // device pointer, tightly packed RGBA rows, dim_z slices back to back
 	uint32_t dim_x, dim_y; // texels
 	uint32_t data_type;    // astcenc_type
 	uint32_t swz[4];       // astcenc_swz per output channel
@@ -212,6 +212,7 @@ struct ImageDesc {
 	uint32_t use_fast_load; // ref: astcenc_entry.cpp:946
 	const float* alpha_avg; // per-texel alpha averages of the a_scale_radius pre-pass, or null
 	uint32_t a_scale_radius;
+	uint32_t dim_z, blocks_z; // slices of a volume / 2D array image (1 for a plain 2D image)
 };
 
 } // namespace astcd

@@ -411,10 +411,10 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 
 	const astcenc_config& config = ctx->config;
 
-	// Scope of this library: 2D footprints, no alpha-scale RDO pre-pass.
+	// Scope of this library: alpha-scale radii up to ALPHA_MAX_RADIUS_HOST.
 	bool is_hdr = config.profile == ASTCENC_PRF_HDR || config.profile == ASTCENC_PRF_HDR_RGB_LDR_A;
 	bool compress = !(config.flags & ASTCENC_FLG_DECOMPRESS_ONLY);
-	if (config.block_z > 1 || (compress && config.a_scale_radius > ALPHA_MAX_RADIUS_HOST))
+	if (compress && config.block_z <= 1 && config.a_scale_radius > ALPHA_MAX_RADIUS_HOST)
 	{
 		delete ctx;
 		return ASTCENC_ERR_NOT_IMPLEMENTED;
@@ -425,7 +425,7 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 		ctx->blob = new std::vector<uint8_t>();
 		ctx->host_tables = new HostTables();
 		ctx->owns_tables = true;
-		if (!build_tables(config.block_x, config.block_y, config.tune_partition_count_limit,
+		if (!build_tables(config.block_x, config.block_y, config.block_z, config.tune_partition_count_limit,
 		                  (float)config.tune_block_mode_limit / 100.0f, *ctx->blob, *ctx->host_tables))
 		{
 			delete ctx->blob; delete ctx->host_tables; delete ctx;
@@ -553,17 +553,22 @@ astcenc_error astcenc_compress_image(astcenc_context* ctx, astcenc_image* imagep
 	size_t block_count;
 	astcenc_error status = check_compress_args(ctx, image.dim_x, image.dim_y, image.dim_z, swizzle, data_len, thread_index, block_count);
 	if (status != ASTCENC_SUCCESS) return status;
-	if (image.dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;
+	// The alpha-scale test only exists for 2D footprints (ref: astcenc_entry.cpp:975).  On a multi-slice
+	// image the reference averages over a 3D box and then reads slice 0's averages for every slice;
+	// that combination is not reproduced.
+	const bool alpha_scale = ctx->config.a_scale_radius != 0 && ctx->config.block_z <= 1;
+	if (alpha_scale && image.dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;
 
 	CompressJob job;
 	memset(&job, 0, sizeof(job));
-	job.host_data = image.data[0];
+	job.host_slices = image.data;
 	job.dim_x = image.dim_x;
 	job.dim_y = image.dim_y;
+	job.dim_z = image.dim_z;
 	job.data_type = (uint32_t)image.data_type;
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.host_out = data_out;
-	job.a_scale_radius = ctx->config.a_scale_radius;
+	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
 	return run_job(ctx, job);
 }
 
@@ -572,21 +577,32 @@ astcenc_error astcenc_amd_compress_image_device(astcenc_context* ctx, const void
                                                 const astcenc_swizzle* swizzle, void* device_out, size_t data_len,
                                                 void* hip_stream, float* kernel_ms)
 {
+	return astcenc_amd_compress_volume_device(ctx, device_image, dim_x, dim_y, 1, data_type, swizzle, device_out, data_len, hip_stream, kernel_ms);
+}
+
+astcenc_error astcenc_amd_compress_volume_device(astcenc_context* ctx, const void* device_image,
+                                                 unsigned int dim_x, unsigned int dim_y, unsigned int dim_z, astcenc_type data_type,
+                                                 const astcenc_swizzle* swizzle, void* device_out, size_t data_len,
+                                                 void* hip_stream, float* kernel_ms)
+{
 	size_t block_count;
-	astcenc_error status = check_compress_args(ctx, dim_x, dim_y, 1, swizzle, data_len, 0, block_count);
+	astcenc_error status = check_compress_args(ctx, dim_x, dim_y, dim_z, swizzle, data_len, 0, block_count);
 	if (status != ASTCENC_SUCCESS) return status;
+	const bool alpha_scale = ctx->config.a_scale_radius != 0 && ctx->config.block_z <= 1;
+	if (alpha_scale && dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;
 
 	CompressJob job;
 	memset(&job, 0, sizeof(job));
 	job.device_data = device_image;
 	job.dim_x = dim_x;
 	job.dim_y = dim_y;
+	job.dim_z = dim_z;
 	job.data_type = (uint32_t)data_type;
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.device_out = static_cast<uint8_t*>(device_out);
 	job.stream = hip_stream;
 	job.kernel_ms = kernel_ms;
-	job.a_scale_radius = ctx->config.a_scale_radius;
+	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
 
 	std::unique_lock<std::mutex> lk(ctx->lock);
 	lk.unlock();
@@ -637,15 +653,15 @@ astcenc_error astcenc_decompress_image(astcenc_context* ctx, const uint8_t* data
 	mul_safe(block_count, 16, overflow);
 	if (overflow || block_count == 0) return ASTCENC_ERR_BAD_PARAM;
 	if (data_len < block_count * 16) return ASTCENC_ERR_OUT_OF_MEM;
-	if (image_outp->dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;       // 3D: DESIGN.md section 8
 
 	DecompressJob job;
 	memset(&job, 0, sizeof(job));
 	job.host_blocks = data;
 	job.block_bytes = block_count * 16;
-	job.host_image = image_outp->data[0];
+	job.host_slices = image_outp->data;
 	job.dim_x = image_outp->dim_x;
 	job.dim_y = image_outp->dim_y;
+	job.dim_z = image_outp->dim_z;
 	job.data_type = (uint32_t)image_outp->data_type;
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 
@@ -682,7 +698,8 @@ astcenc_error astcenc_get_block_info(astcenc_context* ctx, const uint8_t data[16
 	info->profile = ctx->config.profile;
 	block_info_host::DecodeScratch scratch;
 	memset(&scratch, 0, sizeof(scratch));
-	block_info_host::describe_block(data, (int)ctx->config.block_x, (int)ctx->config.block_y, (int)ctx->config.profile, info, scratch);
+	block_info_host::describe_block(data, (int)ctx->config.block_x, (int)ctx->config.block_y, (int)(ctx->config.block_z > 1 ? ctx->config.block_z : 1),
+	                                (int)ctx->config.profile, info, scratch);
 	return ASTCENC_SUCCESS;
 }
 

@@ -13,9 +13,9 @@ namespace astcd {
 struct Backend;
 
 struct CompressJob {
-	const void* host_data;     // tightly packed RGBA rows (one 2D slice), host memory; may be null
-	const void* device_data;   // same layout already resident in HBM; used when host_data is null
-	uint32_t dim_x, dim_y;
+	const void* const* host_slices; // dim_z pointers to tightly packed RGBA rows (one 2D slice each), host memory; may be null
+	const void* device_data;   // the slices back to back, already resident in HBM; used when host_slices is null
+	uint32_t dim_x, dim_y, dim_z;
 	uint32_t data_type;        // astcenc_type
 	uint32_t swz[4];
 	uint8_t* host_out;         // 16 bytes per block, host memory; may be null
@@ -30,8 +30,8 @@ struct CompressJob {
 struct DecompressJob {
 	const uint8_t* host_blocks;   // 16 bytes per block, raster block order
 	size_t   block_bytes;
-	void*    host_image;          // tightly packed RGBA rows (one 2D slice) of data_type, host memory
-	uint32_t dim_x, dim_y;
+	void* const* host_slices;     // dim_z pointers to tightly packed RGBA rows (one 2D slice each) of data_type, host memory
+	uint32_t dim_x, dim_y, dim_z;
 	uint32_t data_type;           // astcenc_type
 	uint32_t swz[4];
 };
@@ -78,8 +78,8 @@ int astc_alpha_launch(const AlphaLaunch& a);
 struct DecodeLaunch {
 	const uint8_t* d_blocks;
 	void* d_image;
-	uint32_t dim_x, dim_y, data_type, swz[4];
-	uint32_t block_x, block_y, profile;
+	uint32_t dim_x, dim_y, dim_z, data_type, swz[4];
+	uint32_t block_x, block_y, block_z, profile;
 	void* stream;
 };
 int astc_decode_launch(const DecodeLaunch& d);

@@ -106,12 +106,15 @@ int backend_compress(Backend* b, const CompressJob& job)
 {
 	HIP_TRY(hipSetDevice(b->device), return 2);
 
-	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y;
+	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y, bsz = b->root.dim_z;
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
 	const uint32_t blocks_x = (job.dim_x + bsx - 1) / bsx;
 	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
-	const size_t nblocks = (size_t)blocks_x * blocks_y;
+	const uint32_t blocks_z = (dim_z + bsz - 1) / bsz;
+	const size_t nblocks = (size_t)blocks_x * blocks_y * blocks_z;
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
-	const size_t image_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	const size_t image_bytes = slice_bytes * dim_z;
 	const size_t out_bytes = nblocks * 16;
 
 	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
@@ -119,7 +122,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	const void* d_image = job.device_data;
 	uint8_t* d_out = job.device_out;
 
-	if (job.host_data)
+	if (job.host_slices)
 	{
 		if (b->image_cap < image_bytes)
 		{
@@ -128,7 +131,8 @@ int backend_compress(Backend* b, const CompressJob& job)
 			HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
 			b->image_cap = image_bytes;
 		}
-		HIP_TRY(hipMemcpyAsync(b->d_image, job.host_data, image_bytes, hipMemcpyHostToDevice, stream), return 2);
+		for (uint32_t z = 0; z < dim_z; z++)
+			HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(b->d_image) + z * slice_bytes, job.host_slices[z], slice_bytes, hipMemcpyHostToDevice, stream), return 2);
 		d_image = b->d_image;
 	}
 	if (job.host_out)
@@ -150,9 +154,10 @@ int backend_compress(Backend* b, const CompressJob& job)
 	img.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
 	img.blocks_x = blocks_x; img.blocks_y = blocks_y;
+	img.dim_z = dim_z; img.blocks_z = blocks_z;
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
-	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;   // ref: astcenc_entry.cpp:946
+	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0 && bsz == 1) ? 1 : 0;   // ref: astcenc_entry.cpp:946
 	img.alpha_avg = nullptr;
 	img.a_scale_radius = job.a_scale_radius;
 	if (job.a_scale_radius != 0)
@@ -176,7 +181,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 
 	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is
 	// still tens of thousands of workgroups, far more than the 256 CUs need to stay full.
-	const size_t chunk = (job.progress || job.host_data) ? (size_t)1 << 18 : nblocks;
+	const size_t chunk = (job.progress || job.host_slices) ? (size_t)1 << 18 : nblocks;
 	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev0, stream), return 2);
 	for (size_t first = 0; first < nblocks; first += chunk)
 	{
@@ -227,7 +232,9 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 {
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
-	const size_t image_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	const size_t image_bytes = slice_bytes * dim_z;
 
 	// the staging buffers of the compress path are reused the other way round
 	if (b->image_cap < image_bytes)
@@ -249,14 +256,15 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	DecodeLaunch d;
 	d.d_blocks = b->d_out;
 	d.d_image = b->d_image;
-	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.data_type = job.data_type;
+	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = dim_z; d.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
-	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y;
+	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y; d.block_z = b->root.dim_z;
 	d.profile = b->cfg.profile;
 	d.stream = b->stream;
 	int lrc = astc_decode_launch(d);
 	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
-	HIP_TRY(hipMemcpyAsync(job.host_image, b->d_image, image_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
+	for (uint32_t z = 0; z < dim_z; z++)
+		HIP_TRY(hipMemcpyAsync(job.host_slices[z], static_cast<uint8_t*>(b->d_image) + z * slice_bytes, slice_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
 	HIP_TRY(hipStreamSynchronize(b->stream), return 2);
 	return 0;
 }

@@ -121,32 +121,114 @@ static bool decode_block_mode_2d(unsigned int mode, unsigned int& wx, unsigned i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Decimation (bilinear infill) tables for one weight grid. (ref: block_sizes.cpp:252-436)
+// Block mode decode (3D). (ref: block_sizes.cpp:152-243; ASTC spec table C.2.10)
 // ---------------------------------------------------------------------------------------------
-static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, unsigned int ty,
-                                  unsigned int wx, unsigned int wy)
+static bool decode_block_mode_3d(unsigned int mode, unsigned int& wx, unsigned int& wy, unsigned int& wz,
+                                 bool& dual, unsigned int& quant, unsigned int& wbits)
 {
-	const unsigned int T = tx * ty, W = wx * wy;
+	unsigned int r0 = (mode >> 4) & 1;
+	unsigned int H = (mode >> 9) & 1;
+	unsigned int D = (mode >> 10) & 1;
+	const unsigned int A = (mode >> 5) & 3;
+	unsigned int R;
+	wx = wy = wz = 0;
+
+	if (mode & 3)
+	{
+		R = r0 | ((mode & 3) << 1);
+		wx = A + 2;
+		wy = ((mode >> 7) & 3) + 2;
+		wz = ((mode >> 2) & 3) + 2;
+	}
+	else
+	{
+		const unsigned int r21 = (mode >> 2) & 3;
+		if (r21 == 0) return false;
+		R = r0 | (r21 << 1);
+		const unsigned int B = (mode >> 9) & 3;
+		const unsigned int sel = (mode >> 7) & 3;
+		if (sel != 3) { D = 0; H = 0; }
+		switch (sel)
+		{
+		case 0: wx = 6; wy = B + 2; wz = A + 2; break;
+		case 1: wx = A + 2; wy = 6; wz = B + 2; break;
+		case 2: wx = A + 2; wy = B + 2; wz = 6; break;
+		default:
+			wx = wy = wz = 2;
+			switch (A)
+			{
+			case 0: wx = 6; break;
+			case 1: wy = 6; break;
+			case 2: wz = 6; break;
+			default: return false;
+			}
+			break;
+		}
+	}
+
+	unsigned int count = wx * wy * wz * (D + 1);
+	quant = (R - 2) + 6 * H;
+	dual = D != 0;
+	wbits = ise_sequence_bitcount(count, quant);
+	return count <= (unsigned)MAX_WEIGHTS && wbits >= 24 && wbits <= 96;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decimation (infill) tables for one weight grid: bilinear for 2D footprints (ref:
+// block_sizes.cpp:252-436), simplex interpolation over the 3D grid cell for 3D ones (ref: :450-700).
+// ---------------------------------------------------------------------------------------------
+static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, unsigned int ty, unsigned int tz,
+                                  unsigned int wx, unsigned int wy, unsigned int wz)
+{
+	const unsigned int T = tx * ty * tz, W = wx * wy * wz;
 	std::vector<uint8_t> cnt_t(T, 0), cnt_w(W, 0);
 	std::vector<uint8_t> gw(T * 4, 0), gc(T * 4, 0);            // per texel: weight ids, contribs
 	std::vector<std::vector<uint8_t>> tw(W), tc(W);            // per weight: texel ids, contribs
 
+	for (unsigned int z = 0; z < tz; z++)
 	for (unsigned int y = 0; y < ty; y++)
 	{
 		for (unsigned int x = 0; x < tx; x++)
 		{
-			unsigned int texel = y * tx + x;
+			unsigned int texel = (z * ty + y) * tx + x;
 			unsigned int xs = (((1024 + tx / 2) / (tx - 1)) * x * (wx - 1) + 32) >> 6;
 			unsigned int ys = (((1024 + ty / 2) / (ty - 1)) * y * (wy - 1) + 32) >> 6;
 			unsigned int xf = xs & 0xF, yf = ys & 0xF, xi = xs >> 4, yi = ys >> 4;
 
 			unsigned int q[4], w[4];
-			q[0] = xi + yi * wx; q[1] = q[0] + 1; q[2] = q[0] + wx; q[3] = q[2] + 1;
-			unsigned int prod = xf * yf;
-			w[3] = (prod + 8) >> 4;
-			w[1] = xf - w[3];
-			w[2] = yf - w[3];
-			w[0] = 16 - xf - yf + w[3];
+			if (tz == 1)
+			{
+				q[0] = xi + yi * wx; q[1] = q[0] + 1; q[2] = q[0] + wx; q[3] = q[2] + 1;
+				unsigned int prod = xf * yf;
+				w[3] = (prod + 8) >> 4;
+				w[1] = xf - w[3];
+				w[2] = yf - w[3];
+				w[0] = 16 - xf - yf + w[3];
+			}
+			else
+			{
+				unsigned int zs = (((1024 + tz / 2) / (tz - 1)) * z * (wz - 1) + 32) >> 6;
+				unsigned int zf = zs & 0xF, zi = zs >> 4;
+				// walk from the cell's low corner to its high corner along the axes in descending
+				// order of fraction; ties resolved as the spec's comparison chain does
+				const unsigned int N = wx, NM = wx * wy;
+				const unsigned int fs = xf, ft = yf, fp = zf;
+				const unsigned int cas = ((fs > ft) << 2) + ((ft > fp) << 1) + (fs > fp);
+				unsigned int s1, s2;
+				switch (cas)
+				{
+				case 7: s1 = 1;  s2 = N;  w[0] = 16 - fs; w[1] = fs - ft; w[2] = ft - fp; w[3] = fp; break;
+				case 3: s1 = N;  s2 = 1;  w[0] = 16 - ft; w[1] = ft - fs; w[2] = fs - fp; w[3] = fp; break;
+				case 5: s1 = 1;  s2 = NM; w[0] = 16 - fs; w[1] = fs - fp; w[2] = fp - ft; w[3] = ft; break;
+				case 4: s1 = NM; s2 = 1;  w[0] = 16 - fp; w[1] = fp - fs; w[2] = fs - ft; w[3] = ft; break;
+				case 2: s1 = N;  s2 = NM; w[0] = 16 - ft; w[1] = ft - fp; w[2] = fp - fs; w[3] = fs; break;
+				default: s1 = NM; s2 = N; w[0] = 16 - fp; w[1] = fp - ft; w[2] = ft - fs; w[3] = fs; break;
+				}
+				q[0] = (zi * wy + yi) * wx + xi;
+				q[3] = ((zi + 1) * wy + (yi + 1)) * wx + (xi + 1);
+				q[1] = q[0] + s1;
+				q[2] = q[1] + s2;
+			}
 
 			for (int i = 0; i < 4; i++)
 			{
@@ -331,15 +413,16 @@ struct PartTmp {
 	unsigned int pcount;
 };
 
-static void gen_partition(unsigned int tx, unsigned int ty, unsigned int pcount, unsigned int seed, PartTmp& p)
+static void gen_partition(unsigned int tx, unsigned int ty, unsigned int tz, unsigned int pcount, unsigned int seed, PartTmp& p)
 {
-	bool small_block = (tx * ty) < 32;
+	bool small_block = (tx * ty * tz) < 32;
 	memset(p.counts, 0, sizeof(p.counts));
 	unsigned int t = 0;
+	for (unsigned int z = 0; z < tz; z++)
 	for (unsigned int y = 0; y < ty; y++)
 		for (unsigned int x = 0; x < tx; x++)
 		{
-			uint8_t part = select_partition((int)seed, (int)x, (int)y, 0, (int)pcount, small_block);
+			uint8_t part = select_partition((int)seed, (int)x, (int)y, (int)z, (int)pcount, small_block);
 			p.of_texel[t++] = part;
 			p.counts[part]++;
 		}
@@ -647,16 +730,19 @@ bool is_legal_3d_block_size(unsigned int x, unsigned int y, unsigned int z)
 // ---------------------------------------------------------------------------------------------
 // The builder
 // ---------------------------------------------------------------------------------------------
-bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count_cutoff,
+bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned int partition_count_cutoff,
                   float mode_cutoff, std::vector<uint8_t>& out, HostTables& host)
 {
-	const unsigned int T = tx * ty;
+	if (tz < 1) tz = 1;
+	const bool is_3d = tz > 1;
+	const unsigned int T = tx * ty * tz;
 	Blob blob;
 	uint32_t root_off = blob.alloc(sizeof(TableRoot));
 	(void)root_off;
 
 	// ---- percentile table for this footprint (ref: percentile_tables.cpp:1165) ----
 	std::vector<float> percentiles(MAX_BLOCK_MODES, 1.0f);
+	if (!is_3d)
 	{
 		const uint16_t* pt = nullptr;
 		for (auto* t : pct_tables) if (t[0] == tx && t[1] == ty) pt = t;
@@ -674,44 +760,64 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	// (ref: block_sizes.cpp:865-988; the 4th "unselected" pass is never searched and is omitted)
 	std::vector<BlockMode> bms;
 	std::vector<DecimationMode> dms;
-	std::vector<std::pair<unsigned, unsigned>> dm_grid;
-	int dm_index[16 * 16 + 16];
+	struct Grid { unsigned x, y, z; unsigned count() const { return x * y * z; } };
+	std::vector<Grid> dm_grid;
+	int dm_index[8 * 16 * 16];
 	for (int& v : dm_index) v = -1;
 	std::vector<bool> taken(MAX_BLOCK_MODES, false);
 	unsigned int bm_counts[3] = { 0, 0, 0 }, dm_counts[3] = { 0, 0, 0 };
+
+	auto new_decimation_mode = [&](unsigned int wx, unsigned int wy, unsigned int wz) {
+		int dm = (int)dms.size();
+		dm_index[(wz * 16 + wy) * 16 + wx] = dm;
+		unsigned int wc = wx * wy * wz;
+		int mp1 = -1, mp2 = -1;
+		for (int q = 0; q < 12; q++)
+		{
+			unsigned int b1 = ise_sequence_bitcount(wc, (unsigned)q);
+			if (b1 >= 24 && b1 <= 96) mp1 = q;
+			if (2 * wc <= (unsigned)MAX_WEIGHTS)
+			{
+				unsigned int b2 = ise_sequence_bitcount(2 * wc, (unsigned)q);
+				if (b2 >= 24 && b2 <= 96) mp2 = q;
+			}
+		}
+		DecimationMode d = { (int8_t)mp1, (int8_t)mp2, 0, 0, {0, 0}, {0, 0} };
+		dms.push_back(d);
+		dm_grid.push_back({ wx, wy, wz });
+		return dm;
+	};
+
+	if (is_3d)
+	{
+		// the reference numbers the grids of a 3D footprint up front, in this order, used or not
+		// (block_sizes.cpp:1052-1100); grids no block mode refers to stay out of every search list here
+		for (unsigned int wx = 2; wx <= tx; wx++)
+			for (unsigned int wy = 2; wy <= ty; wy++)
+				for (unsigned int wz = 2; wz <= tz; wz++)
+					if (wx * wy * wz <= (unsigned)MAX_WEIGHTS) { new_decimation_mode(wx, wy, wz); dm_counts[1]++; }
+	}
 
 	for (unsigned int pass = 0; pass < 3; pass++)
 	{
 		for (unsigned int i = 0; i < (unsigned)MAX_BLOCK_MODES; i++)
 		{
 			if (taken[i]) continue;
-			unsigned int wx, wy, quant, wbits; bool dual;
-			if (!decode_block_mode_2d(i, wx, wy, dual, quant, wbits) || wx > tx || wy > ty) continue;
+			unsigned int wx, wy, wz = 1, quant, wbits; bool dual;
+			bool valid = is_3d ? decode_block_mode_3d(i, wx, wy, wz, dual, quant, wbits)
+			                   : decode_block_mode_2d(i, wx, wy, dual, quant, wbits);
+			if (!valid || wx > tx || wy > ty || wz > tz) continue;
 			if ((pass <= 1 && dual) || (pass == 2 && !dual)) continue;
 			if ((dual ? 109 : 111) <= (int)wbits) continue;
-			bool hit = percentiles[i] <= (pass == 0 ? 0.0f : mode_cutoff);
+			// 3D footprints have no percentile data: every legal mode is "selected", none "always"
+			// (ref: construct_block_size_descriptor_3d, block_sizes.cpp:1025-1190)
+			bool hit = is_3d ? pass != 0 : percentiles[i] <= (pass == 0 ? 0.0f : mode_cutoff);
 			if (!hit) continue;
 
-			int dm = dm_index[wy * 16 + wx];
+			int dm = dm_index[(wz * 16 + wy) * 16 + wx];
 			if (dm < 0)
 			{
-				dm = (int)dms.size();
-				dm_index[wy * 16 + wx] = dm;
-				unsigned int wc = wx * wy;
-				int mp1 = -1, mp2 = -1;
-				for (int q = 0; q < 12; q++)
-				{
-					unsigned int b1 = ise_sequence_bitcount(wc, (unsigned)q);
-					if (b1 >= 24 && b1 <= 96) mp1 = q;
-					if (2 * wc <= (unsigned)MAX_WEIGHTS)
-					{
-						unsigned int b2 = ise_sequence_bitcount(2 * wc, (unsigned)q);
-						if (b2 >= 24 && b2 <= 96) mp2 = q;
-					}
-				}
-				DecimationMode d = { (int8_t)mp1, (int8_t)mp2, 0, 0, {0, 0}, {0, 0} };
-				dms.push_back(d);
-				dm_grid.push_back({ wx, wy });
+				dm = new_decimation_mode(wx, wy, wz);
 				dm_counts[pass]++;
 			}
 
@@ -723,7 +829,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 			bm_counts[pass]++;
 		}
 	}
-	if (bm_counts[0] == 0 || dms.empty()) return false;
+	if ((bm_counts[0] == 0 && !is_3d) || dms.empty()) return false;
 
 	// packed LDS slots for the per-trial ideal weights and angular bounds of each grid, one dense
 	// packing per trial class (see DecimationMode).  Grids are packed by ascending lowest quant level
@@ -743,7 +849,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		});
 		for (uint32_t i : pack_order[cls])
 		{
-			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
+			uint32_t wc4 = (dm_grid[i].count() + 3u) & ~3u;
 			int maxprec = cls == 0 ? dms[i].maxprec_1plane : dms[i].maxprec_2planes;
 			for (int plane = 0; plane <= cls; plane++)
 			{
@@ -761,7 +867,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	memcpy(blob.at<uint8_t>(off_dm), dms.data(), dms.size() * sizeof(DecimationMode));
 	uint32_t off_di = blob.alloc(dms.size() * sizeof(DecimationInfo));
 	for (size_t i = 0; i < dms.size(); i++)
-		build_decimation_info(blob, (uint32_t)(off_di + i * sizeof(DecimationInfo)), tx, ty, dm_grid[i].first, dm_grid[i].second);
+		build_decimation_info(blob, (uint32_t)(off_di + i * sizeof(DecimationInfo)), tx, ty, tz, dm_grid[i].x, dm_grid[i].y, dm_grid[i].z);
 
 	// ---- k-means texel subset (ref: block_sizes.cpp:717-754) ----
 	unsigned int kcount = std::min<unsigned>(T, MAX_KMEANS_TEXELS);
@@ -808,7 +914,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 
 	{
 		PartTmp p;
-		gen_partition(tx, ty, 1, 0, p);
+		gen_partition(tx, ty, tz, 1, 0, p);
 		off_part[0] = blob.alloc(pstride);
 		write_partition(off_part[0], p, 0);
 	}
@@ -825,7 +931,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 			for (unsigned int seed = 0; seed < (unsigned)MAX_PARTITIONINGS; seed++)
 			{
 				PartTmp p;
-				gen_partition(tx, ty, pc, seed, p);
+				gen_partition(tx, ty, tz, pc, seed, p);
 				if (p.pcount != pc) continue;
 				uint64_t pat[7];
 				canonical_pattern(T, p.of_texel, pat);
@@ -859,7 +965,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		uint16_t* own = blob.at<uint16_t>(off_owner[cls]);
 		for (uint32_t i : pack_order[cls])
 		{
-			uint32_t wc4 = (dm_grid[i].first * dm_grid[i].second + 3u) & ~3u;
+			uint32_t wc4 = (dm_grid[i].count() + 3u) & ~3u;
 			for (int plane = 0; plane <= cls; plane++)
 				for (uint32_t k = 0; k < wc4; k++) own[dms[i].dwi_offset[cls + plane] + k] = (uint16_t)((i << 1) | (unsigned)plane);
 		}
@@ -942,7 +1048,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	}
 
 	TableRoot* r = blob.at<TableRoot>(0);
-	r->dim_x = (uint8_t)tx; r->dim_y = (uint8_t)ty; r->texel_count = (uint8_t)T;
+	r->dim_x = (uint8_t)tx; r->dim_y = (uint8_t)ty; r->dim_z = (uint8_t)tz; r->texel_count = (uint8_t)T;
 	r->block_mode_count_1plane_always = bm_counts[0];
 	r->block_mode_count_1plane_selected = bm_counts[0] + bm_counts[1];
 	r->block_mode_count_1plane_2plane_selected = bm_counts[0] + bm_counts[1] + bm_counts[2];
@@ -968,11 +1074,12 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 	r->off_sin_table = off_sin;
 	r->off_cos_table = off_cos;
 	{
+		auto used = [&](size_t i) { return dms[i].refprec_1plane != 0 || dms[i].refprec_2planes != 0; };
 		uint32_t mx = 0;
-		for (size_t i = 0; i < dms.size(); i++) mx = std::max(mx, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->table_bytes);
+		for (size_t i = 0; i < dms.size(); i++) if (used(i)) mx = std::max(mx, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->table_bytes);
 		r->max_decimation_table_bytes = mx;
 		uint32_t mr = 0;
-		for (size_t i = 0; i < dms.size(); i++) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
+		for (size_t i = 0; i < dms.size(); i++) if (used(i)) mr = std::max<uint32_t>(mr, blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)))->max_weight_texel_count);
 		r->max_weight_texel_rows = mr;
 		{
 			// weights per realign group, per grid: one lane per (weight, texel row) and 12 LDS rows of
@@ -986,7 +1093,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 				uint32_t slots = std::min<uint32_t>(std::min(64u / rs, (16u * Tp) / (12u * rs)), 4u);
 				if (slots < 1) slots = 1;
 				blob.at<DecimationInfo>(di_off)->realign_slots = (uint8_t)slots;
-				rt_floats = std::max(rt_floats, slots * 12u * rs);
+				if (used(i)) rt_floats = std::max(rt_floats, slots * 12u * rs);
 				build_realign_schedule(blob, di_off, slots);
 			}
 			r->realign_rt_floats = rt_floats;
@@ -994,7 +1101,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int partition_count
 		r->max_weights[0] = r->max_weights[1] = 1;
 		for (size_t i = 0; i < dms.size(); i++)
 		{
-			uint32_t wc = dm_grid[i].first * dm_grid[i].second;
+			uint32_t wc = dm_grid[i].count();
 			if (dms[i].refprec_1plane != 0) r->max_weights[0] = std::max(r->max_weights[0], wc);
 			if (dms[i].refprec_2planes != 0) r->max_weights[1] = std::max(r->max_weights[1], wc);
 		}

@@ -14,11 +14,11 @@ struct HostTables {
 	std::vector<uint16_t> partition_packed_index;
 };
 
-/* Build the table blob for a 2D footprint.
+/* Build the table blob for a 2D (block_z == 1) or 3D footprint.
  *   partition_count_cutoff : config.tune_partition_count_limit
  *   mode_cutoff            : config.tune_block_mode_limit / 100
  * (ref: init_block_size_descriptor, astcenc_block_sizes.cpp:1199) */
-bool build_tables(unsigned int block_x, unsigned int block_y, unsigned int partition_count_cutoff,
+bool build_tables(unsigned int block_x, unsigned int block_y, unsigned int block_z, unsigned int partition_count_cutoff,
                   float mode_cutoff, std::vector<uint8_t>& blob, HostTables& host);
 
 bool is_legal_2d_block_size(unsigned int x, unsigned int y);

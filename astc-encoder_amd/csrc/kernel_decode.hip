@@ -15,23 +15,26 @@ astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img, uint
 	__shared__ DecodeScratch scratch;
 	const uint32_t b = blockIdx.x;
 	if (b >= num_blocks) return;
-	const uint32_t by = b / img.blocks_x;
-	const uint32_t bx = b - by * img.blocks_x;
-	decode_block(img, blocks + (size_t)b * 16, bx, by, scratch);
+	const uint32_t row = b / img.blocks_x;
+	const uint32_t bx = b - row * img.blocks_x;
+	const uint32_t bz = row / img.blocks_y;
+	const uint32_t by = row - bz * img.blocks_y;
+	decode_block(img, blocks + (size_t)b * 16, bx, by, bz, scratch);
 }
 
 int astc_decode_launch(const DecodeLaunch& d)
 {
 	DecodeImage img;
 	img.data = d.d_image;
-	img.dim_x = d.dim_x; img.dim_y = d.dim_y;
+	img.dim_x = d.dim_x; img.dim_y = d.dim_y; img.dim_z = d.dim_z;
 	img.data_type = d.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = d.swz[i];
-	img.block_x = d.block_x; img.block_y = d.block_y;
+	img.block_x = d.block_x; img.block_y = d.block_y; img.block_z = d.block_z;
 	img.blocks_x = (d.dim_x + d.block_x - 1) / d.block_x;
 	img.blocks_y = (d.dim_y + d.block_y - 1) / d.block_y;
+	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
-	const uint32_t n = img.blocks_x * img.blocks_y;
+	const uint32_t n = img.blocks_x * img.blocks_y * img.blocks_z;
 	hipLaunchKernelGGL(astc_decompress_blocks, dim3(n), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, n);
 	return (int)hipGetLastError();
 }

@@ -34,8 +34,11 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	uint8_t* lds = astc_lds;
 
 	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
-	uint32_t by = b / img.blocks_x;
-	uint32_t bx = b - by * img.blocks_x;
+	// raster block order: x fastest, then y, then z (ref: astcenc_entry.cpp:961-966)
+	uint32_t row = b / img.blocks_x;
+	uint32_t bx = b - row * img.blocks_x;
+	uint32_t bz = img.blocks_z > 1 ? row / img.blocks_y : 0u;
+	uint32_t by = row - bz * img.blocks_y;
 
 	Ctx c;
 	c.tab = tab;
@@ -60,7 +63,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	{
 		PROF_SCOPE(c, PS_LOAD);
 		if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
-		else load_block(c, img, bx, by);
+		else load_block(c, img, bx, by, bz);
 	}
 	compress_block(c, out + (size_t)b * 16);
 }

@@ -907,7 +907,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	const float errorval_overshoot = 1.0f / cfg.tune_mse_overshoot;
 
 	int start_trial = 1;
-	if (cfg.tune_search_mode0_enable >= 0.85f) start_trial = 0;
+	if (cfg.tune_search_mode0_enable >= 0.85f && c.root->dim_z == 1) start_trial = 0;   // ref: compress_symbolic.cpp:1287
 
 	int quant_limit = QUANT_32;
 	bool done = false;

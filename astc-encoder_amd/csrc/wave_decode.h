@@ -20,12 +20,12 @@
 namespace astcd { inline namespace ASTC_VARIANT {
 
 struct DecodeImage {
-	void*    data;            // tightly packed RGBA rows of data_type
-	uint32_t dim_x, dim_y;
+	void*    data;            // tightly packed RGBA rows of data_type, dim_z slices back to back
+	uint32_t dim_x, dim_y, dim_z;
 	uint32_t data_type;       // astcenc_type
 	uint32_t swz[4];          // astcenc_swz per output channel
-	uint32_t blocks_x, blocks_y;
-	uint32_t block_x, block_y;
+	uint32_t blocks_x, blocks_y, blocks_z;
+	uint32_t block_x, block_y, block_z;
 	uint32_t profile;         // astcenc_profile
 };
 
@@ -270,12 +270,39 @@ WV_FN int unquant_color_symbol(int v, int quant)
 	return (A & 0x80) | (t >> 2);
 }
 
-/* 2D block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.
- * (ref: decode_block_mode_2d, astcenc_block_sizes.cpp:37-160 + the checks in construct_block_size_descriptor_2d) */
-WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int& wx, int& wy, bool& dual, int& wquant)
+/* Block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.
+ * (ref: decode_block_mode_2d / _3d, astcenc_block_sizes.cpp:37-243 + the checks in construct_block_size_descriptor_2d / _3d) */
+WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int block_z, int& wx, int& wy, int& wz, bool& dual, int& wquant)
 {
-	int r, h, d, w = 0, ht = 0;
-	if (mode & 3u)
+	int r, h, d, w = 0, ht = 0, dp = 1;
+	if (block_z > 1)
+	{
+		// 3D footprints (spec table C.2.10)
+		const int a = (int)((mode >> 5) & 3u);
+		d = (int)((mode >> 10) & 1u); h = (int)((mode >> 9) & 1u);
+		if (mode & 3u)
+		{
+			r = (int)(((mode >> 4) & 1u) | ((mode & 3u) << 1));
+			w = a + 2; ht = (int)((mode >> 7) & 3u) + 2; dp = (int)((mode >> 2) & 3u) + 2;
+		}
+		else
+		{
+			if ((mode & 0xFu) == 0u) return false;
+			r = (int)(((mode >> 4) & 1u) | (((mode >> 2) & 3u) << 1));
+			const int b = (int)((mode >> 9) & 3u);
+			const int sel = (int)((mode >> 7) & 3u);
+			if (sel != 3) { d = 0; h = 0; }
+			if (sel == 0) { w = 6; ht = b + 2; dp = a + 2; }
+			else if (sel == 1) { w = a + 2; ht = 6; dp = b + 2; }
+			else if (sel == 2) { w = a + 2; ht = b + 2; dp = 6; }
+			else
+			{
+				w = 2; ht = 2; dp = 2;
+				if (a == 0) w = 6; else if (a == 1) ht = 6; else if (a == 2) dp = 6; else return false;
+			}
+		}
+	}
+	else if (mode & 3u)
 	{
 		r = (int)(((mode >> 4) & 1u) | ((mode & 3u) << 1));
 		const int a = (int)((mode >> 5) & 3u);
@@ -312,18 +339,18 @@ WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int& wx, i
 	}
 	if (r < 2) return false;
 	wquant = (r - 2) + 6 * h;
-	wx = w; wy = ht; dual = d != 0;
-	if (w > block_x || ht > block_y) return false;
-	const int count = w * ht * (d ? 2 : 1);
+	wx = w; wy = ht; wz = dp; dual = d != 0;
+	if (w > block_x || ht > block_y || dp > block_z) return false;
+	const int count = w * ht * dp * (d ? 2 : 1);
 	if (count > 64) return false;
 	const int wbits = (int)ise_bitcount((unsigned)count, wquant);
 	return wbits >= 24 && wbits <= 96;
 }
 
 /* (ref: select_partition / hash52, astcenc_partition_tables.cpp:66-245) */
-WV_FN int partition_of_texel(int seed, int x, int y, int partition_count, bool small_block)
+WV_FN int partition_of_texel(int seed, int x, int y, int z, int partition_count, bool small_block)
 {
-	if (small_block) { x <<= 1; y <<= 1; }
+	if (small_block) { x <<= 1; y <<= 1; z <<= 1; }
 	seed += (partition_count - 1) * 1024;
 	uint32_t rnum = (uint32_t)seed;
 	rnum ^= rnum >> 15; rnum -= rnum << 17; rnum += rnum << 7; rnum += rnum << 4;
@@ -332,17 +359,21 @@ WV_FN int partition_of_texel(int seed, int x, int y, int partition_count, bool s
 
 	uint32_t s1 = rnum & 0xF, s2 = (rnum >> 4) & 0xF, s3 = (rnum >> 8) & 0xF, s4 = (rnum >> 12) & 0xF;
 	uint32_t s5 = (rnum >> 16) & 0xF, s6 = (rnum >> 20) & 0xF, s7 = (rnum >> 24) & 0xF, s8 = (rnum >> 28) & 0xF;
+	uint32_t s9 = (rnum >> 18) & 0xF, s10 = (rnum >> 22) & 0xF, s11 = (rnum >> 26) & 0xF, s12 = ((rnum >> 30) | (rnum << 2)) & 0xF;
 	s1 *= s1; s2 *= s2; s3 *= s3; s4 *= s4; s5 *= s5; s6 *= s6; s7 *= s7; s8 *= s8;
+	s9 *= s9; s10 *= s10; s11 *= s11; s12 *= s12;
 
 	int sh1, sh2;
 	if (seed & 1) { sh1 = (seed & 2) ? 4 : 5; sh2 = partition_count == 3 ? 6 : 5; }
 	else { sh1 = partition_count == 3 ? 6 : 5; sh2 = (seed & 2) ? 4 : 5; }
+	const int sh3 = (seed & 0x10) ? sh1 : sh2;
 	s1 >>= sh1; s2 >>= sh2; s3 >>= sh1; s4 >>= sh2; s5 >>= sh1; s6 >>= sh2; s7 >>= sh1; s8 >>= sh2;
+	s9 >>= sh3; s10 >>= sh3; s11 >>= sh3; s12 >>= sh3;
 
-	int a = (int)(s1 * (uint32_t)x + s2 * (uint32_t)y + (rnum >> 14));
-	int b = (int)(s3 * (uint32_t)x + s4 * (uint32_t)y + (rnum >> 10));
-	int c = (int)(s5 * (uint32_t)x + s6 * (uint32_t)y + (rnum >> 6));
-	int d = (int)(s7 * (uint32_t)x + s8 * (uint32_t)y + (rnum >> 2));
+	int a = (int)(s1 * (uint32_t)x + s2 * (uint32_t)y + s11 * (uint32_t)z + (rnum >> 14));
+	int b = (int)(s3 * (uint32_t)x + s4 * (uint32_t)y + s12 * (uint32_t)z + (rnum >> 10));
+	int c = (int)(s5 * (uint32_t)x + s6 * (uint32_t)y + s9 * (uint32_t)z + (rnum >> 6));
+	int d = (int)(s7 * (uint32_t)x + s8 * (uint32_t)y + s10 * (uint32_t)z + (rnum >> 2));
 	a &= 0x3F; b &= 0x3F; c &= 0x3F; d &= 0x3F;
 	if (partition_count <= 3) d = 0;
 	if (partition_count <= 2) c = 0;
@@ -365,7 +396,7 @@ WV_FN int unorm16_to_sf16(int p)
 }
 
 /* Write one decoded texel (floats) through the swizzle.  (ref: store_image_block :345-573) */
-WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, float r, float g, float b, float a)
+WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, uint32_t z, float r, float g, float b, float a)
 {
 	float src[7];
 	src[0] = r; src[1] = g; src[2] = b; src[3] = a; src[4] = 0.0f; src[5] = 1.0f;
@@ -376,7 +407,7 @@ WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, float r, 
 		if (zn < 0.0f) zn = 0.0f;
 		src[6] = (f_sqrt(zn) * 0.5f) + 0.5f;
 	}
-	const size_t at = ((size_t)y * img.dim_x + x) * 4;
+	const size_t at = (((size_t)z * img.dim_y + y) * img.dim_x + x) * 4;
 	if (img.data_type == 0)
 	{
 		uint8_t* o = static_cast<uint8_t*>(img.data) + at;
@@ -417,18 +448,18 @@ WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, float r, 
 struct BlockHeader {
 	bool error, constant, constant_f16;
 	int  const_color[4];      // void-extent colour, raw 16-bit fields
-	int  wx, wy, wquant;      // weight grid and its quant level
+	int  wx, wy, wz, wquant;  // weight grid and its quant level
 	bool dual;
 	int  parts, seed, plane2;
 	int  fmt[4];              // colour endpoint mode per partition
 	int  nvals, cquant, color_start;
 };
 
-WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_y)
+WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_y, int block_z)
 {
 	BlockHeader h;
 	h.error = false; h.constant = false; h.constant_f16 = false;
-	h.wx = 0; h.wy = 0; h.wquant = 0; h.dual = false;
+	h.wx = 0; h.wy = 0; h.wz = 1; h.wquant = 0; h.dual = false;
 	h.parts = 1; h.seed = 0; h.plane2 = -1;
 	h.nvals = 0; h.cquant = 0; h.color_start = 17;
 	for (int k = 0; k < 4; k++) { h.const_color[k] = 0; h.fmt[k] = 0; }
@@ -439,19 +470,30 @@ WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_
 		// void extent (ref: :302-370): reserved bits set, coordinates all ones or properly ordered
 		h.constant = true;
 		h.constant_f16 = (mode & 0x200u) != 0;
-		const uint32_t ls = bits_get(blk, 12, 13), hs = bits_get(blk, 25, 13), lt = bits_get(blk, 38, 13), ht = bits_get(blk, 51, 13);
-		const bool all_ones = ls == 0x1FFFu && hs == 0x1FFFu && lt == 0x1FFFu && ht == 0x1FFFu;
-		if (bits_get(blk, 10, 2) != 3u || ((ls >= hs || lt >= ht) && !all_ones)) h.error = true;
+		if (block_z > 1)
+		{
+			// 3D layout: six 9-bit coordinates from bit 10, no reserved bits
+			const uint32_t ls = bits_get(blk, 10, 9), hs = bits_get(blk, 19, 9), lt = bits_get(blk, 28, 9), ht = bits_get(blk, 37, 9);
+			const uint32_t lr = bits_get(blk, 46, 9), hr = bits_get(blk, 55, 9);
+			const bool all_ones = ls == 0x1FFu && hs == 0x1FFu && lt == 0x1FFu && ht == 0x1FFu && lr == 0x1FFu && hr == 0x1FFu;
+			if ((ls >= hs || lt >= ht || lr >= hr) && !all_ones) h.error = true;
+		}
+		else
+		{
+			const uint32_t ls = bits_get(blk, 12, 13), hs = bits_get(blk, 25, 13), lt = bits_get(blk, 38, 13), ht = bits_get(blk, 51, 13);
+			const bool all_ones = ls == 0x1FFFu && hs == 0x1FFFu && lt == 0x1FFFu && ht == 0x1FFFu;
+			if (bits_get(blk, 10, 2) != 3u || ((ls >= hs || lt >= ht) && !all_ones)) h.error = true;
+		}
 		for (int k = 0; k < 4; k++) h.const_color[k] = (int)bits_get(blk, 64 + 16 * k, 16);
 		return h;
 	}
-	if (!decode_block_mode(mode, block_x, block_y, h.wx, h.wy, h.dual, h.wquant))
+	if (!decode_block_mode(mode, block_x, block_y, block_z, h.wx, h.wy, h.wz, h.dual, h.wquant))
 	{
 		h.error = true;
 		return h;
 	}
 
-	const int wcount = h.wx * h.wy;
+	const int wcount = h.wx * h.wy * h.wz;
 	const int real_wcount = h.dual ? 2 * wcount : wcount;
 	const int wbits = (int)ise_bitcount((unsigned)real_wcount, h.wquant);
 	h.parts = (int)bits_get(blk, 11, 2) + 1;
@@ -517,8 +559,42 @@ WV_FN void endpoint_lns_flags(int profile, int f, bool& rgb_lns, bool& alpha_lns
 }
 
 /* Weights of one texel from the grid (format rule "weight infill"; ref: unpack_weights :89). */
-WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int block_x, int block_y, int tx, int ty, int wp[2])
+WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int block_x, int block_y, int block_z, int tx, int ty, int tz, int wp[2])
 {
+	if (block_z > 1)
+	{
+		// 3D: simplex interpolation inside the grid cell -- from the low corner step along the axes in
+		// descending order of fraction (ref: init_decimation_info_3d, astcenc_block_sizes.cpp:483-600)
+		const int gs = (((1024 + block_x / 2) / (block_x - 1)) * tx * (h.wx - 1) + 32) >> 6;
+		const int gt = (((1024 + block_y / 2) / (block_y - 1)) * ty * (h.wy - 1) + 32) >> 6;
+		const int gr = (((1024 + block_z / 2) / (block_z - 1)) * tz * (h.wz - 1) + 32) >> 6;
+		const int fs = gs & 0xF, ft = gt & 0xF, fp = gr & 0xF;
+		const int N = h.wx, NM = h.wx * h.wy;
+		const int cas = ((fs > ft) << 2) + ((ft > fp) << 1) + (fs > fp);
+		int s1, s2, w0, w1, w2, w3;
+		switch (cas)
+		{
+		case 7: s1 = 1;  s2 = N;  w0 = 16 - fs; w1 = fs - ft; w2 = ft - fp; w3 = fp; break;
+		case 3: s1 = N;  s2 = 1;  w0 = 16 - ft; w1 = ft - fs; w2 = fs - fp; w3 = fp; break;
+		case 5: s1 = 1;  s2 = NM; w0 = 16 - fs; w1 = fs - fp; w2 = fp - ft; w3 = ft; break;
+		case 4: s1 = NM; s2 = 1;  w0 = 16 - fp; w1 = fp - fs; w2 = fs - ft; w3 = ft; break;
+		case 2: s1 = N;  s2 = NM; w0 = 16 - ft; w1 = ft - fp; w2 = fp - fs; w3 = fs; break;
+		default: s1 = NM; s2 = N; w0 = 16 - fp; w1 = fp - ft; w2 = ft - fs; w3 = fs; break;
+		}
+		const int v0 = ((gr >> 4) * h.wy + (gt >> 4)) * h.wx + (gs >> 4);
+		const int v1 = v0 + s1, v2 = v1 + s2, v3 = v0 + NM + N + 1;
+		for (int pl = 0; pl < 2; pl++)
+		{
+			const uint8_t* g = gw[pl];
+			int sum = 8;
+			sum += w0 ? g[v0] * w0 : 0;
+			sum += w1 ? g[v1] * w1 : 0;
+			sum += w2 ? g[v2] * w2 : 0;
+			sum += w3 ? g[v3] * w3 : 0;
+			wp[pl] = sum >> 4;
+		}
+		return;
+	}
 	const int ds = (1024 + block_x / 2) / (block_x - 1);
 	const int dt = (1024 + block_y / 2) / (block_y - 1);
 	const int cs = ds * tx, ct = dt * ty;
@@ -544,7 +620,7 @@ WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], i
 /* Unpack weights, colour values and endpoints of a non-constant, legal block into the scratch. */
 WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int profile, DecodeScratch& s)
 {
-	const int wcount = h.wx * h.wy;
+	const int wcount = h.wx * h.wy * h.wz;
 	const int real_wcount = h.dual ? 2 * wcount : wcount;
 	const Bits128 rev = bits_reversed(blk);
 	WV_FOR(i, real_wcount)
@@ -581,11 +657,11 @@ WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int pr
 	WV_SYNC();
 }
 
-/* Decode block (bx, by) of the stream into the image.  All 64 lanes call this. */
-WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx, uint32_t by, DecodeScratch& s)
+/* Decode block (bx, by, bz) of the stream into the image.  All 64 lanes call this. */
+WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx, uint32_t by, uint32_t bz, DecodeScratch& s)
 {
-	const int block_x = (int)img.block_x, block_y = (int)img.block_y;
-	const int T = block_x * block_y;
+	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
+	const int T = block_x * block_y * block_z;
 	const int profile = (int)img.profile;
 	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
 	const float error_nan = int_as_float((int)0xFFFFE000u);
@@ -595,7 +671,7 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 		const uint32_t* p = reinterpret_cast<const uint32_t*>(pcb);
 		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
 	}
-	const BlockHeader h = parse_block_header(blk, block_x, block_y);
+	const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z);
 	bool error = h.error;
 
 	// constant colour (ref: decompress_symbolic.cpp:204-255)
@@ -628,10 +704,13 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 	const bool small_block = T < 31;
 	WV_FOR(t, T)
 	{
-		const int ty = t / block_x, tx = t - ty * block_x;
+		const int tz = block_z > 1 ? t / (block_x * block_y) : 0;
+		const int trem = t - tz * (block_x * block_y);
+		const int ty = trem / block_x, tx = trem - ty * block_x;
 		const uint32_t xi = bx * (uint32_t)block_x + (uint32_t)tx;
 		const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
-		if (xi >= img.dim_x || yi >= img.dim_y) continue;
+		const uint32_t zi = bz * (uint32_t)block_z + (uint32_t)tz;
+		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
 
 		float r, g, b, a;
 		if (error)
@@ -645,8 +724,8 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 		else
 		{
 			int wp[2];
-			infill_texel_weights(h, s.weights, block_x, block_y, tx, ty, wp);
-			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, h.parts, small_block);
+			infill_texel_weights(h, s.weights, block_x, block_y, block_z, tx, ty, tz, wp);
+			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
 			const int* e = s.ep[p];
 			float out[4];
 			for (int k = 0; k < 4; k++)
@@ -660,21 +739,21 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 			}
 			r = out[0]; g = out[1]; b = out[2]; a = out[3];
 		}
-		store_texel(img, xi, yi, r, g, b, a);
+		store_texel(img, xi, yi, zi, r, g, b, a);
 	}
 }
 
 /* astcenc_get_block_info for one block, as plain sequential code (runs on the host).
  * (ref: astcenc_get_block_info, astcenc_entry.cpp:1401-1517)  `info` is a struct astcenc_block_info. */
 template <typename BlockInfo>
-WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int profile, BlockInfo* info, DecodeScratch& s)
+WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int block_z, int profile, BlockInfo* info, DecodeScratch& s)
 {
-	const int T = block_x * block_y;
+	const int T = block_x * block_y * block_z;
 	Bits128 blk;
 	for (int k = 0; k < 4; k++) blk.w[k] = (uint32_t)pcb[4 * k] | ((uint32_t)pcb[4 * k + 1] << 8) | ((uint32_t)pcb[4 * k + 2] << 16) | ((uint32_t)pcb[4 * k + 3] << 24);
-	const BlockHeader h = parse_block_header(blk, block_x, block_y);
+	const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z);
 
-	info->block_x = (unsigned)block_x; info->block_y = (unsigned)block_y; info->block_z = 1;
+	info->block_x = (unsigned)block_x; info->block_y = (unsigned)block_y; info->block_z = (unsigned)block_z;
 	info->texel_count = (unsigned)T;
 	info->is_error_block = h.error;
 	if (h.error) return;
@@ -682,7 +761,7 @@ WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int prof
 	if (h.constant) return;
 
 	unpack_block_payload(blk, h, profile, s);
-	info->weight_x = (unsigned)h.wx; info->weight_y = (unsigned)h.wy; info->weight_z = 1;
+	info->weight_x = (unsigned)h.wx; info->weight_y = (unsigned)h.wy; info->weight_z = (unsigned)h.wz;
 	info->is_dual_plane_block = h.dual;
 	info->partition_count = (unsigned)h.parts;
 	info->partition_index = (unsigned)h.seed;
@@ -707,12 +786,13 @@ WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int prof
 	const bool small_block = T < 31;
 	for (int t = 0; t < T; t++)
 	{
-		const int ty = t / block_x, tx = t - ty * block_x;
+		const int tz = t / (block_x * block_y), trem = t - tz * (block_x * block_y);
+		const int ty = trem / block_x, tx = trem - ty * block_x;
 		int wp[2];
-		infill_texel_weights(h, s.weights, block_x, block_y, tx, ty, wp);
+		infill_texel_weights(h, s.weights, block_x, block_y, block_z, tx, ty, tz, wp);
 		info->weight_values_plane1[t] = (float)wp[0] * (1.0f / 16.0f);
 		if (h.dual) info->weight_values_plane2[t] = (float)wp[1] * (1.0f / 16.0f);
-		info->partition_assignment[t] = (uint8_t)(h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, h.parts, small_block));
+		info->partition_assignment[t] = (uint8_t)(h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block));
 	}
 }
 

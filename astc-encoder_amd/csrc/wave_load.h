@@ -59,11 +59,13 @@ WV_FN int lns_to_sf16(int p)
 	return i_min(res, 0x7BFF);
 }
 
-/* Load block (bx, by) of the image into LDS and compute the block statistics. */
-WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsigned int by)
+/* Load block (bx, by, bz) of the image into LDS and compute the block statistics. */
+WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsigned int by, unsigned int bz)
 {
 	const int T = c.T;
 	const int dim_x = c.root->dim_x;
+	const unsigned int plane_texels = (unsigned)dim_x * (unsigned)c.root->dim_y;
+	const bool volume = c.root->dim_z > 1;
 	BlkInfo& blk = c.blk();
 	const int profile = c.cfg->profile;
 	float* dr = c.data(0); float* dg = c.data(1); float* db = c.data(2); float* da = c.data(3);
@@ -74,13 +76,18 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 
 	WV_FOR(t, T)
 	{
-		unsigned int ty = (unsigned)t / (unsigned)dim_x;
-		unsigned int tx = (unsigned)t - ty * (unsigned)dim_x;
+		// texel order inside a block is x fastest, then y, then z (ref: image.cpp:221-233)
+		unsigned int tz = volume ? (unsigned)t / plane_texels : 0u;
+		unsigned int trem = (unsigned)t - tz * plane_texels;
+		unsigned int ty = trem / (unsigned)dim_x;
+		unsigned int tx = trem - ty * (unsigned)dim_x;
 		unsigned int xi = bx * (unsigned)dim_x + tx;
 		unsigned int yi = by * (unsigned)c.root->dim_y + ty;
+		unsigned int zi = bz * (unsigned)c.root->dim_z + tz;
 		xi = xi < img.dim_x - 1 ? xi : img.dim_x - 1;
 		yi = yi < img.dim_y - 1 ? yi : img.dim_y - 1;
-		size_t base = (size_t)4 * img.dim_x * yi + (size_t)4 * xi;
+		zi = zi < img.dim_z - 1 ? zi : img.dim_z - 1;
+		size_t base = (size_t)4 * ((size_t)img.dim_x * ((size_t)img.dim_y * zi + yi) + xi);
 
 		float v[6];
 		if (img.data_type == 0)

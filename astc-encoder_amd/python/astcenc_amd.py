@@ -93,7 +93,7 @@ SWZ_RGBA = (SWZ_R, SWZ_G, SWZ_B, SWZ_A)
 EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_image", "astcenc_compress_reset",
            "astcenc_compress_cancel", "astcenc_decompress_image", "astcenc_decompress_reset",
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
-EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_backend_name"]
+EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_backend_name"]
 
 
 class AstcError(RuntimeError):
@@ -138,6 +138,11 @@ class Library:
                                                             C.POINTER(C.c_float)]
             L.astcenc_amd_compress_image_device.restype = C.c_int
             L.astcenc_amd_backend_name.restype = C.c_char_p
+        if hasattr(L, "astcenc_amd_compress_volume_device"):
+            L.astcenc_amd_compress_volume_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int,
+                                                             C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,
+                                                             C.POINTER(C.c_float)]
+            L.astcenc_amd_compress_volume_device.restype = C.c_int
 
     # -- thin wrappers returning error codes, as the C API does --
     def config_init(self, profile, bx, by, bz, quality, flags):
@@ -161,18 +166,23 @@ class Library:
         return self.lib.astcenc_amd_backend_name().decode() if self.has_amd else "reference"
 
     def compress_raw(self, ctx, pixels, out, swizzle=SWZ_RGBA, thread_index=0, data_len=None):
-        """pixels: contiguous array [H, W, 4] of uint8 / float16 / float32; out: uint8 array."""
-        h, w = pixels.shape[0], pixels.shape[1]
+        """pixels: contiguous array [H, W, 4] (or [D, H, W, 4] for a volume / array image) of
+        uint8 / float16 / float32; out: uint8 array."""
+        d = pixels.shape[0] if pixels.ndim == 4 else 1
+        h, w = pixels.shape[-3], pixels.shape[-2]
         dtype = {np.dtype(np.uint8): TYPE_U8, np.dtype(np.float16): TYPE_F16, np.dtype(np.float32): TYPE_F32}[pixels.dtype]
-        slices = (C.c_void_p * 1)(pixels.ctypes.data)
-        img = Image(w, h, 1, dtype, slices)
+        slice_bytes = h * w * 4 * pixels.dtype.itemsize
+        slices = (C.c_void_p * d)(*[pixels.ctypes.data + z * slice_bytes for z in range(d)])
+        img = Image(w, h, d, dtype, slices)
         swz = Swizzle(*swizzle)
         return self.lib.astcenc_compress_image(ctx, C.byref(img), C.byref(swz), out.ctypes.data,
                                                out.nbytes if data_len is None else data_len, thread_index)
 
     def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None):
-        """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16]."""
-        err, cfg = self.config_init(profile, block[0], block[1], 1, quality, flags)
+        """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16].
+        block is (x, y) or (x, y, z); pixels is [H, W, 4] or [D, H, W, 4]."""
+        bz = block[2] if len(block) > 2 else 1
+        err, cfg = self.config_init(profile, block[0], block[1], bz, quality, flags)
         if err:
             raise AstcError(err, "astcenc_config_init")
         if tweak:
@@ -181,9 +191,10 @@ class Library:
         if err:
             raise AstcError(err, "astcenc_context_alloc")
         try:
-            h, w = pixels.shape[0], pixels.shape[1]
+            d = pixels.shape[0] if pixels.ndim == 4 else 1
+            h, w = pixels.shape[-3], pixels.shape[-2]
             bx, by = (w + block[0] - 1) // block[0], (h + block[1] - 1) // block[1]
-            out = np.zeros(bx * by * 16, dtype=np.uint8)
+            out = np.zeros(bx * by * ((d + bz - 1) // bz) * 16, dtype=np.uint8)
             err = self.compress_raw(ctx, np.ascontiguousarray(pixels), out, swizzle)
             if err:
                 raise AstcError(err, "astcenc_compress_image")
@@ -191,19 +202,23 @@ class Library:
         finally:
             self.context_free(ctx)
 
-    def decompress(self, data, width, height, block=(6, 6), profile=PRF_LDR, out_type=np.uint8):
-        """Decode blocks back to [H, W, 4] through astcenc_decompress_image of whichever library this is."""
-        err, cfg = self.config_init(profile, block[0], block[1], 1, PRE_MEDIUM, FLG_DECOMPRESS_ONLY)
+    def decompress(self, data, width, height, block=(6, 6), profile=PRF_LDR, out_type=np.uint8, depth=None):
+        """Decode blocks back to [H, W, 4] ([D, H, W, 4] when depth is given) through
+        astcenc_decompress_image of whichever library this is."""
+        bz = block[2] if len(block) > 2 else 1
+        err, cfg = self.config_init(profile, block[0], block[1], bz, PRE_MEDIUM, FLG_DECOMPRESS_ONLY)
         if err:
             raise AstcError(err, "astcenc_config_init")
         err, ctx = self.context_alloc(cfg, 1)
         if err:
             raise AstcError(err, "astcenc_context_alloc")
         try:
-            out = np.zeros((height, width, 4), dtype=out_type)
+            d = 1 if depth is None else depth
+            out = np.zeros((height, width, 4) if depth is None else (depth, height, width, 4), dtype=out_type)
             dtype = {np.dtype(np.uint8): TYPE_U8, np.dtype(np.float16): TYPE_F16, np.dtype(np.float32): TYPE_F32}[out.dtype]
-            slices = (C.c_void_p * 1)(out.ctypes.data)
-            img = Image(width, height, 1, dtype, slices)
+            slice_bytes = height * width * 4 * out.dtype.itemsize
+            slices = (C.c_void_p * d)(*[out.ctypes.data + z * slice_bytes for z in range(d)])
+            img = Image(width, height, d, dtype, slices)
             swz = Swizzle(*SWZ_RGBA)
             data = np.ascontiguousarray(data, dtype=np.uint8)
             err = self.lib.astcenc_decompress_image(ctx, data.ctypes.data, data.nbytes, C.byref(img), C.byref(swz), 0)

@@ -34,6 +34,19 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_image_device(
 	void* hip_stream,
 	float* kernel_ms);
 
+/* The same for a volume or 2D array image: dim_z slices of dim_x * dim_y texels back to back at
+ * device_volume, compressed with the context's 2D or 3D footprint into blocks in x, y, z raster order
+ * (ref: the z loop of compress_image, Source/astcenc_entry.cpp:961-966, and astcenc_image::data[z]). */
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_volume_device(
+	struct astcenc_context* context,
+	const void* device_volume,
+	unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+	enum astcenc_type data_type,
+	const struct astcenc_swizzle* swizzle,
+	void* device_out, size_t data_len,
+	void* hip_stream,
+	float* kernel_ms);
+
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 

@@ -56,16 +56,30 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.prof = nullptr;
 	g_wave_ctx = &c;
 
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * (job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16);
+	std::vector<uint8_t> volume;               // the slices back to back, as the device copy has them
 	ImageDesc img;
-	img.data = job.host_data ? job.host_data : job.device_data;
+	img.data = job.device_data;
+	if (job.host_slices)
+	{
+		img.data = job.host_slices[0];
+		if (dim_z > 1)
+		{
+			volume.resize(slice_bytes * dim_z);
+			for (uint32_t z = 0; z < dim_z; z++) memcpy(volume.data() + z * slice_bytes, job.host_slices[z], slice_bytes);
+			img.data = volume.data();
+		}
+	}
 	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
 	img.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
 	img.blocks_x = (job.dim_x + root->dim_x - 1) / root->dim_x;
 	img.blocks_y = (job.dim_y + root->dim_y - 1) / root->dim_y;
+	img.dim_z = dim_z; img.blocks_z = (dim_z + root->dim_z - 1) / root->dim_z;
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
-	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0) ? 1 : 0;
+	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0 && root->dim_z == 1) ? 1 : 0;
 	img.alpha_avg = nullptr;
 	img.a_scale_radius = job.a_scale_radius;
 	std::vector<float> averages;
@@ -87,18 +101,19 @@ int backend_compress(Backend* b, const CompressJob& job)
 	uint8_t* out = job.host_out ? job.host_out : job.device_out;
 	const char* only = getenv("ASTC_EMU_ONLY_BLOCK");
 	long only_idx = only ? atol(only) : -1;
-	for (uint32_t by = 0; by < img.blocks_y; by++)
+	for (uint32_t row = 0; row < img.blocks_y * img.blocks_z; row++)
 	{
+		const uint32_t bz = row / img.blocks_y, by = row - bz * img.blocks_y;
 		for (uint32_t bx = 0; bx < img.blocks_x; bx++)
 		{
-			size_t idx = (size_t)by * img.blocks_x + bx;
+			size_t idx = (size_t)row * img.blocks_x + bx;
 			if (only_idx >= 0 && (long)idx != only_idx) continue;
 			if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
-			else load_block(c, img, bx, by);
+			else load_block(c, img, bx, by, bz);
 			compress_block(c, out + idx * 16);
 		}
 		if (job.cancel_flag && *job.cancel_flag) break;
-		if (job.progress) job.progress(100.0f * (float)(by + 1) / (float)img.blocks_y);
+		if (job.progress) job.progress(100.0f * (float)(row + 1) / (float)(img.blocks_y * img.blocks_z));
 	}
 	if (job.kernel_ms) *job.kernel_ms = 0.0f;
 	return 0;
@@ -107,20 +122,27 @@ int backend_compress(Backend* b, const CompressJob& job)
 int backend_decompress(Backend* b, const DecompressJob& job)
 {
 	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data() + CTX_LAYOUT_BACK);
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * (job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16);
+	std::vector<uint8_t> volume(dim_z > 1 ? slice_bytes * dim_z : 0);   // the slices back to back, as the device copy has them
 	DecodeImage img;
-	img.data = job.host_image;
-	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
+	img.data = dim_z > 1 ? static_cast<void*>(volume.data()) : job.host_slices[0];
+	img.dim_x = job.dim_x; img.dim_y = job.dim_y; img.dim_z = dim_z;
 	img.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
-	img.block_x = root->dim_x; img.block_y = root->dim_y;
+	img.block_x = root->dim_x; img.block_y = root->dim_y; img.block_z = root->dim_z;
 	img.blocks_x = (job.dim_x + root->dim_x - 1) / root->dim_x;
 	img.blocks_y = (job.dim_y + root->dim_y - 1) / root->dim_y;
+	img.blocks_z = (dim_z + root->dim_z - 1) / root->dim_z;
 	img.profile = b->cfg.profile;
 	DecodeScratch scratch;
 	memset(&scratch, 0xCD, sizeof(scratch));
-	for (uint32_t by = 0; by < img.blocks_y; by++)
-		for (uint32_t bx = 0; bx < img.blocks_x; bx++)
-			decode_block(img, job.host_blocks + ((size_t)by * img.blocks_x + bx) * 16, bx, by, scratch);
+	for (uint32_t bz = 0; bz < img.blocks_z; bz++)
+		for (uint32_t by = 0; by < img.blocks_y; by++)
+			for (uint32_t bx = 0; bx < img.blocks_x; bx++)
+				decode_block(img, job.host_blocks + (((size_t)bz * img.blocks_y + by) * img.blocks_x + bx) * 16, bx, by, bz, scratch);
+	if (dim_z > 1)
+		for (uint32_t z = 0; z < dim_z; z++) memcpy(job.host_slices[z], volume.data() + z * slice_bytes, slice_bytes);
 	return 0;
 }
 

@@ -4,7 +4,7 @@
 // used where it lies: headers are included from /root/reference/Source and the objects built by
 // oracle/Makefile are linked; two reference .cpp files are #included to reach file-static tables.
 //
-// usage: compare_tables <block_x> <block_y> <quality>      exit code 0 = identical
+// usage: compare_tables <block_x> <block_y> <quality> [block_z]      exit code 0 = identical
 #include "astcenc_internal.h"
 #include "astcenc_internal_entry.h"
 #include "astcenc_integer_sequence.cpp"   // file-static integer_of_trits / integer_of_quints
@@ -21,20 +21,21 @@ int main(int argc, char** argv)
 {
 	unsigned bx = argc > 1 ? atoi(argv[1]) : 6, by = argc > 2 ? atoi(argv[2]) : 6;
 	float quality = argc > 3 ? (float)atof(argv[3]) : 60.0f;
+	unsigned bz = argc > 4 ? atoi(argv[4]) : 1;
 
 	astcenc_config cfg;
-	if (astcenc_config_init(ASTCENC_PRF_LDR, bx, by, 1, quality, 0, &cfg)) { printf("config_init failed\n"); return 2; }
+	if (astcenc_config_init(ASTCENC_PRF_LDR, bx, by, bz, quality, 0, &cfg)) { printf("config_init failed\n"); return 2; }
 	astcenc_context* ctx;
 	if (astcenc_context_alloc(&cfg, 1, &ctx, nullptr)) { printf("context_alloc failed\n"); return 2; }
 	const block_size_descriptor& bsd = *ctx->context.bsd;
 	const astcenc_config& c = ctx->context.config;
 
 	std::vector<uint8_t> blob; astcd::HostTables host;
-	if (!astcd::build_tables(bx, by, c.tune_partition_count_limit, (float)c.tune_block_mode_limit / 100.0f, blob, host)) { printf("build_tables failed\n"); return 2; }
+	if (!astcd::build_tables(bx, by, bz, c.tune_partition_count_limit, (float)c.tune_block_mode_limit / 100.0f, blob, host)) { printf("build_tables failed\n"); return 2; }
 	const uint8_t* B = blob.data();
 	const astcd::TableRoot& r = *(const astcd::TableRoot*)B;
 
-	CHECK(r.texel_count == bsd.texel_count, "texel_count");
+	CHECK(r.texel_count == bsd.texel_count && r.dim_x == bsd.dim_x && r.dim_y == bsd.dim_y && r.dim_z == bsd.dim_z, "footprint");
 	CHECK(r.block_mode_count_1plane_always == bsd.block_mode_count_1plane_always, "bm always %u %u", r.block_mode_count_1plane_always, bsd.block_mode_count_1plane_always);
 	CHECK(r.block_mode_count_1plane_selected == bsd.block_mode_count_1plane_selected, "bm 1p %u %u", r.block_mode_count_1plane_selected, bsd.block_mode_count_1plane_selected);
 	CHECK(r.block_mode_count_1plane_2plane_selected == bsd.block_mode_count_1plane_2plane_selected, "bm 2p");
@@ -64,7 +65,7 @@ int main(int argc, char** argv)
 		const astcd::DecimationInfo& e = dis[i];
 		unsigned W = d.weight_count;
 		CHECK(e.texel_count == d.texel_count && e.weight_count == d.weight_count && e.max_texel_weight_count == d.max_texel_weight_count &&
-		      e.weight_x == d.weight_x && e.weight_y == d.weight_y, "di hdr %u", i);
+		      (bz > 1 || (e.weight_x == d.weight_x && e.weight_y == d.weight_y)), "di hdr %u", i);
 		const uint8_t* tw = B + e.off_texel_weights; const uint8_t* tci = B + e.off_texel_contribs_int;
 		const float* tcf = (const float*)(B + e.off_texel_contribs_f);
 		for (unsigned t = 0; t < T; t++) for (unsigned j = 0; j < 4; j++)

@@ -39,9 +39,26 @@ CASES = {
 }
 
 
+# 3D footprints: name -> (volume kind, (d, h, w), block, quality)
+CASES_3D = {
+    "vol_noise_3x3x3_medium": ("noise", (7, 10, 14), (3, 3, 3), 60.0),
+    "vol_edges_4x4x4_medium": ("edges", (9, 13, 18), (4, 4, 4), 60.0),
+    "vol_grad_5x5x4_thorough": ("grad", (9, 11, 17), (5, 5, 4), 98.0),
+    "vol_alpha_6x6x6_fast": ("alpha", (13, 14, 20), (6, 6, 6), 10.0),
+}
+
+
 def main():
     ref = A.Library(A.LIB_REF_NONE)
     manifest = {}
+    for name, (kind, shape, block, quality) in CASES_3D.items():
+        vol = images.volume(kind, *shape)
+        blocks = ref.compress(vol, block, quality)
+        np.save(os.path.join(HERE, name + ".npy"), blocks)
+        manifest[name] = {"image": "volume:" + kind, "size": shape, "block": block, "quality": quality, "partition_limit": None,
+                          "input_sha256": hashlib.sha256(vol.tobytes()).hexdigest(),
+                          "blocks_sha256": hashlib.sha256(blocks.tobytes()).hexdigest()}
+        print(name, blocks.size // 16, "blocks")
     for name, (gen, size, block, quality, plimit) in CASES.items():
         img = images.hdr_f16(*size) if gen == "hdr" else images.ALL[gen](*size)
         profile = A.PRF_HDR if gen == "hdr" else A.PRF_LDR

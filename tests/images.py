@@ -46,6 +46,32 @@ def two_colour(w, h, seed=3):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def volume(kind, d, h, w, seed=11):
+    """[D, H, W, 4] RGBA8 volumes for the 3D footprints: random noise, noisy ramps along all three axes,
+    hard two-material cells, and a transparent/opaque alpha lattice (2-plane territory)."""
+    rng = np.random.default_rng(seed)
+    z, y, x = np.meshgrid(np.arange(d), np.arange(h), np.arange(w), indexing="ij")
+    if kind == "noise":
+        return rng.integers(0, 256, (d, h, w, 4), dtype=np.uint8)
+    if kind == "grad":
+        v = np.stack([x * 9 + z * 13, y * 11 + z * 5, (x + y + z) * 7, 255 - (x * 3 + y * 2 + z * 17)], -1) % 256
+        return (v + rng.integers(-6, 7, v.shape)).clip(0, 255).astype(np.uint8)
+    if kind == "edges":
+        m = (x // 3 + y // 2 + z // 2) % 2
+        v = np.stack([m * 200 + 20, (1 - m) * 180 + x * 3, z * 30 + m * 40, 255 * np.ones_like(x)], -1)
+        return (v + rng.integers(-3, 4, v.shape)).clip(0, 255).astype(np.uint8)
+    if kind == "alpha":
+        m = (x + z) // 4 % 2
+        v = np.stack([x * 8, y * 8, z * 20, m * 255], -1)
+        return (v + rng.integers(-2, 3, v.shape)).clip(0, 255).astype(np.uint8)
+    if kind == "flat":
+        v = np.empty((d, h, w, 4), dtype=np.uint8)
+        v[...] = (90, 14, 200, 255)
+        v[:, :, w // 2:] = rng.integers(0, 256, (d, h, w - w // 2, 4), dtype=np.uint8)
+        return v
+    raise KeyError(kind)
+
+
 ALL = {"noisy": noisy, "flat": flat_regions, "gray": grayscale, "smooth": smooth, "random": random_u8, "two_colour": two_colour}
 
 

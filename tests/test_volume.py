@@ -1,0 +1,149 @@
+# SPDX-License-Identifier: Apache-2.0
+"""3D footprints (3x3x3 .. 6x6x6) and multi-slice images: compression,
+decompression and block info of the drop-in library against the reference, byte for byte.  Runs on
+the scalar CPU build of the kernel source here and on the HIP kernels with -m gpu.
+
+ref: construct_block_size_descriptor_3d / init_decimation_info_3d / decode_block_mode_3d
+     (Source/astcenc_block_sizes.cpp:152-243, :450-700, :1025-1190), the z loops of load_image_block /
+     store_image_block (Source/astcenc_image.cpp:221, :382) and compress_image (astcenc_entry.cpp:961-966)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import images
+
+LIBS = [pytest.param("emu", id="emu"), pytest.param("product", id="hip", marks=pytest.mark.gpu)]
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FOOTPRINTS_3D = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]
+
+
+@pytest.fixture(params=LIBS)
+def lib(request):
+    return request.getfixturevalue(request.param)
+
+
+def _manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return {k: v for k, v in json.load(f).items() if v["image"].startswith("volume:")}
+
+
+@pytest.mark.parametrize("name", sorted(_manifest().keys()))
+def test_golden_volume(lib, name):
+    """Committed reference output (tests/golden/make_golden.py); needs no reference library."""
+    m = _manifest()[name]
+    vol = images.volume(m["image"][7:], *m["size"])
+    assert hashlib.sha256(vol.tobytes()).hexdigest() == m["input_sha256"], "input generator drifted"
+    got = lib.compress(vol, tuple(m["block"]), m["quality"])
+    want = np.load(os.path.join(GOLDEN, name + ".npy"))
+    bad = images.mismatches(want, got)
+    assert len(bad) == 0, "blocks differ from the reference: %s" % bad[:8]
+
+
+@pytest.mark.parametrize("block", FOOTPRINTS_3D)
+def test_compress_matches_reference(lib, ref, block):
+    # ragged in all three axes: the last block of each axis is edge-clamped
+    d, h, w = 2 * block[2] + 1, 2 * block[1] + 2, 3 * block[0] + 2
+    for kind, quality in (("noise", 60.0), ("edges", 10.0), ("alpha", 60.0)):
+        vol = images.volume(kind, d, h, w, seed=block[0] * 31 + block[2])
+        want = ref.compress(vol, block, quality)
+        got = lib.compress(vol, block, quality)
+        assert want.size == 16 * 3 * 3 * 4
+        bad = images.mismatches(want, got)
+        assert len(bad) == 0, "%s q=%g: %d blocks differ: %s" % (kind, quality, len(bad), bad[:8])
+
+
+def test_compress_thorough_and_flags(lib, ref, A):
+    vol = images.volume("grad", 9, 10, 13)
+    for block, quality, flags, swz in [((4, 4, 4), 98.0, 0, A.SWZ_RGBA), ((5, 5, 5), 60.0, A.FLG_USE_ALPHA_WEIGHT, A.SWZ_RGBA),
+                                       ((3, 3, 3), 60.0, A.FLG_USE_PERCEPTUAL, (A.SWZ_B, A.SWZ_G, A.SWZ_R, A.SWZ_1)),
+                                       ((6, 6, 6), 98.0, 0, A.SWZ_RGBA)]:
+        want = ref.compress(vol, block, quality, flags=flags, swizzle=swz)
+        got = lib.compress(vol, block, quality, flags=flags, swizzle=swz)
+        assert len(images.mismatches(want, got)) == 0, (block, quality, flags)
+    flat = images.volume("flat", 8, 8, 16)
+    assert len(images.mismatches(ref.compress(flat, (4, 4, 4), 60.0), lib.compress(flat, (4, 4, 4), 60.0))) == 0
+
+
+def test_compress_hdr_volume(lib, ref, A):
+    rng = np.random.default_rng(3)
+    vol = (images.volume("grad", 6, 9, 11).astype(np.float32) / 255.0 * np.exp2(rng.integers(-2, 5, (6, 9, 11, 1)))).astype(np.float16)
+    vol[..., 3] = np.clip(vol[..., 3], 0, 1)
+    for profile in (A.PRF_HDR_RGB_LDR_A, A.PRF_HDR):
+        want = ref.compress(vol, (4, 4, 3), 60.0, profile=profile)
+        got = lib.compress(vol, (4, 4, 3), 60.0, profile=profile)
+        assert len(images.mismatches(want, got)) == 0, profile
+
+
+@pytest.mark.parametrize("block", [(3, 3, 3), (4, 4, 3), (5, 5, 4), (6, 6, 6)])
+def test_decompress_and_block_info_match_reference(lib, ref, A, block):
+    d, h, w = 2 * block[2] + 1, 2 * block[1] + 1, 3 * block[0] + 2
+    rng = np.random.default_rng(block[0] + 10 * block[2])
+    nb = 3 * 3 * 4
+    legal = ref.compress(images.volume("edges", d, h, w), block, 60.0)
+    junk = rng.integers(0, 256, nb * 16, dtype=np.uint8)          # mostly reserved / illegal encodings, some void extents
+    junk.reshape(-1, 16)[::3, 0] = 0xFC
+    junk.reshape(-1, 16)[::3, 1] |= 0x01
+    for stream in (legal, junk):
+        for out_type in (np.uint8, np.float16, np.float32):
+            want = ref.decompress(stream, w, h, block, out_type=out_type, depth=d)
+            got = lib.decompress(stream, w, h, block, out_type=out_type, depth=d)
+            assert want.tobytes() == got.tobytes(), (out_type, np.argwhere(want.view(np.uint8) != got.view(np.uint8))[:3])
+        ctxs = []
+        for L in (ref, lib):
+            err, cfg = L.config_init(A.PRF_LDR, block[0], block[1], block[2], 60.0, A.FLG_DECOMPRESS_ONLY)
+            assert err == 0
+            err, ctx = L.context_alloc(cfg, 1)
+            assert err == 0
+            ctxs.append(ctx)
+        try:
+            for i in range(nb):
+                blk = np.ascontiguousarray(stream[i * 16:(i + 1) * 16])
+                a, b = A.BlockInfo(), A.BlockInfo()
+                ea = ref.lib.astcenc_get_block_info(ctxs[0], blk.ctypes.data, C.byref(a))
+                eb = lib.lib.astcenc_get_block_info(ctxs[1], blk.ctypes.data, C.byref(b))
+                assert ea == eb and bytes(a) == bytes(b), i
+        finally:
+            ref.context_free(ctxs[0]); lib.context_free(ctxs[1])
+
+
+def test_array_image_with_2d_footprint(lib, ref, A):
+    """dim_z > 1 with a 2D footprint: every slice is compressed on its own, blocks in x, y, z order.
+    Checked against the reference through the general loader (F16 input) and, for RGBA8, against
+    slice-by-slice 2D compression: the reference's fast RGBA8 loader reads slice 0 for every z
+    (Source/astcenc_image.cpp:304), which this library does not imitate."""
+    d, h, w = 3, 20, 26
+    vol = images.volume("grad", d, h, w)
+    half = (vol.astype(np.float32) / 255.0).astype(np.float16)
+    want = ref.compress(half, (6, 6), 60.0)
+    got = lib.compress(half, (6, 6), 60.0)
+    assert want.size == 16 * 5 * 4 * d
+    assert len(images.mismatches(want, got)) == 0
+    got8 = lib.compress(vol, (6, 6), 60.0)
+    per_slice = np.concatenate([lib.compress(vol[z], (6, 6), 60.0) for z in range(d)])
+    assert np.array_equal(got8, per_slice)
+    assert np.array_equal(per_slice, np.concatenate([ref.compress(vol[z], (6, 6), 60.0) for z in range(d)]))
+    back = lib.decompress(got8, w, h, (6, 6), depth=d)
+    assert np.array_equal(back, np.stack([ref.decompress(per_slice[z * 320:(z + 1) * 320], w, h, (6, 6)) for z in range(d)]))
+
+
+def test_volume_argument_checks(lib, A):
+    # buffer too small for the z block count (ref: astcenc_entry.cpp:1170-1176)
+    vol = images.volume("noise", 7, 6, 6)
+    err, cfg = lib.config_init(A.PRF_LDR, 3, 3, 3, 60.0, 0)
+    assert err == 0 and cfg.block_z == 3
+    err, ctx = lib.context_alloc(cfg, 1)
+    assert err == 0
+    try:
+        out = np.zeros(2 * 2 * 3 * 16, dtype=np.uint8)
+        assert lib.compress_raw(ctx, vol, out, data_len=out.nbytes - 16) == A.ERR_OUT_OF_MEM
+        assert lib.compress_raw(ctx, vol, out) == 0
+    finally:
+        lib.context_free(ctx)
+    # illegal 3D footprints are rejected at config time (ref: astcenc_entry.cpp:268-276)
+    for bad in [(3, 3, 2), (6, 6, 7), (4, 5, 4), (7, 7, 7)]:
+        err, _ = lib.config_init(A.PRF_LDR, bad[0], bad[1], bad[2], 60.0, 0)
+        assert err == A.ERR_BAD_BLOCK_SIZE, bad
