@@ -332,3 +332,60 @@ def read_astc(path):
     if len(raw) - 16 < n * 16:
         raise ValueError("truncated .astc payload")
     return np.frombuffer(raw, dtype=np.uint8, count=n * 16, offset=16).copy(), dims[0], dims[1], dims[2], (bx, by, bz)
+
+
+# ---- KTX 1.1 container for compressed data (ref: store_ktx_compressed_image / load_ktx_compressed_image,
+# astcenccli_image_load_store.cpp:1294-1437; GL enums :725-775) ----
+
+KTX_MAGIC = bytes([0xAB, 0x4B, 0x54, 0x58, 0x20, 0x31, 0x31, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A])
+GL_RGBA = 0x1908
+_KTX_2D = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8), (10, 10), (12, 10), (12, 12)]
+_KTX_3D = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]
+
+
+def ktx_gl_format(block, srgb=False):
+    """glInternalFormat of an ASTC footprint: COMPRESSED_RGBA_ASTC_* / COMPRESSED_SRGB8_ALPHA8_ASTC_* (+ _OES for 3D)."""
+    bz = block[2] if len(block) > 2 else 1
+    if bz <= 1:
+        return (0x93D0 if srgb else 0x93B0) + _KTX_2D.index((block[0], block[1]))
+    return (0x93E0 if srgb else 0x93C0) + _KTX_3D.index((block[0], block[1], bz))
+
+
+def write_ktx(path, blocks, width, height, block, depth=1, srgb=False):
+    """Write a block stream as a single-level KTX 1.1 file, little endian, no key/value data."""
+    import struct
+    data = np.ascontiguousarray(blocks, dtype=np.uint8).tobytes()
+    header = KTX_MAGIC + struct.pack("<13I", 0x04030201, 0, 1, 0, ktx_gl_format(block, srgb), GL_RGBA,
+                                     width, height, 0 if depth == 1 else depth, 0, 1, 1, 0)
+    with open(path, "wb") as f:
+        f.write(header + struct.pack("<I", len(data)) + data)
+
+
+def read_ktx(path):
+    """-> (blocks uint8[], width, height, depth, (bx, by, bz), is_srgb); either byte order; raises ValueError
+    on anything that is not a compressed ASTC KTX file, like the reference loader."""
+    import struct
+    raw = open(path, "rb").read()
+    if len(raw) < 68 or raw[:12] != KTX_MAGIC:
+        raise ValueError("not a KTX file")
+    endian = struct.unpack_from("<I", raw, 12)[0]
+    if endian not in (0x04030201, 0x01020304):
+        raise ValueError("corrupt KTX header")
+    e = "<" if endian == 0x04030201 else ">"
+    (gl_type, type_size, gl_format, internal, base, w, h, d, _arrays, _faces, _mips, kv) = struct.unpack_from(e + "12I", raw, 16)
+    if gl_type != 0 or gl_format != 0 or type_size != 1 or base != GL_RGBA:
+        raise ValueError("unsupported KTX format")
+    for first, table, srgb in ((0x93B0, _KTX_2D, False), (0x93D0, _KTX_2D, True), (0x93C0, _KTX_3D, False), (0x93E0, _KTX_3D, True)):
+        if first <= internal < first + len(table):
+            blk = table[internal - first]
+            break
+    else:
+        raise ValueError("unsupported KTX format")
+    at = 64 + kv
+    if len(raw) < at + 4:
+        raise ValueError("truncated KTX file")
+    n = struct.unpack_from(e + "I", raw, at)[0]
+    if len(raw) < at + 4 + n:
+        raise ValueError("truncated KTX file")
+    block = (blk[0], blk[1], blk[2] if len(blk) > 2 else 1)
+    return np.frombuffer(raw, dtype=np.uint8, count=n, offset=at + 4).copy(), w, h, d if d else 1, block, srgb

@@ -268,15 +268,44 @@ static int unquant_color(int v, int q)
 
 /* ------------------------------------------------------------------------------- block mode */
 
-typedef struct { int ok, void_extent, wx, wy, dual, wq; } BlockModeInfo;
+typedef struct { int ok, void_extent, wx, wy, wz, dual, wq; } BlockModeInfo;
 
-static BlockModeInfo decode_block_mode(unsigned mode, int bx, int by)
+static BlockModeInfo decode_block_mode(unsigned mode, int bx, int by, int bz)
 {
 	BlockModeInfo m; memset(&m, 0, sizeof m);
-	int R, H, D, W = 0, Ht = 0;
+	int R, H, D, W = 0, Ht = 0, Dp = 1;
 	if ((mode & 0x1FF) == 0x1FC) { m.void_extent = 1; m.ok = 1; return m; }
 
-	if (mode & 3)
+	if (bz > 1)
+	{
+		/* 3D footprints: spec table C.2.10 (ref: decode_block_mode_3d, astcenc_block_sizes.cpp:152-243) */
+		int A = (int)((mode >> 5) & 3);
+		D = (int)((mode >> 10) & 1); H = (int)((mode >> 9) & 1);
+		if (mode & 3)
+		{
+			R = (int)(((mode >> 4) & 1) | ((mode & 3) << 1));
+			W = A + 2; Ht = (int)((mode >> 7) & 3) + 2; Dp = (int)((mode >> 2) & 3) + 2;
+		}
+		else
+		{
+			if ((mode & 0xF) == 0) return m;        /* reserved */
+			R = (int)(((mode >> 4) & 1) | (((mode >> 2) & 3) << 1));
+			int B = (int)((mode >> 9) & 3);
+			int sel = (int)((mode >> 7) & 3);
+			if (sel != 3) { D = 0; H = 0; }
+			switch (sel)
+			{
+			case 0: W = 6; Ht = B + 2; Dp = A + 2; break;
+			case 1: W = A + 2; Ht = 6; Dp = B + 2; break;
+			case 2: W = A + 2; Ht = B + 2; Dp = 6; break;
+			default:
+				W = Ht = Dp = 2;
+				if (A == 0) W = 6; else if (A == 1) Ht = 6; else if (A == 2) Dp = 6; else return m;
+				break;
+			}
+		}
+	}
+	else if (mode & 3)
 	{
 		R = (int)(((mode >> 4) & 1) | ((mode & 3) << 1));
 		int A = (int)((mode >> 5) & 3), B = (int)((mode >> 7) & 3);
@@ -313,9 +342,9 @@ static BlockModeInfo decode_block_mode(unsigned mode, int bx, int by)
 	}
 	if (R < 2) return m;                             /* reserved weight ranges */
 	m.wq = (R - 2) + 6 * H;
-	m.wx = W; m.wy = Ht; m.dual = D;
-	if (W > bx || Ht > by) return m;
-	int count = W * Ht * (D ? 2 : 1);
+	m.wx = W; m.wy = Ht; m.wz = Dp; m.dual = D;
+	if (W > bx || Ht > by || Dp > bz) return m;
+	int count = W * Ht * Dp * (D ? 2 : 1);
 	if (count > 64) return m;
 	int wbits = ise_bits(count, m.wq);
 	if (wbits < 24 || wbits > 96) return m;
@@ -472,19 +501,32 @@ static void fill_block(uint8_t *texels, int count, int r, int g, int b, int a)
 	}
 }
 
-/* Decode one 128-bit block to bx*by RGBA8 texels.  Returns 0 ok, 1 error block (magenta written). */
-EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int srgb, uint8_t *texels)
+/* Decode one 128-bit block to bx*by*bz RGBA8 texels (x fastest, then y, then z; bz = 1 for a 2D
+ * footprint).  Returns 0 ok, 1 error block (magenta written). */
+EXPORT int astc_oracle_decode_block_3d(const uint8_t pcb[16], int bx, int by, int bz, int srgb, uint8_t *texels)
 {
-	const int T = bx * by;
+	const int T = bx * by * bz;
 	unsigned mode = rd_bits(pcb, 0, 11);
-	BlockModeInfo bm = decode_block_mode(mode, bx, by);
+	BlockModeInfo bm = decode_block_mode(mode, bx, by, bz);
 
 	if (bm.void_extent)
 	{
-		/* 2D void extent: two reserved bits must be set, coordinates either all-ones or ordered */
-		unsigned ls = rd_bits(pcb, 12, 13), hs = rd_bits(pcb, 25, 13), lt = rd_bits(pcb, 38, 13), ht = rd_bits(pcb, 51, 13);
-		int all_ones = ls == 0x1FFF && hs == 0x1FFF && lt == 0x1FFF && ht == 0x1FFF;
-		int bad = rd_bits(pcb, 10, 2) != 3 || ((ls >= hs || lt >= ht) && !all_ones);
+		int bad;
+		if (bz > 1)
+		{
+			/* 3D void extent: six 9-bit coordinates from bit 10, all-ones or ordered on every axis */
+			unsigned c[6];
+			int all_ones = 1;
+			for (int i = 0; i < 6; i++) { c[i] = rd_bits(pcb, 10 + 9 * (unsigned)i, 9); all_ones = all_ones && c[i] == 0x1FF; }
+			bad = (c[0] >= c[1] || c[2] >= c[3] || c[4] >= c[5]) && !all_ones;
+		}
+		else
+		{
+			/* 2D void extent: two reserved bits must be set, coordinates either all-ones or ordered */
+			unsigned ls = rd_bits(pcb, 12, 13), hs = rd_bits(pcb, 25, 13), lt = rd_bits(pcb, 38, 13), ht = rd_bits(pcb, 51, 13);
+			int all_ones = ls == 0x1FFF && hs == 0x1FFF && lt == 0x1FFF && ht == 0x1FFF;
+			bad = rd_bits(pcb, 10, 2) != 3 || ((ls >= hs || lt >= ht) && !all_ones);
+		}
 		if (bad || (mode & 0x200))      /* FP16 constant colour is an error in LDR profiles */
 		{
 			fill_block(texels, T, 0xFF, 0, 0xFF, 0xFF);
@@ -498,7 +540,7 @@ EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int s
 	if (!bm.ok) goto error;
 
 	{
-		int wcount = bm.wx * bm.wy;
+		int wcount = bm.wx * bm.wy * bm.wz;
 		int real_wcount = bm.dual ? 2 * wcount : wcount;
 		int wbits = ise_bits(real_wcount, bm.wq);
 		int parts = (int)rd_bits(pcb, 11, 2) + 1;
@@ -603,6 +645,8 @@ EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int s
 		int small_block = T < 31;
 		int Ds = (1024 + bx / 2) / (bx - 1);
 		int Dt = (1024 + by / 2) / (by - 1);
+		int Dr = bz > 1 ? (1024 + bz / 2) / (bz - 1) : 0;
+		for (int z = 0; z < bz; z++)
 		for (int y = 0; y < by; y++)
 		{
 			for (int x = 0; x < bx; x++)
@@ -611,11 +655,39 @@ EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int s
 				int gs = (cs * (bm.wx - 1) + 32) >> 6;
 				int gt = (ct * (bm.wy - 1) + 32) >> 6;
 				int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
-				int w11 = (fs * ft + 8) >> 4;
-				int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
-				int v0 = js + jt * bm.wx;
-				int idx[4] = { v0, v0 + 1, v0 + bm.wx, v0 + bm.wx + 1 };
-				int wt[4] = { w00, w01, w10, w11 };
+				int idx[4], wt[4];
+				if (bz > 1)
+				{
+					/* 3D weight infill (spec C.2.19): simplex interpolation -- from the low corner of the
+					 * grid cell, step along the axes in descending order of the fractional position */
+					int gr = (Dr * z * (bm.wz - 1) + 32) >> 6;
+					int jr = gr >> 4, fr = gr & 0xF;
+					int N = bm.wx, NM = bm.wx * bm.wy;
+					int v0 = (jr * bm.wy + jt) * bm.wx + js;
+					int f[3] = { fs, ft, fr };
+					int step[3] = { 1, N, NM };
+					/* stable descending sort with the format's tie rules: s > t, t > r, s > r comparisons */
+					int cas = ((fs > ft) << 2) + ((ft > fr) << 1) + (fs > fr);
+					int o0, o1, o2;          /* axis order */
+					switch (cas)
+					{
+					case 7: o0 = 0; o1 = 1; o2 = 2; break;
+					case 3: o0 = 1; o1 = 0; o2 = 2; break;
+					case 5: o0 = 0; o1 = 2; o2 = 1; break;
+					case 4: o0 = 2; o1 = 0; o2 = 1; break;
+					case 2: o0 = 1; o1 = 2; o2 = 0; break;
+					default: o0 = 2; o1 = 1; o2 = 0; break;
+					}
+					idx[0] = v0; idx[1] = v0 + step[o0]; idx[2] = idx[1] + step[o1]; idx[3] = v0 + 1 + N + NM;
+					wt[0] = 16 - f[o0]; wt[1] = f[o0] - f[o1]; wt[2] = f[o1] - f[o2]; wt[3] = f[o2];
+				}
+				else
+				{
+					int w11 = (fs * ft + 8) >> 4;
+					int v0 = js + jt * bm.wx;
+					idx[0] = v0; idx[1] = v0 + 1; idx[2] = v0 + bm.wx; idx[3] = v0 + bm.wx + 1;
+					wt[0] = 16 - fs - ft + w11; wt[1] = fs - w11; wt[2] = ft - w11; wt[3] = w11;
+				}
 				int tw[2];
 				for (int p = 0; p < 2; p++)
 				{
@@ -626,8 +698,8 @@ EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int s
 					}
 					tw[p] = sum >> 4;
 				}
-				int part = parts == 1 ? 0 : select_partition(seed, x, y, 0, parts, small_block);
-				uint8_t *o = texels + 4 * (y * bx + x);
+				int part = parts == 1 ? 0 : select_partition(seed, x, y, z, parts, small_block);
+				uint8_t *o = texels + 4 * ((z * by + y) * bx + x);
 				for (int k = 0; k < 4; k++)
 				{
 					int wk = (k == plane2) ? tw[1] : tw[0];
@@ -642,6 +714,31 @@ EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int s
 error:
 	fill_block(texels, T, 0xFF, 0, 0xFF, 0xFF);
 	return 1;
+}
+
+EXPORT int astc_oracle_decode_block(const uint8_t pcb[16], int bx, int by, int srgb, uint8_t *texels)
+{
+	return astc_oracle_decode_block_3d(pcb, bx, by, 1, srgb, texels);
+}
+
+/* Decode a volume (or a stack of 2D slices when bz == 1): blocks in x, y, z raster order, out is
+ * d slices of tightly packed RGBA8 rows.  Returns the number of error blocks. */
+EXPORT int astc_oracle_decode_volume(const uint8_t *blocks, int bx, int by, int bz, int w, int h, int d, int srgb, uint8_t *out)
+{
+	int nbx = (w + bx - 1) / bx, nby = (h + by - 1) / by, nbz = (d + bz - 1) / bz;
+	int errors = 0;
+	uint8_t tex[216 * 4];
+	for (int k = 0; k < nbz; k++)
+	for (int j = 0; j < nby; j++)
+	for (int i = 0; i < nbx; i++)
+	{
+		errors += astc_oracle_decode_block_3d(blocks + 16 * (((size_t)k * nby + j) * nbx + i), bx, by, bz, srgb, tex);
+		for (int z = 0; z < bz && k * bz + z < d; z++)
+		for (int y = 0; y < by && j * by + y < h; y++)
+		for (int x = 0; x < bx && i * bx + x < w; x++)
+			memcpy(out + 4 * (((size_t)(k * bz + z) * h + (j * by + y)) * w + (i * bx + x)), tex + 4 * ((z * by + y) * bx + x), 4);
+	}
+	return errors;
 }
 
 /* Decode a whole 2D image.  `blocks` holds ceil(w/bx)*ceil(h/by) blocks in raster order; out is

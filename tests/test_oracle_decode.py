@@ -95,3 +95,59 @@ def test_golden_encoder_output_decodes_cleanly(dec):
         assert psnr > floor, (name, psnr)
         checked += 1
     assert checked >= 6
+
+
+@pytest.fixture(scope="module")
+def dec_volume(dec):
+    lib = ctypes.CDLL(LIB_DECODE)
+    lib.astc_oracle_decode_volume.restype = ctypes.c_int
+    lib.astc_oracle_decode_volume.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+
+    def decode(blocks, block, w, h, d, srgb=False):
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint8)
+        out = np.zeros((d, h, w, 4), dtype=np.uint8)
+        errors = lib.astc_oracle_decode_volume(blocks.ctypes.data, block[0], block[1], block[2], w, h, d, int(srgb), out.ctypes.data)
+        return out, errors
+    return decode
+
+
+FOOTPRINTS_3D = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]
+
+
+@pytest.mark.parametrize("block", FOOTPRINTS_3D)
+def test_3d_decoder_matches_reference(ref, dec_volume, block):
+    """The 3D block modes, simplex weight infill, z-aware partition hash and 3D void extents of the
+    oracle decoder against the reference decoder: encoder output and random bit patterns."""
+    d, h, w = 2 * block[2] + 1, 2 * block[1] + 2, 3 * block[0] + 1
+    for kind, quality in (("noise", 60.0), ("edges", 60.0), ("alpha", 10.0)):
+        data = ref.compress(images.volume(kind, d, h, w), block, quality)
+        want = ref.decompress(data, w, h, block, depth=d)
+        got, errors = dec_volume(data, block, w, h, d)
+        assert errors == 0
+        assert np.array_equal(want, got), (kind, np.argwhere(want != got)[:4])
+    rng = np.random.default_rng(99 + block[0] + block[2])
+    junk = rng.integers(0, 256, size=3 * 3 * 4 * 16, dtype=np.uint8)
+    junk.reshape(-1, 16)[::3, 0] = 0xFC
+    junk.reshape(-1, 16)[::3, 1] |= 0x01
+    junk.reshape(-1, 16)[::6, 1:8] = 0xFF
+    want = ref.decompress(junk, w, h, block, depth=d)
+    got, errors = dec_volume(junk, block, w, h, d)
+    assert errors > 0 and np.array_equal(want, got), np.argwhere(want != got)[:4]
+
+
+def test_golden_volume_output_decodes_cleanly(dec_volume):
+    gold = os.path.join(ROOT, "tests", "golden")
+    manifest = json.load(open(os.path.join(gold, "manifest.json")))
+    checked = 0
+    for name, case in sorted(manifest.items()):
+        if not case["image"].startswith("volume:"):
+            continue
+        vol = images.volume(case["image"][7:], *case["size"])
+        d, h, w = case["size"]
+        out, errors = dec_volume(np.load(os.path.join(gold, name + ".npy")), tuple(case["block"]), w, h, d)
+        assert errors == 0, name
+        mse = np.mean((out.astype(np.float64) - vol.astype(np.float64)) ** 2)
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        assert psnr > (9.0 if case["image"] == "volume:noise" else 18.0), (name, psnr)
+        checked += 1
+    assert checked >= 4
