@@ -611,6 +611,61 @@ astcenc_error astcenc_amd_compress_volume_device(astcenc_context* ctx, const voi
 	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
 }
 
+astcenc_error astcenc_amd_decompress_image_device(astcenc_context* ctx, const void* device_blocks, size_t data_len,
+                                                  void* device_image, unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+                                                  astcenc_type data_type, const astcenc_swizzle* swizzle, void* hip_stream)
+{
+	if (!swz_ok(swizzle->r, true) || !swz_ok(swizzle->g, true) || !swz_ok(swizzle->b, true) || !swz_ok(swizzle->a, true))
+	{
+		return ASTCENC_ERR_BAD_SWIZZLE;
+	}
+	bool overflow = false;
+	size_t texel_count = mul_safe(mul_safe(dim_x, dim_y, overflow), dim_z, overflow);
+	if (overflow || texel_count == 0 || !device_blocks || !device_image) return ASTCENC_ERR_BAD_PARAM;
+	size_t block_count = mul_safe(mul_safe(block_count_axis(dim_x, ctx->config.block_x), block_count_axis(dim_y, ctx->config.block_y), overflow),
+	                              block_count_axis(dim_z, ctx->config.block_z), overflow);
+	mul_safe(block_count, 16, overflow);
+	if (overflow || block_count == 0) return ASTCENC_ERR_BAD_PARAM;
+	if (data_len < block_count * 16) return ASTCENC_ERR_OUT_OF_MEM;
+
+	DecompressDeviceJob job;
+	memset(&job, 0, sizeof(job));
+	job.device_blocks = static_cast<const uint8_t*>(device_blocks);
+	job.device_image = device_image;
+	job.dim_x = dim_x; job.dim_y = dim_y; job.dim_z = dim_z;
+	job.data_type = (uint32_t)data_type;
+	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
+	job.stream = hip_stream;
+	int rc = backend_decompress_device(ctx->backend, job);
+	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+}
+
+astcenc_error astcenc_amd_compare_images_device(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
+                                                const void* device_image2, astcenc_type type2,
+                                                unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+                                                void* hip_stream, astcenc_amd_error_sums* sums)
+{
+	bool overflow = false;
+	size_t texel_count = mul_safe(mul_safe(dim_x, dim_y, overflow), dim_z, overflow);
+	if (overflow || texel_count == 0 || !device_image1 || !device_image2 || !sums) return ASTCENC_ERR_BAD_PARAM;
+	if ((unsigned)type1 > 2u || (unsigned)type2 > 2u) return ASTCENC_ERR_BAD_PARAM;
+
+	double raw[10];
+	CompareJob job;
+	memset(&job, 0, sizeof(job));
+	job.device_a = device_image1; job.type_a = (uint32_t)type1;
+	job.device_b = device_image2; job.type_b = (uint32_t)type2;
+	job.texels = texel_count;
+	job.stream = hip_stream;
+	job.sums = raw;
+	int rc = backend_compare(ctx->backend, job);
+	if (rc != 0) return rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+	for (int k = 0; k < 4; k++) { sums->squared_error[k] = raw[k]; sums->alpha_scaled_squared_error[k] = raw[4 + k]; }
+	sums->rgb_peak = raw[8];
+	sums->texels = (double)texel_count;
+	return ASTCENC_SUCCESS;
+}
+
 const char* astcenc_amd_backend_name(void)
 {
 	return backend_name();

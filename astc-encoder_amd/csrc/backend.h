@@ -36,11 +36,32 @@ struct DecompressJob {
 	uint32_t swz[4];
 };
 
+/* Decompression with both ends in device memory (emu: host memory). */
+struct DecompressDeviceJob {
+	const uint8_t* device_blocks;
+	void*    device_image;        // dim_z slices back to back
+	uint32_t dim_x, dim_y, dim_z;
+	uint32_t data_type;
+	uint32_t swz[4];
+	void*    stream;
+};
+
+/* Squared-error sums of two images of the same size (wave_metrics.h); sums[METRIC_SUMS] on the host. */
+struct CompareJob {
+	const void* device_a; uint32_t type_a;
+	const void* device_b; uint32_t type_b;
+	size_t texels;
+	void* stream;
+	double* sums;
+};
+
 /* status: 0 ok, 1 out of memory, 2 no usable device / launch failure */
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status);
 void backend_destroy(Backend* b);
 int backend_compress(Backend* b, const CompressJob& job);
 int backend_decompress(Backend* b, const DecompressJob& job);
+int backend_decompress_device(Backend* b, const DecompressDeviceJob& job);
+int backend_compare(Backend* b, const CompareJob& job);
 const char* backend_name();
 
 
@@ -83,5 +104,15 @@ struct DecodeLaunch {
 	void* stream;
 };
 int astc_decode_launch(const DecodeLaunch& d);
+
+/* Image comparison launch (kernel_metrics.hip); d_sums = 10 zeroed doubles in device memory. */
+struct CompareLaunch {
+	const void* d_a; uint32_t type_a;
+	const void* d_b; uint32_t type_b;
+	size_t texels;
+	double* d_sums;
+	void* stream;
+};
+int astc_compare_launch(const CompareLaunch& c);
 
 } // namespace astcd

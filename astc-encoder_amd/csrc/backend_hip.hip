@@ -31,6 +31,7 @@ struct Backend {
 	uint8_t* d_out; size_t out_cap;
 	float* d_alpha; size_t alpha_cap;   // alpha averages of the a_scale_radius pre-pass
 	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds)
+	double* d_sums;               // totals of the image comparison kernel
 };
 
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
@@ -95,6 +96,7 @@ void backend_destroy(Backend* b)
 	if (b->d_image) (void)hipFree(b->d_image);
 	if (b->d_out) (void)hipFree(b->d_out);
 	if (b->d_alpha) (void)hipFree(b->d_alpha);
+	if (b->d_sums) (void)hipFree(b->d_sums);
 	(void)hipEventDestroy(b->ev0);
 	(void)hipEventDestroy(b->ev1);
 	(void)hipStreamDestroy(b->stream);
@@ -266,6 +268,40 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	for (uint32_t z = 0; z < dim_z; z++)
 		HIP_TRY(hipMemcpyAsync(job.host_slices[z], static_cast<uint8_t*>(b->d_image) + z * slice_bytes, slice_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
 	HIP_TRY(hipStreamSynchronize(b->stream), return 2);
+	return 0;
+}
+
+int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
+{
+	HIP_TRY(hipSetDevice(b->device), return 2);
+	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+	DecodeLaunch d;
+	d.d_blocks = job.device_blocks;
+	d.d_image = job.device_image;
+	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = job.dim_z ? job.dim_z : 1u; d.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
+	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y; d.block_z = b->root.dim_z;
+	d.profile = b->cfg.profile;
+	d.stream = stream;
+	int lrc = astc_decode_launch(d);
+	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
+	HIP_TRY(hipStreamSynchronize(stream), return 2);
+	return 0;
+}
+
+int backend_compare(Backend* b, const CompareJob& job)
+{
+	HIP_TRY(hipSetDevice(b->device), return 2);
+	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+	if (!b->d_sums) HIP_TRY(hipMalloc(&b->d_sums, 16 * sizeof(double)), return 1);
+	HIP_TRY(hipMemsetAsync(b->d_sums, 0, 16 * sizeof(double), stream), return 2);
+	CompareLaunch c;
+	c.d_a = job.device_a; c.type_a = job.type_a; c.d_b = job.device_b; c.type_b = job.type_b;
+	c.texels = job.texels; c.d_sums = b->d_sums; c.stream = stream;
+	int lrc = astc_compare_launch(c);
+	if (lrc != 0) { fprintf(stderr, "astcenc_amd: compare kernel launch failed (hip error %d)\n", lrc); return 2; }
+	HIP_TRY(hipMemcpyAsync(job.sums, b->d_sums, 10 * sizeof(double), hipMemcpyDeviceToHost, stream), return 2);
+	HIP_TRY(hipStreamSynchronize(stream), return 2);
 	return 0;
 }
 

@@ -1,0 +1,53 @@
+// SPDX-License-Identifier: Apache-2.0
+// Image comparison for the on-device quality metric (the CLI's -tl test mode).
+//   ref: compute_error_metrics   Source/astcenccli_error_metrics.cpp:110-300 (LDR sums: per-channel
+//        squared error, alpha-scaled squared error, RGB peak of the first image)
+// Per-texel arithmetic is the reference's (fp32 differences and squares of values / 255, or of
+// half/float values clamped to 0..65504); the sums are fp64 as there, but added in a tree instead of
+// texel by texel, so the totals agree to fp64 rounding rather than bit for bit.
+#pragma once
+#include "wave.h"
+
+namespace astcd { inline namespace ASTC_VARIANT {
+
+constexpr int METRIC_SUMS = 10;   // [0..3] squared error rgba, [4..7] alpha-scaled squared error rgba, [8] rgb peak, [9] unused
+
+WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, float c[4])
+{
+	if (data_type == 0)
+	{
+		const uint8_t* p = static_cast<const uint8_t*>(img) + texel * 4;
+		for (int k = 0; k < 4; k++) c[k] = (float)p[k] / 255.0f;
+	}
+	else
+	{
+		for (int k = 0; k < 4; k++)
+		{
+			float v = data_type == 1 ? half_to_float(static_cast<const uint16_t*>(img)[texel * 4 + k])
+			                         : static_cast<const float*>(img)[texel * 4 + k];
+			v = v > 0.0f ? v : 0.0f;               // clamp(0, 65504, v), NaN -> 0 as the reference's max/min pair
+			v = v < 65504.0f ? v : 65504.0f;
+			c[k] = v;
+		}
+	}
+}
+
+/* Error terms of one texel: e[0..3] squared difference, e[4..7] the same with RGB differences scaled by
+ * the first image's alpha; returns max(r, g, b) of the first image. */
+WV_FN float metric_texel_terms(const void* a, uint32_t type_a, const void* b, uint32_t type_b, size_t texel, float e[8])
+{
+	float c1[4], c2[4];
+	metric_load_texel(a, texel, type_a, c1);
+	metric_load_texel(b, texel, type_b, c2);
+	for (int k = 0; k < 4; k++)
+	{
+		float d = c1[k] - c2[k];
+		e[k] = d * d;
+		float ds = k < 3 ? d * c1[3] : d;
+		e[4 + k] = ds * ds;
+	}
+	float m = c1[0] > c1[1] ? c1[0] : c1[1];
+	return m > c1[2] ? m : c1[2];
+}
+
+} } // namespace astcd::ASTC_VARIANT

@@ -93,7 +93,20 @@ SWZ_RGBA = (SWZ_R, SWZ_G, SWZ_B, SWZ_A)
 EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_image", "astcenc_compress_reset",
            "astcenc_compress_cancel", "astcenc_decompress_image", "astcenc_decompress_reset",
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
-EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_backend_name"]
+EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
+               "astcenc_amd_compare_images_device", "astcenc_amd_backend_name"]
+
+
+class ErrorSums(C.Structure):
+    """struct astcenc_amd_error_sums (include/astcenc_amd.h)."""
+    _fields_ = [("squared_error", C.c_double * 4), ("alpha_scaled_squared_error", C.c_double * 4),
+                ("rgb_peak", C.c_double), ("texels", C.c_double)]
+
+    def psnr(self, channels=4, alpha_scaled=False):
+        """PSNR over the first `channels` channels as the reference CLI reports it (999 dB when identical)."""
+        src = self.alpha_scaled_squared_error if alpha_scaled else self.squared_error
+        num = sum(src[k] for k in range(channels))
+        return 999.0 if num == 0 else 10.0 * float(np.log10(self.texels * channels / num))
 
 
 class AstcError(RuntimeError):
@@ -138,6 +151,13 @@ class Library:
                                                             C.POINTER(C.c_float)]
             L.astcenc_amd_compress_image_device.restype = C.c_int
             L.astcenc_amd_backend_name.restype = C.c_char_p
+        if hasattr(L, "astcenc_amd_compare_images_device"):
+            L.astcenc_amd_decompress_image_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint,
+                                                              C.c_int, C.POINTER(Swizzle), C.c_void_p]
+            L.astcenc_amd_decompress_image_device.restype = C.c_int
+            L.astcenc_amd_compare_images_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint,
+                                                            C.c_void_p, C.POINTER(ErrorSums)]
+            L.astcenc_amd_compare_images_device.restype = C.c_int
         if hasattr(L, "astcenc_amd_compress_volume_device"):
             L.astcenc_amd_compress_volume_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int,
                                                              C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,

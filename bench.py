@@ -108,6 +108,22 @@ def decoded_psnr(img, gpu_blocks):
     return {"psnr_db": round(psnr, 4), "error_blocks": int(errors), "decoder": "oracle/astc_decode.c (plain-C restatement)"}
 
 
+def device_psnr(lib, ctx, d_img, d_blocks, dev):
+    """The same figure without leaving the GPU: the product's decode kernel writes the decoded image into
+    HBM and its comparison kernel reduces the squared error there (include/astcenc_amd.h); not timed."""
+    d_dec = torch.empty_like(d_img)
+    swz = A.Swizzle(*A.SWZ_RGBA)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    e = lib.lib.astcenc_amd_decompress_image_device(ctx, d_blocks.data_ptr(), d_blocks.numel(), d_dec.data_ptr(), WIDTH, HEIGHT, 1,
+                                                    A.TYPE_U8, ctypes.byref(swz), stream)
+    assert e == 0, e
+    sums = A.ErrorSums()
+    e = lib.lib.astcenc_amd_compare_images_device(ctx, d_img.data_ptr(), A.TYPE_U8, d_dec.data_ptr(), A.TYPE_U8, WIDTH, HEIGHT, 1,
+                                                  stream, ctypes.byref(sums))
+    assert e == 0, e
+    return round(sums.psnr(), 4)
+
+
 def measured_traffic():
     """HBM bytes per launch from the newest committed PMC summary of this same workload
     (profiles/*/traffic.json, written by tools/gpu_profile.sh); None when there is none."""
@@ -203,7 +219,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_quality:
-            out["quality"] = decoded_psnr(img_host, gpu_blocks)
+            out["quality"] = decoded_psnr(img_host, gpu_blocks) or {}
+            out["quality"]["psnr_db_on_device"] = device_psnr(lib, ctx, d_img, d_out, dev)
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_reference_baseline(img_host, gpu_blocks, blocks_x)
             if base:

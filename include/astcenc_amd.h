@@ -47,6 +47,41 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_volume_device(
 	void* hip_stream,
 	float* kernel_ms);
 
+/* Decompress blocks that are resident in device memory into a device image (dim_z slices of tightly
+ * packed RGBA rows of data_type, back to back).  Same checks, profiles, output types and swizzles as
+ * astcenc_decompress_image (ref: Source/astcenc_entry.cpp:1274-1390); returns when the work on
+ * hip_stream (NULL = the context's own stream) has completed. */
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_decompress_image_device(
+	struct astcenc_context* context,
+	const void* device_blocks, size_t data_len,
+	void* device_image,
+	unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+	enum astcenc_type data_type,
+	const struct astcenc_swizzle* swizzle,
+	void* hip_stream);
+
+/* Error sums of two device-resident images of the same size, the quantities the reference CLI's quality
+ * report is made of (ref: compute_error_metrics, Source/astcenccli_error_metrics.cpp:110-300):
+ *   PSNR (LDR-RGBA)     = 10 log10(4 texels / (squared_error[0] + .. + [3]))
+ *   PSNR (LDR-RGB)      = 10 log10(3 texels / (squared_error[0] + .. + [2]))
+ *   alpha-weighted PSNR = the RGBA form over alpha_scaled_squared_error
+ * U8 texels are compared as value / 255, F16 / F32 texels clamped to 0..65504, exactly as there.  The
+ * HDR-only figures (mPSNR, log RMSE) are not computed. */
+struct astcenc_amd_error_sums {
+	double squared_error[4];               /* per channel, image1 - image2 */
+	double alpha_scaled_squared_error[4];  /* RGB differences scaled by image1's alpha first */
+	double rgb_peak;                       /* largest R, G or B value of image1 */
+	double texels;
+};
+
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_device(
+	struct astcenc_context* context,
+	const void* device_image1, enum astcenc_type type1,
+	const void* device_image2, enum astcenc_type type2,
+	unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+	void* hip_stream,
+	struct astcenc_amd_error_sums* sums);
+
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 

@@ -9,6 +9,7 @@
 #include "wave_block.h"
 #include "wave_decode.h"
 #include "wave_alpha.h"
+#include "wave_metrics.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -143,6 +144,35 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 				decode_block(img, job.host_blocks + (((size_t)bz * img.blocks_y + by) * img.blocks_x + bx) * 16, bx, by, bz, scratch);
 	if (dim_z > 1)
 		for (uint32_t z = 0; z < dim_z; z++) memcpy(job.host_slices[z], volume.data() + z * slice_bytes, slice_bytes);
+	return 0;
+}
+
+int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
+{
+	// "device" memory of the emulator is host memory: one contiguous volume, decode straight into it
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * (job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16);
+	std::vector<void*> slices(dim_z);
+	for (uint32_t z = 0; z < dim_z; z++) slices[z] = static_cast<uint8_t*>(job.device_image) + z * slice_bytes;
+	DecompressJob h;
+	memset(&h, 0, sizeof(h));
+	h.host_blocks = job.device_blocks;
+	h.host_slices = slices.data();
+	h.dim_x = job.dim_x; h.dim_y = job.dim_y; h.dim_z = dim_z; h.data_type = job.data_type;
+	for (int i = 0; i < 4; i++) h.swz[i] = job.swz[i];
+	return backend_decompress(b, h);
+}
+
+int backend_compare(Backend*, const CompareJob& job)
+{
+	for (int k = 0; k < METRIC_SUMS; k++) job.sums[k] = 0.0;
+	for (size_t t = 0; t < job.texels; t++)
+	{
+		float e[8];
+		float m = metric_texel_terms(job.device_a, job.type_a, job.device_b, job.type_b, t, e);
+		for (int k = 0; k < 8; k++) job.sums[k] += (double)e[k];
+		if ((double)m > job.sums[8]) job.sums[8] = (double)m;
+	}
 	return 0;
 }
 
