@@ -86,7 +86,7 @@ int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
 
 /* Alpha-average pre-pass launch (kernel_alpha.hip); radius <= ALPHA_MAX_RADIUS_HOST. */
-constexpr uint32_t ALPHA_MAX_RADIUS_HOST = 8;
+constexpr uint32_t ALPHA_MAX_RADIUS_HOST = 80;
 struct AlphaLaunch {
 	const void* d_image;
 	float* d_averages;

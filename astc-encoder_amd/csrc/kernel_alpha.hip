@@ -24,6 +24,13 @@ int astc_alpha_launch(const AlphaLaunch& a)
 	job.swz_a = a.swz_a; job.radius = a.radius;
 	const uint32_t tiles_x = (a.dim_x + ALPHA_TILE - 1) / ALPHA_TILE, tiles_y = (a.dim_y + ALPHA_TILE - 1) / ALPHA_TILE;
 	const uint32_t pad = ALPHA_TILE + 2 * a.radius + 1;
+	const uint32_t lds_bytes = pad * pad * (uint32_t)sizeof(float);
+	if (lds_bytes > 48u * 1024u)
+	{
+		// large radii: opt in to more than the default dynamic-LDS allowance
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(astc_alpha_averages), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		if (e != hipSuccess) return (int)e;
+	}
 	hipLaunchKernelGGL(astc_alpha_averages, dim3(tiles_x * tiles_y), dim3(64), pad * pad * sizeof(float), static_cast<hipStream_t>(a.stream), job, tiles_x);
 	return (int)hipGetLastError();
 }

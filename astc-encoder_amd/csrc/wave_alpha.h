@@ -17,7 +17,7 @@
 namespace astcd { inline namespace ASTC_VARIANT {
 
 constexpr int ALPHA_TILE = 32;                 // ref: max_blk_size_xy for 2D images
-constexpr int ALPHA_MAX_RADIUS = 8;            // padded tile (32 + 2r + 1)^2 floats of LDS
+constexpr int ALPHA_MAX_RADIUS = 80;           // padded tile (32 + 2r + 1)^2 floats must fit the 160 KiB of LDS
 
 struct AlphaJob {
 	const void* image;        // tightly packed RGBA rows

@@ -34,7 +34,7 @@ def holes(w, h, seed, dtype=np.uint8):
     return f.astype(dtype)
 
 
-@pytest.mark.parametrize("radius", [1, 2, 4, 8])
+@pytest.mark.parametrize("radius", [1, 2, 4, 8, 13, 40, 80])
 @pytest.mark.parametrize("block", [(4, 4), (6, 6), (8, 5), (12, 12)])
 def test_alpha_scale_matches_reference(lib, ref, A, radius, block):
     w, h = 97, 75                                        # several 32x32 regions with ragged edges
@@ -65,5 +65,5 @@ def test_alpha_scale_float_inputs_and_swizzle(lib, ref, A, dtype):
 
 def test_alpha_scale_radius_limit(lib, A):
     err, cfg = lib.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, 0)
-    cfg.a_scale_radius = 9                               # beyond the LDS tile this library supports
+    cfg.a_scale_radius = 81                              # beyond the LDS tile this library supports
     assert lib.context_alloc(cfg, 1)[0] == A.ERR_NOT_IMPLEMENTED

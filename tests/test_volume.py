@@ -147,3 +147,14 @@ def test_volume_argument_checks(lib, A):
     for bad in [(3, 3, 2), (6, 6, 7), (4, 5, 4), (7, 7, 7)]:
         err, _ = lib.config_init(A.PRF_LDR, bad[0], bad[1], bad[2], 60.0, 0)
         assert err == A.ERR_BAD_BLOCK_SIZE, bad
+
+
+def test_config_init_3d_matches_reference(lib, ref, A):
+    """Preset interpolation depends on the texel count of the footprint (ref: astcenc_entry.cpp:538-600)."""
+    for block in FOOTPRINTS_3D:
+        for quality in (0.0, 10.0, 35.0, 60.0, 98.0, 99.5, 100.0):
+            for profile, flags in ((A.PRF_LDR, 0), (A.PRF_HDR, 0), (A.PRF_LDR_SRGB, A.FLG_USE_PERCEPTUAL), (A.PRF_LDR, A.FLG_MAP_NORMAL)):
+                e0, want = ref.config_init(profile, block[0], block[1], block[2], quality, flags)
+                e1, got = lib.config_init(profile, block[0], block[1], block[2], quality, flags)
+                assert e0 == e1 == A.SUCCESS
+                assert want.as_dict() == got.as_dict(), (block, quality, profile, flags)
