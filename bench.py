@@ -148,11 +148,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    # (debug aid for boxes with fewer GPUs than ranks: ASTC_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    #  uses gloo for the barrier / max-time reduction, since RCCL refuses two ranks on one device)
+    share_gpu = os.environ.get("ASTC_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     lib = A.Library(A.LIB_PRODUCT)
     assert lib.backend_name() == "hip:gfx950"
@@ -191,7 +199,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -48,8 +48,8 @@ def emu(built, A):
 
 @pytest.fixture(scope="session")
 def product(built, A):
-    # torch carries its own HIP runtime and must see the device before the library's runtime does
-    # (INTEGRATION.md section 5); tests that keep data in HBM through torch rely on this order
+    # torch ships its own HIP runtime under the soname the library links: imported first, both share that
+    # one runtime; tests that keep data in HBM through torch rely on this order
     import torch
     if torch.cuda.is_available():
         torch.zeros(1, device="cuda:0")
