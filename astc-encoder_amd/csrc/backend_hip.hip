@@ -34,6 +34,10 @@ struct Backend {
 	double* d_sums;               // totals of the image comparison kernel
 };
 
+// The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
+// of a mapped page.
+constexpr size_t ALLOC_SLACK = 4096;
+
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	fprintf(stderr, "astcenc_amd: %s -> %s\n", #expr, hipGetErrorString(e_)); fail; } } while (0)
 
@@ -74,7 +78,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
 	memcpy(full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
 	b->tab_bytes = full.size();
-	HIP_TRY(hipMalloc(&b->d_base, full.size()), { delete b; *status = 1; return nullptr; });
+	HIP_TRY(hipMalloc(&b->d_base, full.size() + ALLOC_SLACK), { delete b; *status = 1; return nullptr; });
 	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
 	b->d_tab = b->d_base + CTX_LAYOUT_BACK;
 	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
@@ -130,7 +134,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			if (b->d_image) (void)hipFree(b->d_image);
 			b->d_image = nullptr; b->image_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
+			HIP_TRY(hipMalloc(&b->d_image, image_bytes + ALLOC_SLACK), return 1);
 			b->image_cap = image_bytes;
 		}
 		for (uint32_t z = 0; z < dim_z; z++)
@@ -143,7 +147,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			if (b->d_out) (void)hipFree(b->d_out);
 			b->d_out = nullptr; b->out_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_out, out_bytes), return 1);
+			HIP_TRY(hipMalloc(&b->d_out, out_bytes + ALLOC_SLACK), return 1);
 			b->out_cap = out_bytes;
 		}
 		d_out = b->d_out;
@@ -169,7 +173,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			if (b->d_alpha) (void)hipFree(b->d_alpha);
 			b->d_alpha = nullptr; b->alpha_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_alpha, need), return 1);
+			HIP_TRY(hipMalloc(&b->d_alpha, need + ALLOC_SLACK), return 1);
 			b->alpha_cap = need;
 		}
 		AlphaLaunch a;
@@ -243,14 +247,14 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	{
 		if (b->d_image) (void)hipFree(b->d_image);
 		b->d_image = nullptr; b->image_cap = 0;
-		HIP_TRY(hipMalloc(&b->d_image, image_bytes), return 1);
+		HIP_TRY(hipMalloc(&b->d_image, image_bytes + ALLOC_SLACK), return 1);
 		b->image_cap = image_bytes;
 	}
 	if (b->out_cap < job.block_bytes)
 	{
 		if (b->d_out) (void)hipFree(b->d_out);
 		b->d_out = nullptr; b->out_cap = 0;
-		HIP_TRY(hipMalloc(&b->d_out, job.block_bytes), return 1);
+		HIP_TRY(hipMalloc(&b->d_out, job.block_bytes + ALLOC_SLACK), return 1);
 		b->out_cap = job.block_bytes;
 	}
 	HIP_TRY(hipMemcpyAsync(b->d_out, job.host_blocks, job.block_bytes, hipMemcpyHostToDevice, b->stream), return 2);

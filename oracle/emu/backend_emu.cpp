@@ -50,7 +50,13 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.root = root;
 	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
 	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
+	// LDS starts out as garbage on the device: poison it (ASTC_EMU_POISON = byte value, or "rand")
 	std::vector<uint8_t> lds(c.L->total + 64, 0xCD);
+	if (const char* poison = getenv("ASTC_EMU_POISON"))
+	{
+		if (poison[0] == 'r') { uint32_t x = 0x2545F491u; for (auto& v : lds) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; v = (uint8_t)(x >> 11); } }
+		else memset(lds.data(), atoi(poison), lds.size());
+	}
 	c.lds = lds.data();
 	c.T = root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
