@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: random footprints (2D and 3D), qualities, profiles, flags,
+swizzles, channel weights, alpha-scale radii, hand-edited tune_* fields and image classes; HIP library vs the
+reference (AVX2 build, all host threads).  usage: gpu_fuzz.py [seconds] [seed]"""
+import os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import astcenc_amd as A, images
+
+BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(SEED)
+gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(A.LIB_REF_AVX2)
+threads = min(64, len(os.sched_getaffinity(0)))
+FOOT2 = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8), (10, 10), (12, 10), (12, 12)]
+FOOT3 = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]
+
+
+def run(lib, cfg, pixels, swz, nthreads):
+    err, ctx = lib.context_alloc(cfg, nthreads)
+    assert err == 0, (lib.path, err)
+    d = pixels.shape[0] if pixels.ndim == 4 else 1
+    h, w = pixels.shape[-3], pixels.shape[-2]
+    bz = max(cfg.block_z, 1)
+    out = np.zeros(((w + cfg.block_x - 1) // cfg.block_x) * ((h + cfg.block_y - 1) // cfg.block_y) * ((d + bz - 1) // bz) * 16, dtype=np.uint8)
+    errs = [0] * nthreads
+    def work(i):
+        errs[i] = lib.compress_raw(ctx, pixels, out, swz, thread_index=i)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    lib.context_free(ctx)
+    assert not any(errs), errs
+    return out
+
+
+cases = blocks = bad = 0
+t0 = time.time()
+while time.time() - t0 < BUDGET:
+    is3d = rng.random() < 0.25
+    block = FOOT3[rng.integers(len(FOOT3))] if is3d else FOOT2[rng.integers(len(FOOT2))] + (1,)
+    quality = float(rng.choice([0.0, 10.0, 60.0, 98.0, 100.0, rng.uniform(0, 100)], p=[0.15, 0.2, 0.3, 0.1, 0.02, 0.23]))
+    hdr = rng.random() < 0.2
+    profile = int(rng.choice([A.PRF_HDR, A.PRF_HDR_RGB_LDR_A])) if hdr else int(rng.choice([A.PRF_LDR, A.PRF_LDR_SRGB]))
+    flags = 0
+    r = rng.random()
+    if r < 0.1: flags |= A.FLG_MAP_NORMAL
+    elif r < 0.2: flags |= A.FLG_MAP_RGBM
+    elif r < 0.3: flags |= A.FLG_USE_PERCEPTUAL
+    if rng.random() < 0.2: flags |= A.FLG_USE_ALPHA_WEIGHT
+    if rng.random() < 0.1 and not hdr: flags |= A.FLG_USE_DECODE_UNORM8
+    # image
+    if is3d:
+        d, h, w = int(rng.integers(1, 3 * block[2] + 2)), int(rng.integers(2, 4 * block[1] + 2)), int(rng.integers(2, 5 * block[0] + 2))
+        pixels = images.volume(str(rng.choice(["noise", "grad", "edges", "alpha", "flat"])), d, h, w, seed=int(rng.integers(1 << 30)))
+    else:
+        big = quality < 80 and rng.random() < 0.5
+        h, w = int(rng.integers(1, 160 if big else 60)), int(rng.integers(1, 200 if big else 70))
+        pixels = images.ALL[str(rng.choice(list(images.ALL)))](w, h).copy()
+        if rng.random() < 0.3:
+            pixels[: h // 2, : w // 2, 3] = 0
+    if hdr or rng.random() < 0.15:
+        f = pixels.astype(np.float32) / 255.0
+        if hdr:
+            f[..., :3] *= np.exp2(rng.integers(-3, 6, size=f.shape[:-1] + (1,))).astype(np.float32)
+        pixels = f.astype(np.float16 if rng.random() < 0.7 else np.float32)
+    pixels = np.ascontiguousarray(pixels)
+    swz = A.SWZ_RGBA if rng.random() < 0.7 else tuple(int(v) for v in rng.integers(0, 6, 4))
+    if flags & A.FLG_MAP_NORMAL:
+        swz = (A.SWZ_R, A.SWZ_R, A.SWZ_R, A.SWZ_G)
+    errc, cfg = ref.config_init(profile, block[0], block[1], block[2], quality, flags)
+    if errc:
+        continue
+    if rng.random() < 0.3:
+        cfg.cw_r_weight, cfg.cw_g_weight, cfg.cw_b_weight, cfg.cw_a_weight = [float(v) for v in rng.choice([0.0, 0.25, 1.0, 2.0, 10.0], 4)]
+        if cfg.cw_r_weight + cfg.cw_g_weight + cfg.cw_b_weight + cfg.cw_a_weight == 0:
+            cfg.cw_g_weight = 1.0
+    if rng.random() < 0.25:
+        cfg.tune_partition_count_limit = int(rng.integers(1, 5))
+        cfg.tune_candidate_limit = int(rng.integers(1, 9))
+        cfg.tune_refinement_limit = int(rng.integers(1, 5))
+        cfg.tune_2partition_index_limit = int(rng.integers(1, 200))
+        cfg.tune_3partition_index_limit = int(rng.integers(1, 120))
+        cfg.tune_4partition_index_limit = int(rng.integers(1, 80))
+        cfg.tune_block_mode_limit = int(rng.integers(1, 101))
+        cfg.tune_2partitioning_candidate_limit = int(rng.integers(1, 5))
+        cfg.tune_3partitioning_candidate_limit = int(rng.integers(1, 5))
+        cfg.tune_4partitioning_candidate_limit = int(rng.integers(1, 5))
+        cfg.tune_db_limit = float(rng.choice([0.0, 30.0, 45.0, 200.0]))
+        cfg.tune_2plane_early_out_limit_correlation = float(rng.choice([0.5, 0.8, 0.99, 1.0]))
+        cfg.tune_search_mode0_enable = float(rng.choice([0.0, 1.0]))
+    if not is3d and pixels.ndim == 3 and rng.random() < 0.15:
+        cfg.a_scale_radius = int(rng.integers(1, 12))
+    want = run(ref, cfg, pixels, swz, threads)
+    got = run(gpu, cfg, pixels, swz, 1)
+    n = int((want.reshape(-1, 16) != got.reshape(-1, 16)).any(axis=1).sum())
+    cases += 1; blocks += want.size // 16
+    if n:
+        bad += 1
+        print("MISMATCH case %d: block %s q %.2f profile %d flags %#x swz %s shape %s %s: %d of %d blocks; cfg %s" %
+              (cases, block, quality, profile, flags, swz, pixels.shape, pixels.dtype, n, want.size // 16, cfg.as_dict()), flush=True)
+print("fuzz seed %d: %d cases, %d blocks, %d mismatching cases, %.0f s" % (SEED, cases, blocks, bad, time.time() - t0))
