@@ -25,7 +25,8 @@ struct Backend {
 	bool hdr;
 	TableRoot root;
 	hipStream_t stream;
-	hipEvent_t ev0, ev1;
+	hipStream_t copy_stream;      // PCIe traffic of the banded host-pointer path
+	hipEvent_t ev0, ev1, ev_copy[2], ev_band;
 	// staging for the host-pointer API
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
@@ -82,6 +83,10 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
 	b->d_tab = b->d_base + CTX_LAYOUT_BACK;
 	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
+	HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking), { *status = 2; return nullptr; });
+	HIP_TRY(hipEventCreateWithFlags(&b->ev_copy[0], hipEventDisableTiming), { *status = 2; return nullptr; });
+	HIP_TRY(hipEventCreateWithFlags(&b->ev_copy[1], hipEventDisableTiming), { *status = 2; return nullptr; });
+	HIP_TRY(hipEventCreateWithFlags(&b->ev_band, hipEventDisableTiming), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
 	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
 #if defined(ASTC_PROFILE)
@@ -101,6 +106,10 @@ void backend_destroy(Backend* b)
 	if (b->d_out) (void)hipFree(b->d_out);
 	if (b->d_alpha) (void)hipFree(b->d_alpha);
 	if (b->d_sums) (void)hipFree(b->d_sums);
+	(void)hipEventDestroy(b->ev_copy[0]);
+	(void)hipEventDestroy(b->ev_copy[1]);
+	(void)hipEventDestroy(b->ev_band);
+	(void)hipStreamDestroy(b->copy_stream);
 	(void)hipEventDestroy(b->ev0);
 	(void)hipEventDestroy(b->ev1);
 	(void)hipStreamDestroy(b->stream);
@@ -137,9 +146,17 @@ int backend_compress(Backend* b, const CompressJob& job)
 			HIP_TRY(hipMalloc(&b->d_image, image_bytes + ALLOC_SLACK), return 1);
 			b->image_cap = image_bytes;
 		}
+		d_image = b->d_image;
+	}
+	// Host-pointer calls on a plain 2D image are pipelined by bands of block rows: band k+1 travels over
+	// PCIe on the copy stream while band k is being compressed, and band k's blocks travel back while band
+	// k+1 runs (a block only reads texel rows of its own band).  The alpha-scale pre-pass and volumes need
+	// the whole image first.
+	const bool banded = job.host_slices && job.host_out && dim_z == 1 && job.a_scale_radius == 0;
+	if (job.host_slices && !banded)
+	{
 		for (uint32_t z = 0; z < dim_z; z++)
 			HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(b->d_image) + z * slice_bytes, job.host_slices[z], slice_bytes, hipMemcpyHostToDevice, stream), return 2);
-		d_image = b->d_image;
 	}
 	if (job.host_out)
 	{
@@ -187,17 +204,51 @@ int backend_compress(Backend* b, const CompressJob& job)
 
 	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is
 	// still tens of thousands of workgroups, far more than the 256 CUs need to stay full.
-	const size_t chunk = (job.progress || job.host_slices) ? (size_t)1 << 18 : nblocks;
+	size_t chunk = (job.progress || job.host_slices) ? (size_t)1 << 18 : nblocks;
+	if (banded)
+	{
+		// whole block rows per band, at least four bands when the image has that many block rows
+		size_t rows = chunk / blocks_x;
+		if (rows * 4 > blocks_y) rows = (blocks_y + 3) / 4;
+		if (rows < 1) rows = 1;
+		chunk = rows * blocks_x;
+	}
+	const size_t row_bytes = (size_t)job.dim_x * texel_bytes;
+	auto upload_band = [&](size_t band_first, size_t band_blocks) -> int {
+		const size_t y0 = (band_first / blocks_x) * bsy;
+		size_t y1 = ((band_first + band_blocks) / blocks_x) * bsy;
+		if (y1 > job.dim_y) y1 = job.dim_y;
+		HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(b->d_image) + y0 * row_bytes, static_cast<const uint8_t*>(job.host_slices[0]) + y0 * row_bytes,
+		                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, b->copy_stream), return 2);
+		HIP_TRY(hipEventRecord(b->ev_copy[(band_first / chunk) & 1], b->copy_stream), return 2);
+		return 0;
+	};
 	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev0, stream), return 2);
 	for (size_t first = 0; first < nblocks; first += chunk)
 	{
 		if (job.cancel_flag && *job.cancel_flag) break;
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
+		if (banded)
+		{
+			// band 0 first; from then on the next band is queued before this band's kernel, so that it
+			// crosses PCIe while the kernel runs (and ahead of this band's results on the copy stream)
+			if (first == 0 && upload_band(0, n) != 0) return 2;
+			const size_t next = first + n;
+			if (next < nblocks && upload_band(next, nblocks - next < chunk ? nblocks - next : chunk) != 0) return 2;
+			HIP_TRY(hipStreamWaitEvent(stream, b->ev_copy[(first / chunk) & 1], 0), return 2);
+		}
 		KernelLaunch k;
 		k.d_tab = b->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
 		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = b->d_prof;
 		int lrc = b->hdr ? astc_kernel_launch_hdr(k) : astc_kernel_launch_ldr(k);
 		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }
+		if (banded)
+		{
+			// this band's blocks go home on the copy stream once its kernel is done
+			HIP_TRY(hipEventRecord(b->ev_band, stream), return 2);
+			HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_band, 0), return 2);
+			HIP_TRY(hipMemcpyAsync(job.host_out + first * 16, d_out + first * 16, n * 16, hipMemcpyDeviceToHost, b->copy_stream), return 2);
+		}
 		if (job.progress)
 		{
 			HIP_TRY(hipStreamSynchronize(stream), return 2);
@@ -206,11 +257,12 @@ int backend_compress(Backend* b, const CompressJob& job)
 	}
 	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev1, stream), return 2);
 
-	if (job.host_out)
+	if (job.host_out && !banded)
 	{
 		HIP_TRY(hipMemcpyAsync(job.host_out, d_out, out_bytes, hipMemcpyDeviceToHost, stream), return 2);
 	}
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
+	if (banded) HIP_TRY(hipStreamSynchronize(b->copy_stream), return 2);
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
 #if defined(ASTC_PROFILE)
 	{
