@@ -388,8 +388,7 @@ WV_FN int unorm16_to_sf16(int p)
 {
 	if (p == 0xFFFF) return 0x3C00;
 	if (p < 4) return p << 8;
-	int lz = 0;
-	while (!((p << lz) & 0x8000)) lz++;          // leading zeros within 16 bits
+	const int lz = __builtin_clz((unsigned)p) - 16;   // leading zeros within 16 bits (4 <= p < 0xFFFF here)
 	int v = (p << (lz + 1)) & 0xFFFF;
 	v >>= 6;
 	return v | ((14 - lz) << 10);
@@ -410,32 +409,34 @@ WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, uint32_t 
 	const size_t at = (((size_t)z * img.dim_y + y) * img.dim_x + x) * 4;
 	if (img.data_type == 0)
 	{
-		uint8_t* o = static_cast<uint8_t*>(img.data) + at;
-		if (r != r)
+		// one 32-bit store per texel (the image base is at least 4-byte aligned, rows are tightly packed)
+		uint32_t px = 0xFFFF00FFu;                                       // error colour: magenta, opaque
+		if (!(r != r))
 		{
-			o[0] = 0xFF; o[1] = 0x00; o[2] = 0xFF; o[3] = 0xFF;      // error colour
-			return;
-		}
-		for (int k = 0; k < 4; k++)
-		{
-			uint32_t sw = img.swz[k];
-			int v;
-			if (sw == 4) v = 0;
-			else if (sw == 5) v = 255;
-			else
+			px = 0;
+			for (int k = 0; k < 4; k++)
 			{
-				float f = src[sw];
-				if (sw == 6) f = f < 1.0f ? f : 1.0f;                    // min(z, 1), z is never negative
-				else f = v_clampzo(f);
-				v = (int)(f * 255.0f + 0.5f);
+				uint32_t sw = img.swz[k];
+				int v;
+				if (sw == 4) v = 0;
+				else if (sw == 5) v = 255;
+				else
+				{
+					float f = src[sw];
+					if (sw == 6) f = f < 1.0f ? f : 1.0f;                    // min(z, 1), z is never negative
+					else f = v_clampzo(f);
+					v = (int)(f * 255.0f + 0.5f);
+				}
+				px |= ((uint32_t)v & 0xFFu) << (8 * k);
 			}
-			o[k] = (uint8_t)v;
 		}
+		__builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
 	}
 	else if (img.data_type == 1)
 	{
-		uint16_t* o = static_cast<uint16_t*>(img.data) + at;
-		for (int k = 0; k < 4; k++) o[k] = float_to_half(src[img.swz[k]]);
+		uint16_t h4[4];
+		for (int k = 0; k < 4; k++) h4[k] = float_to_half(src[img.swz[k]]);
+		__builtin_memcpy(static_cast<uint16_t*>(img.data) + at, h4, 8);
 	}
 	else
 	{

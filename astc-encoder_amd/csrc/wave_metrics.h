@@ -16,15 +16,19 @@ WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, 
 {
 	if (data_type == 0)
 	{
-		const uint8_t* p = static_cast<const uint8_t*>(img) + texel * 4;
-		for (int k = 0; k < 4; k++) c[k] = (float)p[k] / 255.0f;
+		uint32_t px;                                   // one 32-bit load per texel
+		__builtin_memcpy(&px, static_cast<const uint8_t*>(img) + texel * 4, 4);
+		for (int k = 0; k < 4; k++) c[k] = (float)((px >> (8 * k)) & 0xFFu) / 255.0f;
 	}
 	else
 	{
+		uint16_t h4[4] = { 0, 0, 0, 0 };
+		float f4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+		if (data_type == 1) __builtin_memcpy(h4, static_cast<const uint16_t*>(img) + texel * 4, 8);
+		else __builtin_memcpy(f4, static_cast<const float*>(img) + texel * 4, 16);
 		for (int k = 0; k < 4; k++)
 		{
-			float v = data_type == 1 ? half_to_float(static_cast<const uint16_t*>(img)[texel * 4 + k])
-			                         : static_cast<const float*>(img)[texel * 4 + k];
+			float v = data_type == 1 ? half_to_float(h4[k]) : f4[k];
 			v = v > 0.0f ? v : 0.0f;               // clamp(0, 65504, v), NaN -> 0 as the reference's max/min pair
 			v = v < 65504.0f ? v : 65504.0f;
 			c[k] = v;
