@@ -105,7 +105,8 @@ struct DecodeLaunch {
 };
 int astc_decode_launch(const DecodeLaunch& d);
 
-/* Image comparison launch (kernel_metrics.hip); d_sums = 10 zeroed doubles in device memory. */
+/* Image comparison launch (kernel_metrics.hip); d_sums = astc_compare_scratch_doubles() doubles of device memory,
+ * the totals arrive in the first ten. */
 struct CompareLaunch {
 	const void* d_a; uint32_t type_a;
 	const void* d_b; uint32_t type_b;
@@ -114,5 +115,6 @@ struct CompareLaunch {
 	void* stream;
 };
 int astc_compare_launch(const CompareLaunch& c);
+size_t astc_compare_scratch_doubles();
 
 } // namespace astcd

@@ -349,8 +349,7 @@ int backend_compare(Backend* b, const CompareJob& job)
 {
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
-	if (!b->d_sums) HIP_TRY(hipMalloc(&b->d_sums, 16 * sizeof(double)), return 1);
-	HIP_TRY(hipMemsetAsync(b->d_sums, 0, 16 * sizeof(double), stream), return 2);
+	if (!b->d_sums) HIP_TRY(hipMalloc(&b->d_sums, astc_compare_scratch_doubles() * sizeof(double)), return 1);
 	CompareLaunch c;
 	c.d_a = job.device_a; c.type_a = job.type_a; c.d_b = job.device_b; c.type_b = job.type_b;
 	c.texels = job.texels; c.d_sums = b->d_sums; c.stream = stream;

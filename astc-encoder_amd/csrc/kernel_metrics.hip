@@ -2,7 +2,8 @@
 // Image comparison kernel: squared-error sums of two images resident in HBM, for PSNR without a host
 // round trip (ref: compute_error_metrics, Source/astcenccli_error_metrics.cpp:110).  Streaming and
 // HBM-bound: every lane walks texels with a grid stride (coalesced 4 / 8 / 16-byte texel loads), keeps
-// fp64 partial sums, the wave folds them with DPP shuffles and lane 0 adds them to the totals.
+// fp64 partial sums, the workgroup folds them in a fixed order and a one-workgroup second pass adds the
+// workgroups' partials in index order (no atomics: the totals are reproducible).
 #define ASTC_VARIANT v_metrics
 #include "backend.h"
 #include "wave_metrics.h"
@@ -10,10 +11,19 @@
 
 namespace astcd {
 
+constexpr uint32_t COMPARE_MAX_GROUPS = 2048;
+
+/* Pass 1: every workgroup reduces its texels to nine fp64 partials (fixed order inside the group: lane
+ * shuffles, then wave 0 adds the four waves' results) and writes them to its own slot -- no atomics, so
+ * the totals do not depend on scheduling. */
 __global__ void __launch_bounds__(256)
 astc_compare_images(const void* __restrict__ a, uint32_t type_a, const void* __restrict__ b, uint32_t type_b,
-                    size_t texels, double* __restrict__ sums)
+                    size_t texels, double* __restrict__ partials)
 {
+	__shared__ float unorm8[256];
+	__shared__ double wave_sums[4][9];
+	unorm8[threadIdx.x] = (float)threadIdx.x / 255.0f;      // blockDim.x == 256
+	__syncthreads();
 	double acc[8];
 	for (int k = 0; k < 8; k++) acc[k] = 0.0;
 	float peak = 0.0f;
@@ -21,7 +31,7 @@ astc_compare_images(const void* __restrict__ a, uint32_t type_a, const void* __r
 	for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < texels; t += stride)
 	{
 		float e[8];
-		float m = metric_texel_terms(a, type_a, b, type_b, t, e);
+		float m = metric_texel_terms(a, type_a, b, type_b, t, unorm8, e);
 		peak = m > peak ? m : peak;
 		for (int k = 0; k < 8; k++) acc[k] += (double)e[k];
 	}
@@ -31,22 +41,50 @@ astc_compare_images(const void* __restrict__ a, uint32_t type_a, const void* __r
 		float o = __shfl_down(peak, off);
 		peak = o > peak ? o : peak;
 	}
+	const int wave = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 0)
 	{
-		for (int k = 0; k < 8; k++) atomicAdd(&sums[k], acc[k]);
-		// the peak is never negative, so its bit pattern orders like the value
-		atomicMax(reinterpret_cast<unsigned long long*>(&sums[8]), (unsigned long long)__double_as_longlong((double)peak));
+		for (int k = 0; k < 8; k++) wave_sums[wave][k] = acc[k];
+		wave_sums[wave][8] = (double)peak;
 	}
+	__syncthreads();
+	if (threadIdx.x < 9)
+	{
+		const int k = threadIdx.x;
+		double v = wave_sums[0][k];
+		for (int w = 1; w < 4; w++) v = k < 8 ? v + wave_sums[w][k] : (wave_sums[w][k] > v ? wave_sums[w][k] : v);
+		partials[(size_t)blockIdx.x * 16 + k] = v;
+	}
+}
+
+/* Pass 2: one thread per quantity adds the workgroups' partials in index order. */
+__global__ void __launch_bounds__(64)
+astc_compare_finish(const double* __restrict__ partials, uint32_t groups, double* __restrict__ sums)
+{
+	const int k = threadIdx.x;
+	if (k >= 9) return;
+	double v = partials[k];
+	for (uint32_t g = 1; g < groups; g++)
+	{
+		const double p = partials[(size_t)g * 16 + k];
+		v = k < 8 ? v + p : (p > v ? p : v);
+	}
+	sums[k] = v;
 }
 
 int astc_compare_launch(const CompareLaunch& c)
 {
 	size_t groups = (c.texels + 255) / 256;
-	if (groups > 256 * 16) groups = 256 * 16;          // 16 workgroups per CU is plenty for a streaming pass
+	if (groups > COMPARE_MAX_GROUPS) groups = COMPARE_MAX_GROUPS;     // 8 workgroups of 256 per CU: plenty for a streaming pass
 	if (groups == 0) groups = 1;
+	double* partials = c.d_sums + 16;
 	hipLaunchKernelGGL(astc_compare_images, dim3((uint32_t)groups), dim3(256), 0, static_cast<hipStream_t>(c.stream),
-	                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, c.d_sums);
+	                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, partials);
+	hipLaunchKernelGGL(astc_compare_finish, dim3(1), dim3(64), 0, static_cast<hipStream_t>(c.stream), partials, (uint32_t)groups, c.d_sums);
 	return (int)hipGetLastError();
 }
+
+/* Doubles the caller must provide at d_sums: the ten totals (padded to 16) followed by the per-workgroup partials. */
+size_t astc_compare_scratch_doubles() { return 16 + (size_t)COMPARE_MAX_GROUPS * 16; }
 
 } // namespace astcd

@@ -12,13 +12,19 @@ namespace astcd { inline namespace ASTC_VARIANT {
 
 constexpr int METRIC_SUMS = 10;   // [0..3] squared error rgba, [4..7] alpha-scaled squared error rgba, [8] rgb peak, [9] unused
 
-WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, float c[4])
+/* `unorm8` is an optional table of (float)i / 255.0f, i = 0..255 (the same correctly rounded quotients,
+ * computed once per workgroup instead of eight times per texel). */
+WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, const float* unorm8, float c[4])
 {
 	if (data_type == 0)
 	{
 		uint32_t px;                                   // one 32-bit load per texel
 		__builtin_memcpy(&px, static_cast<const uint8_t*>(img) + texel * 4, 4);
-		for (int k = 0; k < 4; k++) c[k] = (float)((px >> (8 * k)) & 0xFFu) / 255.0f;
+		for (int k = 0; k < 4; k++)
+		{
+			const uint32_t v = (px >> (8 * k)) & 0xFFu;
+			c[k] = unorm8 ? unorm8[v] : (float)v / 255.0f;
+		}
 	}
 	else
 	{
@@ -38,11 +44,11 @@ WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, 
 
 /* Error terms of one texel: e[0..3] squared difference, e[4..7] the same with RGB differences scaled by
  * the first image's alpha; returns max(r, g, b) of the first image. */
-WV_FN float metric_texel_terms(const void* a, uint32_t type_a, const void* b, uint32_t type_b, size_t texel, float e[8])
+WV_FN float metric_texel_terms(const void* a, uint32_t type_a, const void* b, uint32_t type_b, size_t texel, const float* unorm8, float e[8])
 {
 	float c1[4], c2[4];
-	metric_load_texel(a, texel, type_a, c1);
-	metric_load_texel(b, texel, type_b, c2);
+	metric_load_texel(a, texel, type_a, unorm8, c1);
+	metric_load_texel(b, texel, type_b, unorm8, c2);
 	for (int k = 0; k < 4; k++)
 	{
 		float d = c1[k] - c2[k];

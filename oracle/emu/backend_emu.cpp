@@ -175,7 +175,7 @@ int backend_compare(Backend*, const CompareJob& job)
 	for (size_t t = 0; t < job.texels; t++)
 	{
 		float e[8];
-		float m = metric_texel_terms(job.device_a, job.type_a, job.device_b, job.type_b, t, e);
+		float m = metric_texel_terms(job.device_a, job.type_a, job.device_b, job.type_b, t, nullptr, e);
 		for (int k = 0; k < 8; k++) job.sums[k] += (double)e[k];
 		if ((double)m > job.sums[8]) job.sums[8] = (double)m;
 	}
