@@ -566,7 +566,15 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	WV_SYNC();
 
 	bool adjustments = false;
-	const f4 error_weight = load4(blk.cw);
+	// wave-uniform values read from LDS: keep them in scalar registers
+	auto uniform4 = [](f4 v) {
+#if WV_DEVICE
+		return mk4(wv_uniform(v.x), wv_uniform(v.y), wv_uniform(v.z), wv_uniform(v.w));
+#else
+		return v;
+#endif
+	};
+	const f4 error_weight = uniform4(load4(blk.cw));
 
 	for (int pl = 0; pl <= max_plane; pl++)
 	{
@@ -658,8 +666,8 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 			// with one partition the endpoint base / step are the same for every texel
 			const bool one_partition = pc == 1;
-			const f4 color_offset_1 = load4(&tr.fbox[4]);
-			const f4 color_base_1 = load4(&tr.fbox[0]);
+			const f4 color_offset_1 = uniform4(load4(&tr.fbox[4]));
+			const f4 color_base_1 = uniform4(load4(&tr.fbox[0]));
 
 			// The reference visits the weights one by one; a weight's decision only depends on earlier
 			// weights that share a texel with it, so the host-built schedule (DecimationInfo) groups
