@@ -258,83 +258,19 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 }
 
 // Out-of-line pieces of the refinement loop (see the note on stage functions below): each one
-// rebuilds the views it needs from LDS.
-/* One refinement step's front half: least-squares endpoints for the current weights, then pack them
- * (one lane per partition; ref: :542-555, :925-931).  With to_scratch the re-fit is skipped and the
- * formats / values go to the retry buffer of the matched-format case instead of the working block. */
-WV_OUT void refine_recompute_pack(bool dual, int partition_count, int partition_packed, int decimation_mode, int plane2_component,
-                                  int candidate, int quant_level, bool to_scratch)
+// rebuilds the views it needs from LDS.  refine_candidates() itself is scalar control flow around
+// calls: it keeps no vector value alive across a call, so it has no callee-saved registers to spill.
+
+/* The quantized weights of the chosen candidates (the reference keeps them for every block mode,
+ * compress_symbolic.cpp:469-478); after this the search-phase LDS (ideal weights, angular bounds, mode
+ * records) is dead and the refine-phase tables reuse it. */
+WV_OUT void refine_quantize_candidates(bool dual)
 {
 	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
-	decimation_mode = wv_uniform(decimation_mode); plane2_component = wv_uniform(plane2_component);
-	candidate = wv_uniform(candidate); quant_level = wv_uniform(quant_level); to_scratch = wv_uniform(to_scratch);
+	dual = wv_uniform(dual);
 	TrialInfo& tr = c.tr();
-	Scb& workscb = c.wscb();
-
-	if (!to_scratch)
-	{
-		const DecView di = dec_view_lds(c, decimation_mode);
-		PROF_SCOPE(c, PS_RECOMPUTE);
-		// (the single-partition case is by far the most frequent: give it its own specialised copy)
-		if (dual) recompute_ideal_colors_2planes(c, di, plane2_component);
-		else if (partition_count == 1) recompute_ideal_colors_1plane(c, part_view_lds(c, 1, 0), di);
-		else recompute_ideal_colors_1plane(c, part_view_lds(c, partition_count, partition_packed), di);
-	}
-
-	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8] scratch copy for the matched-format retry
-	uint8_t* fmts = colorvals + 32;                                   // [4]
-	PROF_SCOPE(c, PS_PACK);
-	WV_FOR(j, partition_count)
-	{
-		uint8_t* vals = to_scratch ? colorvals + j * 8 : workscb.color_values[j];
-		uint8_t f = (uint8_t)pack_color_endpoints(
-		    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
-		    tr.cand_formats[candidate][j], vals, quant_level);
-		if (to_scratch) fmts[j] = f; else workscb.color_formats[j] = f;
-	}
-	WV_SYNC();
-}
-
-WV_OUT float refine_difference(int partition_count, int partition_packed, int decimation_mode)
-{
-	const Ctx c = ctx_make();
-	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
-	PROF_SCOPE(c, PS_DIFF);
-	if (partition_count == 1) return compute_symbolic_block_difference(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode));
-	return compute_symbolic_block_difference(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode));
-}
-
-WV_OUT bool refine_realign(int partition_count, int partition_packed, int decimation_mode)
-{
-	const Ctx c = ctx_make();
-	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
-	const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
-	PROF_SCOPE(c, PS_REALIGN);
-	if (partition_count == 1) return realign_weights(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode), qat);
-	return realign_weights(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode), qat);
-}
-
-/* Shared tail of both trials: refine the chosen candidates. Returns best error seen in this trial. */
-WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_packed,
-                              int plane2_component, float tune_errorval_threshold)
-{
-	TrialInfo& tr = c.tr();
-	Scb& scb = c.scb();
-	Scb& workscb = c.wscb();
-	const bool dual = plane2_component >= 0;
-	const int T = c.T;
-
-	float best_errorval_in_mode = ERROR_CALC_DEFAULT;
-	// (values read from LDS look lane-variant to the compiler; wv_uniform() puts them in SGPRs so that the
-	//  control flow and the table addressing below run on the scalar unit)
-	float best_errorval_in_scb = wv_uniform(scb.errorval);
 	const int candidate_count = wv_uniform(tr.cand_count);
-
-	// The quantized weights of the chosen candidates are produced now (the reference keeps them
-	// for every block mode, compress_symbolic.cpp:469-478); after this the search-phase LDS
-	// (ideal weights, angular bounds, mode records) is dead and the refine-phase tables reuse it.
-	{ PROF_SCOPE(c, PS_Y0);
+	PROF_SCOPE(c, PS_Y0);
 	// quantization parameters of each (candidate, plane) once, then one lane per (candidate, plane, weight)
 	const int plane_shift = dual ? 1 : 0;
 	ModeQ* cq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni);          // [candidate][plane]; the scoring scratch is idle now
@@ -372,8 +308,207 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 		const bool mask = ((float)ixli + (float)ixhi) < (128.0f * ix);
 		c.candw(cp >> plane_shift)[(cp & plane_shift) * PLANE2_OFFSET + i] = (uint8_t)(mask ? ixhi : ixli);
 	}
-	WV_SYNC(); }
+	WV_SYNC();
+}
+
+/* Per candidate: stage what the refinement loop reads in serial, latency-bound code into LDS (grid tables
+ * and quant transfer table only when they differ from what is there), set up the working endpoints and
+ * weights (ref: :497-540). */
+WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_component, int candidate,
+                                   int stage_dm, int stage_wq, int color_quant_level)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); plane2_component = wv_uniform(plane2_component);
+	candidate = wv_uniform(candidate); stage_dm = wv_uniform(stage_dm); stage_wq = wv_uniform(stage_wq);
+	color_quant_level = wv_uniform(color_quant_level);
+	TrialInfo& tr = c.tr();
+	Scb& workscb = c.wscb();
+	{
+		PROF_SCOPE(c, PS_X0);
+		if (stage_dm >= 0)
+		{
+			const DecimationInfo& dinfo = c.dec_info(stage_dm);
+			stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
+		}
+		if (stage_wq >= 0)
+		{
+			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(stage_wq)), (int)(sizeof(QuantXfer) / 4));
+		}
+		stage_color_rows(c, color_quant_level);      // ends with a sync
+	}
+
+	// workep = ideal endpoints (merged across planes for dual plane); quantized weights come from
+	// refine_quantize_candidates()
+	PROF_SCOPE(c, PS_Y1);
+	WV_FOR(k, partition_count * 4)
+	{
+		int p = k >> 2, ch = k & 3;
+		int plane = (dual && ch == plane2_component) ? 1 : 0;
+		tr.wep0[p][ch] = tr.ep0[plane][p][ch];
+		tr.wep1[p][ch] = tr.ep1[plane][p][ch];
+	}
+	{
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(c.candw(candidate));
+		uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
+		WV_FOR(k, 16) { dst[k] = src[k]; }
+	}
+	WV_SYNC();
+}
+
+/* One refinement step's front half, part 1: least-squares endpoints for the current weights
+ * (ref: :542-555, :925-931).  Three out-of-line variants -- the single-partition case is by far the most
+ * frequent and should not carry the register needs of the other two. */
+WV_OUT void refine_recompute_1partition(int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	decimation_mode = wv_uniform(decimation_mode);
+	PROF_SCOPE(c, PS_RECOMPUTE);
+	recompute_ideal_colors_1plane(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode));
+}
+WV_OUT void refine_recompute_partitions(int partition_count, int partition_packed, int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
+	PROF_SCOPE(c, PS_RECOMPUTE);
+	recompute_ideal_colors_1plane(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode));
+}
+WV_OUT void refine_recompute_2planes(int decimation_mode, int plane2_component)
+{
+	const Ctx c = ctx_make();
+	decimation_mode = wv_uniform(decimation_mode); plane2_component = wv_uniform(plane2_component);
+	PROF_SCOPE(c, PS_RECOMPUTE);
+	recompute_ideal_colors_2planes(c, dec_view_lds(c, decimation_mode), plane2_component);
+}
+
+/* Part 2: pack the endpoints (one lane per partition), retry at the higher quant level that matched
+ * formats allow (ref: :561-598), and fill in the header of the working block. */
+WV_OUT void refine_pack(bool dual, int partition_count, int partition_packed, int plane2_component,
+                        int candidate, int quant_level, int quant_level_mod, int block_mode_packed)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component);
+	candidate = wv_uniform(candidate); quant_level = wv_uniform(quant_level); quant_level_mod = wv_uniform(quant_level_mod);
+	block_mode_packed = wv_uniform(block_mode_packed);
+	TrialInfo& tr = c.tr();
+	Scb& workscb = c.wscb();
+
+	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8] scratch copy for the matched-format retry
+	uint8_t* fmts = colorvals + 32;                                   // [4]
+	int formats_matched = 0;
+	{ PROF_SCOPE(c, PS_PACK);
+	// pass 0 packs into the working block; pass 1 (only when every partition got the same format and a
+	// higher quant level is then possible) packs again at that level into the retry buffer
+	for (int pass = 0; pass < 2; pass++)
+	{
+		const bool to_scratch = pass == 1;
+		const int q = to_scratch ? quant_level_mod : quant_level;
+		WV_FOR(j, partition_count)
+		{
+			uint8_t* vals = to_scratch ? colorvals + j * 8 : workscb.color_values[j];
+			uint8_t f = (uint8_t)pack_color_endpoints(
+			    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
+			    tr.cand_formats[candidate][j], vals, q);
+			if (to_scratch) fmts[j] = f; else workscb.color_formats[j] = f;
+		}
+		WV_SYNC();
+		if (pass == 1 || dual || partition_count < 2 || quant_level == quant_level_mod) break;
+		bool all_same = true;
+		for (int j = 1; j < partition_count; j++) all_same = all_same && workscb.color_formats[j] == workscb.color_formats[0];
+		if (!wv_uniform(all_same)) break;
+	}
+	}
+
+	PROF_SCOPE(c, PS_Y2);
+	if (!dual && partition_count >= 2 && quant_level != quant_level_mod)
+	{
+		bool all_same = true;
+		for (int j = 1; j < partition_count; j++) all_same = all_same && workscb.color_formats[j] == workscb.color_formats[0];
+		if (wv_uniform(all_same))
+		{
+			bool all_same_mod = true;
+			for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
+			if (wv_uniform(all_same_mod))
+			{
+				formats_matched = 1;
+				WV_FOR(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
+				WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; }
+			}
+			WV_SYNC();
+		}
+	}
+	WV_ONE
+	{
+		workscb.color_formats_matched = (uint8_t)formats_matched;
+		workscb.partition_count = (uint8_t)partition_count;
+		workscb.partition_index = (uint16_t)partition_packed;
+		workscb.plane2_component = (int8_t)plane2_component;
+		workscb.quant_mode = (uint8_t)(formats_matched ? quant_level_mod : quant_level);
+		workscb.block_mode = (uint16_t)block_mode_packed;
+		workscb.block_type = SYM_BTYPE_NONCONST;
+	}
+	WV_SYNC();
+}
+
+WV_OUT float refine_difference(int partition_count, int partition_packed, int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
+	float errorval;
+	{
+		PROF_SCOPE(c, PS_DIFF);
+		if (partition_count == 1) errorval = compute_symbolic_block_difference(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode));
+		else errorval = compute_symbolic_block_difference(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode));
+	}
+	errorval = wv_uniform(errorval);
+	if (errorval == -ERROR_CALC_DEFAULT)
+	{
+		// (RGBM blocks whose M channel decodes to zero: ref :612-616)
+		errorval = -errorval;
+		WV_ONE { c.wscb().block_type = SYM_BTYPE_ERROR; }
+		WV_SYNC();
+	}
+	return errorval;
+}
+
+WV_OUT bool refine_realign(int partition_count, int partition_packed, int decimation_mode)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
+	const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
+	PROF_SCOPE(c, PS_REALIGN);
+	if (partition_count == 1) return realign_weights(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode), qat);
+	return realign_weights(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode), qat);
+}
+
+/* The working block becomes the best block so far (ref: :633-636, :676-679). */
+WV_OUT void refine_accept(float errorval)
+{
+	const Ctx c = ctx_make();
+	errorval = wv_uniform(errorval);
+	WV_SYNC();
+	WV_ONE { c.wscb().errorval = errorval; }
+	WV_SYNC();
+	copy_scb(c.scb(), c.wscb());
+	WV_SYNC();
+}
+
+/* Shared tail of both trials: refine the chosen candidates. Returns best error seen in this trial.
+ * (ref: the candidate loops of compress_symbolic_block_for_partition_1plane :497-700 / _2planes :880-1040) */
+WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_packed,
+                              int plane2_component, float tune_errorval_threshold)
+{
+	TrialInfo& tr = c.tr();
+	const bool dual = plane2_component >= 0;
+
+	float best_errorval_in_mode = ERROR_CALC_DEFAULT;
+	// (values read from LDS look lane-variant to the compiler; wv_uniform() puts them in SGPRs so that the
+	//  control flow runs on the scalar unit)
+	float best_errorval_in_scb = wv_uniform(c.scb().errorval);
+	const int candidate_count = wv_uniform(tr.cand_count);
 	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
+
+	refine_quantize_candidates(dual);
 
 	int staged_dm = -1, staged_wq = -1;                 // what the candidate tables in LDS currently hold
 	for (int i = 0; i < candidate_count; i++)
@@ -383,92 +518,25 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 		const int color_quant_level = wv_uniform(tr.cand_quant[i]);
 		const int color_quant_level_mod = wv_uniform(tr.cand_quant_mod[i]);
 		const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
+		const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
 
-		// stage what the refinement loop reads in serial, latency-bound code into LDS
-		{
-			PROF_SCOPE(c, PS_X0);
-			const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
-			if (cand_dm != staged_dm)
-			{
-				const DecimationInfo& dinfo = c.dec_info(cand_dm);
-				stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
-				staged_dm = cand_dm;
-			}
-			if (cand_wq != staged_wq)
-			{
-				stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(cand_wq)), (int)(sizeof(QuantXfer) / 4));
-				staged_wq = cand_wq;
-			}
-			stage_color_rows(c, color_quant_level);      // ends with a sync
-		}
-
-		// workep = ideal endpoints (merged across planes for dual plane); quantized weights are
-		// recomputed here instead of being stored for every block mode
-		{ PROF_SCOPE(c, PS_Y1);
-		WV_FOR(k, partition_count * 4)
-		{
-			int p = k >> 2, ch = k & 3;
-			int plane = (dual && ch == plane2_component) ? 1 : 0;
-			tr.wep0[p][ch] = tr.ep0[plane][p][ch];
-			tr.wep1[p][ch] = tr.ep1[plane][p][ch];
-		}
-		{
-			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.candw(i));
-			uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
-			WV_FOR(k, 16) { dst[k] = src[k]; }
-		}
-		WV_SYNC(); }
+		refine_candidate_setup(dual, partition_count, plane2_component, i, cand_dm != staged_dm ? cand_dm : -1,
+		                       cand_wq != staged_wq ? cand_wq : -1, color_quant_level);
+		staged_dm = cand_dm;
+		staged_wq = cand_wq;
 
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
-			refine_recompute_pack(dual, partition_count, partition_packed, cand_dm, plane2_component, i, color_quant_level, false);
-
-			int formats_matched = 0;
-			{ PROF_SCOPE(c, PS_Y2);
-			if (!dual && partition_count >= 2 && color_quant_level != color_quant_level_mod)
-			{
-				bool all_same = true;
-				for (int j = 1; j < partition_count; j++) all_same = all_same && workscb.color_formats[j] == workscb.color_formats[0];
-				if (all_same)
-				{
-					// retry at the higher quant level that matched formats allow (ref: :561-598)
-					uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8]
-					uint8_t* fmts = colorvals + 32;                                   // [4]
-					refine_recompute_pack(dual, partition_count, partition_packed, cand_dm, plane2_component, i, color_quant_level_mod, true);
-					bool all_same_mod = true;
-					for (int j = 1; j < partition_count; j++) all_same_mod = all_same_mod && fmts[j] == fmts[0];
-					if (all_same_mod)
-					{
-						formats_matched = 1;
-						WV_FOR(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
-						WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; }
-					}
-					WV_SYNC();
-				}
-			}
-
-			WV_ONE
-			{
-				workscb.color_formats_matched = (uint8_t)formats_matched;
-				workscb.partition_count = (uint8_t)partition_count;
-				workscb.partition_index = (uint16_t)partition_packed;
-				workscb.plane2_component = (int8_t)plane2_component;
-				workscb.quant_mode = (uint8_t)(formats_matched ? color_quant_level_mod : color_quant_level);
-				workscb.block_mode = (uint16_t)bm_packed_index;
-				workscb.block_type = SYM_BTYPE_NONCONST;
-			}
-			WV_SYNC(); }
+			if (dual) refine_recompute_2planes(cand_dm, plane2_component);
+			else if (partition_count == 1) refine_recompute_1partition(cand_dm);
+			else refine_recompute_partitions(partition_count, partition_packed, cand_dm);
+			refine_pack(dual, partition_count, partition_packed, plane2_component, i,
+			            color_quant_level, color_quant_level_mod, bm_packed_index);
 
 			if (l == 0)
 			{
-				float errorval;
-				errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
-				if (errorval == -ERROR_CALC_DEFAULT)
-				{
-					errorval = -errorval;
-					WV_ONE { workscb.block_type = SYM_BTYPE_ERROR; }
-				}
+				const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
 				best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
 
 				int iters_remaining = refinement_limit - l;
@@ -481,11 +549,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 				if (errorval < best_errorval_in_scb)
 				{
 					best_errorval_in_scb = errorval;
-					WV_SYNC();
-					WV_ONE { workscb.errorval = errorval; }
-					WV_SYNC();
-					copy_scb(scb, workscb);
-					WV_SYNC();
+					refine_accept(errorval);
 					if (errorval < tune_errorval_threshold)
 					{
 						stop_all = true;
@@ -494,17 +558,9 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 				}
 			}
 
-			WV_SYNC();
-			bool adjustments;
-			adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
+			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
-			float errorval;
-			errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
-			if (errorval == -ERROR_CALC_DEFAULT)
-			{
-				errorval = -errorval;
-				WV_ONE { workscb.block_type = SYM_BTYPE_ERROR; }
-			}
+			const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
 			best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
 
 			int iters_remaining = refinement_limit - 1 - l;
@@ -517,11 +573,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 			if (errorval < best_errorval_in_scb)
 			{
 				best_errorval_in_scb = errorval;
-				WV_SYNC();
-				WV_ONE { workscb.errorval = errorval; }
-				WV_SYNC();
-				copy_scb(scb, workscb);
-				WV_SYNC();
+				refine_accept(errorval);
 				if (errorval < tune_errorval_threshold)
 				{
 					stop_all = true;
@@ -534,10 +586,8 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 				break;
 			}
 		}
-		WV_SYNC();
 		if (stop_all) break;
 	}
-	(void)T;
 	return best_errorval_in_mode;
 }
 
