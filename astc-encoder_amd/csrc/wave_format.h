@@ -101,7 +101,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 	const BlkInfo& blk = c.blk();
 	const int T = c.T, pc = pv.pcount;
 
-	CompSel rgb; rgb.ncomp = 3; rgb.comps[0] = 0; rgb.comps[1] = 1; rgb.comps[2] = 2; rgb.comps[3] = 0;
+	CompSel rgb; rgb.ncomp = 3; rgb.set(0, 1, 2, 0);
 	compute_avgs_and_dirs(c, pv, rgb);
 
 	// processed lines per partition -> fbox[p*16 + ..]: uncor amod(3) bs(3), samec bs(3), rgbl amod(3)

@@ -5,16 +5,21 @@
 //        compute_ideal_colors_and_weights_{1..4}_comp  Source/astcenc_ideal_endpoints_and_weights.cpp:107-609
 //        compute_ideal_colors_and_weights_{1,2}plane(s) Source/astcenc_ideal_endpoints_and_weights.cpp:612-685
 //
-// Vectors are handled in "component-lane space": lane j holds image channel comps[j]; lanes >= ncomp
+// Vectors are handled in "component-lane space": lane j holds image channel comp(j); lanes >= ncomp
 // are zero, exactly like the reference's vfloat2/vfloat3 helpers.
 #pragma once
 #include "wave_ctx.h"
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
+/* Which image channels a computation runs over.  The channel list is a packed 2-bit-per-entry word
+ * rather than an array: it is indexed with run-time values, and an indexed array would live in scratch
+ * memory. */
 struct CompSel {
 	int ncomp;
-	int comps[4];
+	uint32_t packed;
+	WV_FN int comp(int j) const { return (int)((packed >> (2 * j)) & 3u); }
+	WV_FN void set(int c0, int c1, int c2, int c3) { packed = (uint32_t)(c0 | (c1 << 2) | (c2 << 4) | (c3 << 6)); }
 };
 
 /* Partition means and dominant directions -> tr.pm_avg / tr.pm_dir (component-lane space). */
@@ -28,7 +33,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	{
 		WV_FOR(j, 4)
 		{
-			tr.pm_avg[0][j] = j < n ? blk.data_mean[cs.comps[j]] : 0.0f;
+			tr.pm_avg[0][j] = j < n ? blk.data_mean[cs.comp(j)] : 0.0f;
 		}
 	}
 	else
@@ -37,7 +42,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 		WV_FOR(k, (pc - 1) * n * 4)
 		{
 			int l = k & 3, j = (k >> 2) % n, p = (k >> 2) / n;
-			const float* d = c.data(cs.comps[j]);
+			const float* d = c.data(cs.comp(j));
 			float acc = 0.0f;
 			for (int i = l; i < T; i += 4)
 			{
@@ -51,7 +56,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 		{
 			if (j < n)
 			{
-				float block_total = blk.data_mean[cs.comps[j]] * (float)T;
+				float block_total = blk.data_mean[cs.comp(j)] * (float)T;
 				float rest = block_total;
 				for (int p = 0; p < pc - 1; p++)
 				{
@@ -74,8 +79,8 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	WV_FOR(k, pc * n * n)
 	{
 		int j = k % n, which = (k / n) % n, p = k / (n * n);
-		const float* dj = c.data(cs.comps[j]);
-		const float* dw = c.data(cs.comps[which]);
+		const float* dj = c.data(cs.comp(j));
+		const float* dw = c.data(cs.comp(which));
 		float avg_j = tr.pm_avg[p][j], avg_w = tr.pm_avg[p][which];
 		const uint8_t* tix = pv.sorted + pv.off(p);
 		float sum = 0.0f;
@@ -202,7 +207,7 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	{
 		int p = pv.of_texel[t];
 		f4 pt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-		for (int j = 0; j < n; j++) set_lane(pt, j, c.data(cs.comps[j])[t]);
+		for (int j = 0; j < n; j++) set_lane(pt, j, c.data(cs.comp(j))[t]);
 		f4 a = load4(tr.pm_avg[p]);
 		f4 b = load4(&tr.fbox[32 + p * 4]);
 		float param = n == 3 ? dot3_s(pt - a, b) : dot_s(pt - a, b);
@@ -241,8 +246,8 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 		}
 		for (int j = 0; j < n; j++)
 		{
-			tr.ep0[plane][p][cs.comps[j]] = lane(lo, j);
-			tr.ep1[plane][p][cs.comps[j]] = lane(hi, j);
+			tr.ep0[plane][p][cs.comp(j)] = lane(lo, j);
+			tr.ep1[plane][p][cs.comp(j)] = lane(hi, j);
 		}
 	}
 	WV_SYNC();
@@ -282,12 +287,12 @@ WV_FN void ideal_colors_and_weights_1plane(const Ctx& c, const PartView& pv)
 	float ew;
 	if (uses_alpha)
 	{
-		cs.ncomp = 4; cs.comps[0] = 0; cs.comps[1] = 1; cs.comps[2] = 2; cs.comps[3] = 3;
+		cs.ncomp = 4; cs.set(0, 1, 2, 3);
 		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) / 4.0f;
 	}
 	else
 	{
-		cs.ncomp = 3; cs.comps[0] = 0; cs.comps[1] = 1; cs.comps[2] = 2; cs.comps[3] = 0;
+		cs.ncomp = 3; cs.set(0, 1, 2, 0);
 		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], 0.0f) * (1.0f / 3.0f);
 	}
 	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
@@ -306,9 +311,8 @@ WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, in
 		// three remaining components; NB the reference's weight for omitted component 0 uses
 		// channels <0,1,2> (ref: ideal_endpoints_and_weights.cpp:373-404)
 		cs.ncomp = 3;
-		int k = 0;
-		for (int ch = 0; ch < 4; ch++) if (ch != plane2_component) cs.comps[k++] = ch;
-		cs.comps[3] = 0;
+		// the three channels other than plane2_component, ascending
+		cs.set(plane2_component == 0 ? 1 : 0, plane2_component <= 1 ? 2 : 1, plane2_component <= 2 ? 3 : 2, 0);
 		float a, b, d;
 		switch (plane2_component)
 		{
@@ -322,10 +326,10 @@ WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, in
 	else
 	{
 		cs.ncomp = 2;
-		int k = 0;
-		for (int ch = 0; ch < 3; ch++) if (ch != plane2_component) cs.comps[k++] = ch;
-		cs.comps[2] = 0; cs.comps[3] = 0;
-		ew = hadd4(blk.cw[cs.comps[0]], blk.cw[cs.comps[1]], 0.0f, 0.0f) / 2.0f;
+		// the two colour channels other than plane2_component (0..2), ascending
+		const int c0 = plane2_component == 0 ? 1 : 0, c1 = plane2_component <= 1 ? 2 : 1;
+		cs.set(c0, c1, 0, 0);
+		ew = hadd4(blk.cw[c0], blk.cw[c1], 0.0f, 0.0f) / 2.0f;
 	}
 	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
 	ideal_colors_and_weights_1comp(c, pv, 1, plane2_component);
