@@ -885,12 +885,35 @@ WV_FN float prepare_block_statistics(const Ctx& c)
 	return lowest_correlation;
 }
 
-WV_OUT int stage_partition_search(int partition_count, int requested_indices, int requested_trials)
+WV_OUT int stage_partition_order(int partition_count)
 {
 	const Ctx c = ctx_make();
-	partition_count = wv_uniform(partition_count); requested_indices = wv_uniform(requested_indices); requested_trials = wv_uniform(requested_trials);
+	partition_count = wv_uniform(partition_count);
 	PROF_SCOPE(c, PS_KMEANS);
-	return find_best_partition_candidates(c, partition_count, requested_indices, requested_trials);
+	return partition_search_order(c, partition_count);
+}
+WV_OUT void stage_partition_score(int partition_count, int search_limit)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); search_limit = wv_uniform(search_limit);
+	PROF_SCOPE(c, PS_KMEANS);
+	partition_search_score(c, partition_count, search_limit);
+}
+WV_OUT int stage_partition_select(int search_limit, int requested_trials)
+{
+	const Ctx c = ctx_make();
+	search_limit = wv_uniform(search_limit); requested_trials = wv_uniform(requested_trials);
+	PROF_SCOPE(c, PS_KMEANS);
+	return partition_search_select(c, search_limit, requested_trials);
+}
+
+/* (ref: find_best_partition_candidates :551) candidates -> PartScratch::best[], returns how many */
+WV_FN int stage_partition_search(int partition_count, int requested_indices, int requested_trials)
+{
+	const int sequence_len = wv_uniform(stage_partition_order(partition_count));
+	const int search_limit = i_min(requested_indices, sequence_len);
+	stage_partition_score(partition_count, search_limit);
+	return stage_partition_select(search_limit, i_min(search_limit, requested_trials));
 }
 
 WV_OUT float stage_block_statistics()
@@ -951,9 +974,9 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	}
 	WV_SYNC();
 
-	float best_errorvals_for_pcount[4] = { ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT, ERROR_CALC_DEFAULT };
-	float exit_thresholds_for_pcount[4] = { 0.0f, cfg.tune_partition_early_out_limit_factor[0], cfg.tune_partition_early_out_limit_factor[1], 0.0f };
-	float errorval_mult[2] = { 1.0f / cfg.tune_mse_overshoot, 1.0f };
+	// (the reference's best_errorvals_for_pcount[] / exit_thresholds_for_pcount[] / errorval_mult[] as scalars:
+	//  run-time indexed local arrays would live in scratch memory)
+	float best_errorval_prev_pcount = ERROR_CALC_DEFAULT;      // best error with one partition fewer
 	const float errorval_overshoot = 1.0f / cfg.tune_mse_overshoot;
 
 	int start_trial = 1;
@@ -965,14 +988,15 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	// trial A: 1 partition, 1 plane (ref: :1292-1318)
 	for (int i = start_trial; i < 2 && !done; i++)
 	{
-		float errorval = compress_block_1plane(c, i == 0, error_threshold * errorval_mult[i] * errorval_overshoot, 1, 0, QUANT_32);
+		const float errorval_mult = i == 0 ? 1.0f / cfg.tune_mse_overshoot : 1.0f;
+		float errorval = compress_block_1plane(c, i == 0, error_threshold * errorval_mult * errorval_overshoot, 1, 0, QUANT_32);
 		WV_SYNC();
 		if (scb.block_type != SYM_BTYPE_ERROR)
 		{
 			quant_limit = c.block_mode(scb.block_mode).quant_mode;
 		}
-		best_errorvals_for_pcount[0] = f_min(best_errorvals_for_pcount[0], errorval);
-		if (errorval < (error_threshold * errorval_mult[i])) done = true;
+		best_errorval_prev_pcount = f_min(best_errorval_prev_pcount, errorval);
+		if (errorval < (error_threshold * errorval_mult)) done = true;
 	}
 
 	// trial B: 1 partition, 2 planes (ref: :1320-1369)
@@ -989,7 +1013,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 
 			float errorval = compress_block_2planes(c, error_threshold * errorval_overshoot, i, quant_limit);
 			WV_SYNC();
-			if (errorval > (best_errorvals_for_pcount[0] * 1.85f)) break;
+			if (errorval > (best_errorval_prev_pcount * 1.85f)) break;
 			if (errorval < error_threshold) done = true;
 		}
 	}
@@ -1006,33 +1030,34 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 
 			int actual_trials;
 			actual_trials = wv_uniform(stage_partition_search(partition_count, requested_indices, requested_trials));
-			// copy out of the scratch region: the trials below reuse it
-			int partition_indices[MAX_PARTITIONING_CANDIDATES];
+			// copy out of the scratch region (the trials below reuse it): candidate i sits in lane i
+			LaneArray128 partition_indices;
+			partition_indices.clear();
 			{
 				const PartScratch& ps = *reinterpret_cast<const PartScratch*>(c.part());
-				for (int i = 0; i < MAX_PARTITIONING_CANDIDATES; i++) partition_indices[i] = i < actual_trials ? ps.best[i] : 0;
+				WV_FOR(i, actual_trials) { partition_indices.set(i, ps.best[i]); }
 			}
 			WV_SYNC();
 
-			float best_error_in_prev = best_errorvals_for_pcount[partition_count - 2];
+			const float best_error_in_prev = best_errorval_prev_pcount;
+			const float exit_threshold = partition_count == 2 ? cfg.tune_partition_early_out_limit_factor[0]
+			                           : partition_count == 3 ? cfg.tune_partition_early_out_limit_factor[1] : 0.0f;
+			float best_error = ERROR_CALC_DEFAULT;               // best error with this partition count
 
 			for (int i = 0; i < actual_trials; i++)
 			{
 				float errorval = compress_block_1plane(c, false, error_threshold * errorval_overshoot,
-				                                       partition_count, partition_indices[i], quant_limit);
+				                                       partition_count, partition_indices.get(i), quant_limit);
 				WV_SYNC();
-				best_errorvals_for_pcount[partition_count - 1] = f_min(best_errorvals_for_pcount[partition_count - 1], errorval);
+				best_error = f_min(best_error, errorval);
 
-				float best_error = best_errorvals_for_pcount[partition_count - 1];
-				float best_error_scale = exit_thresholds_for_pcount[partition_count - 1] * 1.85f;
-				if (best_error > (best_error_in_prev * best_error_scale)) { done = true; break; }
+				if (best_error > (best_error_in_prev * (exit_threshold * 1.85f))) { done = true; break; }
 				if (errorval < error_threshold) { done = true; break; }
 			}
 			if (done) break;
 
-			float best_error = best_errorvals_for_pcount[partition_count - 1];
-			float best_error_scale = exit_thresholds_for_pcount[partition_count - 1];
-			if (best_error > (best_error_in_prev * best_error_scale)) { done = true; break; }
+			if (best_error > (best_error_in_prev * exit_threshold)) { done = true; break; }
+			best_errorval_prev_pcount = best_error;
 		}
 	}
 

@@ -513,11 +513,14 @@ WV_FN void insert_result(int max_values, float this_error, int this_partition, f
 
 /* (ref: find_best_partition_candidates :551).  Returns the number of PACKED partition indices
  * written to ps.best[]. */
-WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_search_limit, int requested_candidates)
+/* Partition search in three steps (ref: find_best_partition_candidates :551-780); each is its own
+ * out-of-line stage in the kernel so that none of them needs callee-saved registers. */
+
+/* Step 1: k-means clustering of the texels, ordering of the partitionings by how well they match it.
+ * Returns the length of the ordered sequence. */
+WV_FN int partition_search_order(const Ctx& c, int pc)
 {
 	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
-	const BlkInfo& blk = c.blk();
-	const int T = c.T;
 	WV_ONE
 	{
 		uint32_t lim = c.cfg->tune_partition_index_limit[0];
@@ -528,16 +531,20 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 		ps.lim = (int)(lim < n ? lim : n);
 	}
 	WV_SYNC();
+	return kmeans_partition_ordering(c, pc, ps);
+}
 
+/* Step 2: line-fit errors of the first partition_search_limit partitionings of the ordering. */
+WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_limit)
+{
+	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
+	const BlkInfo& blk = c.blk();
+	const int T = c.T;
 	float weight_imprecision_estim = 0.055f;
 	if (T <= 20) weight_imprecision_estim = 0.03f;
 	else if (T <= 31) weight_imprecision_estim = 0.04f;
 	else if (T <= 41) weight_imprecision_estim = 0.05f;
 	weight_imprecision_estim = weight_imprecision_estim * weight_imprecision_estim;
-
-	int sequence_len = kmeans_partition_ordering(c, pc, ps);
-	partition_search_limit = i_min(partition_search_limit, sequence_len);
-	requested_candidates = i_min(partition_search_limit, requested_candidates);
 
 	bool uses_alpha = !(blk.data_min[3] == blk.data_max[3]);
 
@@ -583,6 +590,13 @@ WV_FN int find_best_partition_candidates(const Ctx& c, int pc, int partition_sea
 	}
 	}
 
+}
+
+/* Step 3: the best requested_candidates partitionings by uncorrelated and by same-chroma error,
+ * interleaved and deduplicated -> ps.best[]; returns how many. */
+WV_FN int partition_search_select(const Ctx& c, int partition_search_limit, int requested_candidates)
+{
+	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
 	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
 	WV_ONE
 	{
