@@ -537,7 +537,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 			if (l == 0)
 			{
 				const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
-				best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
+				best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
 				int iters_remaining = refinement_limit - l;
 				float threshold = (0.045f * (float)iters_remaining) + 1.08f;
@@ -561,7 +561,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
 			const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
-			best_errorval_in_mode = f_min(errorval, best_errorval_in_mode);
+			best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
 			int iters_remaining = refinement_limit - 1 - l;
 			float threshold = (0.045f * (float)iters_remaining) + 1.0f;
