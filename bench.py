@@ -125,10 +125,11 @@ def device_psnr(lib, ctx, d_img, d_blocks, dev):
 
 
 def measured_traffic():
-    """HBM bytes per launch from the newest committed PMC summary of this same workload
+    """HBM bytes per launch from the latest committed PMC summary of this same workload
     (profiles/*/traffic.json, written by tools/gpu_profile.sh); None when there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), key=os.path.getmtime)
+    # newest = highest round tag (profiles/r01a < r01b < ... < r02a); mtimes mean nothing in a fresh checkout
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
     if not files:
         return None, None
     t = json.load(open(files[-1]))
