@@ -9,25 +9,16 @@
 
 namespace astcd {
 
-/* Blocks per workgroup.  One block is a few microseconds of work for one wavefront, so a launch with one
- * workgroup per block is bound by the rate at which workgroups can be dispatched, not by the decoding:
- * each wavefront takes a run of consecutive blocks instead. */
-constexpr uint32_t DECODE_BLOCKS_PER_WAVE = 8;
-
+/* One block is a few microseconds of work that keeps under half of a wavefront busy, so every wavefront
+ * takes a run of DECODE_BATCH consecutive blocks and decodes them together (decode_block_batch). */
 __global__ void __launch_bounds__(64)
 astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img, uint32_t num_blocks)
 {
-	__shared__ DecodeScratch scratch;
-	const uint32_t first = blockIdx.x * DECODE_BLOCKS_PER_WAVE;
-	for (uint32_t b = first; b < first + DECODE_BLOCKS_PER_WAVE && b < num_blocks; b++)
-	{
-		const uint32_t row = b / img.blocks_x;
-		const uint32_t bx = b - row * img.blocks_x;
-		const uint32_t bz = row / img.blocks_y;
-		const uint32_t by = row - bz * img.blocks_y;
-		decode_block(img, blocks + (size_t)b * 16, bx, by, bz, scratch);
-		WV_SYNC();          // the scratch is reused by the next block
-	}
+	__shared__ DecodeBatch batch;
+	const uint32_t first = blockIdx.x * (uint32_t)DECODE_BATCH;
+	if (first >= num_blocks) return;
+	const uint32_t left = num_blocks - first;
+	decode_block_batch(img, blocks, first, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
 }
 
 int astc_decode_launch(const DecodeLaunch& d)
@@ -43,7 +34,7 @@ int astc_decode_launch(const DecodeLaunch& d)
 	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
 	const uint32_t n = img.blocks_x * img.blocks_y * img.blocks_z;
-	hipLaunchKernelGGL(astc_decompress_blocks, dim3((n + DECODE_BLOCKS_PER_WAVE - 1) / DECODE_BLOCKS_PER_WAVE), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, n);
+	hipLaunchKernelGGL(astc_decompress_blocks, dim3((n + (uint32_t)DECODE_BATCH - 1) / (uint32_t)DECODE_BATCH), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, n);
 	return (int)hipGetLastError();
 }
 

@@ -744,6 +744,170 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 	}
 }
 
+/* A batch of consecutive blocks decoded together by one wavefront.  Decoding one block keeps few lanes
+ * busy (a header, <= 64 weights, <= 18 colour values, <= 4 endpoint pairs, T texels, one after the other);
+ * over a batch every phase is one flat loop over (block, element) pairs, so the lanes stay filled and
+ * the per-block phases cost one pass per batch instead of one per block. */
+constexpr int DECODE_BATCH = 8;
+struct DecodeBatch {
+	BlockHeader hdr[DECODE_BATCH];
+	Bits128     bits[DECODE_BATCH];
+	Bits128     rev[DECODE_BATCH];        // the same bits reversed: the weight stream
+	float       constant[DECODE_BATCH][4];
+	int         error[DECODE_BATCH];
+	DecodeScratch payload[DECODE_BATCH];
+};
+
+/* Decode blocks [first, first + count) of the stream (count <= DECODE_BATCH) into the image.  All 64 lanes
+ * call this.  Same arithmetic as decode_block(), block by block. */
+WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uint32_t first, int count, DecodeBatch& s)
+{
+	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
+	const int T = block_x * block_y * block_z;
+	const int profile = (int)img.profile;
+	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
+	const float error_nan = int_as_float((int)0xFFFFE000u);
+
+	// ---- headers and constant colours: one lane per block ----
+	WV_FOR(k, count)
+	{
+		Bits128 blk;
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(blocks + (size_t)(first + (uint32_t)k) * 16);
+		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
+		const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z);
+		bool error = h.error;
+		float cc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+		if (h.constant && !error)
+		{
+			// constant colour (ref: decompress_symbolic.cpp:204-255)
+			if (h.constant_f16)
+			{
+				// FP16 constant colour: legal in the HDR profiles only
+				if (profile == 2 || profile == 3)
+				{
+					for (int q = 0; q < 4; q++) cc[q] = half_to_float((uint16_t)h.const_color[q]);
+				}
+				else error = true;
+			}
+			else
+			{
+				for (int q = 0; q < 4; q++)
+				{
+					int v = u8_out ? (h.const_color[q] >> 8) * 257 : h.const_color[q];
+					cc[q] = half_to_float((uint16_t)unorm16_to_sf16(v));
+				}
+			}
+		}
+		s.hdr[k] = h;
+		s.bits[k] = blk;
+		s.rev[k] = bits_reversed(blk);
+		for (int q = 0; q < 4; q++) s.constant[k][q] = cc[q];
+		s.error[k] = error ? 1 : 0;
+	}
+	WV_SYNC();
+
+	// ---- weights: one lane per (block, weight) ----
+	WV_FOR(j, count * 64)
+	{
+		const int k = j >> 6, i = j & 63;
+		const BlockHeader& h = s.hdr[k];
+		if (s.error[k] || h.constant) continue;
+		const int wcount = h.wx * h.wy * h.wz;
+		const int real_wcount = h.dual ? 2 * wcount : wcount;
+		if (i >= real_wcount) continue;
+		int sym = ise_symbol(s.rev[k], 0, h.wquant, real_wcount, i);
+		int w = unquant_weight_symbol(sym, h.wquant);
+		if (h.dual) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
+		else s.payload[k].weights[0][i] = (uint8_t)w;
+	}
+	// ---- colour values: one lane per (block, value) ----
+	WV_FOR(j, count * 32)
+	{
+		const int k = j >> 5, i = j & 31;
+		const BlockHeader& h = s.hdr[k];
+		if (s.error[k] || h.constant || i >= h.nvals) continue;
+		int sym = ise_symbol(s.bits[k], h.color_start, h.cquant, h.nvals, i);
+		s.payload[k].colors[i] = (uint8_t)unquant_color_symbol(sym, h.cquant);
+	}
+	WV_SYNC();
+	// ---- endpoints: one lane per (block, partition) ----
+	WV_FOR(j, count * 4)
+	{
+		const int k = j >> 2, p = j & 3;
+		const BlockHeader& h = s.hdr[k];
+		if (s.error[k] || h.constant || p >= h.parts) continue;
+		DecodeScratch& ps = s.payload[k];
+		int start = 0;
+		for (int i = 0; i < 4; i++) start += i < p ? 2 * (h.fmt[i] >> 2) + 2 : 0;
+		const int f = p == 0 ? h.fmt[0] : p == 1 ? h.fmt[1] : p == 2 ? h.fmt[2] : h.fmt[3];
+		uint8_t in[8];
+		const int n = 2 * (f >> 2) + 2;
+		for (int q = 0; q < 8; q++) in[q] = q < n ? ps.colors[start + q] : 0;
+		i4 e0, e1;
+		unpack_color_endpoints(profile, f, in, e0, e1);
+		int* o = ps.ep[p];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+		bool rgb_lns, alpha_lns;
+		endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
+		ps.lns[p][0] = rgb_lns ? 1 : 0;
+		ps.lns[p][1] = alpha_lns ? 1 : 0;
+	}
+	WV_SYNC();
+
+	// ---- texels: one lane per (block, texel) ----
+	const bool small_block = T < 31;
+	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;     // j / T == (j * t_inv) >> 24 for j < 2^24 / T
+	WV_FOR(j, count * T)
+	{
+		const int k = (int)(((uint32_t)j * t_inv) >> 24), t = j - k * T;
+		const uint32_t b = first + (uint32_t)k;
+		const uint32_t row = b / img.blocks_x;
+		const uint32_t bx = b - row * img.blocks_x;
+		const uint32_t bz = row / img.blocks_y;
+		const uint32_t by = row - bz * img.blocks_y;
+		const int tz = block_z > 1 ? t / (block_x * block_y) : 0;
+		const int trem = t - tz * (block_x * block_y);
+		const int ty = trem / block_x, tx = trem - ty * block_x;
+		const uint32_t xi = bx * (uint32_t)block_x + (uint32_t)tx;
+		const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
+		const uint32_t zi = bz * (uint32_t)block_z + (uint32_t)tz;
+		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
+
+		const BlockHeader& h = s.hdr[k];
+		float r, g, bl, a;
+		if (s.error[k])
+		{
+			r = g = bl = a = error_nan;
+		}
+		else if (h.constant)
+		{
+			r = s.constant[k][0]; g = s.constant[k][1]; bl = s.constant[k][2]; a = s.constant[k][3];
+		}
+		else
+		{
+			const DecodeScratch& ps = s.payload[k];
+			int wp[2];
+			infill_texel_weights(h, ps.weights, block_x, block_y, block_z, tx, ty, tz, wp);
+			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
+			const int* e = ps.ep[p];
+			float out[4];
+			for (int q = 0; q < 4; q++)
+			{
+				const int wk = (h.dual && q == h.plane2) ? wp[1] : wp[0];
+				int cval = (e[q] * (64 - wk) + e[4 + q] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
+				if (u8_out) cval = (cval >> 8) * 257;
+				const bool lns = ps.lns[p][q == 3 ? 1 : 0] != 0;
+				const int hf = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
+				out[q] = half_to_float((uint16_t)hf);
+			}
+			r = out[0]; g = out[1]; bl = out[2]; a = out[3];
+		}
+		store_texel(img, xi, yi, zi, r, g, bl, a);
+	}
+	WV_SYNC();          // the batch scratch is reused by the next call
+}
+
 /* astcenc_get_block_info for one block, as plain sequential code (runs on the host).
  * (ref: astcenc_get_block_info, astcenc_entry.cpp:1401-1517)  `info` is a struct astcenc_block_info. */
 template <typename BlockInfo>
