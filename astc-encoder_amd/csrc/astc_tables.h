@@ -213,6 +213,8 @@ struct ImageDesc {
 	const float* alpha_avg; // per-texel alpha averages of the a_scale_radius pre-pass, or null
 	uint32_t a_scale_radius;
 	uint32_t dim_z, blocks_z; // slices of a volume / 2D array image (1 for a plain 2D image)
+	uint32_t fast_load_slice0; // reference behaviour of the RGBA8 fast loader on a multi-slice image: every slice's
+	                           // blocks are read from slice 0 (ref: astcenc_image.cpp:304); 0 = read the block's own slice
 };
 
 } // namespace astcd

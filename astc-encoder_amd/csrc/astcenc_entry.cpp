@@ -240,7 +240,8 @@ struct astcenc_context {
 	astcenc_error result;
 	int dstate;                       // same protocol for decompress (ref: manage_decompress)
 	astcenc_error dresult;
-	volatile int cancel_flag;
+	std::atomic<int> cancel_flag;     // (ref: ParallelManager::m_is_cancelled, astcenc_internal_entry.h:104)
+	bool per_slice_fast_load;         // ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD
 };
 
 extern "C" {
@@ -398,7 +399,8 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 	ctx->state = astcenc_context::IDLE;
 	ctx->dstate = astcenc_context::IDLE;
 	ctx->result = ASTCENC_SUCCESS;
-	ctx->cancel_flag = 0;
+	ctx->cancel_flag.store(0);
+	ctx->per_slice_fast_load = false;
 
 	// NB: like the reference, a child context re-validates (and below re-converts) the parent's
 	// already processed config (ref: astcenc_entry.cpp:761-777, :811-821).
@@ -527,7 +529,13 @@ static astcenc_error run_job(astcenc_context* ctx, CompressJob& job)
 	// Every caller thread of the context enters here; the first one drives the device, the rest
 	// wait for the same completion (ref: ParallelManager init/wait, astcenc_internal_entry.h:97-329).
 	std::unique_lock<std::mutex> lk(ctx->lock);
-	if (ctx->thread_count == 1) ctx->state = astcenc_context::IDLE;   // single caller auto-resets
+	if (ctx->thread_count == 1)
+	{
+		// a single caller resets implicitly, which also clears a pending cancel (ref: astcenc_entry.cpp:1185-1188,
+		// astcenc_compress_reset -> ParallelManager::reset)
+		ctx->state = astcenc_context::IDLE;
+		ctx->cancel_flag.store(0);
+	}
 
 	if (ctx->state == astcenc_context::IDLE)
 	{
@@ -569,6 +577,7 @@ astcenc_error astcenc_compress_image(astcenc_context* ctx, astcenc_image* imagep
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.host_out = data_out;
 	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
+	job.fast_load_slice0 = ctx->per_slice_fast_load ? 0u : 1u;
 	return run_job(ctx, job);
 }
 
@@ -603,12 +612,16 @@ astcenc_error astcenc_amd_compress_volume_device(astcenc_context* ctx, const voi
 	job.stream = hip_stream;
 	job.kernel_ms = kernel_ms;
 	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
+	job.fast_load_slice0 = ctx->per_slice_fast_load ? 0u : 1u;
 
-	std::unique_lock<std::mutex> lk(ctx->lock);
-	lk.unlock();
+	// A device-resident call is a single-caller operation: like a thread_count == 1 compress it starts from a
+	// clean state (a cancel issued before the call is forgotten; one issued while it runs stops it at the next
+	// chunk).  Calls on one context are serialised per device inside the backend.
+	ctx->cancel_flag.store(0);
 	job.cancel_flag = &ctx->cancel_flag;
+	job.progress = ctx->config.progress_callback;
 	int rc = backend_compress(ctx->backend, job);
-	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : rc == 3 ? ASTCENC_ERR_BAD_PARAM : ASTCENC_ERR_BAD_CONTEXT;
 }
 
 astcenc_error astcenc_amd_decompress_image_device(astcenc_context* ctx, const void* device_blocks, size_t data_len,
@@ -637,7 +650,7 @@ astcenc_error astcenc_amd_decompress_image_device(astcenc_context* ctx, const vo
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.stream = hip_stream;
 	int rc = backend_decompress_device(ctx->backend, job);
-	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : rc == 3 ? ASTCENC_ERR_BAD_PARAM : ASTCENC_ERR_BAD_CONTEXT;
 }
 
 astcenc_error astcenc_amd_compare_images_device(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
@@ -671,19 +684,37 @@ const char* astcenc_amd_backend_name(void)
 	return backend_name();
 }
 
+int astcenc_amd_context_device_count(const astcenc_context* ctx)
+{
+	return ctx && ctx->backend ? backend_device_count(ctx->backend) : 0;
+}
+
+astcenc_error astcenc_amd_context_set_option(astcenc_context* ctx, astcenc_amd_option option, int value)
+{
+	if (!ctx) return ASTCENC_ERR_BAD_CONTEXT;
+	switch ((int)option)
+	{
+	case ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD:
+		ctx->per_slice_fast_load = value != 0;
+		return ASTCENC_SUCCESS;
+	default:
+		return ASTCENC_ERR_BAD_PARAM;
+	}
+}
+
 astcenc_error astcenc_compress_reset(astcenc_context* ctx)
 {
 	if (ctx->config.flags & ASTCENC_FLG_DECOMPRESS_ONLY) return ASTCENC_ERR_BAD_CONTEXT;
 	std::lock_guard<std::mutex> lk(ctx->lock);
 	ctx->state = astcenc_context::IDLE;
-	ctx->cancel_flag = 0;
+	ctx->cancel_flag.store(0);
 	return ASTCENC_SUCCESS;
 }
 
 astcenc_error astcenc_compress_cancel(astcenc_context* ctx)
 {
 	if (ctx->config.flags & ASTCENC_FLG_DECOMPRESS_ONLY) return ASTCENC_ERR_BAD_CONTEXT;
-	ctx->cancel_flag = 1;
+	ctx->cancel_flag.store(1);
 	return ASTCENC_SUCCESS;
 }
 

@@ -6,6 +6,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include "astc_tables.h"
 
 namespace astcd {
@@ -23,8 +24,10 @@ struct CompressJob {
 	void*    stream;           // hipStream_t for the device-resident path (null = backend's own)
 	float*   kernel_ms;        // optional: elapsed kernel time measured with HIP events
 	uint32_t a_scale_radius;   // != 0: alpha-average pre-pass, fully transparent neighbourhoods encode as constant zero
-	volatile int* cancel_flag; // polled between chunks
-	void (*progress)(float);   // optional
+	const std::atomic<int>* cancel_flag; // polled between chunks
+	void (*progress)(float);   // optional; called with a monotonically increasing percentage
+	uint32_t fast_load_slice0; // multi-slice RGBA8 / LDR / identity-swizzle input with a 2D footprint: 1 = every slice reads
+	                           // slice 0 like the reference's fast loader (astcenc_image.cpp:304), 0 = each slice reads itself
 };
 
 struct DecompressJob {
@@ -55,9 +58,15 @@ struct CompareJob {
 	double* sums;
 };
 
-/* status: 0 ok, 1 out of memory, 2 no usable device / launch failure */
+/* status / return codes: 0 ok, 1 out of memory, 2 no usable device / launch failure, 3 bad argument
+ * (a stream of another device than the buffers).
+ * backend_create builds one device slot per GPU the context may use: every visible device by default, or the
+ * ordinals listed in the environment variable ASTCENC_AMD_DEVICES.  backend_compress deals contiguous ranges of
+ * block rows of a host image to those devices and joins them (the reference's N worker threads, N = devices);
+ * device-resident buffers are compressed on the device that owns them. */
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status);
 void backend_destroy(Backend* b);
+int backend_device_count(const Backend* b);
 int backend_compress(Backend* b, const CompressJob& job);
 int backend_decompress(Backend* b, const DecompressJob& job);
 int backend_decompress_device(Backend* b, const DecompressDeviceJob& job);

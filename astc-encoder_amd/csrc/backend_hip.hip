@@ -10,29 +10,41 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace astcd {
 
-struct Backend {
+// Everything that lives on one GPU: the table blob, two streams, events and the staging buffers of the
+// host-pointer API.  A context owns one slot per device it may run on (see backend_create).
+struct DeviceSlot {
 	int device;
 	uint8_t* d_base;              // device allocation: context records, then the table blob
 	uint8_t* d_tab;               // the blob inside it
-	size_t tab_bytes;
-	DeviceConfig cfg;
-	uint32_t lds_bytes;
-	bool hdr;
-	TableRoot root;
 	hipStream_t stream;
 	hipStream_t copy_stream;      // PCIe traffic of the banded host-pointer path
-	hipEvent_t ev0, ev1, ev_copy[2], ev_band;
+	hipEvent_t ev0, ev1, ev_copy[2], ev_band, ev_done[3];
 	// staging for the host-pointer API
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
 	float* d_alpha; size_t alpha_cap;   // alpha averages of the a_scale_radius pre-pass
 	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds)
 	double* d_sums;               // totals of the image comparison kernel
+	std::mutex busy;              // one call at a time per slot: the staging buffers and events are shared state
+};
+
+struct Backend {
+	std::vector<DeviceSlot*> slots;   // slot 0 is the default device of the context
+	std::mutex slots_mu;              // guards `slots` (slots for further devices are added on first use)
+	std::vector<uint8_t> full;        // host copy of [LdsLayout][DeviceConfig][table blob], uploaded to every slot
+	DeviceConfig cfg;
+	uint32_t lds_bytes;
+	bool hdr;
+	TableRoot root;
 };
 
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
@@ -44,6 +56,145 @@ constexpr size_t ALLOC_SLACK = 4096;
 
 const char* backend_name() { return "hip:gfx950"; }
 
+namespace {
+
+/* The calling thread's current device is the caller's business (a torch process, an engine): every
+ * entry point puts it back on exit. */
+struct DeviceGuard {
+	int saved; bool ok;
+	DeviceGuard() : saved(0), ok(hipGetDevice(&saved) == hipSuccess) {}
+	~DeviceGuard() { if (ok) (void)hipSetDevice(saved); }
+};
+
+void slot_destroy(DeviceSlot* s)
+{
+	if (!s) return;
+	(void)hipSetDevice(s->device);
+	if (s->d_image) (void)hipFree(s->d_image);
+	if (s->d_out) (void)hipFree(s->d_out);
+	if (s->d_alpha) (void)hipFree(s->d_alpha);
+	if (s->d_sums) (void)hipFree(s->d_sums);
+	if (s->d_prof) (void)hipFree(s->d_prof);
+	for (hipEvent_t e : { s->ev_copy[0], s->ev_copy[1], s->ev_band, s->ev_done[0], s->ev_done[1], s->ev_done[2], s->ev0, s->ev1 })
+		if (e) (void)hipEventDestroy(e);
+	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+	if (s->stream) (void)hipStreamDestroy(s->stream);
+	if (s->d_base) (void)hipFree(s->d_base);
+	delete s;
+}
+
+/* One slot on `device`: uploads the tables, sets the kernels' dynamic-LDS attribute there, creates streams
+ * and events.  Every failure leaves through slot_destroy (the record starts zeroed). status: 1 = out of
+ * memory, 2 = anything else. */
+DeviceSlot* slot_create(Backend* b, int device, int* status)
+{
+	DeviceSlot* s = new DeviceSlot();
+	s->device = device;
+	s->d_base = nullptr; s->d_tab = nullptr; s->stream = nullptr; s->copy_stream = nullptr;
+	s->ev0 = s->ev1 = s->ev_copy[0] = s->ev_copy[1] = s->ev_band = nullptr;
+	s->ev_done[0] = s->ev_done[1] = s->ev_done[2] = nullptr;
+	s->d_image = nullptr; s->image_cap = 0; s->d_out = nullptr; s->out_cap = 0; s->d_alpha = nullptr; s->alpha_cap = 0;
+	s->d_prof = nullptr; s->d_sums = nullptr;
+#define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
+	SLOT_TRY(hipSetDevice(device), 2);
+	{
+		uint8_t layout[256]; uint32_t layout_bytes = 0, lds_bytes = 0;
+		int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &lds_bytes, layout, &layout_bytes)
+		                 : astc_kernel_prepare_ldr(b->root, b->cfg, &lds_bytes, layout, &layout_bytes);
+		if (prc != 0)
+		{
+			fprintf(stderr, "astcenc_amd: kernel setup failed on device %d (hip error %d)\n", device, prc);
+			slot_destroy(s); *status = 2; return nullptr;
+		}
+	}
+	SLOT_TRY(hipMalloc(&s->d_base, b->full.size() + ALLOC_SLACK), 1);
+	SLOT_TRY(hipMemcpy(s->d_base, b->full.data(), b->full.size(), hipMemcpyHostToDevice), 2);
+	s->d_tab = s->d_base + CTX_LAYOUT_BACK;
+	SLOT_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), 2);
+	SLOT_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking), 2);
+	SLOT_TRY(hipEventCreateWithFlags(&s->ev_copy[0], hipEventDisableTiming), 2);
+	SLOT_TRY(hipEventCreateWithFlags(&s->ev_copy[1], hipEventDisableTiming), 2);
+	SLOT_TRY(hipEventCreateWithFlags(&s->ev_band, hipEventDisableTiming), 2);
+	for (int i = 0; i < 3; i++) SLOT_TRY(hipEventCreateWithFlags(&s->ev_done[i], hipEventDisableTiming), 2);
+	SLOT_TRY(hipEventCreate(&s->ev0), 2);
+	SLOT_TRY(hipEventCreate(&s->ev1), 2);
+#if defined(ASTC_PROFILE)
+	enum { PS_COUNT = 40 };
+	SLOT_TRY(hipMalloc(&s->d_prof, 2 * PS_COUNT * sizeof(unsigned long long)), 1);
+	SLOT_TRY(hipMemset(s->d_prof, 0, 2 * PS_COUNT * sizeof(unsigned long long)), 2);
+#endif
+#undef SLOT_TRY
+	*status = 0;
+	return s;
+}
+
+/* Device list of a context.  ASTCENC_AMD_DEVICES = "all" (default: every visible device) or a comma
+ * separated list of device ordinals; an ordinal may repeat ("0,0": two slots on one GPU, which is how the
+ * multi-device path is tested on a one-GPU box). */
+std::vector<int> device_list(int ndev)
+{
+	std::vector<int> out;
+	const char* env = getenv("ASTCENC_AMD_DEVICES");
+	if (env && *env && strcmp(env, "all") != 0)
+	{
+		const char* p = env;
+		while (*p)
+		{
+			char* e = nullptr;
+			long v = strtol(p, &e, 10);
+			if (e == p) break;
+			if (v >= 0 && v < ndev) out.push_back((int)v);
+			else fprintf(stderr, "astcenc_amd: ASTCENC_AMD_DEVICES names device %ld, %d visible; ignored\n", v, ndev);
+			p = e;
+			while (*p == ',' || *p == ' ') p++;
+		}
+	}
+	if (out.empty())
+	{
+		// current device first, so that a one-device caller keeps what it had selected
+		int cur = 0;
+		if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+		out.push_back(cur);
+		if (!(env && *env && strcmp(env, "all") != 0)) for (int d = 0; d < ndev; d++) if (d != cur) out.push_back(d);
+	}
+	return out;
+}
+
+/* Slot that owns `ptr` (device memory); slot 0 when the runtime does not know the pointer. */
+DeviceSlot* slot_for_pointer(Backend* b, const void* ptr, int* status)
+{
+	*status = 0;
+	hipPointerAttribute_t attr;
+	memset(&attr, 0, sizeof(attr));
+	if (!ptr || hipPointerGetAttributes(&attr, ptr) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return b->slots[0];
+	}
+	std::lock_guard<std::mutex> lk(b->slots_mu);
+	for (DeviceSlot* s : b->slots) if (s->device == attr.device) return s;
+	DeviceSlot* s = slot_create(b, attr.device, status);
+	if (s) b->slots.push_back(s);
+	return s;
+}
+
+/* Completed-block counter shared by the slots of one call; the callback sees a monotonic percentage
+ * (ref: ParallelManager::complete_task_assignment, astcenc_internal_entry.h:255-290). */
+struct Progress {
+	std::mutex mu;
+	size_t done, total;
+	void (*callback)(float);
+	void add(size_t n)
+	{
+		if (!callback) return;
+		std::lock_guard<std::mutex> lk(mu);
+		done += n;
+		callback(100.0f * (float)done / (float)total);
+	}
+};
+
+} // namespace
+
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
 {
 	int ndev = 0;
@@ -53,47 +204,50 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		*status = 2;
 		return nullptr;
 	}
+	DeviceGuard guard;
 
 	Backend* b = new Backend;
-	memset(b, 0, sizeof(*b));
-	HIP_TRY(hipGetDevice(&b->device), { delete b; *status = 2; return nullptr; });
 	b->cfg = cfg;
-	b->tab_bytes = blob_bytes;
 	memcpy(&b->root, blob, sizeof(TableRoot));
 	b->hdr = cfg.profile >= 2;
+	b->lds_bytes = 0;
 	uint8_t layout[256];
 	uint32_t layout_bytes = 0;
-	int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes)
-	                 : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes);
-
-	if (prc != 0 || b->lds_bytes > 160 * 1024)
 	{
-		fprintf(stderr, "astcenc_amd: kernel setup failed (hip error %d, block working set %u B; a CU has 160 KiB of LDS)\n", prc, b->lds_bytes);
+		// layout record of the block's LDS working set (the kernels' dynamic-LDS attribute is per device: slot_create)
+		int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes)
+		                 : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes);
+		if (prc != 0)
+		{
+			fprintf(stderr, "astcenc_amd: kernel setup failed (hip error %d)\n", prc);
+			delete b; *status = 2; return nullptr;
+		}
+	}
+	if (b->lds_bytes > 160 * 1024)
+	{
+		fprintf(stderr, "astcenc_amd: block working set %u B; a CU has 160 KiB of LDS\n", b->lds_bytes);
 		delete b; *status = 2; return nullptr;
 	}
 
 	// device allocation = [LdsLayout, 256 B][DeviceConfig, 256 B][table blob]; kernels get the blob pointer
-	std::vector<uint8_t> full(CTX_LAYOUT_BACK + blob_bytes, 0);
-	memcpy(full.data(), layout, layout_bytes);
+	b->full.assign(CTX_LAYOUT_BACK + blob_bytes, 0);
+	memcpy(b->full.data(), layout, layout_bytes);
 	static_assert(sizeof(DeviceConfig) <= 256, "DeviceConfig outgrew its slot");
-	memcpy(full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
-	memcpy(full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
-	b->tab_bytes = full.size();
-	HIP_TRY(hipMalloc(&b->d_base, full.size() + ALLOC_SLACK), { delete b; *status = 1; return nullptr; });
-	HIP_TRY(hipMemcpy(b->d_base, full.data(), full.size(), hipMemcpyHostToDevice), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
-	b->d_tab = b->d_base + CTX_LAYOUT_BACK;
-	HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), { (void)hipFree(b->d_base); delete b; *status = 2; return nullptr; });
-	HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking), { *status = 2; return nullptr; });
-	HIP_TRY(hipEventCreateWithFlags(&b->ev_copy[0], hipEventDisableTiming), { *status = 2; return nullptr; });
-	HIP_TRY(hipEventCreateWithFlags(&b->ev_copy[1], hipEventDisableTiming), { *status = 2; return nullptr; });
-	HIP_TRY(hipEventCreateWithFlags(&b->ev_band, hipEventDisableTiming), { *status = 2; return nullptr; });
-	HIP_TRY(hipEventCreate(&b->ev0), { *status = 2; return nullptr; });
-	HIP_TRY(hipEventCreate(&b->ev1), { *status = 2; return nullptr; });
-#if defined(ASTC_PROFILE)
-	enum { PS_COUNT = 40, PS_TOTAL = 14 };
-	HIP_TRY(hipMalloc(&b->d_prof, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 1; return nullptr; });
-	HIP_TRY(hipMemset(b->d_prof, 0, 2 * PS_COUNT * sizeof(unsigned long long)), { *status = 2; return nullptr; });
-#endif
+	memcpy(b->full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
+	memcpy(b->full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
+
+	for (int device : device_list(ndev))
+	{
+		int st = 0;
+		DeviceSlot* s = slot_create(b, device, &st);
+		if (!s)
+		{
+			if (b->slots.empty()) { delete b; *status = st; return nullptr; }
+			fprintf(stderr, "astcenc_amd: device %d not usable, continuing with %zu device(s)\n", device, b->slots.size());
+			continue;
+		}
+		b->slots.push_back(s);
+	}
 	*status = 0;
 	return b;
 }
@@ -101,25 +255,18 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 void backend_destroy(Backend* b)
 {
 	if (!b) return;
-	(void)hipSetDevice(b->device);
-	if (b->d_image) (void)hipFree(b->d_image);
-	if (b->d_out) (void)hipFree(b->d_out);
-	if (b->d_alpha) (void)hipFree(b->d_alpha);
-	if (b->d_sums) (void)hipFree(b->d_sums);
-	(void)hipEventDestroy(b->ev_copy[0]);
-	(void)hipEventDestroy(b->ev_copy[1]);
-	(void)hipEventDestroy(b->ev_band);
-	(void)hipStreamDestroy(b->copy_stream);
-	(void)hipEventDestroy(b->ev0);
-	(void)hipEventDestroy(b->ev1);
-	(void)hipStreamDestroy(b->stream);
-	(void)hipFree(b->d_base);
+	DeviceGuard guard;
+	for (DeviceSlot* s : b->slots) slot_destroy(s);
 	delete b;
 }
 
-int backend_compress(Backend* b, const CompressJob& job)
+int backend_device_count(const Backend* b) { return (int)b->slots.size(); }
+
+/* The blocks of `job` on one slot.  Returns 0 ok, 1 out of memory, 2 device failure, 3 bad argument. */
+static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress)
 {
-	HIP_TRY(hipSetDevice(b->device), return 2);
+	std::lock_guard<std::mutex> busy(s->busy);
+	HIP_TRY(hipSetDevice(s->device), return 2);
 
 	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y, bsz = b->root.dim_z;
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
@@ -132,21 +279,33 @@ int backend_compress(Backend* b, const CompressJob& job)
 	const size_t image_bytes = slice_bytes * dim_z;
 	const size_t out_bytes = nblocks * 16;
 
-	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+	hipStream_t stream = s->stream;
+	if (job.stream)
+	{
+		// a caller's stream must belong to the device the buffers (and this slot's tables) live on
+		stream = static_cast<hipStream_t>(job.stream);
+		hipDevice_t sdev = -1;
+		if (hipStreamGetDevice(stream, &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = s->device; }
+		if ((int)sdev != s->device)
+		{
+			fprintf(stderr, "astcenc_amd: the stream belongs to device %d, the buffers to device %d\n", (int)sdev, s->device);
+			return 3;
+		}
+	}
 
 	const void* d_image = job.device_data;
 	uint8_t* d_out = job.device_out;
 
 	if (job.host_slices)
 	{
-		if (b->image_cap < image_bytes)
+		if (s->image_cap < image_bytes)
 		{
-			if (b->d_image) (void)hipFree(b->d_image);
-			b->d_image = nullptr; b->image_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_image, image_bytes + ALLOC_SLACK), return 1);
-			b->image_cap = image_bytes;
+			if (s->d_image) (void)hipFree(s->d_image);
+			s->d_image = nullptr; s->image_cap = 0;
+			HIP_TRY(hipMalloc(&s->d_image, image_bytes + ALLOC_SLACK), return 1);
+			s->image_cap = image_bytes;
 		}
-		d_image = b->d_image;
+		d_image = s->d_image;
 	}
 	// Host-pointer calls on a plain 2D image are pipelined by bands of block rows: band k+1 travels over
 	// PCIe on the copy stream while band k is being compressed, and band k's blocks travel back while band
@@ -156,18 +315,18 @@ int backend_compress(Backend* b, const CompressJob& job)
 	if (job.host_slices && !banded)
 	{
 		for (uint32_t z = 0; z < dim_z; z++)
-			HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(b->d_image) + z * slice_bytes, job.host_slices[z], slice_bytes, hipMemcpyHostToDevice, stream), return 2);
+			HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->d_image) + z * slice_bytes, job.host_slices[z], slice_bytes, hipMemcpyHostToDevice, stream), return 2);
 	}
 	if (job.host_out)
 	{
-		if (b->out_cap < out_bytes)
+		if (s->out_cap < out_bytes)
 		{
-			if (b->d_out) (void)hipFree(b->d_out);
-			b->d_out = nullptr; b->out_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_out, out_bytes + ALLOC_SLACK), return 1);
-			b->out_cap = out_bytes;
+			if (s->d_out) (void)hipFree(s->d_out);
+			s->d_out = nullptr; s->out_cap = 0;
+			HIP_TRY(hipMalloc(&s->d_out, out_bytes + ALLOC_SLACK), return 1);
+			s->out_cap = out_bytes;
 		}
-		d_out = b->d_out;
+		d_out = s->d_out;
 	}
 	if (!d_image || !d_out) return 2;
 
@@ -181,30 +340,32 @@ int backend_compress(Backend* b, const CompressJob& job)
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
 	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0 && bsz == 1) ? 1 : 0;   // ref: astcenc_entry.cpp:946
+	img.fast_load_slice0 = job.fast_load_slice0;
 	img.alpha_avg = nullptr;
 	img.a_scale_radius = job.a_scale_radius;
 	if (job.a_scale_radius != 0)
 	{
 		const size_t need = (size_t)job.dim_x * job.dim_y * sizeof(float);
-		if (b->alpha_cap < need)
+		if (s->alpha_cap < need)
 		{
-			if (b->d_alpha) (void)hipFree(b->d_alpha);
-			b->d_alpha = nullptr; b->alpha_cap = 0;
-			HIP_TRY(hipMalloc(&b->d_alpha, need + ALLOC_SLACK), return 1);
-			b->alpha_cap = need;
+			if (s->d_alpha) (void)hipFree(s->d_alpha);
+			s->d_alpha = nullptr; s->alpha_cap = 0;
+			HIP_TRY(hipMalloc(&s->d_alpha, need + ALLOC_SLACK), return 1);
+			s->alpha_cap = need;
 		}
 		AlphaLaunch a;
-		a.d_image = d_image; a.d_averages = b->d_alpha;
+		a.d_image = d_image; a.d_averages = s->d_alpha;
 		a.dim_x = job.dim_x; a.dim_y = job.dim_y; a.data_type = job.data_type;
 		a.swz_a = job.swz[3]; a.radius = job.a_scale_radius; a.stream = stream;
 		int arc = astc_alpha_launch(a);
 		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
-		img.alpha_avg = b->d_alpha;
+		img.alpha_avg = s->d_alpha;
 	}
 
 	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is
 	// still tens of thousands of workgroups, far more than the 256 CUs need to stay full.
-	size_t chunk = (job.progress || job.host_slices) ? (size_t)1 << 18 : nblocks;
+	const bool chunked = (progress && progress->callback) || job.host_slices;
+	size_t chunk = chunked ? (size_t)1 << 18 : nblocks;
 	if (banded)
 	{
 		// whole block rows per band, at least four bands when the image has that many block rows
@@ -218,15 +379,20 @@ int backend_compress(Backend* b, const CompressJob& job)
 		const size_t y0 = (band_first / blocks_x) * bsy;
 		size_t y1 = ((band_first + band_blocks) / blocks_x) * bsy;
 		if (y1 > job.dim_y) y1 = job.dim_y;
-		HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(b->d_image) + y0 * row_bytes, static_cast<const uint8_t*>(job.host_slices[0]) + y0 * row_bytes,
-		                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, b->copy_stream), return 2);
-		HIP_TRY(hipEventRecord(b->ev_copy[(band_first / chunk) & 1], b->copy_stream), return 2);
+		HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->d_image) + y0 * row_bytes, static_cast<const uint8_t*>(job.host_slices[0]) + y0 * row_bytes,
+		                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, s->copy_stream), return 2);
+		HIP_TRY(hipEventRecord(s->ev_copy[(band_first / chunk) & 1], s->copy_stream), return 2);
 		return 0;
 	};
-	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev0, stream), return 2);
-	for (size_t first = 0; first < nblocks; first += chunk)
+	if (job.kernel_ms) HIP_TRY(hipEventRecord(s->ev0, stream), return 2);
+	// The host stays at most two chunks ahead of the device: chunk k-1's completion event is waited for
+	// (and reported to the progress callback) after chunk k has been queued, so the device always has its
+	// next kernel waiting, a cancel takes effect within two chunks, and nothing synchronises a whole stream.
+	size_t launched = 0, chunk_index = 0, prev_blocks = 0;
+	bool cancelled = false;
+	for (size_t first = 0; first < nblocks; first += chunk, chunk_index++)
 	{
-		if (job.cancel_flag && *job.cancel_flag) break;
+		if (job.cancel_flag && job.cancel_flag->load(std::memory_order_relaxed)) { cancelled = true; break; }
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
 		if (banded)
 		{
@@ -235,35 +401,44 @@ int backend_compress(Backend* b, const CompressJob& job)
 			if (first == 0 && upload_band(0, n) != 0) return 2;
 			const size_t next = first + n;
 			if (next < nblocks && upload_band(next, nblocks - next < chunk ? nblocks - next : chunk) != 0) return 2;
-			HIP_TRY(hipStreamWaitEvent(stream, b->ev_copy[(first / chunk) & 1], 0), return 2);
+			HIP_TRY(hipStreamWaitEvent(stream, s->ev_copy[(first / chunk) & 1], 0), return 2);
 		}
 		KernelLaunch k;
-		k.d_tab = b->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
-		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = b->d_prof;
+		k.d_tab = s->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
+		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = s->d_prof;
 		int lrc = b->hdr ? astc_kernel_launch_hdr(k) : astc_kernel_launch_ldr(k);
 		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }
+		launched = first + n;
 		if (banded)
 		{
 			// this band's blocks go home on the copy stream once its kernel is done
-			HIP_TRY(hipEventRecord(b->ev_band, stream), return 2);
-			HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_band, 0), return 2);
-			HIP_TRY(hipMemcpyAsync(job.host_out + first * 16, d_out + first * 16, n * 16, hipMemcpyDeviceToHost, b->copy_stream), return 2);
+			HIP_TRY(hipEventRecord(s->ev_band, stream), return 2);
+			HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_band, 0), return 2);
+			HIP_TRY(hipMemcpyAsync(job.host_out + first * 16, d_out + first * 16, n * 16, hipMemcpyDeviceToHost, s->copy_stream), return 2);
 		}
-		if (job.progress)
+		if (chunked)
 		{
-			HIP_TRY(hipStreamSynchronize(stream), return 2);
-			job.progress(100.0f * (float)(first + n) / (float)nblocks);
+			HIP_TRY(hipEventRecord(s->ev_done[chunk_index % 3], stream), return 2);
+			if (chunk_index > 0)
+			{
+				HIP_TRY(hipEventSynchronize(s->ev_done[(chunk_index - 1) % 3]), return 2);
+				if (progress) progress->add(prev_blocks);
+			}
+			prev_blocks = n;
 		}
 	}
-	if (job.kernel_ms) HIP_TRY(hipEventRecord(b->ev1, stream), return 2);
+	if (job.kernel_ms) HIP_TRY(hipEventRecord(s->ev1, stream), return 2);
 
-	if (job.host_out && !banded)
+	if (job.host_out && !banded && launched)
 	{
-		HIP_TRY(hipMemcpyAsync(job.host_out, d_out, out_bytes, hipMemcpyDeviceToHost, stream), return 2);
+		// after a cancel only the blocks that were compressed go home; the rest of the caller's buffer stays untouched
+		HIP_TRY(hipMemcpyAsync(job.host_out, d_out, launched * 16, hipMemcpyDeviceToHost, stream), return 2);
 	}
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
-	if (banded) HIP_TRY(hipStreamSynchronize(b->copy_stream), return 2);
-	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, b->ev0, b->ev1), return 2);
+	if (banded) HIP_TRY(hipStreamSynchronize(s->copy_stream), return 2);
+	if (chunked && progress && prev_blocks && !cancelled) progress->add(prev_blocks);
+	else if (chunked && progress && prev_blocks && cancelled && launched) progress->add(prev_blocks);
+	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, s->ev0, s->ev1), return 2);
 #if defined(ASTC_PROFILE)
 	{
 		enum { PS_COUNT = 40, PS_TOTAL = 14 };
@@ -274,8 +449,8 @@ int backend_compress(Backend* b, const CompressJob& job)
 		                                        "  cand staging", "  physical", "  refine (all)", "  trial (all)",
 		                                        "  y0 cand quantize", "  y1 cand setup", "  y2 after pack", "  y3 accept/copy", "  y4", "  y5", "  y6", "  y7" };
 		unsigned long long h[2 * PS_COUNT];
-		HIP_TRY(hipMemcpy(h, b->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
-		HIP_TRY(hipMemset(b->d_prof, 0, sizeof(h)), return 2);
+		HIP_TRY(hipMemcpy(h, s->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
+		HIP_TRY(hipMemset(s->d_prof, 0, sizeof(h)), return 2);
 		fprintf(stderr, "stage cycles per block (lane-0 shader clock), %zu blocks:   [calls per block]\n", nblocks);
 		for (int i = 0; i < PS_COUNT; i++)
 			if (i != 15 && h[i])
@@ -286,8 +461,82 @@ int backend_compress(Backend* b, const CompressJob& job)
 	return 0;
 }
 
-int backend_decompress(Backend* b, const DecompressJob& job)
+/* Smallest shard worth a device of its own: below this a second GPU's fixed costs (its PCIe transfers start
+ * later, its L2 has to fetch the tables again) outweigh the kernel time it takes over. */
+constexpr size_t MIN_BLOCKS_PER_DEVICE = 16384;
+
+int backend_compress(Backend* b, const CompressJob& job)
 {
+	DeviceGuard guard;
+	Progress progress;
+	progress.done = 0; progress.callback = job.progress;
+	{
+		const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y, bsz = b->root.dim_z;
+		const uint32_t dz = job.dim_z ? job.dim_z : 1u;
+		progress.total = (size_t)((job.dim_x + bsx - 1) / bsx) * ((job.dim_y + bsy - 1) / bsy) * ((dz + bsz - 1) / bsz);
+	}
+
+	// Buffers that already live on a device are compressed there.
+	if (!job.host_slices)
+	{
+		int st = 0;
+		DeviceSlot* s = slot_for_pointer(b, job.device_data, &st);
+		if (!s) return st ? st : 2;
+		return compress_on_slot(b, s, job, &progress);
+	}
+
+	// Host images: contiguous ranges of block rows, one per device, each running its own banded pipeline
+	// on its own streams from its own host thread; the caller's thread takes the first shard and joins the
+	// rest (ref: the block loop of compress_image, astcenc_entry.cpp:1009-1038 -- blocks are independent,
+	// so the split needs no exchange).  Volumes and the alpha-scale pre-pass (which reads a halo around
+	// each block) stay on one device.
+	const uint32_t bsy = b->root.dim_y;
+	const uint32_t blocks_x = (job.dim_x + b->root.dim_x - 1) / b->root.dim_x;
+	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
+	size_t ndev = b->slots.size();
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	if (dim_z != 1 || job.a_scale_radius != 0 || !job.host_out) ndev = 1;
+	const size_t by_size = progress.total / MIN_BLOCKS_PER_DEVICE;
+	if (ndev > by_size) ndev = by_size < 1 ? 1 : by_size;
+	if (ndev > blocks_y) ndev = blocks_y;
+	if (ndev <= 1) return compress_on_slot(b, b->slots[0], job, &progress);
+
+	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
+	const uint32_t rows_per = (uint32_t)((blocks_y + ndev - 1) / ndev);
+	struct Shard { CompressJob job; const void* slice; int rc; };
+	std::vector<Shard> shards;
+	for (size_t g = 0; g < ndev; g++)
+	{
+		const uint32_t r0 = (uint32_t)g * rows_per;
+		if (r0 >= blocks_y) break;
+		const uint32_t r1 = r0 + rows_per < blocks_y ? r0 + rows_per : blocks_y;
+		const uint32_t y0 = r0 * bsy;
+		const uint32_t y1 = r1 * bsy < job.dim_y ? r1 * bsy : job.dim_y;
+		Shard sh;
+		sh.job = job;
+		sh.slice = static_cast<const uint8_t*>(job.host_slices[0]) + (size_t)y0 * job.dim_x * texel_bytes;
+		sh.job.dim_y = y1 - y0;
+		sh.job.host_out = job.host_out + (size_t)r0 * blocks_x * 16;
+		sh.job.progress = nullptr;
+		sh.rc = 0;
+		shards.push_back(sh);
+	}
+	for (Shard& sh : shards) sh.job.host_slices = &sh.slice;      // (after the vector stopped growing)
+	std::vector<std::thread> workers;
+	for (size_t g = 1; g < shards.size(); g++)
+		workers.emplace_back([&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); });
+	shards[0].rc = compress_on_slot(b, b->slots[0], shards[0].job, &progress);
+	for (std::thread& t : workers) t.join();
+	int rc = 0;
+	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
+	return rc;
+}
+
+int backend_decompress(Backend* bk, const DecompressJob& job)
+{
+	DeviceGuard guard;
+	DeviceSlot* b = bk->slots[0];
+	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
@@ -316,8 +565,8 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	d.d_image = b->d_image;
 	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = dim_z; d.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
-	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y; d.block_z = b->root.dim_z;
-	d.profile = b->cfg.profile;
+	d.block_x = bk->root.dim_x; d.block_y = bk->root.dim_y; d.block_z = bk->root.dim_z;
+	d.profile = bk->cfg.profile;
 	d.stream = b->stream;
 	int lrc = astc_decode_launch(d);
 	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
@@ -327,8 +576,13 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	return 0;
 }
 
-int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
+int backend_decompress_device(Backend* bk, const DecompressDeviceJob& job)
 {
+	DeviceGuard guard;
+	int st = 0;
+	DeviceSlot* b = slot_for_pointer(bk, job.device_image, &st);
+	if (!b) return st ? st : 2;
+	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
 	DecodeLaunch d;
@@ -336,8 +590,8 @@ int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
 	d.d_image = job.device_image;
 	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = job.dim_z ? job.dim_z : 1u; d.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
-	d.block_x = b->root.dim_x; d.block_y = b->root.dim_y; d.block_z = b->root.dim_z;
-	d.profile = b->cfg.profile;
+	d.block_x = bk->root.dim_x; d.block_y = bk->root.dim_y; d.block_z = bk->root.dim_z;
+	d.profile = bk->cfg.profile;
 	d.stream = stream;
 	int lrc = astc_decode_launch(d);
 	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
@@ -345,8 +599,13 @@ int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
 	return 0;
 }
 
-int backend_compare(Backend* b, const CompareJob& job)
+int backend_compare(Backend* bk, const CompareJob& job)
 {
+	DeviceGuard guard;
+	int st = 0;
+	DeviceSlot* b = slot_for_pointer(bk, job.device_a, &st);
+	if (!b) return st ? st : 2;
+	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
 	if (!b->d_sums) HIP_TRY(hipMalloc(&b->d_sums, astc_compare_scratch_doubles() * sizeof(double)), return 1);

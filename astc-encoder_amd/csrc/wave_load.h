@@ -87,6 +87,8 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 		xi = xi < img.dim_x - 1 ? xi : img.dim_x - 1;
 		yi = yi < img.dim_y - 1 ? yi : img.dim_y - 1;
 		zi = zi < img.dim_z - 1 ? zi : img.dim_z - 1;
+		// the reference's RGBA8 fast loader reads slice 0 whatever the block's z (ref: astcenc_image.cpp:304)
+		if (fast && img.fast_load_slice0) zi = 0;
 		size_t base = (size_t)4 * ((size_t)img.dim_x * ((size_t)img.dim_y * zi + yi) + xi);
 
 		float v[6];

@@ -1,11 +1,9 @@
 # SPDX-License-Identifier: Apache-2.0
 """ctypes binding of the astcenc C ABI (include/astcenc.h + include/astcenc_amd.h).
 
-The same binding drives three shared objects, selected by path:
-  * astc-encoder_amd/libastcenc_amd.so   -- the product (HIP kernels, gfx950)
-  * oracle/_ref/libastcenc-{none,avx2}.so -- the reference encoder built from /root/reference (oracle)
-  * oracle/emu/_build/libastcenc_emu.so   -- scalar CPU build of the kernel source (oracle/README.md)
-so parity tests read: compress with A, compress with B, compare bytes.
+LIB_PRODUCT is astc-encoder_amd/libastcenc_amd.so (HIP kernels, gfx950).  Library(path) binds any shared
+object with the astcenc ABI, which is how the tests drive the checker libraries (their paths live in
+oracle/oracle_libs.py, not here) through the very same calls: compress with A, compress with B, compare bytes.
 
 Names mirror the C API (ref: Source/astcenc.h); see include/astcenc.h for field meaning.
 """
@@ -16,9 +14,6 @@ import numpy as np
 
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 LIB_PRODUCT = os.environ.get("ASTCENC_AMD_LIB", os.path.join(REPO, "astc-encoder_amd", "libastcenc_amd.so"))
-LIB_REF_NONE = os.path.join(REPO, "oracle", "_ref", "libastcenc-none.so")
-LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
-LIB_EMU = os.path.join(REPO, "oracle", "emu", "_build", "libastcenc_emu.so")
 
 # enum astcenc_error
 (SUCCESS, ERR_OUT_OF_MEM, ERR_BAD_CPU_FLOAT, ERR_BAD_PARAM, ERR_BAD_BLOCK_SIZE, ERR_BAD_PROFILE,
@@ -94,7 +89,9 @@ EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_ima
            "astcenc_compress_cancel", "astcenc_decompress_image", "astcenc_decompress_reset",
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
 EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
-               "astcenc_amd_compare_images_device", "astcenc_amd_backend_name"]
+               "astcenc_amd_compare_images_device", "astcenc_amd_backend_name", "astcenc_amd_context_device_count",
+               "astcenc_amd_context_set_option"]
+OPT_PER_SLICE_FAST_LOAD = 1
 
 
 class ErrorSums(C.Structure):
@@ -158,6 +155,11 @@ class Library:
             L.astcenc_amd_compare_images_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint,
                                                             C.c_void_p, C.POINTER(ErrorSums)]
             L.astcenc_amd_compare_images_device.restype = C.c_int
+        if hasattr(L, "astcenc_amd_context_device_count"):
+            L.astcenc_amd_context_device_count.argtypes = [C.c_void_p]
+            L.astcenc_amd_context_device_count.restype = C.c_int
+            L.astcenc_amd_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.astcenc_amd_context_set_option.restype = C.c_int
         if hasattr(L, "astcenc_amd_compress_volume_device"):
             L.astcenc_amd_compress_volume_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int,
                                                              C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,
@@ -198,9 +200,10 @@ class Library:
         return self.lib.astcenc_compress_image(ctx, C.byref(img), C.byref(swz), out.ctypes.data,
                                                out.nbytes if data_len is None else data_len, thread_index)
 
-    def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None):
+    def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None, options=None):
         """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16].
-        block is (x, y) or (x, y, z); pixels is [H, W, 4] or [D, H, W, 4]."""
+        block is (x, y) or (x, y, z); pixels is [H, W, 4] or [D, H, W, 4]; options: {OPT_*: value} for
+        astcenc_amd_context_set_option (product library only)."""
         bz = block[2] if len(block) > 2 else 1
         err, cfg = self.config_init(profile, block[0], block[1], bz, quality, flags)
         if err:
@@ -211,6 +214,10 @@ class Library:
         if err:
             raise AstcError(err, "astcenc_context_alloc")
         try:
+            for opt, value in (options or {}).items():
+                err = self.lib.astcenc_amd_context_set_option(ctx, opt, value)
+                if err:
+                    raise AstcError(err, "astcenc_amd_context_set_option")
             d = pixels.shape[0] if pixels.ndim == 4 else 1
             h, w = pixels.shape[-3], pixels.shape[-2]
             bx, by = (w + block[0] - 1) // block[0], (h + block[1] - 1) // block[1]

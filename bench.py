@@ -34,6 +34,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
 import astcenc_amd as A  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_libs as O  # noqa: E402  (checker libraries: used by the cpu_baseline / parity legs only, never inside the timed region)
 
 WIDTH = HEIGHT = 8192
 BLOCK = (6, 6)
@@ -43,9 +45,9 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 
 def cpu_reference_baseline(img, gpu_blocks, blocks_x):
     """Time the reference AVX2 encoder on all host cores on a crop sized for roughly 10-20 s."""
-    if not os.path.exists(A.LIB_REF_AVX2):
+    if not os.path.exists(O.LIB_REF_AVX2):
         return None
-    ref = A.Library(A.LIB_REF_AVX2)
+    ref = A.Library(O.LIB_REF_AVX2)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
     def run(crop):

@@ -85,4 +85,26 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_device(
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 
+/* Number of GPUs the context runs on.  astcenc_context_alloc() prepares every visible device (or the
+ * ordinals listed in the environment variable ASTCENC_AMD_DEVICES, e.g. "0,1,2,3"); astcenc_compress_image()
+ * then deals contiguous ranges of block rows of the host image to those devices -- each with its own
+ * tables, streams and PCIe pipeline -- and joins them, the way the reference deals blocks to its N worker
+ * threads (ref: Source/astcenc_entry.cpp:1009-1038).  Buffers that already live on a device (the *_device
+ * entry points) are processed on the device that owns them. */
+ASTCENC_PUBLIC int astcenc_amd_context_device_count(const struct astcenc_context* context);
+
+/* Behaviour switches that have no counterpart in the reference API. */
+enum astcenc_amd_option {
+	/* Multi-slice RGBA8 input (image.dim_z > 1) with a 2D footprint, LDR profile and identity swizzle: the
+	 * reference's fast block loader reads slice 0 for every slice (Source/astcenc_image.cpp:304), so it emits
+	 * slice 0's blocks dim_z times.  0 (default): do exactly that, byte for byte.  1: every slice is loaded
+	 * from its own data (the output equals compressing the slices one by one). */
+	ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD = 1
+};
+
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_context_set_option(
+	struct astcenc_context* context,
+	enum astcenc_amd_option option,
+	int value);
+
 #endif

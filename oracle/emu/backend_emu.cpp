@@ -40,6 +40,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 }
 
 void backend_destroy(Backend* b) { delete b; }
+int backend_device_count(const Backend*) { return 1; }
 const char* backend_name() { return "emu:cpu"; }
 
 int backend_compress(Backend* b, const CompressJob& job)
@@ -87,6 +88,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	bool hdr = b->cfg.profile >= 2;
 	img.use_fast_load = (!needs_swz && !hdr && job.data_type == 0 && root->dim_z == 1) ? 1 : 0;
+	img.fast_load_slice0 = job.fast_load_slice0;
 	img.alpha_avg = nullptr;
 	img.a_scale_radius = job.a_scale_radius;
 	std::vector<float> averages;
@@ -110,6 +112,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	long only_idx = only ? atol(only) : -1;
 	for (uint32_t row = 0; row < img.blocks_y * img.blocks_z; row++)
 	{
+		if (job.cancel_flag && job.cancel_flag->load()) break;
 		const uint32_t bz = row / img.blocks_y, by = row - bz * img.blocks_y;
 		for (uint32_t bx = 0; bx < img.blocks_x; bx++)
 		{
@@ -119,7 +122,6 @@ int backend_compress(Backend* b, const CompressJob& job)
 			else load_block(c, img, bx, by, bz);
 			compress_block(c, out + idx * 16);
 		}
-		if (job.cancel_flag && *job.cancel_flag) break;
 		if (job.progress) job.progress(100.0f * (float)(row + 1) / (float)(img.blocks_y * img.blocks_z));
 	}
 	if (job.kernel_ms) *job.kernel_ms = 0.0f;

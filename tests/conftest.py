@@ -7,6 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 
 
 def pytest_configure(config):
@@ -27,7 +29,7 @@ def A():
 def built():
     """Build product + emulator (+ oracle when the reference tree is present) once per session."""
     import astcenc_amd as A
-    if not (_have(A.LIB_PRODUCT) and _have(A.LIB_EMU) and (_have(A.LIB_REF_NONE) or not os.path.isdir("/root/reference"))):
+    if not (_have(A.LIB_PRODUCT) and _have(O.LIB_EMU) and (_have(O.LIB_REF_NONE) or not os.path.isdir("/root/reference"))):
         import __graft_entry__
         __graft_entry__.build()
     return True
@@ -36,14 +38,14 @@ def built():
 @pytest.fixture(scope="session")
 def ref(built, A):
     """The real reference encoder (oracle/_ref). Built here from /root/reference; travels prebuilt to the GPU box."""
-    if not _have(A.LIB_REF_NONE):
+    if not _have(O.LIB_REF_NONE):
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
-    return A.Library(A.LIB_REF_NONE)
+    return A.Library(O.LIB_REF_NONE)
 
 
 @pytest.fixture(scope="session")
 def emu(built, A):
-    return A.Library(A.LIB_EMU)
+    return A.Library(O.LIB_EMU)
 
 
 @pytest.fixture(scope="session")

@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import astcenc_amd as A  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "oracle")); import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 import images  # noqa: E402
 
 # name -> (image generator, (w, h), block, quality, partition limit override)
@@ -49,7 +50,7 @@ CASES_3D = {
 
 
 def main():
-    ref = A.Library(A.LIB_REF_NONE)
+    ref = A.Library(O.LIB_REF_NONE)
     manifest = {}
     for name, (kind, shape, block, quality) in CASES_3D.items():
         vol = images.volume(kind, *shape)

@@ -10,6 +10,7 @@ kernel source (oracle/emu, here) and through libastcenc_amd.so on the GPU (-m gp
 import ctypes as C
 import os
 import threading
+import oracle_libs as O  # (path set up by conftest.py)
 
 import numpy as np
 import pytest
@@ -70,7 +71,7 @@ def test_data_buffer_exceeded(lib, A):
 @pytest.mark.parametrize("profile_name", ["PRF_LDR", "PRF_HDR", "PRF_HDR_RGB_LDR_A"])
 def test_non_finite_input(lib, A, request, bad, profile_name):
     profile = getattr(A, profile_name)
-    ref = request.getfixturevalue("ref") if os.path.exists(A.LIB_REF_NONE) else None
+    ref = request.getfixturevalue("ref") if os.path.exists(O.LIB_REF_NONE) else None
     for offset in range(4):
         img = np.full((4, 4, 4), 0.5, dtype=np.float32)
         flat = img.reshape(-1)
@@ -192,6 +193,39 @@ def test_cancel_then_reset(lib, A):
     img = images.noisy(24, 24, 4)
     out = np.zeros(16 * 16, dtype=np.uint8)
     assert lib.compress_raw(ctx, img, out) == A.SUCCESS
+    assert out.tobytes() == lib.compress(img, (6, 6), A.PRE_FASTEST).tobytes()
+    lib.context_free(ctx)
+
+
+def test_cancel_without_reset_on_single_thread_context(lib, A):
+    """thread_count == 1: astcenc_compress_image resets implicitly, which also forgets a pending cancel
+    (ref: astcenc_entry.cpp:1185-1188 -> astcenc_compress_reset -> ParallelManager::reset); the image after a
+    cancel must therefore be compressed completely."""
+    ctx = _ctx(lib, A, block=(6, 6), quality=A.PRE_FASTEST)
+    img = images.noisy(48, 48, 8)
+    want = lib.compress(img, (6, 6), A.PRE_FASTEST).tobytes()
+    for _ in range(2):
+        assert lib.lib.astcenc_compress_cancel(ctx) == A.SUCCESS
+        out = np.full(64 * 16, 0xEE, dtype=np.uint8)
+        assert lib.compress_raw(ctx, img, out) == A.SUCCESS
+        assert out.tobytes() == want
+    lib.context_free(ctx)
+
+
+def test_cancel_is_sticky_on_multi_thread_context_until_reset(lib, A):
+    """thread_count > 1: a cancelled context leaves the output untouched until astcenc_compress_reset."""
+    ctx = _ctx(lib, A, block=(6, 6), quality=A.PRE_FASTEST, threads=2)
+    img = images.noisy(48, 48, 9)
+    assert lib.lib.astcenc_compress_cancel(ctx) == A.SUCCESS
+    out = np.full(64 * 16, 0xEE, dtype=np.uint8)
+    results = []
+    ts = [threading.Thread(target=lambda i=i: results.append(lib.compress_raw(ctx, img, out, thread_index=i))) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert results == [A.SUCCESS, A.SUCCESS]
+    assert (out == 0xEE).all()                      # nothing was compressed, nothing was written
+    assert lib.lib.astcenc_compress_reset(ctx) == A.SUCCESS
+    ts = [threading.Thread(target=lambda i=i: results.append(lib.compress_raw(ctx, img, out, thread_index=i))) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
     assert out.tobytes() == lib.compress(img, (6, 6), A.PRE_FASTEST).tobytes()
     lib.context_free(ctx)
 

@@ -4,6 +4,7 @@ profiles against the reference library on the GPU box's host threads."""
 import os
 import subprocess
 import sys
+import oracle_libs as O  # (path set up by conftest.py)
 
 import pytest
 
@@ -12,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_sweep_all_footprints_presets_profiles(product, A):
-    if not os.path.exists(A.LIB_REF_AVX2):
+    if not os.path.exists(O.LIB_REF_AVX2):
         pytest.skip("oracle/_ref not present")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_sweep.py"), "120"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-2000:]

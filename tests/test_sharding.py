@@ -6,6 +6,7 @@ with one image per rank; there is no data-path collective to test.)"""
 import os
 import socket
 import sys
+import oracle_libs as O  # (path set up by conftest.py)
 
 import numpy as np
 import pytest
@@ -48,7 +49,7 @@ def _worker(rank, world, port, block, size, quality, result_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
-        lib = A.Library(A.LIB_EMU)
+        lib = A.Library(O.LIB_EMU)
         img = A.synthetic_image(size[0], size[1], 11)
         err, cfg = lib.config_init(A.PRF_LDR, block[0], block[1], 1, quality, 0)
         assert err == 0

@@ -111,10 +111,10 @@ def test_decompress_and_block_info_match_reference(lib, ref, A, block):
 
 
 def test_array_image_with_2d_footprint(lib, ref, A):
-    """dim_z > 1 with a 2D footprint: every slice is compressed on its own, blocks in x, y, z order.
-    Checked against the reference through the general loader (F16 input) and, for RGBA8, against
-    slice-by-slice 2D compression: the reference's fast RGBA8 loader reads slice 0 for every z
-    (Source/astcenc_image.cpp:304), which this library does not imitate."""
+    """dim_z > 1 with a 2D footprint: blocks in x, y, z order.  Through the general loader (F16 input) every
+    slice is compressed on its own.  For RGBA8 / LDR / identity swizzle the reference's fast loader reads slice 0
+    for every z (Source/astcenc_image.cpp:304): by default this library emits exactly the reference's bytes;
+    with ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD it compresses every slice from its own data instead."""
     d, h, w = 3, 20, 26
     vol = images.volume("grad", d, h, w)
     half = (vol.astype(np.float32) / 255.0).astype(np.float16)
@@ -122,11 +122,21 @@ def test_array_image_with_2d_footprint(lib, ref, A):
     got = lib.compress(half, (6, 6), 60.0)
     assert want.size == 16 * 5 * 4 * d
     assert len(images.mismatches(want, got)) == 0
+    # default: the reference's own bytes, quirk included
+    want8 = ref.compress(vol, (6, 6), 60.0)
     got8 = lib.compress(vol, (6, 6), 60.0)
-    per_slice = np.concatenate([lib.compress(vol[z], (6, 6), 60.0) for z in range(d)])
-    assert np.array_equal(got8, per_slice)
-    assert np.array_equal(per_slice, np.concatenate([ref.compress(vol[z], (6, 6), 60.0) for z in range(d)]))
-    back = lib.decompress(got8, w, h, (6, 6), depth=d)
+    assert np.array_equal(got8, want8)
+    slice0 = ref.compress(vol[0], (6, 6), 60.0)
+    assert np.array_equal(want8, np.concatenate([slice0] * d))          # (this is what the quirk amounts to)
+    # a swizzle takes the general loader: per-slice data again, still the reference's bytes
+    swz = (A.SWZ_B, A.SWZ_G, A.SWZ_R, A.SWZ_A)
+    assert np.array_equal(lib.compress(vol, (6, 6), 60.0, swizzle=swz), ref.compress(vol, (6, 6), 60.0, swizzle=swz))
+    # opt-in: every slice from its own data
+    fixed = lib.compress(vol, (6, 6), 60.0, options={A.OPT_PER_SLICE_FAST_LOAD: 1})
+    per_slice = np.concatenate([ref.compress(vol[z], (6, 6), 60.0) for z in range(d)])
+    assert np.array_equal(fixed, per_slice)
+    assert not np.array_equal(fixed, want8)
+    back = lib.decompress(fixed, w, h, (6, 6), depth=d)
     assert np.array_equal(back, np.stack([ref.decompress(per_slice[z * 320:(z + 1) * 320], w, h, (6, 6)) for z in range(d)]))
 
 

@@ -7,11 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import astcenc_amd as A, images
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")); import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(SEED)
-gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(A.LIB_REF_AVX2)
+gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(O.LIB_REF_AVX2)
 threads = min(64, len(os.sched_getaffinity(0)))
 FOOT2 = [(4, 4), (5, 4), (5, 5), (6, 5), (6, 6), (8, 5), (8, 6), (8, 8), (10, 5), (10, 6), (10, 8), (10, 10), (12, 10), (12, 12)]
 FOOT3 = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]

@@ -7,9 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import astcenc_amd as A, images
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")); import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(A.LIB_REF_NONE)   # the scalar build is the authority: the AVX2 build converts NaN-producing HDR blocks differently (F16C, SSE min/max)
+gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(O.LIB_REF_NONE)   # the scalar build is the authority: the AVX2 build converts NaN-producing HDR blocks differently (F16C, SSE min/max)
 cases = bad = blocks = 0
 t0 = time.time()
 FOOT = [(4, 4), (5, 4), (6, 6), (8, 5), (8, 8), (10, 6), (12, 12), (3, 3, 3), (4, 4, 3), (5, 5, 4), (6, 6, 6)]

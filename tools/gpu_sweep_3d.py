@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import astcenc_amd as A, images
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")); import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 
 torch.zeros(1, device="cuda")
 FOOT = [(3, 3, 3), (4, 3, 3), (4, 4, 3), (4, 4, 4), (5, 4, 4), (5, 5, 4), (5, 5, 5), (6, 5, 5), (6, 6, 5), (6, 6, 6)]
 PRESETS = [("fastest", 0.0), ("fast", 10.0), ("medium", 60.0), ("thorough", 98.0)]
 EDGE = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(A.LIB_REF_AVX2)
+gpu = A.Library(A.LIB_PRODUCT); ref = A.Library(O.LIB_REF_AVX2)
 threads = len(os.sched_getaffinity(0))
 
 

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import astcenc_amd as A, images
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")); import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lib = A.Library(A.LIB_PRODUCT)
 err, cfg = lib.config_init(A.PRF_HDR, 6, 6, 1, A.PRE_MEDIUM, 0); assert err == 0
@@ -20,8 +21,8 @@ for i in range(3):
     if i: best = min(best, ms.value)
 print("HDR %dx%d RGBA16F 6x6 medium: kernel %.2f ms -> %.2f Mtexels/s" % (size, size, best, size * size / best / 1e3))
 # cross-check a crop against the reference
-if os.path.exists(A.LIB_REF_AVX2):
-    ref = A.Library(A.LIB_REF_AVX2)
+if os.path.exists(O.LIB_REF_AVX2):
+    ref = A.Library(O.LIB_REF_AVX2)
     crop = np.ascontiguousarray(img_h[:240, :240])
     want = ref.compress(crop, (6, 6), A.PRE_MEDIUM, profile=A.PRF_HDR).reshape(-1, 16)
     bx = (size + 5) // 6
