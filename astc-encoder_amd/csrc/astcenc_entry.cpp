@@ -653,17 +653,19 @@ astcenc_error astcenc_amd_decompress_image_device(astcenc_context* ctx, const vo
 	return rc == 0 ? ASTCENC_SUCCESS : rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : rc == 3 ? ASTCENC_ERR_BAD_PARAM : ASTCENC_ERR_BAD_CONTEXT;
 }
 
-astcenc_error astcenc_amd_compare_images_device(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
-                                                const void* device_image2, astcenc_type type2,
-                                                unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
-                                                void* hip_stream, astcenc_amd_error_sums* sums)
+static astcenc_error compare_images(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
+                                    const void* device_image2, astcenc_type type2,
+                                    unsigned int dim_x, unsigned int dim_y, unsigned int dim_z, void* hip_stream,
+                                    astcenc_amd_error_sums* sums, astcenc_amd_hdr_error_sums* hdr_sums, int fstop_lo, int fstop_hi)
 {
 	bool overflow = false;
 	size_t texel_count = mul_safe(mul_safe(dim_x, dim_y, overflow), dim_z, overflow);
 	if (overflow || texel_count == 0 || !device_image1 || !device_image2 || !sums) return ASTCENC_ERR_BAD_PARAM;
 	if ((unsigned)type1 > 2u || (unsigned)type2 > 2u) return ASTCENC_ERR_BAD_PARAM;
+	// the f-stop becomes a float exponent (ref: mpsnr_operator: "should be in range [-125, 125]")
+	if (hdr_sums && (fstop_lo < -125 || fstop_hi > 125 || fstop_hi < fstop_lo)) return ASTCENC_ERR_BAD_PARAM;
 
-	double raw[10];
+	double raw[METRIC_SUMS_HOST];
 	CompareJob job;
 	memset(&job, 0, sizeof(job));
 	job.device_a = device_image1; job.type_a = (uint32_t)type1;
@@ -671,12 +673,36 @@ astcenc_error astcenc_amd_compare_images_device(astcenc_context* ctx, const void
 	job.texels = texel_count;
 	job.stream = hip_stream;
 	job.sums = raw;
+	job.hdr = hdr_sums ? 1 : 0; job.fstop_lo = fstop_lo; job.fstop_hi = fstop_hi;
 	int rc = backend_compare(ctx->backend, job);
 	if (rc != 0) return rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
 	for (int k = 0; k < 4; k++) { sums->squared_error[k] = raw[k]; sums->alpha_scaled_squared_error[k] = raw[4 + k]; }
 	sums->rgb_peak = raw[8];
 	sums->texels = (double)texel_count;
+	if (hdr_sums)
+	{
+		for (int k = 0; k < 4; k++) { hdr_sums->log2_squared_error[k] = raw[10 + k]; hdr_sums->mpsnr_squared_error[k] = raw[14 + k]; }
+		hdr_sums->fstop_lo = fstop_lo; hdr_sums->fstop_hi = fstop_hi;
+	}
 	return ASTCENC_SUCCESS;
+}
+
+astcenc_error astcenc_amd_compare_images_device(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
+                                                const void* device_image2, astcenc_type type2,
+                                                unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+                                                void* hip_stream, astcenc_amd_error_sums* sums)
+{
+	return compare_images(ctx, device_image1, type1, device_image2, type2, dim_x, dim_y, dim_z, hip_stream, sums, nullptr, 0, 0);
+}
+
+astcenc_error astcenc_amd_compare_images_hdr_device(astcenc_context* ctx, const void* device_image1, astcenc_type type1,
+                                                    const void* device_image2, astcenc_type type2,
+                                                    unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+                                                    int fstop_lo, int fstop_hi, void* hip_stream,
+                                                    astcenc_amd_error_sums* sums, astcenc_amd_hdr_error_sums* hdr_sums)
+{
+	if (!hdr_sums) return ASTCENC_ERR_BAD_PARAM;
+	return compare_images(ctx, device_image1, type1, device_image2, type2, dim_x, dim_y, dim_z, hip_stream, sums, hdr_sums, fstop_lo, fstop_hi);
 }
 
 const char* astcenc_amd_backend_name(void)

@@ -55,8 +55,10 @@ struct CompareJob {
 	const void* device_b; uint32_t type_b;
 	size_t texels;
 	void* stream;
-	double* sums;
+	double* sums;              // METRIC_SUMS_HOST doubles: [0..3] squared error, [4..7] alpha-scaled, [8] rgb peak, [10..13] log2, [14..17] mPSNR
+	int hdr, fstop_lo, fstop_hi;   // hdr != 0: also the HDR sums over f-stops fstop_lo..fstop_hi
 };
+constexpr int METRIC_SUMS_HOST = 18;
 
 /* status / return codes: 0 ok, 1 out of memory, 2 no usable device / launch failure, 3 bad argument
  * (a stream of another device than the buffers).
@@ -122,6 +124,7 @@ struct CompareLaunch {
 	size_t texels;
 	double* d_sums;
 	void* stream;
+	int hdr, fstop_lo, fstop_hi;
 };
 int astc_compare_launch(const CompareLaunch& c);
 size_t astc_compare_scratch_doubles();

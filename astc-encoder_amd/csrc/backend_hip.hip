@@ -32,7 +32,8 @@ struct DeviceSlot {
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
 	float* d_alpha; size_t alpha_cap;   // alpha averages of the a_scale_radius pre-pass
-	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds)
+	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds) / search trace (ASTC_TRACE builds)
+	size_t trace_cap;             // bytes at d_prof in ASTC_TRACE builds
 	double* d_sums;               // totals of the image comparison kernel
 	std::mutex busy;              // one call at a time per slot: the staging buffers and events are shared state
 };
@@ -50,6 +51,7 @@ struct Backend {
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
 // of a mapped page.
 constexpr size_t ALLOC_SLACK = 4096;
+constexpr size_t TRACE_WORDS_PER_BLOCK_HOST = 1024;   // = TRACE_WORDS_PER_BLOCK (wave_ctx.h), ASTC_TRACE builds
 
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	fprintf(stderr, "astcenc_amd: %s -> %s\n", #expr, hipGetErrorString(e_)); fail; } } while (0)
@@ -94,7 +96,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	s->ev0 = s->ev1 = s->ev_copy[0] = s->ev_copy[1] = s->ev_band = nullptr;
 	s->ev_done[0] = s->ev_done[1] = s->ev_done[2] = nullptr;
 	s->d_image = nullptr; s->image_cap = 0; s->d_out = nullptr; s->out_cap = 0; s->d_alpha = nullptr; s->alpha_cap = 0;
-	s->d_prof = nullptr; s->d_sums = nullptr;
+	s->d_prof = nullptr; s->trace_cap = 0; s->d_sums = nullptr;
 #define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
 	SLOT_TRY(hipSetDevice(device), 2);
 	{
@@ -384,6 +386,20 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		HIP_TRY(hipEventRecord(s->ev_copy[(band_first / chunk) & 1], s->copy_stream), return 2);
 		return 0;
 	};
+#if defined(ASTC_TRACE)
+	{
+		// debug build: one trace slice per block, dumped to $ASTCENC_AMD_TRACE_FILE after the call (wave_ctx.h: TRACE_PUT)
+		const size_t need = nblocks * TRACE_WORDS_PER_BLOCK_HOST * sizeof(uint32_t);
+		if (s->trace_cap < need)
+		{
+			if (s->d_prof) (void)hipFree(s->d_prof);
+			s->d_prof = nullptr; s->trace_cap = 0;
+			HIP_TRY(hipMalloc(&s->d_prof, need), return 1);
+			s->trace_cap = need;
+		}
+		HIP_TRY(hipMemsetAsync(s->d_prof, 0, need, stream), return 2);
+	}
+#endif
 	if (job.kernel_ms) HIP_TRY(hipEventRecord(s->ev0, stream), return 2);
 	// The host stays at most two chunks ahead of the device: chunk k-1's completion event is waited for
 	// (and reported to the progress callback) after chunk k has been queued, so the device always has its
@@ -439,6 +455,14 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 	if (chunked && progress && prev_blocks && !cancelled) progress->add(prev_blocks);
 	else if (chunked && progress && prev_blocks && cancelled && launched) progress->add(prev_blocks);
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, s->ev0, s->ev1), return 2);
+#if defined(ASTC_TRACE)
+	if (const char* path = getenv("ASTCENC_AMD_TRACE_FILE"))
+	{
+		std::vector<uint32_t> host(nblocks * TRACE_WORDS_PER_BLOCK_HOST);
+		HIP_TRY(hipMemcpy(host.data(), s->d_prof, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), return 2);
+		if (FILE* f = fopen(path, "wb")) { fwrite(host.data(), sizeof(uint32_t), host.size(), f); fclose(f); }
+	}
+#endif
 #if defined(ASTC_PROFILE)
 	{
 		enum { PS_COUNT = 40, PS_TOTAL = 14 };
@@ -612,9 +636,10 @@ int backend_compare(Backend* bk, const CompareJob& job)
 	CompareLaunch c;
 	c.d_a = job.device_a; c.type_a = job.type_a; c.d_b = job.device_b; c.type_b = job.type_b;
 	c.texels = job.texels; c.d_sums = b->d_sums; c.stream = stream;
+	c.hdr = job.hdr; c.fstop_lo = job.fstop_lo; c.fstop_hi = job.fstop_hi;
 	int lrc = astc_compare_launch(c);
 	if (lrc != 0) { fprintf(stderr, "astcenc_amd: compare kernel launch failed (hip error %d)\n", lrc); return 2; }
-	HIP_TRY(hipMemcpyAsync(job.sums, b->d_sums, 10 * sizeof(double), hipMemcpyDeviceToHost, stream), return 2);
+	HIP_TRY(hipMemcpyAsync(job.sums, b->d_sums, METRIC_SUMS_HOST * sizeof(double), hipMemcpyDeviceToHost, stream), return 2);
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
 	return 0;
 }

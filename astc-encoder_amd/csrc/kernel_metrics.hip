@@ -13,61 +13,71 @@ namespace astcd {
 
 constexpr uint32_t COMPARE_MAX_GROUPS = 2048;
 
-/* Pass 1: every workgroup reduces its texels to nine fp64 partials (fixed order inside the group: lane
- * shuffles, then wave 0 adds the four waves' results) and writes them to its own slot -- no atomics, so
- * the totals do not depend on scheduling. */
+/* Pass 1: every workgroup reduces its texels to fp64 partials (fixed order inside the group: lane shuffles,
+ * then one thread per quantity adds the four waves' results) and writes them to its own slot -- no atomics,
+ * so the totals do not depend on scheduling.  HDR: also the eight HDR sums (log2 and mPSNR terms). */
+template <bool HDR>
 __global__ void __launch_bounds__(256)
 astc_compare_images(const void* __restrict__ a, uint32_t type_a, const void* __restrict__ b, uint32_t type_b,
-                    size_t texels, double* __restrict__ partials)
+                    size_t texels, int fstop_lo, int fstop_hi, double* __restrict__ partials)
 {
+	constexpr int NACC = HDR ? 16 : 8;                       // sums (the peak rides along separately)
 	__shared__ float unorm8[256];
-	__shared__ double wave_sums[4][9];
+	__shared__ double wave_sums[4][NACC + 1];
 	unorm8[threadIdx.x] = (float)threadIdx.x / 255.0f;      // blockDim.x == 256
 	__syncthreads();
-	double acc[8];
-	for (int k = 0; k < 8; k++) acc[k] = 0.0;
+	double acc[NACC];
+	for (int k = 0; k < NACC; k++) acc[k] = 0.0;
 	float peak = 0.0f;
 	const size_t stride = (size_t)gridDim.x * blockDim.x;
 	for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < texels; t += stride)
 	{
-		float e[8];
-		float m = metric_texel_terms(a, type_a, b, type_b, t, unorm8, e);
+		float e[8], c1[4], c2[4];
+		float m = metric_texel_terms(a, type_a, b, type_b, t, unorm8, e, c1, c2);
 		peak = m > peak ? m : peak;
 		for (int k = 0; k < 8; k++) acc[k] += (double)e[k];
+		if (HDR)
+		{
+			float h[8];
+			metric_hdr_terms(c1, c2, fstop_lo, fstop_hi, h);
+			for (int k = 0; k < 8; k++) acc[8 + k] += (double)h[k];
+		}
 	}
 	for (int off = 32; off > 0; off >>= 1)
 	{
-		for (int k = 0; k < 8; k++) acc[k] += __shfl_down(acc[k], off);
+		for (int k = 0; k < NACC; k++) acc[k] += __shfl_down(acc[k], off);
 		float o = __shfl_down(peak, off);
 		peak = o > peak ? o : peak;
 	}
 	const int wave = threadIdx.x >> 6;
 	if ((threadIdx.x & 63) == 0)
 	{
-		for (int k = 0; k < 8; k++) wave_sums[wave][k] = acc[k];
-		wave_sums[wave][8] = (double)peak;
+		for (int k = 0; k < NACC; k++) wave_sums[wave][k] = acc[k];
+		wave_sums[wave][NACC] = (double)peak;
 	}
 	__syncthreads();
-	if (threadIdx.x < 9)
+	if (threadIdx.x <= NACC)
 	{
 		const int k = threadIdx.x;
 		double v = wave_sums[0][k];
-		for (int w = 1; w < 4; w++) v = k < 8 ? v + wave_sums[w][k] : (wave_sums[w][k] > v ? wave_sums[w][k] : v);
-		partials[(size_t)blockIdx.x * 16 + k] = v;
+		for (int w = 1; w < 4; w++) v = k < NACC ? v + wave_sums[w][k] : (wave_sums[w][k] > v ? wave_sums[w][k] : v);
+		// slot layout = layout of the totals: [0..7] LDR sums, [8] peak, [10..17] HDR sums
+		const int dst = k == NACC ? 8 : k < 8 ? k : METRIC_HDR_FIRST + (k - 8);
+		partials[(size_t)blockIdx.x * METRIC_STRIDE + dst] = v;
 	}
 }
 
 /* Pass 2: one thread per quantity adds the workgroups' partials in index order. */
 __global__ void __launch_bounds__(64)
-astc_compare_finish(const double* __restrict__ partials, uint32_t groups, double* __restrict__ sums)
+astc_compare_finish(const double* __restrict__ partials, uint32_t groups, int hdr, double* __restrict__ sums)
 {
 	const int k = threadIdx.x;
-	if (k >= 9) return;
+	if (k >= (hdr ? METRIC_SUMS_HDR : 9) || k == 9) return;
 	double v = partials[k];
 	for (uint32_t g = 1; g < groups; g++)
 	{
-		const double p = partials[(size_t)g * 16 + k];
-		v = k < 8 ? v + p : (p > v ? p : v);
+		const double p = partials[(size_t)g * METRIC_STRIDE + k];
+		v = k != 8 ? v + p : (p > v ? p : v);
 	}
 	sums[k] = v;
 }
@@ -77,14 +87,18 @@ int astc_compare_launch(const CompareLaunch& c)
 	size_t groups = (c.texels + 255) / 256;
 	if (groups > COMPARE_MAX_GROUPS) groups = COMPARE_MAX_GROUPS;     // 8 workgroups of 256 per CU: plenty for a streaming pass
 	if (groups == 0) groups = 1;
-	double* partials = c.d_sums + 16;
-	hipLaunchKernelGGL(astc_compare_images, dim3((uint32_t)groups), dim3(256), 0, static_cast<hipStream_t>(c.stream),
-	                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, partials);
-	hipLaunchKernelGGL(astc_compare_finish, dim3(1), dim3(64), 0, static_cast<hipStream_t>(c.stream), partials, (uint32_t)groups, c.d_sums);
+	double* partials = c.d_sums + METRIC_STRIDE;
+	if (c.hdr)
+		hipLaunchKernelGGL(astc_compare_images<true>, dim3((uint32_t)groups), dim3(256), 0, static_cast<hipStream_t>(c.stream),
+		                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, c.fstop_lo, c.fstop_hi, partials);
+	else
+		hipLaunchKernelGGL(astc_compare_images<false>, dim3((uint32_t)groups), dim3(256), 0, static_cast<hipStream_t>(c.stream),
+		                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, 0, 0, partials);
+	hipLaunchKernelGGL(astc_compare_finish, dim3(1), dim3(64), 0, static_cast<hipStream_t>(c.stream), partials, (uint32_t)groups, c.hdr, c.d_sums);
 	return (int)hipGetLastError();
 }
 
-/* Doubles the caller must provide at d_sums: the ten totals (padded to 16) followed by the per-workgroup partials. */
-size_t astc_compare_scratch_doubles() { return 16 + (size_t)COMPARE_MAX_GROUPS * 16; }
+/* Doubles the caller must provide at d_sums: the totals (one slot) followed by the per-workgroup partials. */
+size_t astc_compare_scratch_doubles() { return METRIC_STRIDE + (size_t)COMPARE_MAX_GROUPS * METRIC_STRIDE; }
 
 } // namespace astcd

@@ -520,6 +520,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 		const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
 		const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
 
+		TRACE_PUT(c, TR_CANDIDATE, (float)cand_wq);
 		refine_candidate_setup(dual, partition_count, plane2_component, i, cand_dm != staged_dm ? cand_dm : -1,
 		                       cand_wq != staged_wq ? cand_wq : -1, color_quant_level);
 		staged_dm = cand_dm;
@@ -537,6 +538,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 			if (l == 0)
 			{
 				const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
+				TRACE_PUT(c, TR_ERR_PRE, errorval);
 				best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
 				int iters_remaining = refinement_limit - l;
@@ -561,6 +563,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
 			const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
+			TRACE_PUT(c, TR_ERR_POST, errorval);
 			best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
 			int iters_remaining = refinement_limit - 1 - l;
@@ -777,6 +780,10 @@ WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune
                            int partition_count, int partition_packed, int plane2_component, int quant_limit)
 {
 	PROF_SCOPE(c, PS_X3);
+	TRACE_PUT(c, TR_PASS, (float)(partition_count * 64 + (dual ? 2 : 1) * 8 + (plane2_component + 1)));
+#if defined(ASTC_TRACE)
+	if (partition_count > 1) TRACE_PUT(c, TR_PARTITION_INDEX, (float)part_view(c, partition_count, partition_packed).h->partition_index);
+#endif
 	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
 	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
 	const int ref_mask = (int)((1u << (max_weight_quant + 1)) - 1);
@@ -965,6 +972,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	float error_weight_sum = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) * (float)T;
 	float error_threshold = cfg.tune_db_limit * error_weight_sum * block_is_l_scale * block_is_la_scale;
 
+	TRACE_PUT(c, TR_THRESHOLD, error_threshold);
 	WV_ONE
 	{
 		scb.errorval = ERROR_CALC_DEFAULT;
@@ -1004,6 +1012,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	{
 		float lowest_correl;
 		lowest_correl = wv_uniform(stage_block_statistics());
+		TRACE_PUT(c, TR_LOWEST_CORREL, lowest_correl);
 		bool block_skip_two_plane = lowest_correl > cfg.tune_2plane_early_out_limit_correlation;
 		for (int i = 3; i >= 0 && !done; i--)
 		{

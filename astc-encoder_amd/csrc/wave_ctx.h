@@ -329,6 +329,42 @@ struct ProfScope {
 #define PROF_SCOPE(c, id) ((void)0)
 #endif
 
+/* Search trace for debug builds (-DASTC_TRACE): lane 0 appends (tag, float) records to the block's slice of a
+ * global buffer that the backend dumps to $ASTCENC_AMD_TRACE_FILE; tests/test_trace.py diffs it against the
+ * -dtrace JSON of the reference's ASTCENC_DIAGNOSTICS build (ref: trace_add_data calls in
+ * astcenc_compress_symbolic.cpp:618/:667/:952/:1002 and the pass nodes :1295-1392).  In trace builds c.prof is this
+ * block's slice: word 0 counts the records, records follow as (tag, value bits) pairs.  Compiled out otherwise. */
+constexpr uint32_t TRACE_WORDS_PER_BLOCK = 1024;      // 4 KiB per block: 511 records
+enum { TR_PASS = 1,            // value = partition_count * 64 + plane_count * 8 + (plane 2 component + 1) as float
+       TR_PARTITION_INDEX = 2, // value = partition index (the format's, not the packed table index) as float
+       TR_CANDIDATE = 3,       // value = weight quant mode of the candidate as float
+       TR_ERR_PRE = 4,         // error_prerealign
+       TR_ERR_POST = 5,        // error_postrealign
+       TR_THRESHOLD = 6,       // tune_error_threshold
+       TR_LOWEST_CORREL = 7 };
+#if defined(ASTC_TRACE)
+WV_FN void trace_put(const Ctx& c, uint32_t tag, float value)
+{
+	WV_ONE
+	{
+		uint32_t* t = reinterpret_cast<uint32_t*>(c.prof);
+		if (t)
+		{
+			uint32_t n = t[0];
+			if (2 * n + 2 < TRACE_WORDS_PER_BLOCK)
+			{
+				t[1 + 2 * n] = tag;
+				t[2 + 2 * n] = (uint32_t)float_as_int(value);
+				t[0] = n + 1;
+			}
+		}
+	}
+}
+#define TRACE_PUT(c, tag, value) trace_put(c, tag, value)
+#else
+#define TRACE_PUT(c, tag, value) ((void)0)
+#endif
+
 /* View of one partition record. */
 struct PartView {
 	const PartitionHeader* h;

@@ -90,7 +90,7 @@ EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_ima
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
 EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
                "astcenc_amd_compare_images_device", "astcenc_amd_backend_name", "astcenc_amd_context_device_count",
-               "astcenc_amd_context_set_option"]
+               "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device"]
 OPT_PER_SLICE_FAST_LOAD = 1
 
 
@@ -104,6 +104,22 @@ class ErrorSums(C.Structure):
         src = self.alpha_scaled_squared_error if alpha_scaled else self.squared_error
         num = sum(src[k] for k in range(channels))
         return 999.0 if num == 0 else 10.0 * float(np.log10(self.texels * channels / num))
+
+
+class HdrErrorSums(C.Structure):
+    """struct astcenc_amd_hdr_error_sums (include/astcenc_amd.h)."""
+    _fields_ = [("log2_squared_error", C.c_double * 4), ("mpsnr_squared_error", C.c_double * 4),
+                ("fstop_lo", C.c_int), ("fstop_hi", C.c_int)]
+
+    def mpsnr(self, texels):
+        """mPSNR (RGB) as the reference CLI prints it (astcenccli_error_metrics.cpp:389-397)."""
+        num = sum(self.mpsnr_squared_error[k] for k in range(3))
+        stops = self.fstop_hi - self.fstop_lo + 1
+        return 999.0 if num == 0 else 10.0 * float(np.log10(texels * 3.0 * stops * 255.0 * 255.0 / num))
+
+    def log_rmse(self, texels):
+        """LogRMSE (RGB) (astcenccli_error_metrics.cpp:402-403)."""
+        return float(np.sqrt(sum(self.log2_squared_error[k] for k in range(3)) / texels))
 
 
 class AstcError(RuntimeError):
@@ -155,6 +171,10 @@ class Library:
             L.astcenc_amd_compare_images_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint,
                                                             C.c_void_p, C.POINTER(ErrorSums)]
             L.astcenc_amd_compare_images_device.restype = C.c_int
+        if hasattr(L, "astcenc_amd_compare_images_hdr_device"):
+            L.astcenc_amd_compare_images_hdr_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_uint,
+                                                                C.c_int, C.c_int, C.c_void_p, C.POINTER(ErrorSums), C.POINTER(HdrErrorSums)]
+            L.astcenc_amd_compare_images_hdr_device.restype = C.c_int
         if hasattr(L, "astcenc_amd_context_device_count"):
             L.astcenc_amd_context_device_count.argtypes = [C.c_void_p]
             L.astcenc_amd_context_device_count.restype = C.c_int
@@ -283,6 +303,23 @@ def synthetic_image(width, height, seed=0x9E3779B1):
 
     out = np.stack([r + noise(0, 10), g + noise(1, 10), b + noise(2, 10), a + noise(3, 3)], axis=-1)
     return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def synthetic_hdr_image(width, height, seed=0x9E3779B1):
+    """HDR companion of synthetic_image: the LDR generator / 255 with RGB scaled by
+    2^(-2..5) in 8x8 patches (exponent ((tri(x >> 3) + tri(y >> 3)) >> 6) - 2), alpha kept in 0..1, stored as
+    RGBA16F (round to nearest even).  Power-of-two scaling of exact quotients: identical bytes on every host."""
+    base = synthetic_image(width, height, seed).astype(np.float32) / np.float32(255.0)
+    y, x = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
+
+    def tri(v):
+        m = v & 511
+        return np.where(m < 256, m, 511 - m)
+
+    expo = ((tri(x >> 3) + tri(y >> 3)) >> 6) - 2
+    scale = np.ldexp(np.float32(1.0), expo.astype(np.int32)).astype(np.float32)
+    base[..., :3] *= scale[..., None]
+    return base.astype(np.float16)
 
 
 def psnr_rgba8(a, b):

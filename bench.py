@@ -3,22 +3,29 @@
 """Headline benchmark: Mtexels/s of ASTC LDR 6x6 -medium compression of an 8192x8192 RGBA8 image
 (BASELINE.json configs[1]) on MI355X, inputs resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c1]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --single-process     one process, the library's own N-device split behind the C ABI
 
-A "step" is one pass of the block compressor over one 8192x8192 image per rank.  The path shards by
-independent images/block rows with no data-path collective, so N ranks compress N
-images: weak scaling, value = N * texels * K / max-over-ranks time.  torch is used for device
-memory, the stream, and the rank barrier only; the work is libastcenc_amd.so called through its
-C ABI (astcenc_amd_compress_image_device).
+A "step" is one pass of the block compressor over one image per rank.  The path shards by independent
+images / block rows with no data-path collective, so N ranks compress N images: weak
+scaling, value = N * texels * K / max-over-ranks time.  torch is used for device memory, the stream and
+the rank barrier only; the work is libastcenc_amd.so called through its C ABI
+(astcenc_amd_compress_image_device).
 
 Rank 0 prints ONE JSON line with the driver's fields plus:
-  roofline     : algorithmic HBM bytes per launch / mean kernel time (HIP events on the launch stream,
-                 taken inside the library) vs the 8 TB/s HBM peak.  The kernel is compute/latency bound
-                 by four orders of magnitude, which this fraction shows honestly.
-  cpu_baseline : the reference encoder's AVX2 build (oracle/_ref/libastcenc-avx2.so) on all host cores
-                 of this box, timed on a bounded crop of the same image (N = 1 only), plus a byte
-                 comparison of that crop against the GPU output.
+  roofline       : algorithmic HBM bytes per launch / mean kernel time (HIP events recorded by the library on
+                   the launch stream) vs the 8 TB/s HBM peak; `traffic` and the VALU figures come from the
+                   latest committed rocprofv3 PMC passes of this same workload (profiles/*/traffic.json,
+                   named in traffic_source: rocprofv3 cannot run inside this process).
+  value_host_api : the same image through astcenc_compress_image (host pointers, PCIe both ways included).
+  cpu_baseline   : the reference encoder's AVX2 build (oracle/_ref/libastcenc-avx2.so) on this box's host
+                   cores: thread-count sweep on a 2048^2 crop, best of 3 with astcenc_compress_reset in
+                   between, plus the 1-thread rate and the host's CPU model / cgroup quota / load; then a
+                   byte comparison of a larger crop against the GPU output.  N = 1 only.
+  extra_configs  : BASELINE configs[2] (8192^2 8x8 -thorough) and configs[3] (4096^2 RGBA16F HDR 6x6 -medium):
+                   kernel time, Mtexels/s, roofline, byte parity of a block-aligned crop and of the clamped image
+                   tail against the reference, and (HDR) mPSNR / log RMSE from the on-device comparison.
 """
 import argparse
 import ctypes
@@ -37,71 +44,199 @@ import astcenc_amd as A  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_libs as O  # noqa: E402  (checker libraries: used by the cpu_baseline / parity legs only, never inside the timed region)
 
-WIDTH = HEIGHT = 8192
-BLOCK = (6, 6)
-QUALITY = A.PRE_MEDIUM
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
+# BASELINE.json configs (C1..C4); `index` = position in BASELINE.json's list
+CONFIGS = {
+    "c1": dict(index=0, size=512, block=(4, 4), quality=A.PRE_FASTEST, profile="PRF_LDR", hdr=False, plimit=1,
+               label="512x512 RGBA8 LDR, 4x4 block, -fastest, 1 partition"),
+    "c2": dict(index=1, size=8192, block=(6, 6), quality=A.PRE_MEDIUM, profile="PRF_LDR", hdr=False, plimit=None,
+               label="8192x8192 RGBA8 LDR, 6x6 block, -medium"),
+    "c3": dict(index=2, size=8192, block=(8, 8), quality=A.PRE_THOROUGH, profile="PRF_LDR", hdr=False, plimit=None,
+               label="8192x8192 RGBA8 LDR, 8x8 block, -thorough"),
+    "c4": dict(index=3, size=4096, block=(6, 6), quality=A.PRE_MEDIUM, profile="PRF_HDR", hdr=True, plimit=None,
+               label="4096x4096 RGBA16F HDR, 6x6 block, -medium"),
+}
 
-def cpu_reference_baseline(img, gpu_blocks, blocks_x):
-    """Time the reference AVX2 encoder on all host cores on a crop sized for roughly 10-20 s."""
+
+def make_image(cfg, seed):
+    if cfg["hdr"]:
+        return A.synthetic_hdr_image(cfg["size"], cfg["size"], seed)
+    return A.synthetic_image(cfg["size"], cfg["size"], seed)
+
+
+def make_context(lib, cfg, threads=1):
+    err, c = lib.config_init(getattr(A, cfg["profile"]), cfg["block"][0], cfg["block"][1], 1, cfg["quality"], 0)
+    assert err == 0, err
+    if cfg["plimit"]:
+        c.tune_partition_count_limit = cfg["plimit"]
+    err, ctx = lib.context_alloc(c, threads)
+    assert err == 0, "context_alloc failed: %s" % lib.error_string(err)
+    return ctx
+
+
+def block_grid(cfg):
+    s, (bx, by) = cfg["size"], cfg["block"]
+    return (s + bx - 1) // bx, (s + by - 1) // by
+
+
+def algorithmic_bytes(cfg):
+    """every texel read once (4 B RGBA8, 8 B RGBA16F), 16 B per block written once."""
+    nbx, nby = block_grid(cfg)
+    return cfg["size"] * cfg["size"] * (8 if cfg["hdr"] else 4) + nbx * nby * 16
+
+
+def to_device(img, dev):
+    if img.dtype == np.float16:
+        return torch.from_numpy(img.view(np.int16)).to(dev)
+    return torch.from_numpy(img).to(dev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# checker legs (never timed as `value`)
+# ---------------------------------------------------------------------------------------------------------
+
+def reference_threads(ref, cfg, crop, threads, repeats):
+    """astcenc_compress_image of the reference on `threads` caller threads (the API's own threading model,
+    ref: astcenc.h:785-803), best of `repeats` with astcenc_compress_reset in between.  Returns (best s, blocks)."""
+    ctx = make_context(ref, cfg, threads)
+    h, w = crop.shape[:2]
+    bx, by = cfg["block"]
+    out = np.zeros(((w + bx - 1) // bx) * ((h + by - 1) // by) * 16, dtype=np.uint8)
+    best = 1e30
+    for _ in range(repeats):
+        errs = [0] * threads
+        workers = [threading.Thread(target=lambda i=i: errs.__setitem__(i, ref.compress_raw(ctx, crop, out, thread_index=i)))
+                   for i in range(threads)]
+        t0 = time.perf_counter()
+        for t in workers:
+            t.start()
+        for t in workers:
+            t.join()
+        best = min(best, time.perf_counter() - t0)
+        assert not any(errs), errs
+        assert ref.lib.astcenc_compress_reset(ctx) == 0
+    ref.context_free(ctx)
+    return best, out
+
+
+def host_description():
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup_cpu_max"] = open(path).read().strip()
+            break
+        except OSError:
+            continue
+    try:
+        info["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    return info
+
+
+def crop_blocks(gpu_blocks, cfg, x0, y0, w, h):
+    """Blocks of the whole-image stream that cover texels [x0, x0+w) x [y0, y0+h) (origin on a block boundary)."""
+    bx, by = cfg["block"]
+    nbx, _ = block_grid(cfg)
+    g = gpu_blocks.reshape(-1, 16)
+    cx0, cy0, cw, ch = x0 // bx, y0 // by, (w + bx - 1) // bx, (h + by - 1) // by
+    return np.concatenate([g[(cy0 + r) * nbx + cx0: (cy0 + r) * nbx + cx0 + cw] for r in range(ch)])
+
+
+def cpu_reference_baseline(cfg, img, gpu_blocks, budget_s=30.0):
+    """Thread sweep of the reference AVX2 encoder + byte parity against the GPU output."""
+    if not os.path.exists(O.LIB_REF_AVX2):
+        return None
+    ref = A.Library(O.LIB_REF_AVX2)
+    host = host_description()
+    cores = host["affinity"] or host["nproc"] or 1
+    t_start = time.perf_counter()
+    bx, by = cfg["block"]
+
+    # 1 thread on a 512^2 crop (a 2048^2 crop would take ~15 s per repeat on one core)
+    small = np.ascontiguousarray(img[:510 // by * by, :510 // bx * bx])
+    t1, _ = reference_threads(ref, cfg, small, 1, 3)
+    rate1 = small.shape[0] * small.shape[1] / t1 / 1e6
+
+    side = 2048 // by * by
+    crop = np.ascontiguousarray(img[:side, :side])
+    sweep = {}
+    best_rate, best_threads, out_best = 0.0, 1, None
+    for threads in sorted({8, 32, 64, 128, cores} | ({cores // 2} if cores >= 16 else set())):
+        if threads > max(cores, 8) or threads < 1:
+            continue
+        if time.perf_counter() - t_start > budget_s and sweep:
+            break
+        dt, out = reference_threads(ref, cfg, crop, threads, 3)
+        rate = side * side / dt / 1e6
+        sweep[str(threads)] = round(rate, 3)
+        if rate > best_rate:
+            best_rate, best_threads, out_best = rate, threads, out
+    want = crop_blocks(gpu_blocks, cfg, 0, 0, side, side)
+    mismatch = int((want != out_best.reshape(-1, 16)).any(axis=1).sum())
+    return {"value": round(best_rate, 3), "unit": "Mtexels/s", "cores": best_threads, "kind": "reference",
+            "sample": "astcenc-avx2 (oracle/_ref), %dx%d top-left crop of the bench image, best of 3 per thread count with "
+                      "astcenc_compress_reset in between; 1-thread figure on a %dx%d crop" % (side, side, small.shape[1], small.shape[0]),
+            "threads_at_best": best_threads, "value_1thread": round(rate1, 4), "per_thread_at_best": round(best_rate / best_threads, 4),
+            "thread_sweep_mtexels_s": sweep, "cpu_model": host.get("cpu_model"), "nproc": host["nproc"], "affinity": host["affinity"],
+            "cgroup_cpu_max": host.get("cgroup_cpu_max"), "loadavg": host.get("loadavg"),
+            "blocks_compared_with_gpu": int(want.shape[0]), "blocks_mismatching_gpu": mismatch,
+            "seconds": round(time.perf_counter() - t_start, 1)}
+
+
+def parity_crops(cfg, img, gpu_blocks, budget_s):
+    """Byte parity of (a) a block-aligned top-left crop and (b) the bottom-right tail (clamped edge blocks included)
+    against the reference run on those crops alone.  The crop grows until ~budget_s of host time is spent."""
     if not os.path.exists(O.LIB_REF_AVX2):
         return None
     ref = A.Library(O.LIB_REF_AVX2)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-
-    def run(crop):
-        err, cfg = ref.config_init(A.PRF_LDR, BLOCK[0], BLOCK[1], 1, QUALITY, 0)
-        assert err == 0
-        err, ctx = ref.context_alloc(cfg, cores)
-        assert err == 0
-        h, w = crop.shape[:2]
-        out = np.zeros(((w + 5) // 6) * ((h + 5) // 6) * 16, dtype=np.uint8)
-        errs = [0] * cores
-        t0 = time.perf_counter()
-        threads = [threading.Thread(target=lambda i=i: errs.__setitem__(i, ref.compress_raw(ctx, crop, out, thread_index=i)))
-                   for i in range(cores)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        dt = time.perf_counter() - t0
-        ref.context_free(ctx)
-        assert not any(errs), errs
-        return dt, out
-
-    # calibrate on 1536x1536 (enough work for every thread), then scale the crop to ~15 s of CPU time
-    probe = np.ascontiguousarray(img[:1536, :1536])
-    run(probe)
-    dt, _ = run(probe)
-    rate = probe.shape[0] * probe.shape[1] / dt
-    side = int(min(8190, max(1536, (rate * 15.0) ** 0.5)))
-    side = (side // 6) * 6
-    crop = np.ascontiguousarray(img[:side, :side])
-    dt, out = run(crop)
-
-    # byte parity of the crop: its block grid coincides with the image's top-left blocks
-    nb = side // 6
-    g = gpu_blocks.reshape(-1, 16)
-    rows = np.concatenate([g[r * blocks_x: r * blocks_x + nb] for r in range(nb)])
-    mismatch = int((rows != out.reshape(-1, 16)).any(axis=1).sum())
-    return {"value": round(side * side / dt / 1e6, 3), "unit": "Mtexels/s", "cores": cores, "kind": "reference",
-            "sample": "%dx%d top-left crop of the bench image, astcenc-avx2 %d threads, %.1f s" % (side, side, cores, dt),
-            "blocks_compared_with_gpu": nb * nb, "blocks_mismatching_gpu": mismatch}
+    bx, by = cfg["block"]
+    size = cfg["size"]
+    t0 = time.perf_counter()
+    probe = 256 // by * by
+    dt, _ = reference_threads(ref, cfg, np.ascontiguousarray(img[:probe, :probe]), cores, 1)
+    rate = probe * probe / max(dt, 1e-3)
+    side = int(min(size // 2, max(probe, (rate * budget_s / 2.0) ** 0.5)))
+    side_y, side_x = side // by * by, side // bx * bx
+    res = {"threads": cores}
+    # (a) top-left
+    dt, out = reference_threads(ref, cfg, np.ascontiguousarray(img[:side_y, :side_x]), cores, 1)
+    want = crop_blocks(gpu_blocks, cfg, 0, 0, side_x, side_y)
+    res["crop"] = "%dx%d at (0,0)" % (side_x, side_y)
+    res["crop_blocks"] = int(want.shape[0])
+    res["crop_mismatch"] = int((want != out.reshape(-1, 16)).any(axis=1).sum())
+    # (b) tail: from a block-aligned origin to the image's last texel
+    tx0, ty0 = (size - side_x) // bx * bx, (size - side_y) // by * by
+    dt, out = reference_threads(ref, cfg, np.ascontiguousarray(img[ty0:, tx0:]), cores, 1)
+    want = crop_blocks(gpu_blocks, cfg, tx0, ty0, size - tx0, size - ty0)
+    res["tail"] = "%dx%d at (%d,%d)" % (size - tx0, size - ty0, tx0, ty0)
+    res["tail_blocks"] = int(want.shape[0])
+    res["tail_mismatch"] = int((want != out.reshape(-1, 16)).any(axis=1).sum())
+    res["seconds"] = round(time.perf_counter() - t0, 1)
+    return res
 
 
-def decoded_psnr(img, gpu_blocks):
+def decoded_psnr(cfg, img, gpu_blocks):
     """PSNR (dB, RGBA, reference definition astcenccli_error_metrics.cpp:240-346) of the GPU's blocks
     decoded by the independent plain-C decoder in oracle/ (checker only, never timed)."""
     path = os.path.join(ROOT, "oracle", "_build", "libastc_decode.so")
-    if not os.path.exists(path):
+    if not os.path.exists(path) or cfg["hdr"]:
         return None
     dec = ctypes.CDLL(path)
     dec.astc_oracle_decode_image.restype = ctypes.c_int
     dec.astc_oracle_decode_image.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]
     h, w = img.shape[:2]
     out = np.zeros((h, w, 4), dtype=np.uint8)
-    errors = dec.astc_oracle_decode_image(gpu_blocks.ctypes.data, BLOCK[0], BLOCK[1], w, h, 0, out.ctypes.data)
+    errors = dec.astc_oracle_decode_image(gpu_blocks.ctypes.data, cfg["block"][0], cfg["block"][1], w, h, 0, out.ctypes.data)
     sq = 0.0
     for y in range(0, h, 1024):             # chunked: keeps the float64 temporaries small
         d = (img[y:y + 1024].astype(np.float64) - out[y:y + 1024].astype(np.float64)) / 255.0
@@ -110,32 +245,123 @@ def decoded_psnr(img, gpu_blocks):
     return {"psnr_db": round(psnr, 4), "error_blocks": int(errors), "decoder": "oracle/astc_decode.c (plain-C restatement)"}
 
 
-def device_psnr(lib, ctx, d_img, d_blocks, dev):
-    """The same figure without leaving the GPU: the product's decode kernel writes the decoded image into
-    HBM and its comparison kernel reduces the squared error there (include/astcenc_amd.h); not timed."""
+def device_quality(lib, ctx, cfg, d_img, d_blocks, dev):
+    """Quality figures without leaving the GPU: the product's decode kernel writes the decoded image into HBM and
+    its comparison kernel reduces the error sums there (include/astcenc_amd.h); not timed."""
+    size = cfg["size"]
     d_dec = torch.empty_like(d_img)
     swz = A.Swizzle(*A.SWZ_RGBA)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    e = lib.lib.astcenc_amd_decompress_image_device(ctx, d_blocks.data_ptr(), d_blocks.numel(), d_dec.data_ptr(), WIDTH, HEIGHT, 1,
-                                                    A.TYPE_U8, ctypes.byref(swz), stream)
+    ttype = A.TYPE_F16 if cfg["hdr"] else A.TYPE_U8
+    e = lib.lib.astcenc_amd_decompress_image_device(ctx, d_blocks.data_ptr(), d_blocks.numel(), d_dec.data_ptr(), size, size, 1,
+                                                    ttype, ctypes.byref(swz), stream)
     assert e == 0, e
     sums = A.ErrorSums()
-    e = lib.lib.astcenc_amd_compare_images_device(ctx, d_img.data_ptr(), A.TYPE_U8, d_dec.data_ptr(), A.TYPE_U8, WIDTH, HEIGHT, 1,
-                                                  stream, ctypes.byref(sums))
+    if not cfg["hdr"]:
+        e = lib.lib.astcenc_amd_compare_images_device(ctx, d_img.data_ptr(), ttype, d_dec.data_ptr(), ttype, size, size, 1, stream, ctypes.byref(sums))
+        assert e == 0, e
+        return {"psnr_db_on_device": round(sums.psnr(), 4)}
+    hdr = A.HdrErrorSums()
+    e = lib.lib.astcenc_amd_compare_images_hdr_device(ctx, d_img.data_ptr(), ttype, d_dec.data_ptr(), ttype, size, size, 1, -10, 10, stream,
+                                                      ctypes.byref(sums), ctypes.byref(hdr))
     assert e == 0, e
-    return round(sums.psnr(), 4)
+    return {"mpsnr_db_on_device": round(hdr.mpsnr(sums.texels), 4), "log_rmse_on_device": round(hdr.log_rmse(sums.texels), 4),
+            "psnr_rgb_db_on_device": round(sums.psnr(3), 4), "rgb_peak": sums.rgb_peak, "fstops": [-10, 10],
+            "definition": "astcenccli_error_metrics.cpp:60-107, :262-268, :389-403"}
 
 
-def measured_traffic():
-    """HBM bytes per launch from the latest committed PMC summary of this same workload
-    (profiles/*/traffic.json, written by tools/gpu_profile.sh); None when there is none."""
+def measured_counters():
+    """HBM bytes per launch and the VALU figures from the latest committed PMC summary of the headline workload
+    (profiles/*/traffic.json, written by tools/gpu_profile.sh); {} when there is none."""
     import glob
     # newest = highest round tag (profiles/r01a < r01b < ... < r02a); mtimes mean nothing in a fresh checkout
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
     if not files:
-        return None, None
-    t = json.load(open(files[-1]))
-    return t["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+        return {}, None
+    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the timed path
+# ---------------------------------------------------------------------------------------------------------
+
+def time_device_resident(lib, ctx, cfg, d_img, d_out, dev, steps, warmup, barrier):
+    """W warm-up steps, then K timed steps between barriers.  Returns (elapsed s, [kernel ms per step])."""
+    size = cfg["size"]
+    swz = A.Swizzle(*A.SWZ_RGBA)
+    kernel_ms = ctypes.c_float(0.0)
+    stream = torch.cuda.current_stream(dev)
+    ttype = A.TYPE_F16 if cfg["hdr"] else A.TYPE_U8
+
+    def step():
+        e = lib.lib.astcenc_amd_compress_image_device(ctx, d_img.data_ptr(), size, size, ttype, ctypes.byref(swz),
+                                                      d_out.data_ptr(), d_out.numel(), stream.cuda_stream, ctypes.byref(kernel_ms))
+        assert e == 0, e
+        return kernel_ms.value
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kms = [step() for _ in range(steps)]
+    barrier()
+    return time.perf_counter() - t0, kms
+
+
+def roofline_of(cfg, kernel_s, hdr_kernel):
+    algo = algorithmic_bytes(cfg)
+    achieved = algo / kernel_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
+            "kernel": "astcd::astc_compress_blocks_%s" % ("hdr" if hdr_kernel else "ldr"), "kernel_ms": round(kernel_s * 1e3, 3),
+            "algorithmic_bytes_per_launch": algo}
+
+
+def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
+    cfg = CONFIGS[name]
+    img = shared_img if shared_img is not None else make_image(cfg, 0x9E3779B1)
+    ctx = make_context(lib, cfg)
+    d_img = to_device(img, dev)
+    nbx, nby = block_grid(cfg)
+    d_out = torch.zeros(nbx * nby * 16, dtype=torch.uint8, device=dev)
+    elapsed, kms = time_device_resident(lib, ctx, cfg, d_img, d_out, dev, steps, warmup, lambda: torch.cuda.synchronize(dev))
+    kernel_s = sum(kms) / len(kms) / 1e3
+    texels = cfg["size"] * cfg["size"]
+    gpu_blocks = d_out.cpu().numpy()
+    res = {"config": name, "baseline_config_index": cfg["index"], "workload": cfg["label"],
+           "value": round(texels * steps / elapsed / 1e6, 3), "unit": "Mtexels/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "blocks_per_image": nbx * nby,
+           "roofline": roofline_of(cfg, kernel_s, cfg["hdr"]),
+           "parity_vs_reference": parity_crops(cfg, img, gpu_blocks, budget_s),
+           "quality": device_quality(lib, ctx, cfg, d_img, d_out, dev)}
+    lib.context_free(ctx)
+    del d_img, d_out
+    return res
+
+
+def time_host_api(lib, cfg, img, devices, repeats=2):
+    """Mtexels/s through astcenc_compress_image: pageable host memory in and out, PCIe both ways inside the timing."""
+    old = os.environ.get("ASTCENC_AMD_DEVICES")
+    os.environ["ASTCENC_AMD_DEVICES"] = devices
+    try:
+        ctx = make_context(lib, cfg)
+    finally:
+        if old is None:
+            os.environ.pop("ASTCENC_AMD_DEVICES", None)
+        else:
+            os.environ["ASTCENC_AMD_DEVICES"] = old
+    ndev = lib.lib.astcenc_amd_context_device_count(ctx)
+    h, w = img.shape[:2]
+    bx, by = cfg["block"]
+    out = np.zeros(((w + bx - 1) // bx) * ((h + by - 1) // by) * 16, dtype=np.uint8)
+    assert lib.compress_raw(ctx, img, out) == 0          # warm-up: staging buffers get allocated here
+    best = 1e30
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        assert lib.compress_raw(ctx, img, out) == 0
+        best = min(best, time.perf_counter() - t0)
+    lib.context_free(ctx)
+    return h * w / best / 1e6, ndev, out
 
 
 def main():
@@ -143,9 +369,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config timed as the headline line (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true", help="skip decoding the output for PSNR")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (BASELINE configs[2] and [3])")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through the C ABI's own device split (host pointers, PCIe included)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,39 +399,27 @@ def main():
 
     lib = A.Library(A.LIB_PRODUCT)
     assert lib.backend_name() == "hip:gfx950"
-    err, cfg = lib.config_init(A.PRF_LDR, BLOCK[0], BLOCK[1], 1, QUALITY, 0)
-    assert err == 0, err
-    err, ctx = lib.context_alloc(cfg, 1)
-    assert err == 0, "context_alloc failed: %s" % lib.error_string(err)
+
+    if args.single_process:
+        return single_process(lib, cfg, args)
+
+    # one process per GPU: this rank's context lives on this rank's device only
+    os.environ["ASTCENC_AMD_DEVICES"] = str(local_rank)
+    ctx = make_context(lib, cfg)
 
     # synthetic input of BASELINE's shape, one image per rank (different seeds), resident in HBM
-    img_host = A.synthetic_image(WIDTH, HEIGHT, 0x9E3779B1 + rank)
-    d_img = torch.from_numpy(img_host).to(dev)
-    blocks_x, blocks_y = (WIDTH + BLOCK[0] - 1) // BLOCK[0], (HEIGHT + BLOCK[1] - 1) // BLOCK[1]
-    nblocks = blocks_x * blocks_y
+    img_host = make_image(cfg, 0x9E3779B1 + rank)
+    d_img = to_device(img_host, dev)
+    nbx, nby = block_grid(cfg)
+    nblocks = nbx * nby
     d_out = torch.zeros(nblocks * 16, dtype=torch.uint8, device=dev)
-    swz = A.Swizzle(*A.SWZ_RGBA)
-    kernel_ms = ctypes.c_float(0.0)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        e = lib.lib.astcenc_amd_compress_image_device(ctx, d_img.data_ptr(), WIDTH, HEIGHT, A.TYPE_U8, ctypes.byref(swz),
-                                                      d_out.data_ptr(), d_out.numel(), stream.cuda_stream, ctypes.byref(kernel_ms))
-        assert e == 0, e
-        return kernel_ms.value
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    kms = [step() for _ in range(args.steps)]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, kms = time_device_resident(lib, ctx, cfg, d_img, d_out, dev, args.steps, args.warmup, barrier)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
@@ -207,40 +427,90 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        texels = WIDTH * HEIGHT
+        texels = cfg["size"] * cfg["size"]
         value = world * texels * args.steps / elapsed / 1e6
-        algo_bytes = texels * 4 + nblocks * 16            # 4 B/texel in + 16 B/block out
         kernel_s = sum(kms) / len(kms) / 1e3
-        achieved = algo_bytes / kernel_s / 1e9
         gpu_blocks = d_out.cpu().numpy()
-        traffic, traffic_src = measured_traffic()
+        roof = roofline_of(cfg, kernel_s, cfg["hdr"])
+        if args.config == "c2":
+            counters, src = measured_counters()
+            roof["traffic"] = counters.get("hbm_bytes_per_launch")
+            roof["traffic_unit"] = "bytes per launch"
+            roof["traffic_source"] = "%s (committed rocprofv3 --pmc summary of this workload, not measured in this run)" % src if src else None
+            for key in ("valu_insts_per_block", "active_lanes_avg", "valu_issue_frac", "salu_insts_per_block", "lds_insts_per_block",
+                        "scratch_bytes_per_lane", "sgpr_spills"):
+                if key in counters:
+                    roof[key] = counters[key]
         out = {
-            "metric": "Mtexels/s + PSNR-dB, 8192x8192 RGBA8 LDR 6x6 -medium",
+            "metric": "Mtexels/s + PSNR-dB, 8192x8192 RGBA8 LDR 6x6 -medium" if args.config == "c2" else "Mtexels/s, " + cfg["label"],
             "value": round(value, 3), "unit": "Mtexels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "8192x8192 RGBA8 LDR, 6x6 block, -medium, one image per GPU (BASELINE configs[1])",
-                       "blocks_per_image": nblocks, "block": "6x6", "preset": "medium", "sharding": "one image per rank, no collectives"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
-                         "kernel": "astcd::astc_compress_blocks_ldr", "kernel_ms": round(kernel_s * 1e3, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+            "config": {"workload": "%s, one image per GPU (BASELINE configs[%d])" % (cfg["label"], cfg["index"]),
+                       "blocks_per_image": nblocks, "block": "%dx%d" % cfg["block"], "sharding": "one image per rank, no collectives",
+                       "inputs": "resident in HBM (device API); value_host_api is the PCIe-inclusive rate of astcenc_compress_image"},
+            "roofline": roof,
         }
+        if world == 1 and not args.no_host_api:
+            rate, ndev, host_blocks = time_host_api(lib, cfg, img_host, str(local_rank))
+            out["value_host_api"] = {"value": round(rate, 3), "unit": "Mtexels/s", "devices": ndev,
+                                     "what": "astcenc_compress_image, pageable host buffers, H2D + kernels + D2H, best of 2",
+                                     "identical_to_device_path": bool(np.array_equal(host_blocks, gpu_blocks))}
         if world == 1 and not args.no_quality:
-            out["quality"] = decoded_psnr(img_host, gpu_blocks) or {}
-            out["quality"]["psnr_db_on_device"] = device_psnr(lib, ctx, d_img, d_out, dev)
+            q = decoded_psnr(cfg, img_host, gpu_blocks) or {}
+            q.update(device_quality(lib, ctx, cfg, d_img, d_out, dev))
+            out["quality"] = q
         if world == 1 and not args.no_cpu_baseline:
-            base = cpu_reference_baseline(img_host, gpu_blocks, blocks_x)
+            base = cpu_reference_baseline(cfg, img_host, gpu_blocks)
             if base:
                 out["cpu_baseline"] = base
+                out["speedup_vs_cpu_baseline"] = round(value / base["value"], 2)
+        if world == 1 and not args.no_extra and args.config == "c2":
+            del d_img, d_out
+            extra = []
+            for name in ("c3", "c4"):
+                shared = img_host if name == "c3" else None           # c3 is the same RGBA8 image, other footprint / preset
+                extra.append(run_extra_config(lib, name, dev, 2, 1, shared, 8.0))
+            out["extra_configs"] = extra
         print(json.dumps(out), flush=True)
 
     lib.context_free(ctx)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def single_process(lib, cfg, args):
+    """--single-process: what a plain C caller gets.  One context spanning N devices; one host image N times as
+    tall as BASELINE's (so every device compresses one BASELINE image's worth: weak scaling, like the
+    process-per-GPU mode) goes through astcenc_compress_image, which splits it by block rows and joins."""
+    n = args.gpus
+    devices = ",".join(str(i) for i in range(n))
+    if os.environ.get("ASTC_BENCH_SHARE_GPU") == "1":
+        devices = ",".join("0" for _ in range(n))
+    base = make_image(cfg, 0x9E3779B1)
+    img = np.ascontiguousarray(np.concatenate([base] * n, axis=0)) if n > 1 else base
+    os.environ["ASTCENC_AMD_DEVICES"] = devices
+    ctx = make_context(lib, cfg)
+    ndev = lib.lib.astcenc_amd_context_device_count(ctx)
+    h, w = img.shape[:2]
+    bx, by = cfg["block"]
+    out = np.zeros(((w + bx - 1) // bx) * ((h + by - 1) // by) * 16, dtype=np.uint8)
+    for _ in range(max(args.warmup, 1)):
+        assert lib.compress_raw(ctx, img, out) == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        assert lib.compress_raw(ctx, img, out) == 0
+    elapsed = time.perf_counter() - t0
+    lib.context_free(ctx)
+    print(json.dumps({
+        "metric": "Mtexels/s, %s, single process / C-ABI device split, PCIe included" % cfg["label"],
+        "value": round(h * w * args.steps / elapsed / 1e6, 3), "unit": "Mtexels/s", "n_gpus": ndev, "steps": args.steps,
+        "warmup": max(args.warmup, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s x %d stacked vertically, one host image through astcenc_compress_image" % (cfg["label"], n),
+                   "devices": devices, "sharding": "block rows dealt to devices inside libastcenc_amd.so, no collectives"}}), flush=True)
 
 
 if __name__ == "__main__":

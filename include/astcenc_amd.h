@@ -66,7 +66,7 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_decompress_image_device(
  *   PSNR (LDR-RGB)      = 10 log10(3 texels / (squared_error[0] + .. + [2]))
  *   alpha-weighted PSNR = the RGBA form over alpha_scaled_squared_error
  * U8 texels are compared as value / 255, F16 / F32 texels clamped to 0..65504, exactly as there.  The
- * HDR-only figures (mPSNR, log RMSE) are not computed. */
+ * HDR figures (mPSNR, log RMSE) come from astcenc_amd_compare_images_hdr_device below. */
 struct astcenc_amd_error_sums {
 	double squared_error[4];               /* per channel, image1 - image2 */
 	double alpha_scaled_squared_error[4];  /* RGB differences scaled by image1's alpha first */
@@ -81,6 +81,30 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_device(
 	unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
 	void* hip_stream,
 	struct astcenc_amd_error_sums* sums);
+
+/* The HDR part of the same report (ref: Source/astcenccli_error_metrics.cpp:60-107 mpsnr_operator / mpsnr_sumdiff,
+ * :262-268 the log2 terms, :389-403 the printed figures), over the f-stops fstop_lo..fstop_hi (the CLI's
+ * -mpsnr option, default -10..10; both within -125..125):
+ *   mPSNR (RGB)   = 10 log10(texels * 3 * (fstop_hi - fstop_lo + 1) * 255^2 / (mpsnr_squared_error[0] + [1] + [2]))
+ *   LogRMSE (RGB) = sqrt((log2_squared_error[0] + [1] + [2]) / texels)
+ *   PSNR (RGB normalised to peak) = PSNR (LDR-RGB) + 20 log10(rgb_peak)
+ * log2 is the reference's own polynomial; the tone-mapping power is evaluated in double precision and rounded
+ * to float where the reference calls libm's powf. */
+struct astcenc_amd_hdr_error_sums {
+	double log2_squared_error[4];    /* per channel, log2(image1) - log2(image2) */
+	double mpsnr_squared_error[4];   /* per channel, summed over the f-stops */
+	int fstop_lo, fstop_hi;
+};
+
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_hdr_device(
+	struct astcenc_context* context,
+	const void* device_image1, enum astcenc_type type1,
+	const void* device_image2, enum astcenc_type type2,
+	unsigned int dim_x, unsigned int dim_y, unsigned int dim_z,
+	int fstop_lo, int fstop_hi,
+	void* hip_stream,
+	struct astcenc_amd_error_sums* sums,
+	struct astcenc_amd_hdr_error_sums* hdr_sums);
 
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);

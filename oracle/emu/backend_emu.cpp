@@ -11,6 +11,7 @@
 #include "wave_alpha.h"
 #include "wave_metrics.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -108,6 +109,9 @@ int backend_compress(Backend* b, const CompressJob& job)
 	}
 
 	uint8_t* out = job.host_out ? job.host_out : job.device_out;
+#if defined(ASTC_TRACE)
+	std::vector<uint32_t> trace((size_t)img.blocks_x * img.blocks_y * img.blocks_z * TRACE_WORDS_PER_BLOCK, 0u);
+#endif
 	const char* only = getenv("ASTC_EMU_ONLY_BLOCK");
 	long only_idx = only ? atol(only) : -1;
 	for (uint32_t row = 0; row < img.blocks_y * img.blocks_z; row++)
@@ -118,12 +122,19 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			size_t idx = (size_t)row * img.blocks_x + bx;
 			if (only_idx >= 0 && (long)idx != only_idx) continue;
+#if defined(ASTC_TRACE)
+			c.prof = reinterpret_cast<unsigned long long*>(trace.data() + idx * TRACE_WORDS_PER_BLOCK);
+#endif
 			if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
 			else load_block(c, img, bx, by, bz);
 			compress_block(c, out + idx * 16);
 		}
 		if (job.progress) job.progress(100.0f * (float)(row + 1) / (float)(img.blocks_y * img.blocks_z));
 	}
+#if defined(ASTC_TRACE)
+	if (const char* path = getenv("ASTCENC_AMD_TRACE_FILE"))
+		if (FILE* f = fopen(path, "wb")) { fwrite(trace.data(), sizeof(uint32_t), trace.size(), f); fclose(f); }
+#endif
 	if (job.kernel_ms) *job.kernel_ms = 0.0f;
 	return 0;
 }
@@ -176,13 +187,19 @@ int backend_decompress_device(Backend* b, const DecompressDeviceJob& job)
 
 int backend_compare(Backend*, const CompareJob& job)
 {
-	for (int k = 0; k < METRIC_SUMS; k++) job.sums[k] = 0.0;
+	for (int k = 0; k < METRIC_SUMS_HOST; k++) job.sums[k] = 0.0;
 	for (size_t t = 0; t < job.texels; t++)
 	{
-		float e[8];
-		float m = metric_texel_terms(job.device_a, job.type_a, job.device_b, job.type_b, t, nullptr, e);
+		float e[8], c1[4], c2[4];
+		float m = metric_texel_terms(job.device_a, job.type_a, job.device_b, job.type_b, t, nullptr, e, c1, c2);
 		for (int k = 0; k < 8; k++) job.sums[k] += (double)e[k];
 		if ((double)m > job.sums[8]) job.sums[8] = (double)m;
+		if (job.hdr)
+		{
+			float h[8];
+			metric_hdr_terms(c1, c2, job.fstop_lo, job.fstop_hi, h);
+			for (int k = 0; k < 8; k++) job.sums[METRIC_HDR_FIRST + k] += (double)h[k];
+		}
 	}
 	return 0;
 }

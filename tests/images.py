@@ -83,18 +83,7 @@ def mismatches(a, b):
 def hdr_f16(w, h, seed=0x9E3779B1):
     """HDR test image: the LDR generator scaled by 2^(-2..5) in 8x8 patches,
     alpha kept in 0..1, stored as RGBA16F."""
-    base = A.synthetic_image(w, h, seed).astype(np.float32) / 255.0
-    y, x = np.meshgrid(np.arange(h, dtype=np.int64), np.arange(w, dtype=np.int64), indexing="ij")
-
-    def tri(v):
-        m = v & 511
-        return np.where(m < 256, m, 511 - m)
-
-    expo = ((tri(x >> 3) + tri(y >> 3)) >> 6) - 2
-    scale = np.ldexp(np.float32(1.0), expo.astype(np.int32)).astype(np.float32)
-    out = base.copy()
-    out[..., :3] *= scale[..., None]
-    return out.astype(np.float16)
+    return A.synthetic_hdr_image(w, h, seed)
 
 
 def hdr_variants(w, h):

@@ -102,6 +102,109 @@ def test_compare_matches_reference_formula(lib, A, ctx66):
     assert sums.psnr(3) > 0 and sums.psnr(4, alpha_scaled=True) >= sums.psnr() - 1e-9
 
 
+def reference_hdr_sums(a, b, fstop_lo, fstop_hi):
+    """The HDR accumulators of compute_error_metrics (astcenccli_error_metrics.cpp:60-107, :262-268), numpy
+    restatement: fp32 terms, fp64 sums; powf = correctly rounded float power (double pow, rounded)."""
+    def load(x):
+        v = x.astype(np.float32)
+        v = np.where(v > 0, v, np.float32(0))
+        return np.minimum(v, np.float32(65504.0))
+
+    def log2_poly(x):
+        i = x.view(np.int32)
+        e = (((i.astype(np.int64) & 0x7F800000) >> 23) - 127).astype(np.float32)
+        m = ((i & 0x007FFFFF) | 0x3F800000).view(np.float32)
+        p = np.float32(0.0596515482674574969533)
+        for c in (-0.465725644288844778798, 1.48116647521213171641, -2.52074962577807006663, 2.8882704548164776201):
+            p = (p * m).astype(np.float32) + np.float32(c)
+        p = p * (m - np.float32(1.0))
+        return (p + e).astype(np.float32)
+
+    def operator(v, stop):
+        scale = np.float32(2.0) ** np.float32(stop)
+        t = np.power((v * scale).astype(np.float32).astype(np.float64), np.float64(np.float32(1.0) / np.float32(2.2))).astype(np.float32)
+        return np.clip(t * np.float32(255.0), np.float32(0), np.float32(255.0)).astype(np.float32)
+
+    c1, c2 = np.ascontiguousarray(load(a).reshape(-1, 4)), np.ascontiguousarray(load(b).reshape(-1, 4))
+    ld = log2_poly(c1) - log2_poly(c2)
+    log_sq = (ld * ld).astype(np.float64).sum(axis=0)
+    summa = np.zeros_like(c1)
+    for stop in range(fstop_lo, fstop_hi + 1):
+        d = operator(c1, stop) - operator(c2, stop)
+        summa = (summa + d * d).astype(np.float32)
+    return log_sq, summa.astype(np.float64).sum(axis=0)
+
+
+def test_hdr_sums_match_reference_formula(lib, A, ctx66):
+    """mPSNR and log RMSE (what the reference CLI reports for BASELINE config 4).  Tolerance 1e-9 relative on the
+    fp64 sums: the per-texel fp32 terms are the reference's arithmetic, the totals are added in another order, and
+    the one libm call of the reference (powf) is a correctly rounded power on both sides."""
+    rng = np.random.default_rng(12)
+    src = images.hdr_f16(120, 88).astype(np.float16)
+    noisy = (src.astype(np.float32) * (1.0 + rng.normal(0, 0.03, src.shape))).astype(np.float16)
+    noisy[5, 7, 0] = np.float16(0.0); noisy[8, 3, 1] = np.float16(np.inf)
+    types = {np.dtype(np.float16): A.TYPE_F16, np.dtype(np.float32): A.TYPE_F32}
+    for x, y, lo, hi in ((src, noisy, -10, 10), (src.astype(np.float32), noisy, -4, 3), (src, src, 0, 0)):
+        dx, dy = Dev(lib, x), Dev(lib, y)
+        sums, hdr = A.ErrorSums(), A.HdrErrorSums()
+        err = lib.lib.astcenc_amd_compare_images_hdr_device(ctx66, dx.ptr, types[x.dtype], dy.ptr, types[y.dtype], 120, 88, 1, lo, hi,
+                                                            None, C.byref(sums), C.byref(hdr))
+        assert err == 0, lib.error_string(err)
+        log_sq, mp = reference_hdr_sums(x, y, lo, hi)
+        assert np.allclose(np.array(hdr.log2_squared_error), log_sq, rtol=1e-9, atol=0)
+        assert np.allclose(np.array(hdr.mpsnr_squared_error), mp, rtol=1e-9, atol=0)
+        sq, asq, peak = reference_sums(x, y)
+        assert np.allclose(np.array(sums.squared_error), sq, rtol=REL, atol=0) and sums.rgb_peak == peak
+        assert (hdr.fstop_lo, hdr.fstop_hi) == (lo, hi)
+        if x is y:
+            assert hdr.mpsnr(sums.texels) == 999.0 and hdr.log_rmse(sums.texels) == 0.0
+        else:
+            assert 10.0 < hdr.mpsnr(sums.texels) < 80.0 and hdr.log_rmse(sums.texels) > 0.0
+    sums, hdr = A.ErrorSums(), A.HdrErrorSums()
+    d = Dev(lib, src)
+    bad = lib.lib.astcenc_amd_compare_images_hdr_device(ctx66, d.ptr, A.TYPE_F16, d.ptr, A.TYPE_F16, 120, 88, 1, 3, 2, None, C.byref(sums), C.byref(hdr))
+    assert bad == A.ERR_BAD_PARAM
+
+
+def test_figures_match_the_reference_report(lib, A, ctx66, tmp_path):
+    """The reference's own compute_error_metrics (astcenccli_error_metrics.cpp:110, compiled from where it lies into
+    oracle/_ref/metrics_harness) prints its report for two raw images; the figures derived from the device sums must
+    agree to the 4 decimals it prints -- LDR and HDR (mPSNR, LogRMSE, PSNR normalised to peak) alike."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "metrics_harness")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/metrics_harness not built (no /root/reference on this machine)")
+    rng = np.random.default_rng(31)
+    a8 = images.noisy(150, 110)
+    b8 = np.clip(a8.astype(np.int32) + rng.integers(-7, 8, a8.shape), 0, 255).astype(np.uint8)
+    ah = images.hdr_f16(150, 110)
+    bh = (ah.astype(np.float32) * (1.0 + rng.normal(0, 0.02, ah.shape))).astype(np.float16)
+    types = {np.dtype(np.uint8): ("u8", A.TYPE_U8), np.dtype(np.float16): ("f16", A.TYPE_F16)}
+    for x, y, hdr in ((a8, b8, False), (ah, bh, True)):
+        px, py = str(tmp_path / "x.raw"), str(tmp_path / "y.raw")
+        x.tofile(px); y.tofile(py)
+        tname, ttype = types[x.dtype]
+        report = subprocess.run([exe, tname, "150", "110", px, py, "1" if hdr else "0", "-10", "10"], capture_output=True, text=True, check=True).stdout
+
+        def figure(label):
+            m = re.search(re.escape(label) + r"\s*:?\s*(-?[0-9.]+)", report)
+            assert m, (label, report)
+            return float(m.group(1))
+        dx, dy = Dev(lib, x), Dev(lib, y)
+        sums, hs = A.ErrorSums(), A.HdrErrorSums()
+        err = lib.lib.astcenc_amd_compare_images_hdr_device(ctx66, dx.ptr, ttype, dy.ptr, ttype, 150, 110, 1, -10, 10, None, C.byref(sums), C.byref(hs))
+        assert err == 0
+        assert abs(sums.psnr() - figure("PSNR (LDR-RGBA):")) < 6e-5
+        assert abs(sums.psnr(4, alpha_scaled=True) - figure("Alpha-weighted PSNR:")) < 6e-5
+        assert abs(sums.psnr(3) - figure("PSNR (LDR-RGB):")) < 6e-5
+        if hdr:
+            assert abs(hs.mpsnr(sums.texels) - figure("mPSNR (RGB):")) < 6e-5
+            assert abs(hs.log_rmse(sums.texels) - figure("LogRMSE (RGB):")) < 6e-5
+            assert abs(sums.psnr(3) + 20.0 * np.log10(sums.rgb_peak) - figure("PSNR (RGB norm to peak):")) < 6e-5
+
+
 def test_device_round_trip_psnr(lib, ref, A, ctx66):
     """compress -> (blocks stay on the device) -> decompress on the device -> compare on the device."""
     w, h = 200, 150
