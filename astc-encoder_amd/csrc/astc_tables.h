@@ -9,6 +9,12 @@
 #pragma once
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+	#define ASTC_HD __host__ __device__
+#else
+	#define ASTC_HD
+#endif
+
 namespace astcd {
 
 constexpr int MAX_TEXELS       = 216;  // largest footprint (6x6x6)        ref: BLOCK_MAX_TEXELS astcenc_internal.h:68
@@ -41,6 +47,27 @@ enum {
 	QUANT_20, QUANT_24, QUANT_32, QUANT_40, QUANT_48, QUANT_64, QUANT_80, QUANT_96, QUANT_128,
 	QUANT_160, QUANT_192, QUANT_256
 };
+
+// Size of the phase-shared `uni` LDS region (see make_lds_layout, wave_ctx.h).  It depends only on the footprint
+// and the partition-count limit, so the table builder can cut the decimation sweeps into the same chunks the
+// kernel will use.
+constexpr uint32_t MODE_DESC_BYTES = 16 + 2 * 32;   // ModeHdr + ModeQ[2], see score_block_modes (wave_block.h)
+constexpr uint32_t FMT_QUANT_ROWS = 17;
+ASTC_HD inline uint32_t fmt_comb_cols(uint32_t partition_limit) { return partition_limit <= 1 ? 0u : partition_limit == 2 ? 7u : partition_limit == 3 ? 10u : 13u; }
+ASTC_HD inline uint32_t fmt_scratch_bytes(uint32_t partition_limit)
+{
+	uint32_t P = partition_limit < 1 ? 1u : partition_limit > 4 ? 4u : partition_limit;
+	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 4);
+}
+ASTC_HD inline uint32_t uni_region_bytes(uint32_t texel_count, uint32_t partition_limit)
+{
+	const uint32_t Tp = (texel_count + 3u) & ~3u;
+	uint32_t bytes = 64 * 8 * 4;                                   // angular batch
+	if (8u * (MODE_DESC_BYTES + Tp * 4) > bytes) bytes = 8u * (MODE_DESC_BYTES + Tp * 4);   // mode scoring: descriptors + texel terms of 8 modes
+	if (fmt_scratch_bytes(partition_limit) > bytes) bytes = fmt_scratch_bytes(partition_limit);
+	if (5 * Tp * 4 > bytes) bytes = 5 * Tp * 4;                    // encoding-choice rows
+	return (bytes + 15u) & ~15u;
+}
 
 // Symbolic block types (ref: astcenc_internal.h:1059-1068)
 enum { SYM_BTYPE_ERROR = 0, SYM_BTYPE_CONST_F16 = 1, SYM_BTYPE_CONST_U16 = 2, SYM_BTYPE_NONCONST = 3 };
@@ -81,6 +108,19 @@ struct DwiSlot {
 	uint8_t  dm;            // decimation mode
 	uint8_t  set;           // index of the (grid, plane) set in packing order (InfillSet index)
 	uint8_t  index;         // weight index in the grid
+};
+
+// Processing order of the decimation sweeps (TableRoot::off_dwi_order): for every weight quant limit q of a trial,
+// the live slots of the sets that trial uses (a prefix of the packing, TableRoot::dwi_used_sets), cut into the
+// chunks of sets whose texel-resolution infill fits the scratch region together (dwi_sets_per_chunk) and, inside a
+// chunk, sorted by descending tap count: the 64 lanes of a sweep iteration then walk tap lists of similar
+// length instead of waiting for the longest one in packing order.  Copied ("direct") slots come last.
+constexpr int DWI_MAX_CHUNKS = 15;
+struct DwiOrderDir {
+	uint32_t list_off;                       // blob offset of the uint16_t slot indices of this (class, q)
+	uint16_t chunk_start[DWI_MAX_CHUNKS + 1];  // list positions [chunk_start[c], chunk_start[c + 1]) belong to chunk c
+	uint16_t chunks;
+	uint16_t pad;
 };
 
 // The same for the texel-resolution infill of one (grid, plane) of a trial class (TableRoot::off_infill_sets).
@@ -180,6 +220,8 @@ struct TableRoot {
 	uint32_t dwi_sets[2];                     // (grid, plane) sets per class; packed by ascending lowest usable quant level,
 	uint32_t dwi_used_sets[2][12];            // so the sets a trial with weight quant limit q uses are the first [class][q]
 	uint32_t lowhigh_floats[2];               // size of the packed low/high region per trial class
+	uint32_t off_dwi_order[2];                // DwiOrderDir[12] per trial class, indexed by the trial's weight quant limit
+	uint32_t dwi_sets_per_chunk;              // (grid, plane) sets whose infill fits the `uni` LDS region at once
 	uint32_t max_partitionings;               // largest partitioning_count_selected[1..3]
 	uint32_t total_bytes;
 };
@@ -200,6 +242,7 @@ struct DeviceConfig {
 	float    tune_partition_early_out_limit_factor[2]; // 2,3 partitions
 	float    tune_2plane_early_out_limit_correlation;
 	float    tune_search_mode0_enable;
+	uint32_t debug_dup_stage;                      // instruction-count builds only (-DASTC_DUPSTAGE, tools/gpu_stage_counts.sh): stage to run twice
 };
 
 // One image (or image slice) handed to the kernel.

@@ -24,6 +24,7 @@
 namespace block_info_host = astcd::v_host;
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <condition_variable>
@@ -471,6 +472,9 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 		dc.tune_partition_early_out_limit_factor[1] = config.tune_3partition_early_out_limit_factor;
 		dc.tune_2plane_early_out_limit_correlation = config.tune_2plane_early_out_limit_correlation;
 		dc.tune_search_mode0_enable = config.tune_search_mode0_enable;
+#if defined(ASTC_DUPSTAGE)
+		if (const char* dup = getenv("ASTC_DUP_STAGE")) dc.debug_dup_stage = (uint32_t)atoi(dup);   // instruction-count builds only
+#endif
 
 		int bstatus = 0;
 		ctx->backend = backend_create(ctx->blob->data(), ctx->blob->size(), dc, &bstatus);

@@ -1016,6 +1016,50 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 		}
 	}
 
+	// processing order of the decimation sweeps (see DwiOrderDir): per trial class and weight quant limit, the live
+	// slots of the used sets, chunked like the kernel chunks the infill, longest tap lists first inside a chunk
+	uint32_t off_order[2] = { 0, 0 };
+	const uint32_t texel_count_all = tx * ty * tz;
+	uint32_t sets_per_chunk = (uni_region_bytes(texel_count_all, partition_count_cutoff) / 4u) / ((texel_count_all + 3u) & ~3u);
+	if (sets_per_chunk < 1) sets_per_chunk = 1;
+	for (int cls = 0; cls < 2; cls++)
+	{
+		off_order[cls] = blob.alloc(12 * sizeof(DwiOrderDir));
+		for (int q = 0; q < 12; q++)
+		{
+			const uint32_t nsets = used_sets[cls][q];
+			std::vector<uint16_t> list;
+			DwiOrderDir dir;
+			memset(&dir, 0, sizeof(dir));
+			uint32_t chunks = 0;
+			for (uint32_t p0 = 0; p0 < nsets && chunks < (uint32_t)DWI_MAX_CHUNKS; p0 += sets_per_chunk, chunks++)
+			{
+				const uint32_t p1 = std::min(p0 + sets_per_chunk, nsets);
+				std::vector<uint16_t> part;
+				for (uint32_t k = 0; k < dwi_total[cls]; k++)
+				{
+					const DwiSlot* sl = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + k * sizeof(DwiSlot)));
+					if (sl->taps != 0 && sl->set >= p0 && sl->set < p1) part.push_back((uint16_t)k);
+				}
+				std::stable_sort(part.begin(), part.end(), [&](uint16_t a, uint16_t b) {
+					const DwiSlot* sa = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + a * sizeof(DwiSlot)));
+					const DwiSlot* sb = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + b * sizeof(DwiSlot)));
+					const int ta = (sa->flags & 1) ? 0 : sa->taps, tb = (sb->flags & 1) ? 0 : sb->taps;
+					return ta > tb;
+				});
+				dir.chunk_start[chunks] = (uint16_t)list.size();
+				list.insert(list.end(), part.begin(), part.end());
+			}
+			// (more sets than DWI_MAX_CHUNKS chunks can hold: chunks = 0 tells the kernel to use the unsorted sweeps)
+			if (chunks * sets_per_chunk < nsets) { chunks = 0; list.clear(); }
+			dir.chunk_start[chunks] = (uint16_t)list.size();
+			dir.chunks = (uint16_t)chunks;
+			dir.list_off = blob.alloc(std::max<size_t>(list.size(), 1) * sizeof(uint16_t));
+			if (!list.empty()) memcpy(blob.at<uint8_t>(dir.list_off), list.data(), list.size() * sizeof(uint16_t));
+			*blob.at<DwiOrderDir>((uint32_t)(off_order[cls] + q * sizeof(DwiOrderDir))) = dir;
+		}
+	}
+
 	// ---- static tables ----
 	uint32_t off_cq = blob.alloc(17 * 512);
 	uint32_t off_cp = blob.alloc(17 * 256);
@@ -1114,7 +1158,9 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			r->dwi_sets[cls] = n_sets[cls];
 			for (int q = 0; q < 12; q++) r->dwi_used_sets[cls][q] = used_sets[cls][q];
 			r->lowhigh_floats[cls] = lh_total[cls];
+			r->off_dwi_order[cls] = off_order[cls];
 		}
+		r->dwi_sets_per_chunk = sets_per_chunk;
 		r->max_partitionings = std::max(pcounts[1], std::max(pcounts[2], pcounts[3]));
 	}
 	blob.alloc(0, 256);

@@ -67,7 +67,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	{
 		PROF_SCOPE(c, PS_LOAD);
 		if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
-		else load_block(c, img, bx, by, bz);
+		else DUP_STAGE(c, DUP_LOAD, load_block(c, img, bx, by, bz));
 	}
 	compress_block(c, out + (size_t)b * 16);
 }

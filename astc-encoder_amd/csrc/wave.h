@@ -39,7 +39,7 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 	#define WV_DEVICE 1
 	#define WV_FN __host__ __device__ inline
-	#define WV_OUT __host__ __device__ __attribute__((noinline)) inline
+	#define WV_OUT static __host__ __device__ __attribute__((noinline))
 	#define WV_LANE ((int)threadIdx.x)
 	// A workgroup is exactly one wavefront, and a wavefront's LDS instructions execute in issue
 	// order, so a cross-lane hand-off through LDS needs no s_barrier and no s_waitcnt: it only needs
@@ -57,7 +57,7 @@
 	#define WV_DEVICE 0
 	#if defined(__HIPCC__)
 		#define WV_FN __host__ __device__ inline
-		#define WV_OUT __host__ __device__ __attribute__((noinline)) inline
+		#define WV_OUT static __host__ __device__ __attribute__((noinline))
 	#else
 		#define WV_FN inline
 		#define WV_OUT __attribute__((noinline)) inline
@@ -80,6 +80,54 @@ WV_FN bool wv_any(bool flag)
 	return __ballot(flag) != 0ull;
 #else
 	return flag;
+#endif
+}
+
+/* Minimum / maximum over the whole wave of per-lane partial results.  Usage: a variable declared outside a WV_FOR
+ * is folded inside the loop body (`m = x < m ? x : m`), which on the device leaves one partial per lane (lanes
+ * that ran no iteration keep the initial value) and in the sequential CPU build already the total; afterwards
+ * wv_all_minmax(...) makes every argument the wave-wide result on every lane.  Operands must be finite and non-NaN:
+ * then the result is the exact minimum / maximum whatever the association order.  Device: six DPP steps per value
+ * (row_shr 1/2/4/8, row_bcast 15/31: v_min_f32_dpp / v_max_f32_dpp, one instruction each, the values interleaved so
+ * that no wait states are needed between dependent steps) and a v_readlane of lane 63 -- no LDS traffic. */
+#if WV_DEVICE
+#define WV_DPP_MINMAX2(ctrl) \
+	"v_min_f32_dpp %0, %0, %0 " ctrl "\n v_max_f32_dpp %1, %1, %1 " ctrl "\n"
+#define WV_DPP_MINMAX4(ctrl) \
+	"v_min_f32_dpp %0, %0, %0 " ctrl "\n v_max_f32_dpp %1, %1, %1 " ctrl "\n" \
+	"v_min_f32_dpp %2, %2, %2 " ctrl "\n v_max_f32_dpp %3, %3, %3 " ctrl "\n"
+#endif
+/* (mn0, mx0), (mn1, mx1): two (minimum, maximum) pairs at once */
+WV_FN void wv_all_minmax(float& mn0, float& mx0, float& mn1, float& mx1)
+{
+#if WV_DEVICE
+	asm volatile("s_nop 1\n"
+	    WV_DPP_MINMAX4("row_shr:1 row_mask:0xf bank_mask:0xf") WV_DPP_MINMAX4("row_shr:2 row_mask:0xf bank_mask:0xf")
+	    WV_DPP_MINMAX4("row_shr:4 row_mask:0xf bank_mask:0xf") WV_DPP_MINMAX4("row_shr:8 row_mask:0xf bank_mask:0xf")
+	    WV_DPP_MINMAX4("row_bcast:15 row_mask:0xa bank_mask:0xf") WV_DPP_MINMAX4("row_bcast:31 row_mask:0xc bank_mask:0xf")
+	    "s_nop 1\n"
+	    : "+v"(mn0), "+v"(mx0), "+v"(mn1), "+v"(mx1));
+	mn0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn0), 63));
+	mx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx0), 63));
+	mn1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn1), 63));
+	mx1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx1), 63));
+#else
+	(void)mn0; (void)mx0; (void)mn1; (void)mx1;
+#endif
+}
+WV_FN void wv_all_minmax(float& mn0, float& mx0)
+{
+#if WV_DEVICE
+	asm volatile("s_nop 1\n"
+	    WV_DPP_MINMAX2("row_shr:1 row_mask:0xf bank_mask:0xf") "s_nop 0\n" WV_DPP_MINMAX2("row_shr:2 row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+	    WV_DPP_MINMAX2("row_shr:4 row_mask:0xf bank_mask:0xf") "s_nop 0\n" WV_DPP_MINMAX2("row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+	    WV_DPP_MINMAX2("row_bcast:15 row_mask:0xa bank_mask:0xf") "s_nop 0\n" WV_DPP_MINMAX2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+	    "s_nop 1\n"
+	    : "+v"(mn0), "+v"(mx0));
+	mn0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mn0), 63));
+	mx0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx0), 63));
+#else
+	(void)mn0; (void)mx0;
 #endif
 }
 

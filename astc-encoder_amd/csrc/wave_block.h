@@ -264,10 +264,13 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 /* The quantized weights of the chosen candidates (the reference keeps them for every block mode,
  * compress_symbolic.cpp:469-478); after this the search-phase LDS (ideal weights, angular bounds, mode
  * records) is dead and the refine-phase tables reuse it. */
-WV_OUT void refine_quantize_candidates(bool dual)
+WV_OUT void refine_quantize_candidates(bool dual, int partition_count, int partition_packed)
 {
 	const Ctx c = ctx_make();
-	dual = wv_uniform(dual);
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	// per-trial constants of the refinement steps
+	if (partition_count == 1) trial_scale_directions(c, part_view_lds(c, 1, 0), dual);
+	else trial_scale_directions(c, part_view_lds(c, partition_count, partition_packed), false);
 	TrialInfo& tr = c.tr();
 	const int candidate_count = wv_uniform(tr.cand_count);
 	PROF_SCOPE(c, PS_Y0);
@@ -508,7 +511,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 	const int candidate_count = wv_uniform(tr.cand_count);
 	const int refinement_limit = (int)c.cfg->tune_refinement_limit;
 
-	refine_quantize_candidates(dual);
+	DUP_STAGE(c, DUP_CAND_QUANTIZE, refine_quantize_candidates(dual, partition_count, partition_packed));
 
 	int staged_dm = -1, staged_wq = -1;                 // what the candidate tables in LDS currently hold
 	for (int i = 0; i < candidate_count; i++)
@@ -521,23 +524,25 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 		const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
 
 		TRACE_PUT(c, TR_CANDIDATE, (float)cand_wq);
-		refine_candidate_setup(dual, partition_count, plane2_component, i, cand_dm != staged_dm ? cand_dm : -1,
-		                       cand_wq != staged_wq ? cand_wq : -1, color_quant_level);
+		DUP_STAGE(c, DUP_CAND_SETUP, refine_candidate_setup(dual, partition_count, plane2_component, i, cand_dm != staged_dm ? cand_dm : -1,
+		                       cand_wq != staged_wq ? cand_wq : -1, color_quant_level));
 		staged_dm = cand_dm;
 		staged_wq = cand_wq;
 
 		bool stop_all = false;
 		for (int l = 0; l < refinement_limit; l++)
 		{
+			DUP_STAGE(c, DUP_RECOMPUTE, {
 			if (dual) refine_recompute_2planes(cand_dm, plane2_component);
 			else if (partition_count == 1) refine_recompute_1partition(cand_dm);
-			else refine_recompute_partitions(partition_count, partition_packed, cand_dm);
-			refine_pack(dual, partition_count, partition_packed, plane2_component, i,
-			            color_quant_level, color_quant_level_mod, bm_packed_index);
+			else refine_recompute_partitions(partition_count, partition_packed, cand_dm); });
+			DUP_STAGE(c, DUP_PACK, refine_pack(dual, partition_count, partition_packed, plane2_component, i,
+			            color_quant_level, color_quant_level_mod, bm_packed_index));
 
 			if (l == 0)
 			{
-				const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
+				float errorval;
+				DUP_STAGE(c, DUP_DIFF, errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm)));
 				TRACE_PUT(c, TR_ERR_PRE, errorval);
 				best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
@@ -562,7 +567,8 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 
 			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
-			const float errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm));
+			float errorval;
+			DUP_STAGE(c, DUP_DIFF, errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm)));
 			TRACE_PUT(c, TR_ERR_POST, errorval);
 			best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
@@ -766,7 +772,7 @@ WV_OUT void stage_formats(bool dual, int partition_count, int partition_packed, 
 		compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], start, end);
 }
 
-WV_OUT float stage_refine(int partition_count, int partition_packed, int plane2_component, float tune_errorval_threshold)
+WV_FN float stage_refine(int partition_count, int partition_packed, int plane2_component, float tune_errorval_threshold)
 {
 	const Ctx c = ctx_make();
 	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
@@ -799,11 +805,13 @@ WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune
 		mode_end = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
 	}
 
-	stage_ideal(dual, partition_count, partition_packed, plane2_component);
-	stage_decimate(dual ? 2 : 1, ref_mask, max_decimation_modes);
-	stage_angular(dual, partition_count, plane2_component, max_decimation_modes, ref_mask, max_weight_quant);
-	stage_modes(partition_count, mode_start, mode_end, max_weight_quant, dual);
-	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end);
+	DUP_STAGE(c, DUP_IDEAL, stage_ideal(dual, partition_count, partition_packed, plane2_component));
+	DUP_STAGE(c, DUP_DECIMATE, stage_decimate(dual ? 2 : 1, ref_mask, max_decimation_modes));
+	DUP_STAGE(c, DUP_ANGULAR, stage_angular(dual, partition_count, plane2_component, max_decimation_modes, ref_mask, max_weight_quant));
+	// (the format search adds to the mode records in place, so it is doubled together with the scoring that resets them)
+	DUP_STAGE(c, DUP_MODES_FORMATS, {
+	DUP_STAGE(c, DUP_MODES, stage_modes(partition_count, mode_start, mode_end, max_weight_quant, dual));
+	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end); });
 	return wv_uniform(stage_refine(partition_count, partition_packed, dual ? plane2_component : -1, tune_errorval_threshold));
 }
 
@@ -899,7 +907,7 @@ WV_OUT int stage_partition_order(int partition_count)
 	PROF_SCOPE(c, PS_KMEANS);
 	return partition_search_order(c, partition_count);
 }
-WV_OUT void stage_partition_score(int partition_count, int search_limit)
+WV_FN void stage_partition_score(int partition_count, int search_limit)
 {
 	const Ctx c = ctx_make();
 	partition_count = wv_uniform(partition_count); search_limit = wv_uniform(search_limit);
@@ -917,10 +925,14 @@ WV_OUT int stage_partition_select(int search_limit, int requested_trials)
 /* (ref: find_best_partition_candidates :551) candidates -> PartScratch::best[], returns how many */
 WV_FN int stage_partition_search(int partition_count, int requested_indices, int requested_trials)
 {
-	const int sequence_len = wv_uniform(stage_partition_order(partition_count));
+	const Ctx c = ctx_make();
+	int sequence_len;
+	DUP_STAGE(c, DUP_PART_ORDER, sequence_len = wv_uniform(stage_partition_order(partition_count)));
 	const int search_limit = i_min(requested_indices, sequence_len);
-	stage_partition_score(partition_count, search_limit);
-	return stage_partition_select(search_limit, i_min(search_limit, requested_trials));
+	DUP_STAGE(c, DUP_PART_SCORE, stage_partition_score(partition_count, search_limit));
+	int found;
+	DUP_STAGE(c, DUP_PART_SELECT, found = stage_partition_select(search_limit, i_min(search_limit, requested_trials)));
+	return found;
 }
 
 WV_OUT float stage_block_statistics()
@@ -1011,7 +1023,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	if (!done)
 	{
 		float lowest_correl;
-		lowest_correl = wv_uniform(stage_block_statistics());
+		DUP_STAGE(c, DUP_STATS, lowest_correl = wv_uniform(stage_block_statistics()));
 		TRACE_PUT(c, TR_LOWEST_CORREL, lowest_correl);
 		bool block_skip_two_plane = lowest_correl > cfg.tune_2plane_early_out_limit_correlation;
 		for (int i = 3; i >= 0 && !done; i--)
@@ -1084,7 +1096,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			}
 		}
 		PROF_SCOPE(c, PS_X1);
-		symbolic_to_physical(c, scb, pcb);
+		DUP_STAGE(c, DUP_PHYSICAL, symbolic_to_physical(c, scb, pcb));
 	}
 }
 

@@ -125,18 +125,8 @@ struct LdsLayout {
 
 /* Sizes in bytes of the variable scratch regions. */
 
-constexpr uint32_t MODE_DESC_BYTES = 16 + 2 * 32;   // ModeHdr + ModeQ[2], see score_block_modes (wave_block.h)
-
-/* Endpoint-format tables of one trial (see FmtView, wave_format.h).  Only quant levels >= QUANT_6
- * (17 of the 21) are ever read, and the combined tables are as wide as the partition-count limit
- * needs: 7 / 10 / 13 integer-count columns for 2 / 3 / 4 partitions. */
-constexpr uint32_t FMT_QUANT_ROWS = 17;
-WV_FN uint32_t fmt_comb_cols(uint32_t partition_limit) { return partition_limit <= 1 ? 0u : partition_limit == 2 ? 7u : partition_limit == 3 ? 10u : 13u; }
-WV_FN uint32_t fmt_scratch_bytes(uint32_t partition_limit)
-{
-	uint32_t P = partition_limit < 1 ? 1u : partition_limit > 4 ? 4u : partition_limit;
-	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 4);
-}
+/* (MODE_DESC_BYTES, the endpoint-format table sizes and uni_region_bytes() live in astc_tables.h: the table
+ * builder needs them too.) */
 
 WV_FN uint32_t part_scratch_bytes(uint32_t max_partitionings, uint32_t max_index_limit)
 {
@@ -172,15 +162,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.dwi = take((r.dwi_total_floats[0] > r.dwi_total_floats[1] ? r.dwi_total_floats[0] : r.dwi_total_floats[1]) * 4);
 	L.lowhigh = take((r.lowhigh_floats[0] > r.lowhigh_floats[1] ? r.lowhigh_floats[0] : r.lowhigh_floats[1]) * 4);
 	L.modes = take(nbm_max * sizeof(ModeRec));
-	L.uni_bytes = 64 * 8 * 4;                                     // angular batch
-	{
-		// mode scoring: per-mode descriptors + texel terms of a chunk of block modes (score_block_modes)
-		uint32_t chunk = 8u;
-		if (chunk * (MODE_DESC_BYTES + Tp * 4) > L.uni_bytes) L.uni_bytes = chunk * (MODE_DESC_BYTES + Tp * 4);
-	}
-	if (fmt_scratch_bytes(cfg.tune_partition_count_limit) > L.uni_bytes) L.uni_bytes = fmt_scratch_bytes(cfg.tune_partition_count_limit);
-	if (5 * Tp * 4 > L.uni_bytes) L.uni_bytes = 5 * Tp * 4;       // encoding-choice rows
-	L.uni_bytes = (L.uni_bytes + 15u) & ~15u;
+	L.uni_bytes = uni_region_bytes(r.texel_count, cfg.tune_partition_count_limit);
 	L.uni = take(L.uni_bytes);
 	uint32_t end = o;
 	// refine phase
@@ -363,6 +345,19 @@ WV_FN void trace_put(const Ctx& c, uint32_t tag, float value)
 #define TRACE_PUT(c, tag, value) trace_put(c, tag, value)
 #else
 #define TRACE_PUT(c, tag, value) ((void)0)
+#endif
+
+/* Instruction-count builds (-DASTC_DUPSTAGE): DeviceConfig::debug_dup_stage names one stage that is executed twice
+ * (every stage listed here recomputes its outputs from unchanged inputs, so the result bytes do not change).  The
+ * difference of the SQ_INSTS_* counters between a run with the stage doubled and a plain run is that stage's dynamic
+ * instruction count -- a per-stage VALU / SALU / LDS / VMEM profile without PC sampling (tools/gpu_stage_counts.sh). */
+enum { DUP_IDEAL = 1, DUP_DECIMATE, DUP_ANGULAR, DUP_MODES, DUP_MODES_FORMATS, DUP_CAND_QUANTIZE, DUP_CAND_SETUP, DUP_RECOMPUTE,
+       DUP_PACK, DUP_DIFF, DUP_PART_ORDER, DUP_PART_SCORE, DUP_PART_SELECT, DUP_STATS, DUP_LOAD, DUP_PHYSICAL, DUP_ACCEPT,
+       DUP_RECOMPUTE_PACK_DIFF };
+#if defined(ASTC_DUPSTAGE)
+#define DUP_STAGE(c, id, call) do { call; if ((c).cfg->debug_dup_stage == (uint32_t)(id)) { call; } } while (0)
+#else
+#define DUP_STAGE(c, id, call) do { call; } while (0)
 #endif
 
 /* View of one partition record. */

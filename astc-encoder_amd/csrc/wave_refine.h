@@ -66,7 +66,8 @@ WV_FN void expand_weights(const Ctx& c, const DecView& di, const uint8_t* uq, fl
  * plane, produce (ep0, ep1, mask) for the lanes it owns. */
 struct PlaneSolve {
 	f4 ep0, ep1;
-	bool m[4];
+	uint32_t mask;            // bit k: lane k solved (a packed word: a run-time indexed bool[4] would live in scratch)
+	WV_FN bool m(int k) const { return ((mask >> k) & 1u) != 0; }
 };
 
 WV_FN PlaneSolve solve_plane(f4 left_sum, f4 middle_sum, f4 right_sum, f4 color_vec_x, f4 color_vec_y)
@@ -79,24 +80,30 @@ WV_FN PlaneSolve solve_plane(f4 left_sum, f4 middle_sum, f4 right_sum, f4 color_
 	r.ep1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
 	f4 ad = v4_abs(color_det1);
 	f4 th = color_mss1 * 1e-4f;
+	r.mask = 0;
 	for (int k = 0; k < 4; k++)
 	{
 		float e0 = lane(r.ep0, k), e1 = lane(r.ep1, k);
-		r.m[k] = (lane(ad, k) > lane(th, k)) && (e0 == e0) && (e1 == e1);
+		if ((lane(ad, k) > lane(th, k)) && (e0 == e0) && (e1 == e1)) r.mask |= 1u << k;
 	}
 	return r;
 }
 
-/* (ref: recompute_ideal_colors_1plane :1146).  Reads wscb().weights, updates tr.wep0/wep1/rgbs/rgbo. */
-WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const DecView& di)
+/* Scale direction of every partition of the trial (ref: recompute_ideal_colors_1plane :1198-1219, _2planes :1433-1437):
+ * the normalised colour sum of the partition's texels.  It depends on the block and the partitioning only, not on
+ * the weights, so it is computed once per trial (the reference recomputes the same values in every refinement step)
+ * into tr.pm_dir, whose search-phase contents are dead by then. */
+WV_FN void trial_scale_directions(const Ctx& c, const PartView& pv, bool dual)
 {
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
-	const int T = c.T, pc = pv.pcount;
-	float* undec = c.tsc_r(0);
-	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec);
-
-	// pass 1: weighted partition colour sum -> scale direction (ref: :1198-1219)
+	const int pc = pv.pcount;
+	if (dual)
+	{
+		WV_ONE { store4(tr.pm_dir[0], normalize4(xyz0(load4(blk.data_mean)))); }
+		WV_SYNC();
+		return;
+	}
 	if (pc > 1)
 	{
 		WV_FOR(k, pc * 4)
@@ -119,23 +126,41 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * load4(blk.cw);
 		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.cnt(p), splat4(1e-17f));
 		f4 scale_dir = normalize4(xyz0(rgba_sum / rgba_weight_sum));
-		store4(&tr.fbox[112 + p * 4], scale_dir);
+		store4(tr.pm_dir[p], scale_dir);
 	}
 	WV_SYNC();
+}
 
-	// pass 2 (ref: :1241-1269): the reference accumulates 18 running values per partition in
-	// partition-texel order.  Per-texel terms are produced lane-parallel (row r, position i in the
-	// partition-sorted order), then each chain is summed sequentially by its own lane.
+/* (ref: recompute_ideal_colors_1plane :1146).  Reads wscb().weights, updates tr.wep0/wep1/rgbs/rgbo. */
+WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const DecView& di)
+{
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, pc = pv.pcount;
+	float* undec = c.tsc_r(0);
+	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec);
+
+	// (pass 1, the scale direction of each partition, is per trial: trial_scale_directions() -> tr.pm_dir)
+
+	// pass 2 (ref: :1241-1269): the reference accumulates 15 running sums per partition in partition-texel order.
+	// Per-texel terms are produced lane-parallel (row r, position i in the partition-sorted order), then each chain
+	// is summed sequentially -- additions only -- by its own lane.
 	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	// Running minima / maxima of the weights and of the scale projection (ref: :1230-1235, :1247-1253).  With a single
+	// partition they are wave-wide reductions of per-lane partials (exact: the values are finite); with several
+	// partitions the chain lanes of rows 0 and 1 pick them up below.
+	float wmin_part = 1.0f, wmax_part = 0.0f, smin_part = 1e10f, smax_part = 0.0f;
 	WV_FOR(i, T)
 	{
 		int t = pv.sorted[i];
 		int p = pv.of_texel[t];
-		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
+		f4 scale_dir = load4(tr.pm_dir[p]);
 		f4 rgba = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
 		float idx0 = undec[t];
 		float om_idx0 = 1.0f - idx0;
 		float scale = dot3_s(scale_dir, rgba);
+		wmin_part = idx0 < wmin_part ? idx0 : wmin_part; wmax_part = idx0 > wmax_part ? idx0 : wmax_part;
+		smin_part = scale < smin_part ? scale : smin_part; smax_part = scale > smax_part ? scale : smax_part;
 		c.rsc(0)[i] = idx0;
 		c.rsc(1)[i] = scale;
 		c.rsc(2)[i] = om_idx0 * om_idx0;
@@ -149,92 +174,130 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 		c.rsc(14)[i] = idx0 * (scale * ls_weight);
 	}
 	WV_SYNC();
-	WV_FOR(k, pc * 15)
+	if (pc == 1)
 	{
-		int p = k / 15, r = k % 15;
-		const float* v = c.rsc(r) + pv.off(p);
-		const int n = pv.cnt(p);
-		// one branch-free loop for all chains: running sum, min and max of the row
-		float acc = r == 0 ? 1e-17f : 0.0f;   // row 0 doubles as weight_weight_sum (starts at 1e-17)
-		float mn = r == 0 ? 1.0f : 1e10f;
-		float mx = 0.0f;
-		for (int j = 0; j < n; j++)
+		wv_all_minmax(wmin_part, wmax_part, smin_part, smax_part);
+		WV_ONE { tr.fbox[0] = wmin_part; tr.fbox[1] = wmax_part; tr.fbox[2] = smin_part; tr.fbox[3] = smax_part; }
+		// the 14 sums: additions only, four loads in flight
+		WV_FOR(k, 14)
 		{
-			float x = v[j];
-			acc += x;
-			mn = x < mn ? x : mn;
-			mx = x > mx ? x : mx;
+			const int r = k >= 1 ? k + 1 : k;                           // rows 0, 2..14 (row 1 only feeds the scale min / max)
+			const float* v = c.rsc(r);
+			float acc = r == 0 ? 1e-17f : 0.0f;   // row 0 is weight_weight_sum (starts at 1e-17)
+			int j = 0;
+			for (; j + 4 <= T; j += 4)
+			{
+				const float x0 = v[j], x1 = v[j + 1], x2 = v[j + 2], x3 = v[j + 3];
+				acc += x0; acc += x1; acc += x2; acc += x3;
+			}
+			for (; j < T; j++) acc += v[j];
+			float* s = tr.fbox;
+			if (r == 0) s[7] = acc;                                     // weight_weight_sum
+			else if (r <= 4) s[4 + (r - 2)] = acc;                      // left, middle, right
+			else if (r <= 12) s[8 + (r - 5)] = acc;                     // color_vec_x[4], color_vec_y[4]
+			else s[16 + (r - 13)] = acc;                                // scale_vec
 		}
-		float* s = &tr.fbox[p * 24];
-		if (r == 0) { s[0] = mn; s[1] = mx; s[7] = acc; }       // wmin1, wmax1; sum(idx0) completes weight_weight_sum below
-		else if (r == 1) { s[2] = mn; s[3] = mx; }              // scale_min, scale_max
-		else if (r <= 4) s[4 + (r - 2)] = acc;                  // left, middle, right
-		else if (r <= 12) s[8 + (r - 5)] = acc;                 // color_vec_x[4], color_vec_y[4]
-		else s[16 + (r - 13)] = acc;                            // scale_vec
+	}
+	else
+	{
+		WV_FOR(k, pc * 15)
+		{
+			int p = k / 15, r = k % 15;
+			const float* v = c.rsc(r) + pv.off(p);
+			const int n = pv.cnt(p);
+			// one branch-free loop for all chains: running sum, min and max of the row
+			float acc = r == 0 ? 1e-17f : 0.0f;   // row 0 doubles as weight_weight_sum (starts at 1e-17)
+			float mn = r == 0 ? 1.0f : 1e10f;
+			float mx = 0.0f;
+			for (int j = 0; j < n; j++)
+			{
+				float x = v[j];
+				acc += x;
+				mn = x < mn ? x : mn;
+				mx = x > mx ? x : mx;
+			}
+			float* s = &tr.fbox[p * 24];
+			if (r == 0) { s[0] = mn; s[1] = mx; s[7] = acc; }       // wmin1, wmax1; weight_weight_sum
+			else if (r == 1) { s[2] = mn; s[3] = mx; }              // scale_min, scale_max
+			else if (r <= 4) s[4 + (r - 2)] = acc;                  // left, middle, right
+			else if (r <= 12) s[8 + (r - 5)] = acc;                 // color_vec_x[4], color_vec_y[4]
+			else s[16 + (r - 13)] = acc;                            // scale_vec
+		}
 	}
 	WV_SYNC();
 
-	WV_FOR(p, pc)
+	// the solve, one lane per (partition, channel): every quantity below is channel-wise in the reference's vector
+	// code (ref: :1271-1340), the per-partition scalars are simply recomputed by the four lanes of a partition
+	WV_FOR(k, pc * 4)
 	{
+		const int p = k >> 2, ch = k & 3;
 		const float* s = &tr.fbox[p * 24];
-		float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
-		float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6], weight_weight_sum_s = s[7];
-		f4 color_vec_x = load4(&s[8]), color_vec_y = load4(&s[12]);
-		float scale_vec0 = s[16], scale_vec1 = s[17];
-		f4 color_weight = load4(blk.cw);
-		f4 scale_dir = load4(&tr.fbox[112 + p * 4]);
-		f4 rgba_weight_sum = v4_max(color_weight * (float)pv.cnt(p), splat4(1e-17f));
+		const float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
+		const float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6];
+		const float color_weight = blk.cw[ch];
+		const float scale_dir = tr.pm_dir[p][ch];
+		const float cwn = color_weight * (float)pv.cnt(p);
+		const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
 
-		f4 left_sum = splat4(left_sum_s) * color_weight;
-		f4 middle_sum = splat4(middle_sum_s) * color_weight;
-		f4 right_sum = splat4(right_sum_s) * color_weight;
-		f4 lmrs_sum = mk4(left_sum_s, middle_sum_s, right_sum_s, 0.0f) * ls_weight;
+		const float left_sum = left_sum_s * color_weight;
+		const float middle_sum = middle_sum_s * color_weight;
+		const float right_sum = right_sum_s * color_weight;
+		const float lm_x = left_sum_s * ls_weight, lm_y = middle_sum_s * ls_weight, lm_z = right_sum_s * ls_weight;
 
-		color_vec_x = color_vec_x * color_weight;
-		color_vec_y = color_vec_y * color_weight;
+		const float color_vec_x = s[8 + ch] * color_weight;
+		const float color_vec_y = s[12 + ch] * color_weight;
 
 		float scalediv = scale_min / f_max(scale_max, 1e-10f);
 		scalediv = f_clamp1(scalediv);
-		f4 sds = scale_dir * scale_max;
-		f4 rgbs = mk4(sds.x, sds.y, sds.z, scalediv);
+		// lane ch of rgbs: scale_dir * scale for RGB, the scale ratio for A
+		float rgbs = ch < 3 ? scale_dir * scale_max : scalediv;
 
-		f4 ep0 = load4(tr.wep0[p]), ep1 = load4(tr.wep1[p]);
+		float ep0 = tr.wep0[p][ch], ep1 = tr.wep1[p][ch];
 
 		if (wmin1 >= wmax1 * 0.999f)
 		{
 			// all weights (nearly) equal: both endpoints become the mean
-			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
-			for (int k = 0; k < 4; k++)
-			{
-				float a = lane(avg, k);
-				if (a == a) { set_lane(ep0, k, a); set_lane(ep1, k, a); }
-			}
-			rgbs = mk4(sds.x, sds.y, sds.z, 1.0f);
+			const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+			if (avg == avg) { ep0 = avg; ep1 = avg; }
+			if (ch == 3) rgbs = 1.0f;
 		}
 		else
 		{
-			PlaneSolve ps = solve_plane(left_sum, middle_sum, right_sum, color_vec_x, color_vec_y);
-			for (int k = 0; k < 4; k++)
-			{
-				if (ps.m[k]) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
-			}
+			// (ref: solve as in solve_plane(), one channel)
+			const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
+			const float color_rdet1 = 1.0f / color_det1;
+			const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
+			const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
+			const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
+			if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
 
-			float ls_det1 = (lmrs_sum.x * lmrs_sum.z) - (lmrs_sum.y * lmrs_sum.y);
-			float ls_rdet1 = 1.0f / ls_det1;
-			float ls_mss1 = (lmrs_sum.x * lmrs_sum.x) + (2.0f * lmrs_sum.y * lmrs_sum.y) + (lmrs_sum.z * lmrs_sum.z);
-			float scale_ep0 = (lmrs_sum.z * scale_vec0 - lmrs_sum.y * scale_vec1) * ls_rdet1;
-			float scale_ep1 = (lmrs_sum.x * scale_vec1 - lmrs_sum.y * scale_vec0) * ls_rdet1;
+			const float scale_vec0 = s[16], scale_vec1 = s[17];
+			const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
+			const float ls_rdet1 = 1.0f / ls_det1;
+			const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
+			const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
+			const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
 
 			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
 			{
-				float scalediv2 = scale_ep0 / scale_ep1;
-				f4 sdsm = scale_dir * scale_ep1;
-				rgbs = mk4(sdsm.x, sdsm.y, sdsm.z, scalediv2);
+				rgbs = ch < 3 ? scale_dir * scale_ep1 : scale_ep0 / scale_ep1;
 			}
 		}
 
-		if (kHdr && (blk.rgb_lns || blk.alpha_lns))
+		tr.wep0[p][ch] = ep0;
+		tr.wep1[p][ch] = ep1;
+		tr.rgbs[p][ch] = rgbs;
+	}
+	WV_SYNC();
+	if (kHdr && (blk.rgb_lns || blk.alpha_lns))
+	{
+		WV_FOR(p, pc)
 		{
+			const float* s = &tr.fbox[p * 24];
+			const float right_sum_s = s[6], weight_weight_sum_s = s[7];
+			f4 color_weight = load4(blk.cw);
+			f4 rgba_weight_sum = v4_max(color_weight * (float)pv.cnt(p), splat4(1e-17f));
+			f4 color_vec_x = load4(&s[8]) * color_weight, color_vec_y = load4(&s[12]) * color_weight;
 			f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
 			float psum = right_sum_s * hadd_rgb_s(color_weight);
 			f4 rgbq_sum = color_vec_x + color_vec_y;
@@ -242,7 +305,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
 			if (f_isnan(dot_s(rgbovec, rgbovec)))
 			{
-				f4 v0 = ep0, v1 = ep1;
+				f4 v0 = load4(tr.wep0[p]), v1 = load4(tr.wep1[p]);
 				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
 				avgdif = f_max(avgdif, 0.0f);
 				f4 avg = (v0 + v1) * 0.5f;
@@ -251,12 +314,8 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 			}
 			store4(tr.rgbo[p], rgbovec);
 		}
-
-		store4(tr.wep0[p], ep0);
-		store4(tr.wep1[p], ep1);
-		store4(tr.rgbs[p], rgbs);
+		WV_SYNC();
 	}
-	WV_SYNC();
 }
 
 /* (ref: recompute_ideal_colors_2planes :1369) */
@@ -271,17 +330,23 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	expand_weights(c, di, c.wscb().weights + PLANE2_OFFSET, c.wsc(1), undec2);
 
 	const float ls_weight = hadd_rgb_s(load4(blk.cw));
-	const f4 scale_dir = normalize4(xyz0(load4(blk.data_mean)));
+	const f4 scale_dir = load4(tr.pm_dir[0]);              // trial_scale_directions()
 
-	// Per-texel terms lane-parallel, then one sequential lane per running value (ref: :1474-1512).
-	// rows: 0 idx0, 1 idx1, 2 scale, 3-5 l/m/r plane1, 6-8 l/m/r plane2, 9-12 x, 13-16 y, 17-18 scale_vec
+	// running minima / maxima (ref: :1455-1462): per-lane partials, reduced over the wave after the texel pass
+	float wmin1_part = 1.0f, wmax1_part = 0.0f, wmin2_part = 1.0f, wmax2_part = 0.0f, smin_part = 1e10f, smax_part = 0.0f;
+
+	// Per-texel terms lane-parallel, then one sequential lane per running sum (ref: :1474-1512).
+	// rows: 0 idx0, 1 idx1, 3-5 l/m/r plane1, 6-8 l/m/r plane2, 9-12 x, 13-16 y, 17-18 scale_vec
 	WV_FOR(j, T)
 	{
 		f4 rgba = mk4(c.data(0)[j], c.data(1)[j], c.data(2)[j], c.data(3)[j]);
 		float idx0 = undec1[j], idx1 = undec2[j];
 		float om_idx0 = 1.0f - idx0, om_idx1 = 1.0f - idx1;
 		float scale = dot3_s(scale_dir, rgba);
-		c.rsc(0)[j] = idx0; c.rsc(1)[j] = idx1; c.rsc(2)[j] = scale;
+		wmin1_part = idx0 < wmin1_part ? idx0 : wmin1_part; wmax1_part = idx0 > wmax1_part ? idx0 : wmax1_part;
+		wmin2_part = idx1 < wmin2_part ? idx1 : wmin2_part; wmax2_part = idx1 > wmax2_part ? idx1 : wmax2_part;
+		smin_part = scale < smin_part ? scale : smin_part; smax_part = scale > smax_part ? scale : smax_part;
+		c.rsc(0)[j] = idx0; c.rsc(1)[j] = idx1;
 		c.rsc(3)[j] = om_idx0 * om_idx0; c.rsc(4)[j] = om_idx0 * idx0; c.rsc(5)[j] = idx0 * idx0;
 		c.rsc(6)[j] = om_idx1 * om_idx1; c.rsc(7)[j] = om_idx1 * idx1; c.rsc(8)[j] = idx1 * idx1;
 		f4 color_idx = mk4(plane2_component == 0 ? idx1 : idx0, plane2_component == 1 ? idx1 : idx0,
@@ -296,22 +361,27 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	WV_SYNC();
 	// outputs: fbox 0 wmin1 1 wmax1 2 wmin2 3 wmax2 4 scale_min 5 scale_max 6-8 lmr1 9-11 lmr2
 	//          12-15 color_vec_x 16-19 color_vec_y 20-21 scale_vec 22-25 weight_weight_sum
-	WV_FOR(r, 19)
+	wv_all_minmax(wmin1_part, wmax1_part, wmin2_part, wmax2_part);
+	wv_all_minmax(smin_part, smax_part);
+	WV_ONE
 	{
+		tr.fbox[0] = wmin1_part; tr.fbox[1] = wmax1_part; tr.fbox[2] = wmin2_part; tr.fbox[3] = wmax2_part;
+		tr.fbox[4] = smin_part; tr.fbox[5] = smax_part;
+	}
+	WV_FOR(k, 18)
+	{
+		const int r = k >= 2 ? k + 1 : k;        // rows 0, 1, 3..18 (the scale projection only feeds the min / max)
 		const float* v = c.rsc(r);
-		float acc = r <= 1 ? 1e-17f : 0.0f;      // rows 0/1 double as the per-plane weight sums
-		float mn = r == 2 ? 1e10f : 1.0f;
-		float mx = 0.0f;
-		for (int j = 0; j < T; j++)
+		float acc = r <= 1 ? 1e-17f : 0.0f;      // rows 0/1 are the per-plane weight sums
+		int j = 0;
+		for (; j + 4 <= T; j += 4)
 		{
-			float x = v[j];
-			acc += x;
-			mn = x < mn ? x : mn;
-			mx = x > mx ? x : mx;
+			const float x0 = v[j], x1 = v[j + 1], x2 = v[j + 2], x3 = v[j + 3];
+			acc += x0; acc += x1; acc += x2; acc += x3;
 		}
-		if (r == 0) { tr.fbox[0] = mn; tr.fbox[1] = mx; tr.fbox[26] = acc; }
-		else if (r == 1) { tr.fbox[2] = mn; tr.fbox[3] = mx; tr.fbox[27] = acc; }
-		else if (r == 2) { tr.fbox[4] = mn; tr.fbox[5] = mx; }
+		for (; j < T; j++) acc += v[j];
+		if (r == 0) tr.fbox[26] = acc;
+		else if (r == 1) tr.fbox[27] = acc;
 		else if (r <= 8) tr.fbox[6 + (r - 3)] = acc;
 		else if (r <= 16) tr.fbox[12 + (r - 9)] = acc;
 		else tr.fbox[20 + (r - 17)] = acc;
@@ -363,7 +433,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 			float scale_ep1 = (lmrs_sum.x * scale_vec1 - lmrs_sum.y * scale_vec0) * ls_rdet1;
 			for (int k = 0; k < 4; k++)
 			{
-				if (k != plane2_component && ps.m[k]) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
+				if (k != plane2_component && ps.m(k)) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
 			}
 			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
 			{
@@ -382,7 +452,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 		else
 		{
 			PlaneSolve ps = solve_plane(left2_sum, middle2_sum, right2_sum, color_vec_x, color_vec_y);
-			if (ps.m[plane2_component])
+			if (ps.m(plane2_component))
 			{
 				set_lane(ep0, plane2_component, lane(ps.ep0, plane2_component));
 				set_lane(ep1, plane2_component, lane(ps.ep1, plane2_component));

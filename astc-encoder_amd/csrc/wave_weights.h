@@ -41,6 +41,102 @@ WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, ui
 	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]);
 }
 
+/* One slot of sweep 1: initial guess for weight `sl.index` of its grid (ref: :877-905; direct grids copy, :858-866).
+ * Taps in groups of GROUP: all table loads of a group are issued together, then all gathers, then the (strictly
+ * ordered) accumulation -- one memory round trip per group instead of one per tap. */
+template <int GROUP>
+WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
+{
+	const int plane = (sl.flags >> 1) & 1;
+	const float* eiw = c.ei_w(plane);
+	const float* eiwes = c.ei_wes(plane);
+	if (sl.flags & 1) return eiw[sl.index];
+	const uint8_t* tab = c.tab;
+	const float* tabf = reinterpret_cast<const float*>(c.tab);
+	const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)sl.weight_count;
+	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
+	const float wes0 = eiwes[0];
+	float weight_weight = 1e-10f;
+	float initial_weight = 0.0f;
+	const int cnt = sl.taps;
+	for (int j0 = 0; j0 < cnt; j0 += GROUP)
+	{
+		int tx[GROUP]; float wv[GROUP], iw[GROUP], es[GROUP];
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
+			tx[u] = tab[wt + j * uW];
+			wv[u] = tabf[wc + j * uW];
+		}
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			iw[u] = eiw[tx[u]];
+			es[u] = constant_wes ? wes0 : eiwes[tx[u]];
+		}
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			if (j0 + u < cnt)
+			{
+				float contrib_weight = wv[u] * es[u];
+				weight_weight += contrib_weight;
+				initial_weight += iw[u] * contrib_weight;
+			}
+		}
+	}
+	return initial_weight / weight_weight;
+}
+
+/* One slot of sweep 3: the clamped gradient step (ref: :930-970); `inf` = the grid's infill at texel resolution. */
+template <int GROUP>
+WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf, float weight_val)
+{
+	const int plane = (sl.flags >> 1) & 1;
+	const float* eiw = c.ei_w(plane);
+	const float* eiwes = c.ei_wes(plane);
+	const uint8_t* tab = c.tab;
+	const float* tabf = reinterpret_cast<const float*>(c.tab);
+	const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)sl.weight_count;
+	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
+	const float wes0 = eiwes[0];
+	float error_change0 = 1e-10f;
+	float error_change1 = 0.0f;
+	const int cnt = sl.taps;
+	for (int j0 = 0; j0 < cnt; j0 += GROUP)
+	{
+		int tx[GROUP]; float wv[GROUP], iw[GROUP], es[GROUP], ow[GROUP];
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
+			tx[u] = tab[wt + j * uW];
+			wv[u] = tabf[wc + j * uW];
+		}
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			iw[u] = eiw[tx[u]];
+			ow[u] = inf[tx[u]];
+			es[u] = constant_wes ? wes0 : eiwes[tx[u]];
+		}
+		#pragma unroll
+		for (int u = 0; u < GROUP; u++)
+		{
+			if (j0 + u < cnt)
+			{
+				float scale = es[u] * wv[u];
+				error_change0 += wv[u] * scale;
+				error_change1 += (ow[u] - iw[u]) * scale;
+			}
+		}
+	}
+	float step = (error_change1 * -16.0f) / error_change0;
+	step = v_clamp(-0.25f, 0.25f, step);
+	return weight_val + step;
+}
+
 /* Ideal weights on ALL referenced grids of a trial in three lane-parallel sweeps instead of three
  * per grid.
  *   nplanes        : 1 or 2 weight planes in this trial
@@ -56,80 +152,43 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const InfillSet* isets = reinterpret_cast<const InfillSet*>(c.tab + r.off_infill_sets[cls]);
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
 	float* infilled = c.uni_f();
-	const int cap_sets = (int)(c.L->uni_bytes / 4) / Tp;
+	const int cap_sets = (int)r.dwi_sets_per_chunk;
 	// Sets are packed by ascending lowest quant level, so the sets this trial can use are a prefix
 	// (the single-grid "always" pass of trial A is the exception and simply filters by grid index).
 	const int nsets_all = (int)r.dwi_sets[cls];
 	int quant_limit = 0;
 	while (quant_limit < 11 && (ref_mask >> (quant_limit + 1))) quant_limit++;
-	const int nsets_used = max_dm < (int)r.decimation_mode_count_selected ? nsets_all : (int)r.dwi_used_sets[cls][quant_limit];
-	const int slots_end = nsets_used < nsets_all ? (int)isets[nsets_used].dwi_offset : (int)r.dwi_total_floats[cls];
+	const bool all_grids = max_dm >= (int)r.decimation_mode_count_selected;
+	const int nsets_used = all_grids ? (int)r.dwi_used_sets[cls][quant_limit] : nsets_all;
 	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;      // k / T == (k * t_inv) >> 24
+	const DwiOrderDir& dir = reinterpret_cast<const DwiOrderDir*>(c.tab + r.off_dwi_order[cls])[quant_limit];
+	const bool sorted = all_grids && dir.chunks != 0;
+	const uint16_t* order = reinterpret_cast<const uint16_t*>(c.tab + dir.list_off);
 
-	// sweep 1: initial guess for every (grid, plane, weight) (ref: :877-905; direct grids copy, :858-866)
-	{ PROF_SCOPE(c, PS_DEC1);
-	WV_FOR(k, slots_end)
-	{
-		const DwiSlot sl = slots[k];
-		if (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
-		const int plane = (sl.flags >> 1) & 1;
-		const int W = sl.weight_count;
-		const int i = sl.index;
-		const float* eiw = c.ei_w(plane);
-		const float* eiwes = c.ei_wes(plane);
-		if (sl.flags & 1)
-		{
-			dwi_base[k] = eiw[i];
-			continue;
-		}
-		const uint8_t* tab = c.tab;
-		const float* tabf = reinterpret_cast<const float*>(c.tab);
-		const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)W;
-		const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
-		const float wes0 = eiwes[0];
-		float weight_weight = 1e-10f;
-		float initial_weight = 0.0f;
-		int cnt = sl.taps;
-		// groups of 8 taps: all table loads of a group are issued together, then all gathers, then the
-		// (strictly ordered) accumulation -- one memory round trip per level instead of one per tap
-		for (int j0 = 0; j0 < cnt; j0 += 8)
-		{
-			int tx[8]; float wv[8], iw[8], es[8];
-			#pragma unroll
-			for (int u = 0; u < 8; u++)
-			{
-				uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
-				tx[u] = tab[wt + j * uW];
-				wv[u] = tabf[wc + j * uW];
-			}
-			#pragma unroll
-			for (int u = 0; u < 8; u++)
-			{
-				iw[u] = eiw[tx[u]];
-				es[u] = constant_wes ? wes0 : eiwes[tx[u]];
-			}
-			#pragma unroll
-			for (int u = 0; u < 8; u++)
-			{
-				if (j0 + u < cnt)
-				{
-					float contrib_weight = wv[u] * es[u];
-					weight_weight += contrib_weight;
-					initial_weight += iw[u] * contrib_weight;
-				}
-			}
-		}
-		dwi_base[k] = initial_weight / weight_weight;
-	}
-	WV_SYNC(); }
-
-	// sweeps 2+3 over chunks of (grid, plane) sets whose infill fits the scratch region
-	int p0 = 0;
+	// chunks of (grid, plane) sets whose texel-resolution infill fits the scratch region
+	int p0 = 0, chunk = 0;
 	while (p0 < nsets_used)
 	{
 		int p1 = p0 + cap_sets;
 		if (p1 > nsets_used) p1 = nsets_used;
 		const int nsets = p1 - p0;
+		// the chunk's slots: in the table's balanced order (longest tap lists first), or -- for the single-grid
+		// "always" pass -- every slot of the chunk's sets, filtered by grid
+		const int k_begin = (int)isets[p0].dwi_offset;
+		const int k_end = p1 < nsets_all ? (int)isets[p1].dwi_offset : (int)r.dwi_total_floats[cls];
+		const int o_begin = sorted ? (int)dir.chunk_start[chunk] : 0;
+		const int n_items = sorted ? (int)dir.chunk_start[chunk + 1] - o_begin : k_end - k_begin;
+
+		// sweep 1: initial guess for every (grid, plane, weight)
+		{ PROF_SCOPE(c, PS_DEC1);
+		WV_FOR(j, n_items)
+		{
+			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
+			const DwiSlot sl = slots[k];
+			if (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask))) continue;
+			dwi_base[k] = dwi_initial_weight<4>(c, sl);
+		}
+		WV_SYNC(); }
 
 		// sweep 2: infill to texel resolution (ref: :910-926)
 		{ PROF_SCOPE(c, PS_DEC2);
@@ -144,63 +203,18 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		}
 		WV_SYNC(); }
 
-		// sweep 3: one clamped gradient step (ref: :930-970)
-		PROF_SCOPE(c, PS_DEC3);
-		const int k_begin = (int)isets[p0].dwi_offset;
-		const int k_end = p1 < nsets_all ? (int)isets[p1].dwi_offset : (int)r.dwi_total_floats[cls];
-		WV_FOR(kk, k_end - k_begin)
+		// sweep 3: one clamped gradient step
+		{ PROF_SCOPE(c, PS_DEC3);
+		WV_FOR(j, n_items)
 		{
-			int k = k_begin + kk;
+			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
 			const DwiSlot sl = slots[k];
-			if (sl.taps == 0 || (sl.flags & 1) || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
-			const int plane = (sl.flags >> 1) & 1;
-			const int W = sl.weight_count;
-			const float* eiw = c.ei_w(plane);
-			const float* eiwes = c.ei_wes(plane);
-			const uint8_t* tab = c.tab;
-			const float* tabf = reinterpret_cast<const float*>(c.tab);
-			const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)W;
-			const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
-			const float wes0 = eiwes[0];
-			const float* inf = infilled + ((int)sl.set - p0) * Tp;
-			float weight_val = dwi_base[k];
-			float error_change0 = 1e-10f;
-			float error_change1 = 0.0f;
-			int cnt = sl.taps;
-			for (int j0 = 0; j0 < cnt; j0 += 8)
-			{
-				int tx[8]; float wv[8], iw[8], es[8], ow[8];
-				#pragma unroll
-				for (int u = 0; u < 8; u++)
-				{
-					uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
-					tx[u] = tab[wt + j * uW];
-					wv[u] = tabf[wc + j * uW];
-				}
-				#pragma unroll
-				for (int u = 0; u < 8; u++)
-				{
-					iw[u] = eiw[tx[u]];
-					ow[u] = inf[tx[u]];
-					es[u] = constant_wes ? wes0 : eiwes[tx[u]];
-				}
-				#pragma unroll
-				for (int u = 0; u < 8; u++)
-				{
-					if (j0 + u < cnt)
-					{
-						float scale = es[u] * wv[u];
-						error_change0 += wv[u] * scale;
-						error_change1 += (ow[u] - iw[u]) * scale;
-					}
-				}
-			}
-			float step = (error_change1 * -16.0f) / error_change0;
-			step = v_clamp(-0.25f, 0.25f, step);
-			dwi_base[k] = weight_val + step;
+			if ((sl.flags & 1) || (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)))) continue;
+			dwi_base[k] = dwi_refined_weight<4>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
 		}
-		WV_SYNC();
+		WV_SYNC(); }
 		p0 = p1;
+		chunk++;
 	}
 }
 

@@ -3,7 +3,7 @@
 library prints per-stage shader-clock cycles per block to stderr."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["ASTCENC_AMD_LIB"] = os.path.join(ROOT, "astc-encoder_amd", "libastcenc_amd_prof.so")
+os.environ["ASTCENC_AMD_LIB"] = os.environ.get("PROF_LIB", os.path.join(ROOT, "astc-encoder_amd", "libastcenc_amd_prof.so"))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
 import astcenc_amd as A
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048

@@ -24,3 +24,14 @@ for i in range(steps + 1):
     assert e == 0
     if i > 0: best = min(best, ms.value)
 print("%s: %dx%d %dx%d q=%.0f kernel %.2f ms -> %.2f Mtexels/s" % (os.path.basename(sys.argv[1]), size, size, b, b, q, best, size * size / best / 1e3))
+if os.environ.get("CHECK", "1") != "0":
+    # byte parity of a block-aligned 384^2 corner against the reference (checker only)
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); import oracle_libs as O
+    if os.path.exists(O.LIB_REF_AVX2):
+        n = 384 // b
+        crop = np.ascontiguousarray(A.synthetic_image(size, size)[:n * b, :n * b])
+        want = A.Library(O.LIB_REF_AVX2).compress(crop, (b, b), q).reshape(-1, 16)
+        bxn = (size + b - 1) // b
+        got = out.cpu().numpy().reshape(-1, 16)
+        rows = np.concatenate([got[r * bxn: r * bxn + n] for r in range(n)])
+        print("   parity: %d of %d blocks differ from the reference" % (int((rows != want).any(axis=1).sum()), want.shape[0]))
