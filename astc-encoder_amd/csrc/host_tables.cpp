@@ -1134,7 +1134,9 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			{
 				uint32_t di_off = (uint32_t)(off_di + i * sizeof(DecimationInfo));
 				uint32_t rs = ((uint32_t)blob.at<DecimationInfo>(di_off)->max_weight_texel_count + 3u) & ~3u;
-				uint32_t slots = std::min<uint32_t>(std::min(64u / rs, (16u * Tp) / (12u * rs)), 4u);
+				// (a group's (weight, texel row) pairs fill at most one wave; its 12 term rows per weight live in LDS;
+				//  16 = the per-weight decision records the kernel keeps, see realign_weights)
+				uint32_t slots = std::min<uint32_t>(std::min(64u / rs, (16u * Tp) / (12u * rs)), 16u);
 				if (slots < 1) slots = 1;
 				blob.at<DecimationInfo>(di_off)->realign_slots = (uint8_t)slots;
 				if (used(i)) rt_floats = std::max(rt_floats, slots * 12u * rs);

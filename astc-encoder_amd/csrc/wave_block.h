@@ -440,6 +440,16 @@ WV_OUT void refine_pack(bool dual, int partition_count, int partition_packed, in
 			WV_SYNC();
 		}
 	}
+	// The decoded endpoints of what was just packed: the scoring and weight realignment steps that follow (up to three
+	// of them before the next packing) all start from these, so they are unpacked once, here (tr.ibox[p * 8 ..]).
+	WV_FOR(p, partition_count)
+	{
+		i4 e0, e1;
+		unpack_color_endpoints(c.cfg->profile, workscb.color_formats[p], workscb.color_values[p], e0, e1);
+		int* o = &tr.ibox[p * 8];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+	}
 	WV_ONE
 	{
 		workscb.color_formats_matched = (uint8_t)formats_matched;
@@ -565,6 +575,18 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 				}
 			}
 
+#if defined(ASTC_DUPSTAGE)
+			// (realignment changes the weights: for the doubled run they are put back first)
+			uint32_t saved_weights = 0;
+			if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN)
+			{
+				WV_FOR(k, 16) { saved_weights = reinterpret_cast<const uint32_t*>(c.wscb().weights)[k]; }
+				(void)refine_realign(partition_count, partition_packed, cand_dm);
+				WV_SYNC();
+				WV_FOR(k, 16) { reinterpret_cast<uint32_t*>(c.wscb().weights)[k] = saved_weights; }
+				WV_SYNC();
+			}
+#endif
 			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
 
 			float errorval;

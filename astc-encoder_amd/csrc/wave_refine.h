@@ -528,16 +528,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	const bool fast_1p = !dual && pc == 1 && !rgbm;
 	const int p2c = wv_uniform((int)scb.plane2_component);
 
-	// endpoints per partition -> ibox[p*8 ..]
-	WV_FOR(p, pc)
-	{
-		i4 e0, e1;
-		unpack_color_endpoints(profile, scb.color_formats[p], scb.color_values[p], e0, e1);
-		int* o = &tr.ibox[p * 8];
-		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
-		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
-	}
-	WV_SYNC();
+	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
 
 	float* term = c.rsc(0);        // (the endpoint re-fit rows are free between re-fits)
 	float* flag = c.rsc(1);
@@ -625,15 +616,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	const int p2c = wv_uniform((int)scb.plane2_component);
 	const bool decimated = W != T;
 
-	WV_FOR(p, pc)
-	{
-		i4 e0, e1;
-		unpack_color_endpoints(c.cfg->profile, scb.color_formats[p], scb.color_values[p], e0, e1);
-		int* o = &tr.ibox[p * 8];
-		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
-		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
-	}
-	WV_SYNC();
+	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
 
 	bool adjustments = false;
 	// wave-uniform values read from LDS: keep them in scalar registers
@@ -745,8 +728,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			// (weight of the group, texel row of that weight).
 			const uint8_t* order = di.ro;
 			const uint8_t* group_count = di.rc;
-			float* sums = &tr.fbox[64];                 // [slot][12]
-			int* moved_to = &tr.ibox[40];               // [slot] new quantized value or -1
+			int* moved_to = &tr.ibox[40];               // [slot] new quantized value or -1 (<= 16 slots, host_tables.cpp)
 			int pos = 0;
 			for (int lv = 0; lv < di.levels; lv++)
 			{
@@ -789,24 +771,28 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					o[8 * rs] = u.x; o[9 * rs] = u.y; o[10 * rs] = u.z; o[11 * rs] = u.w;
 				}
 				WV_SYNC();
+				// the 12 sums of each weight, in place: lane (slot, j) adds up its own row and leaves the total in the
+				// row's first element
 				WV_FOR(k, gn * 12)
 				{
 					const int slot = k / 12;
 					const int n = wtc[order[pos + slot]];
-					const float* v = rt + k * rs;             // == rt + slot * 12 * rs + (k % 12) * rs
+					float* v = rt + k * rs;                   // == rt + slot * 12 * rs + (k % 12) * rs
 					float acc = 0.0f;
 					for (int te = 0; te < n; te++) acc += v[te];
-					sums[k] = acc;
+					v[0] = acc;
 				}
 				WV_SYNC();
+				bool moved_here = false;                  // per lane on the device; wv_any() folds the lanes
 				WV_FOR(slot, gn)
 				{
 					const int we = order[pos + slot];
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
-					float error_base = hadd_s(load4(&sums[slot * 12]) * error_weight);
-					float error_down = hadd_s(load4(&sums[slot * 12 + 4]) * error_weight);
-					float error_up = hadd_s(load4(&sums[slot * 12 + 8]) * error_weight);
+					const float* sm = rt + slot * 12 * rs;
+					float error_base = hadd_s(mk4(sm[0], sm[rs], sm[2 * rs], sm[3 * rs]) * error_weight);
+					float error_down = hadd_s(mk4(sm[4 * rs], sm[5 * rs], sm[6 * rs], sm[7 * rs]) * error_weight);
+					float error_up = hadd_s(mk4(sm[8 * rs], sm[9 * rs], sm[10 * rs], sm[11 * rs]) * error_weight);
 					int new_value = -1;
 					if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
 					else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
@@ -815,12 +801,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					{
 						uqf[we] = (float)new_value;
 						uq[we] = (uint8_t)new_value;
+						moved_here = true;
 					}
 				}
 				WV_SYNC();
-				bool any_moved = false;
-				for (int slot = 0; slot < gn; slot++) any_moved = any_moved || moved_to[slot] >= 0;
-				if (any_moved)
+				if (wv_any(moved_here))
 				{
 					adjustments = true;
 					WV_FOR(k, gn * rs)
@@ -831,8 +816,8 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						int texel = wt[te * W + we];
 						wb[texel] = infill4(uqf, tw, tcf, T, texel);
 					}
+					WV_SYNC();
 				}
-				WV_SYNC();
 				pos += gn;
 			}
 		}

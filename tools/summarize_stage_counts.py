@@ -3,7 +3,7 @@
 import csv, glob, os, sys
 NAMES = {1: "ideal endpoints+weights", 2: "decimate (all grids)", 3: "angular bounds", 4: "mode scoring", 5: "mode scoring + formats",
          6: "candidate quantize", 7: "candidate setup/staging", 8: "recompute endpoints", 9: "pack endpoints", 10: "difference (decode+score)",
-         11: "partition order (k-means)", 12: "partition score", 13: "partition select", 14: "block statistics", 15: "load block", 16: "physical"}
+         11: "partition order (k-means)", 12: "partition score", 13: "partition select", 14: "block statistics", 15: "load block", 16: "physical", 18: "weight realignment"}
 d = sys.argv[1]
 def load(i):
     tot = {}
@@ -33,4 +33,4 @@ for i in sorted(NAMES):
 if 5 in rows and 4 in rows:
     print("%-28s %9.0f %5.1f%%" % ("  formats (5 minus 4)", rows[5][cols[0]] - rows[4][cols[0]], 100 * (rows[5][cols[0]] - rows[4][cols[0]]) * waves / base[cols[0]]))
 acc = sum(v[cols[0]] for k, v in rows.items() if k != 4)
-print("%-28s %9.0f %5.1f%%   (weight realignment + control code between the stages)" % ("not doubled", base[cols[0]] / waves - acc, 100 * (1 - acc * waves / base[cols[0]])))
+print("%-28s %9.0f %5.1f%%   (control code between the stages, block-level code)" % ("not doubled", base[cols[0]] / waves - acc, 100 * (1 - acc * waves / base[cols[0]])))
