@@ -209,6 +209,7 @@ struct TableRoot {
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
+	uint32_t off_dm_by_weights;               // u8[decimation_mode_count_selected]: the grids by descending weight count (angular batching order)
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
 	uint32_t realign_rt_floats;               // LDS floats the realign term rows need: max over grids of slots * 12 * rows4

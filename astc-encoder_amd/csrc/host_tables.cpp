@@ -1115,6 +1115,17 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	r->off_quant_mode_table = off_qm;
 	r->off_integer_of_trits = off_tr;
 	r->off_integer_of_quints = off_qu;
+	{
+		// grids by descending weight count: the angular search batches (grid, step) pairs onto lanes that each walk
+		// the grid's weights, so a batch of similar grids wastes the fewest iterations
+		std::vector<uint8_t> by_w(dms.size());
+		for (size_t i = 0; i < dms.size(); i++) by_w[i] = (uint8_t)i;
+		std::stable_sort(by_w.begin(), by_w.end(), [&](uint8_t a, uint8_t b) { return dm_grid[a].count() > dm_grid[b].count(); });
+		uint32_t off = blob.alloc(std::max<size_t>(by_w.size(), 1));
+		memcpy(blob.at<uint8_t>(off), by_w.data(), by_w.size());
+		r = blob.at<TableRoot>(0);
+		r->off_dm_by_weights = off;
+	}
 	r->off_sin_table = off_sin;
 	r->off_cos_table = off_cos;
 	{

@@ -710,18 +710,22 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		}
 
 	}
-	// list of the grids this trial uses, in index order
+	// list of the grids this trial uses, largest weight count first (the order the search batches them in)
+	const uint8_t* by_weights = c.tab + c.root->off_dm_by_weights;
+	const int all_dms = (int)c.root->decimation_mode_count_selected;
 #if WV_DEVICE
 	{
 		int n = 0;
-		for (int base = 0; base < max_decimation_modes; base += 64)
+		for (int base = 0; base < all_dms; base += 64)
 		{
-			const int i = base + WV_LANE;
+			const int k = base + WV_LANE;
 			bool used = false;
-			if (i < max_decimation_modes)
+			int i = 0;
+			if (k < all_dms)
 			{
+				i = by_weights[k];
 				const DecimationMode& m = c.dec_mode(i);
-				used = ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
+				used = i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
 			}
 			const unsigned long long mask = __ballot(used);
 			if (used) tr.dm_list[n + __popcll(mask & ((1ull << WV_LANE) - 1ull))] = (uint8_t)i;
@@ -732,10 +736,11 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 #else
 	{
 		int n = 0;
-		for (int i = 0; i < max_decimation_modes; i++)
+		for (int k = 0; k < all_dms; k++)
 		{
+			const int i = by_weights[k];
 			const DecimationMode& m = c.dec_mode(i);
-			if ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) tr.dm_list[n++] = (uint8_t)i;
+			if (i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask)) tr.dm_list[n++] = (uint8_t)i;
 		}
 		tr.dm_count = n;
 	}
@@ -751,6 +756,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		max_precision = i_min(max_precision, max_weight_quant);
 		AngSet a;
 		a.weights = c.dwi(dm, plane, dual);
+		a.rows = c.isample() + (a.weights - reinterpret_cast<const float*>(c.lds + c.L->dwi));
 		a.out = c.lowhigh(plane, dm, dual);
 		a.wcount = c.dec_info(dm).weight_count;
 		a.maxq = max_precision;

@@ -161,7 +161,14 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	uint32_t nbm_max = nbm1 > nbm - nbm1 ? nbm1 : nbm - nbm1;
 	L.dwi = take((r.dwi_total_floats[0] > r.dwi_total_floats[1] ? r.dwi_total_floats[0] : r.dwi_total_floats[1]) * 4);
 	L.lowhigh = take((r.lowhigh_floats[0] > r.lowhigh_floats[1] ? r.lowhigh_floats[0] : r.lowhigh_floats[1]) * 4);
-	L.modes = take(nbm_max * sizeof(ModeRec));
+	{
+		// the mode records; before the modes are scored the same bytes hold one sin/cos table row index per ideal
+		// weight (decimation sweeps -> angular search), so the region is at least one byte per packed weight slot
+		uint32_t bytes = nbm_max * (uint32_t)sizeof(ModeRec);
+		const uint32_t slots = r.dwi_total_floats[0] > r.dwi_total_floats[1] ? r.dwi_total_floats[0] : r.dwi_total_floats[1];
+		if (slots > bytes) bytes = slots;
+		L.modes = take(bytes);
+	}
 	L.uni_bytes = uni_region_bytes(r.texel_count, cfg.tune_partition_count_limit);
 	L.uni = take(L.uni_bytes);
 	uint32_t end = o;
@@ -227,6 +234,8 @@ struct Ctx {
 	WV_FN float* dwi(int dm, int plane, bool dual) const { return reinterpret_cast<float*>(lds + L->dwi) + dec_mode(dm).dwi_offset[dual ? 1 + plane : 0]; }
 	WV_FN float* lowhigh(int plane, int dm, bool dual) const { return reinterpret_cast<float*>(lds + L->lowhigh) + dec_mode(dm).lowhigh_offset[dual ? 1 + plane : 0]; }
 	WV_FN float* ang() const { return reinterpret_cast<float*>(lds + L->uni); }
+	// sin/cos table row of every packed ideal weight (same indexing as the dwi region), see ideal_weights_all_grids
+	WV_FN uint8_t* isample() const { return lds + L->modes; }
 	WV_FN float* uni_f() const { return reinterpret_cast<float*>(lds + L->uni); }
 	// records of the block modes [first, ...) scored by the current trial; index with the packed mode index
 	WV_FN ModeRec* modes(int first) const { return reinterpret_cast<ModeRec*>(lds + L->modes) - first; }

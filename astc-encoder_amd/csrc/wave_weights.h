@@ -41,6 +41,15 @@ WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, ui
 	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]);
 }
 
+/* Row of the sin/cos tables an ideal weight selects in the angular search (ref: compute_angular_offsets,
+ * weight_align.cpp:110-118).  It depends on the weight only, not on the angular step, so it is computed once when
+ * the weight is final instead of once per (weight, step) in the search. */
+WV_FN uint8_t angular_sample_row(float weight)
+{
+	float sample = v_clampzo(weight) * (SINCOS_STEPS - 1.0f);
+	return (uint8_t)(int)(sample + 0.5f);
+}
+
 /* One slot of sweep 1: initial guess for weight `sl.index` of its grid (ref: :877-905; direct grids copy, :858-866).
  * Taps in groups of GROUP: all table loads of a group are issued together, then all gathers, then the (strictly
  * ordered) accumulation -- one memory round trip per group instead of one per tap. */
@@ -151,6 +160,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const DwiSlot* slots = reinterpret_cast<const DwiSlot*>(c.tab + r.off_dwi_slots[cls]);
 	const InfillSet* isets = reinterpret_cast<const InfillSet*>(c.tab + r.off_infill_sets[cls]);
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
+	uint8_t* isamp = c.isample();
 	float* infilled = c.uni_f();
 	const int cap_sets = (int)r.dwi_sets_per_chunk;
 	// Sets are packed by ascending lowest quant level, so the sets this trial can use are a prefix
@@ -186,7 +196,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
 			const DwiSlot sl = slots[k];
 			if (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask))) continue;
-			dwi_base[k] = dwi_initial_weight<4>(c, sl);
+			const float w0 = dwi_initial_weight<4>(c, sl);
+			dwi_base[k] = w0;
+			if (sl.flags & 1) isamp[k] = angular_sample_row(w0);     // copied weights are final here
 		}
 		WV_SYNC(); }
 
@@ -210,7 +222,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
 			const DwiSlot sl = slots[k];
 			if ((sl.flags & 1) || (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)))) continue;
-			dwi_base[k] = dwi_refined_weight<4>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+			const float w1 = dwi_refined_weight<4>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+			dwi_base[k] = w1;
+			isamp[k] = angular_sample_row(w1);
 		}
 		WV_SYNC(); }
 		p0 = p1;
@@ -237,6 +251,7 @@ WV_FN int steps_for_quant_level(int q)
  * Sets are processed in batches of up to 64 (set, step) pairs. */
 struct AngSet {
 	const float* weights;
+	const uint8_t* rows;    // sin/cos table row per weight (angular_sample_row)
 	float* out;
 	int wcount;
 	int maxq;
@@ -290,6 +305,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			int sp = k - base;
 			const int W = a.wcount;
 			const float* wv = a.weights;
+			const uint8_t* rows = a.rows;
 
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
@@ -298,14 +314,13 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			for (int j0 = 0; j0 < W; j0 += 8)
 			{
 				float wj[8], cs[8], sn[8];
+				uint32_t row[8];
 				#pragma unroll
-				for (int u = 0; u < 8; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
+				for (int u = 0; u < 8; u++) { const int j = j0 + u < W ? j0 + u : 0; wj[u] = wv[j]; row[u] = rows[j]; }
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
 				{
-					float sample = v_clampzo(wj[u]) * (SINCOS_STEPS - 1.0f);
-					int isample = (int)(sample + 0.5f);
-					const uint32_t at = (uint32_t)isample * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
+					const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
 					cs[u] = cos_table[at];
 					sn[u] = sin_table[at];
 				}
