@@ -67,7 +67,7 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 /* Per-mode records of one scoring chunk, built once by one lane per (mode, plane) so that the
  * (mode, texel) sweep reads them with a single LDS access instead of chasing
  * block mode -> decimation info -> table pointers through global memory in every lane. */
-struct ModeHdr { uint32_t tw_off, tcf_off; int32_t taps; int32_t mode; };   // mode = packed block mode index
+struct ModeHdr { uint32_t tw_off, tcf_off; int16_t taps, weights; int32_t mode; };   // mode = packed block mode index; weights per plane
 struct ModeQ { float scale, scaled_low_bound, quant_level_m1, rscale, low_bound; int32_t steps_m1; uint32_t q2u_off; uint32_t dwi_off; };
 static_assert(sizeof(ModeHdr) + 2 * sizeof(ModeQ) == MODE_DESC_BYTES, "mode descriptor size");
 
@@ -101,14 +101,17 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	ModeRec* modes = c.modes(start);
 	const int T = c.T, Tp = c.Tp;
 	const int planes = dual ? 2 : 1;
-	const int chunk_modes = (int)(c.L->uni_bytes / (MODE_DESC_BYTES + (uint32_t)Tp * 4));
+	const int chunk_modes = (int)c.L->mode_chunk;
 	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);
 	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
 	float* buf = reinterpret_cast<float*>(c.lds + c.L->uni + (uint32_t)chunk_modes * MODE_DESC_BYTES);
+	uint8_t* uqw = c.lds + c.L->uni + (uint32_t)chunk_modes * (MODE_DESC_BYTES + (uint32_t)Tp * 4);   // [mode][MODE_WEIGHT_BYTES]
+	const int wcap = (int)c.L->mode_wcap[dual ? 1 : 0];
+	const uint32_t wcap_inv = c.L->mode_wcap_inv[dual ? 1 : 0];
 	const float* ldsf = reinterpret_cast<const float*>(c.lds);
 	const float* eiw0 = c.ei_w(0); const float* eiwes0 = c.ei_wes(0);
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
-	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;     // k / T == (k * t_inv) >> 24 for k < 2^24 / T
+	const uint32_t t_inv = c.L->t_inv24;                                      // k / T == (k * t_inv) >> 24 for k < 2^24 / T
 
 	// Windows of 64 block modes.  Only the modes that are legal under this trial's weight quant limit
 	// (less than half of them, typically, once trial A has set the limit) are scored: their window
@@ -156,7 +159,8 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				ModeHdr h;
 				h.tw_off = di.off_texel_weights;
 				h.tcf_off = di.off_texel_contribs_f;
-				h.taps = mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1;
+				h.taps = (int16_t)(mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1);
+				h.weights = (int16_t)di.weight_count;
 				h.mode = base + i;
 				hdr[m] = h;
 			}
@@ -172,6 +176,35 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 		}
 		WV_SYNC(); }
 
+		// Pass A: quantize every grid weight of every mode of the chunk once (a texel interpolates up to four grid
+		// weights and a weight feeds many texels, so quantizing per (mode, texel, tap) would repeat each weight's
+		// quantization several times over); the unquantized levels 0..64 go to LDS as bytes.
+		{ PROF_SCOPE(c, PS_MODE1);
+		WV_FOR(k, nm * wcap)
+		{
+			const int m = (int)(((uint32_t)k * wcap_inv) >> 16), i = k - m * wcap;
+			const ModeHdr h = hdr[m];
+			if (i >= h.weights) continue;
+			for (int plane = 0; plane < planes; plane++)
+			{
+				const ModeQ q = mq[m * 2 + plane];
+				const float ideal = ldsf[q.dwi_off + (uint32_t)i];
+				// (ref: compute_quantized_weights_for_decimation :974; same arithmetic as quantize_weight())
+				float ix = ideal * q.scale - q.scaled_low_bound;
+				ix = v_clampzo(ix);
+				const float ix1 = ix * q.quant_level_m1;
+				const int weightl = (int)ix1;
+				const int weighth = i_min(weightl + 1, q.steps_m1);
+				const int ixli = c.tab[q.q2u_off + (uint32_t)weightl];
+				const int ixhi = c.tab[q.q2u_off + (uint32_t)weighth];
+				const bool up = ((float)ixli + (float)ixhi) < (128.0f * ix);
+				uqw[m * (int)MODE_WEIGHT_BYTES + plane * PLANE2_OFFSET + i] = (uint8_t)(up ? ixhi : ixli);
+			}
+		}
+		WV_SYNC(); }
+
+		// Pass B: one lane per (mode, texel): infill the quantized weights and take the squared difference to the
+		// ideal weight of the texel (ref: compute_error_of_weight_set_{1plane,2planes} :688-842)
 		{ PROF_SCOPE(c, PS_MODE1);
 		WV_FOR(k, nm * T)
 		{
@@ -183,6 +216,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				const float* tabf = reinterpret_cast<const float*>(c.tab);
 				const uint32_t tw = h.tw_off + (uint32_t)t, tcf = (h.tcf_off >> 2) + (uint32_t)t;
 				const uint32_t uT = (uint32_t)T;
+				const uint8_t* uq = uqw + m * (int)MODE_WEIGHT_BYTES;
 				if (h.taps == 4)
 				{
 					const int i0 = tab[tw], i1 = tab[tw + uT], i2 = tab[tw + 2 * uT], i3 = tab[tw + 3 * uT];
@@ -190,12 +224,11 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
-						const float* ideal = ldsf + q.dwi_off;
-						const float w0 = ideal[i0], w1 = ideal[i1], w2 = ideal[i2], w3 = ideal[i3];
-						const float v0 = quantize_weight_q(q, tab, w0) * c0;
-						const float v1 = quantize_weight_q(q, tab, w1) * c1;
-						const float v2 = quantize_weight_q(q, tab, w2) * c2;
-						const float v3 = quantize_weight_q(q, tab, w3) * c3;
+						const uint8_t* u = uq + plane * PLANE2_OFFSET;
+						const float v0 = ((float)(int)u[i0] * q.rscale + q.low_bound) * c0;
+						const float v1 = ((float)(int)u[i1] * q.rscale + q.low_bound) * c1;
+						const float v2 = ((float)(int)u[i2] * q.rscale + q.low_bound) * c2;
+						const float v3 = ((float)(int)u[i3] * q.rscale + q.low_bound) * c3;
 						float current = (v0 + v1) + (v2 + v3);
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
@@ -209,10 +242,9 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
-						const float* ideal = ldsf + q.dwi_off;
-						const float w0 = ideal[i0], w1 = ideal[i1];
-						const float v0 = quantize_weight_q(q, tab, w0) * c0;
-						const float v1 = quantize_weight_q(q, tab, w1) * c1;
+						const uint8_t* u = uq + plane * PLANE2_OFFSET;
+						const float v0 = ((float)(int)u[i0] * q.rscale + q.low_bound) * c0;
+						const float v1 = ((float)(int)u[i1] * q.rscale + q.low_bound) * c1;
 						float current = v0 + v1;
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
@@ -224,8 +256,8 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
-						const float* ideal = ldsf + q.dwi_off;
-						float current = quantize_weight_q(q, tab, ideal[t]);
+						const uint8_t* u = uq + plane * PLANE2_OFFSET;
+						float current = (float)(int)u[t] * q.rscale + q.low_bound;
 						float diff = current - (plane ? eiw1[t] : eiw0[t]);
 						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
 						term = plane ? term + e : e;

@@ -120,6 +120,10 @@ struct LdsLayout {
 	uint32_t part_chunk; // candidates per staging pass
 	uint32_t uni_bytes;  // size of the `uni` region
 	uint32_t tsc_stride; // floats between tsc rows
+	uint32_t t_inv24;    // ceil(2^24 / texel_count): k / T == (k * t_inv24) >> 24 for k < 2^24 / T (no integer divide on the device)
+	uint32_t mode_chunk; // block modes scored per pass of score_block_modes (descriptors + quantized weights + texel terms fit `uni`)
+	uint32_t mode_wcap[2];     // weights per plane the scoring passes provide lanes for, per trial class (1-plane, 2-plane)
+	uint32_t mode_wcap_inv[2]; // ceil(2^16 / mode_wcap): k / wcap == (k * inv) >> 16
 	uint32_t total;
 };
 
@@ -170,6 +174,14 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		L.modes = take(bytes);
 	}
 	L.uni_bytes = uni_region_bytes(r.texel_count, cfg.tune_partition_count_limit);
+	L.t_inv24 = ((1u << 24) + (uint32_t)r.texel_count - 1u) / (uint32_t)r.texel_count;
+	L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);
+	for (int cls = 0; cls < 2; cls++)
+	{
+		const uint32_t cap = (r.max_weights[cls] + 3u) & ~3u;
+		L.mode_wcap[cls] = cap;
+		L.mode_wcap_inv[cls] = (65536u + cap - 1u) / cap;
+	}
 	L.uni = take(L.uni_bytes);
 	uint32_t end = o;
 	// refine phase

@@ -41,7 +41,8 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 		// 4-accumulator masked sums for all but the last partition (ref: :67-84, :238-258)
 		WV_FOR(k, (pc - 1) * n * 4)
 		{
-			int l = k & 3, j = (k >> 2) % n, p = (k >> 2) / n;
+			const uint32_t n_inv = n == 4 ? 64u : n == 3 ? 86u : n == 2 ? 128u : 256u;      // (k >> 2) / n by multiply-shift
+			int l = k & 3, p = (int)((((uint32_t)k >> 2) * n_inv) >> 8), j = (k >> 2) - p * n;
 			const float* d = c.data(cs.comp(j));
 			float acc = 0.0f;
 			for (int i = l; i < T; i += 4)
@@ -78,7 +79,11 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	// sum of offsets over the texels whose component `which` is above the mean (ref: :409-433)
 	WV_FOR(k, pc * n * n)
 	{
-		int j = k % n, which = (k / n) % n, p = k / (n * n);
+		// (n is 2, 3 or 4: divisions by multiply-shift, exact for k < 128 -- the device has no integer divide)
+		const uint32_t n_inv = n == 4 ? 64u : n == 3 ? 86u : n == 2 ? 128u : 256u;
+		const int q = (int)(((uint32_t)k * n_inv) >> 8);
+		const int p = (int)(((uint32_t)q * n_inv) >> 8);
+		const int j = k - q * n, which = q - p * n;
 		const float* dj = c.data(cs.comp(j));
 		const float* dw = c.data(cs.comp(which));
 		float avg_j = tr.pm_avg[p][j], avg_w = tr.pm_avg[p][which];

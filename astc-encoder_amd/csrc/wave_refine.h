@@ -700,6 +700,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const uint8_t* tw = di.tw;
 			const float* tcf = di.tcf;
 			const int rs = (di.rows + 3) & ~3;                       // row stride of the term rows for this grid
+			const uint32_t rs_inv = (65536u + (uint32_t)rs - 1u) / (uint32_t)rs;   // k / rs == (k * rs_inv) >> 16 for k < 1024 (one divide per call)
 			uint32_t* pn = reinterpret_cast<uint32_t*>(c.rsc(0));   // prev/next quant values of each weight's current value
 			float* uqf = c.rsc(1);
 			float* rt = c.rsc(2);                                    // [slots of this grid][12] rows of `rs` floats
@@ -737,7 +738,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				// per-texel squared differences for base / down / up, 4 channels each -> rt[slot][12][rs]
 				WV_FOR(k, gn * rs)
 				{
-					const int slot = k / rs, te = k - slot * rs;
+					const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
 					const int we = order[pos + slot];
 					if (te >= (int)wtc[we]) continue;
 					const int uqw = uq[we];
@@ -810,7 +811,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					adjustments = true;
 					WV_FOR(k, gn * rs)
 					{
-						const int slot = k / rs, te = k - slot * rs;
+						const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
 						const int we = order[pos + slot];
 						if (moved_to[slot] < 0 || te >= (int)wtc[we]) continue;
 						int texel = wt[te * W + we];

@@ -170,7 +170,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	while (quant_limit < 11 && (ref_mask >> (quant_limit + 1))) quant_limit++;
 	const bool all_grids = max_dm >= (int)r.decimation_mode_count_selected;
 	const int nsets_used = all_grids ? (int)r.dwi_used_sets[cls][quant_limit] : nsets_all;
-	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;      // k / T == (k * t_inv) >> 24
+	const uint32_t t_inv = c.L->t_inv24;                                       // k / T == (k * t_inv) >> 24
 	const DwiOrderDir& dir = reinterpret_cast<const DwiOrderDir*>(c.tab + r.off_dwi_order[cls])[quant_limit];
 	const bool sorted = all_grids && dir.chunks != 0;
 	const uint16_t* order = reinterpret_cast<const uint16_t*>(c.tab + dir.list_off);
