@@ -160,7 +160,18 @@ struct DecimationInfo {
 	uint32_t off_realign_order;          // u8 [W]      weight indices
 	uint32_t off_realign_counts;         // u8 [W]      weights per group, realign_levels entries used
 	uint32_t table_bytes;                // all nine arrays are contiguous from off_texel_weights
+	// Grids whose schedule is long (weights decimated in two dimensions: every weight shares texels with its eight
+	// neighbours, so the groups hold one to three weights) are realigned speculatively instead: every weight is
+	// evaluated as if no weight before it moved -- all of them lane-parallel -- and after each weight that does move
+	// (few do) only the later weights that share a texel with it, listed here, are evaluated again.
+	uint32_t off_realign_later;          // u8 [W][REALIGN_LATER_MAX] later neighbours of each weight, 255-terminated (not staged in LDS)
+	uint32_t realign_speculative;        // 1: use the scheme above
 };
+constexpr int REALIGN_LATER_MAX = 16;
+#ifndef ASTC_REALIGN_SPEC_MIN
+#define ASTC_REALIGN_SPEC_MIN 7
+#endif
+constexpr int REALIGN_SPECULATIVE_MIN_LEVELS = ASTC_REALIGN_SPEC_MIN;   // schedules at least this long are replaced by the speculative scheme
 
 // One partitioning; fixed-stride record followed by two u8[T] arrays:
 //   partition_of_texel[T], texels_sorted[T] (texel indices grouped by partition, ascending inside

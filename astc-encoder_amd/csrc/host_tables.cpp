@@ -256,6 +256,7 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	uint32_t o_tcw = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_ro  = blob.alloc(W, 4);          // realign schedule, filled by build_realign_schedules()
 	uint32_t o_rc  = blob.alloc(W, 4);
+	uint32_t o_later = blob.alloc((size_t)W * REALIGN_LATER_MAX, 4);   // later neighbours (not part of the staged range), see build_realign_schedule()
 
 	uint8_t* p_tw = blob.at<uint8_t>(o_tw);
 	uint8_t* p_tci = blob.at<uint8_t>(o_tci);
@@ -322,6 +323,8 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	di->off_texel_contrib_for_weight = o_tcw;
 	di->off_realign_order = o_ro;
 	di->off_realign_counts = o_rc;
+	di->off_realign_later = o_later;
+	di->realign_speculative = 0;
 	di->realign_levels = 0;
 	di->table_bytes = (uint32_t)(o_rc + ((W + 3u) & ~3u) - o_tw);
 }
@@ -358,6 +361,36 @@ static void build_realign_schedule(Blob& blob, uint32_t di_off, unsigned int max
 		counts[nlev++] = (uint8_t)fill[L];
 	}
 	blob.at<DecimationInfo>(di_off)->realign_levels = (uint8_t)nlev;
+
+	// later neighbours of every weight (see DecimationInfo::off_realign_later)
+	std::vector<uint8_t> later((size_t)W * REALIGN_LATER_MAX, 255);
+	bool fits = true;
+	{
+		const DecimationInfo* d = blob.at<DecimationInfo>(di_off);
+		const uint8_t* wtc2 = blob.at<uint8_t>(d->off_weight_texel_count);
+		const uint8_t* wt2 = blob.at<uint8_t>(d->off_weight_texels);
+		std::vector<uint64_t> touches(W, 0), touches_hi(W, 0), touches_3(W, 0), touches_4(W, 0);   // texel sets as 4 x 64 bits (T <= 216)
+		for (unsigned int w = 0; w < W; w++)
+			for (unsigned int j = 0; j < wtc2[w]; j++)
+			{
+				unsigned int t = wt2[j * W + w];
+				(t < 64 ? touches[w] : t < 128 ? touches_hi[w] : t < 192 ? touches_3[w] : touches_4[w]) |= 1ull << (t & 63);
+			}
+		for (unsigned int w = 0; w < W; w++)
+		{
+			unsigned int n = 0;
+			for (unsigned int k = w + 1; k < W; k++)
+			{
+				if (!((touches[w] & touches[k]) | (touches_hi[w] & touches_hi[k]) | (touches_3[w] & touches_3[k]) | (touches_4[w] & touches_4[k]))) continue;
+				if (n >= (unsigned)REALIGN_LATER_MAX - 1) { fits = false; break; }      // (the last entry stays the terminator)
+				later[(size_t)w * REALIGN_LATER_MAX + n++] = (uint8_t)k;
+			}
+		}
+	}
+	// (no allocation here: callers hold pointers into the blob)
+	DecimationInfo* d = blob.at<DecimationInfo>(di_off);
+	memcpy(blob.at<uint8_t>(d->off_realign_later), later.data(), later.size());
+	d->realign_speculative = (fits && nlev >= (unsigned)REALIGN_SPECULATIVE_MIN_LEVELS && W <= 64) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------

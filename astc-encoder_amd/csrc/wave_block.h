@@ -522,7 +522,7 @@ WV_OUT bool refine_realign(int partition_count, int partition_packed, int decima
 	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
 	const QuantXfer& qat = *reinterpret_cast<const QuantXfer*>(c.lds + c.L->qtab);
 	PROF_SCOPE(c, PS_REALIGN);
-	if (partition_count == 1) return realign_weights(c, part_view_lds(c, 1, 0), dec_view_lds(c, decimation_mode), qat);
+	// (one copy for every partition count: the per-texel partition lookup is a run-time branch in there anyway)
 	return realign_weights(c, part_view_lds(c, partition_count, partition_packed), dec_view_lds(c, decimation_mode), qat);
 }
 

@@ -312,6 +312,20 @@ extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation back
 WV_FN Ctx ctx_make() { return *g_wave_ctx; }
 #endif
 
+/* Lowest index i in [0, n), n <= 64, for which pred(i) holds, or -1; the same value on every lane. */
+template <typename Pred>
+WV_FN int wv_find_first(int n, Pred pred)
+{
+#if WV_DEVICE
+	const bool mine = WV_LANE < n && pred(WV_LANE);
+	const unsigned long long mask = __ballot(mine);
+	return mask ? (int)__builtin_ctzll(mask) : -1;
+#else
+	for (int i = 0; i < n; i++) if (pred(i)) return i;
+	return -1;
+#endif
+}
+
 /* Stage timers for profiling builds (-DASTC_PROFILE): lane 0 accumulates shader-clock cycles per
  * stage into c.prof[].  Compiled out otherwise. */
 enum { PS_LOAD, PS_IDEAL, PS_DECIMATE, PS_ANGULAR, PS_MODES, PS_FORMATS, PS_RECOMPUTE, PS_PACK, PS_DIFF, PS_REALIGN,
@@ -485,6 +499,8 @@ struct DecView {
 	const uint8_t* ro;     // [W]  realign schedule: weights in processing order
 	const uint8_t* rc;     // [levels] weights per group
 	int levels;
+	int slots;             // most weights evaluated at once (LDS rows, lanes)
+	const uint8_t* later;  // [W][REALIGN_LATER_MAX] later neighbours (global memory), or null: use the level schedule
 };
 
 WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* address of the texel_weights array */)
@@ -502,6 +518,8 @@ WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* addre
 	v.ro = base + (di.off_realign_order - di.off_texel_weights);
 	v.rc = base + (di.off_realign_counts - di.off_texel_weights);
 	v.levels = di.realign_levels;
+	v.slots = di.realign_slots;
+	v.later = nullptr;
 	return v;
 }
 
@@ -522,7 +540,10 @@ WV_FN DecView dec_view_staged(const Ctx& c, int dm)
 /* The staged view again, without copying (after dec_view_staged() of the same mode). */
 WV_FN DecView dec_view_lds(const Ctx& c, int dm)
 {
-	return dec_view_at(c.dec_info(dm), c.lds + c.L->dtab);
+	const DecimationInfo& di = c.dec_info(dm);
+	DecView v = dec_view_at(di, c.lds + c.L->dtab);
+	if (di.realign_speculative) v.later = c.tab + di.off_realign_later;
+	return v;
 }
 
 } } // namespace astcd::ASTC_VARIANT

@@ -723,23 +723,85 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const f4 color_offset_1 = uniform4(load4(&tr.fbox[4]));
 			const f4 color_base_1 = uniform4(load4(&tr.fbox[0]));
 
-			// The reference visits the weights one by one; a weight's decision only depends on earlier
-			// weights that share a texel with it, so the host-built schedule (DecimationInfo) groups
-			// weights that touch disjoint texels and a whole group is evaluated at once: one lane per
-			// (weight of the group, texel row of that weight).
+			// Two drivers feed ONE group evaluator (a single call site keeps a single copy of it in the kernel):
+			//
+			// * the level schedule (DecimationInfo::off_realign_order): the reference visits the weights one by one; a
+			//   weight's verdict only depends on earlier weights that share a texel with it, so the host-built
+			//   schedule groups weights that touch disjoint texels and a whole group is evaluated and moved at once;
+			//
+			// * long schedules (grids decimated in two dimensions: groups of one to three weights) are replaced by
+			//   speculation: every weight is evaluated against the current state, `slots` weights at a time; then, in
+			//   index order, the first weight whose verdict is "move" is moved for real and only the later weights that
+			//   share a texel with it (DecimationInfo::off_realign_later) are evaluated again.  A verdict only depends
+			//   on the weight itself and on the weights it shares texels with, moves are applied in index order, and
+			//   every verdict a move could invalidate is recomputed before it is looked at: the outcome is the
+			//   reference's one-by-one sweep.  (On the bench content 1.5 to 3.5 weights of ~26 move per call.)
+			uint8_t* verdict = reinterpret_cast<uint8_t*>(&tr.ibox[40]);    // [W <= 64] new quantized value, 255 = stays
 			const uint8_t* order = di.ro;
 			const uint8_t* group_count = di.rc;
-			int* moved_to = &tr.ibox[40];               // [slot] new quantized value or -1 (<= 16 slots, host_tables.cpp)
-			int pos = 0;
-			for (int lv = 0; lv < di.levels; lv++)
+			const int slots = di.slots;
+			const bool speculative = di.later != nullptr;
+			enum { LEVELS, SPEC_ALL, SPEC_LATER };
+			int phase = speculative ? SPEC_ALL : LEVELS;
+			int lv = 0, pos = 0;                          // LEVELS: next group of the schedule
+			int next = 0;                                 // SPEC_ALL: next weight to evaluate; SPEC_LATER: next entry of the mover's list
+			int start = 0, later_count = 0;               // SPEC_LATER: verdicts below `start` are final
+			const uint8_t* later = di.later;
+			for (;;)
 			{
-				const int gn = group_count[lv];
+				// ---- which weights next: `gn` of them, weight of slot s = src[s] (kind 0, 2) or base + s (kind 1) ----
+				int gn, base = 0;
+				const uint8_t* src = nullptr;
+				if (phase == LEVELS)
+				{
+					if (lv >= di.levels) break;
+					gn = group_count[lv];
+					src = order + pos;
+				}
+				else if (phase == SPEC_ALL)
+				{
+					if (next >= W) { phase = SPEC_LATER; next = 0; later_count = 0; continue; }
+					gn = i_min(slots, W - next);
+					base = next;
+				}
+				else
+				{
+					if (next >= later_count)
+					{
+						const int mover = wv_find_first(W, [&](int w) { return w >= start && verdict[w] != 255; });
+						if (mover < 0) break;
+						adjustments = true;
+						const int new_value = wv_uniform((int)verdict[mover]);
+						WV_ONE
+						{
+							uq[mover] = (uint8_t)new_value;
+							uqf[mover] = (float)new_value;
+						}
+						WV_SYNC();
+						WV_FOR(te, (int)wtc[mover])
+						{
+							const int texel = wt[te * W + mover];
+							wb[texel] = infill4(uqf, tw, tcf, T, texel);
+						}
+						WV_SYNC();
+						// the later weights that share a texel with the mover see different infilled weights now
+						later = di.later + mover * REALIGN_LATER_MAX;
+						later_count = 0;
+						while (later_count < REALIGN_LATER_MAX && later[later_count] != 255) later_count++;
+						start = mover + 1;
+						next = 0;
+						if (later_count == 0) continue;
+					}
+					gn = i_min(slots, later_count - next);
+					src = later + next;
+				}
 
-				// per-texel squared differences for base / down / up, 4 channels each -> rt[slot][12][rs]
+				// ---- evaluate the group: one lane per (weight of the group, texel row of that weight) writes the squared
+				//      differences for the current / next lower / next higher quantized value, 4 channels each ----
 				WV_FOR(k, gn * rs)
 				{
 					const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
-					const int we = order[pos + slot];
+					const int we = src ? (int)src[slot] : base + slot;
 					if (te >= (int)wtc[we]) continue;
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
@@ -777,17 +839,18 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				WV_FOR(k, gn * 12)
 				{
 					const int slot = k / 12;
-					const int n = wtc[order[pos + slot]];
+					const int n = wtc[src ? (int)src[slot] : base + slot];
 					float* v = rt + k * rs;                   // == rt + slot * 12 * rs + (k % 12) * rs
 					float acc = 0.0f;
 					for (int te = 0; te < n; te++) acc += v[te];
 					v[0] = acc;
 				}
 				WV_SYNC();
+				// one lane per weight decides (ref: :250-316); under the level schedule the move happens right away
 				bool moved_here = false;                  // per lane on the device; wv_any() folds the lanes
 				WV_FOR(slot, gn)
 				{
-					const int we = order[pos + slot];
+					const int we = src ? (int)src[slot] : base + slot;
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
 					const float* sm = rt + slot * 12 * rs;
@@ -797,8 +860,8 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					int new_value = -1;
 					if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
 					else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
-					moved_to[slot] = new_value;
-					if (new_value >= 0)
+					verdict[we] = (uint8_t)(new_value < 0 ? 255 : new_value);
+					if (phase == LEVELS && new_value >= 0)
 					{
 						uqf[we] = (float)new_value;
 						uq[we] = (uint8_t)new_value;
@@ -806,20 +869,30 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					}
 				}
 				WV_SYNC();
-				if (wv_any(moved_here))
+
+				// ---- what the driver does with the verdicts ----
+				if (phase == LEVELS)
 				{
-					adjustments = true;
-					WV_FOR(k, gn * rs)
+					if (wv_any(moved_here))
 					{
-						const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
-						const int we = order[pos + slot];
-						if (moved_to[slot] < 0 || te >= (int)wtc[we]) continue;
-						int texel = wt[te * W + we];
-						wb[texel] = infill4(uqf, tw, tcf, T, texel);
+						adjustments = true;
+						WV_FOR(k, gn * rs)
+						{
+							const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
+							const int we = order[pos + slot];
+							if (verdict[we] == 255 || te >= (int)wtc[we]) continue;
+							int texel = wt[te * W + we];
+							wb[texel] = infill4(uqf, tw, tcf, T, texel);
+						}
+						WV_SYNC();
 					}
-					WV_SYNC();
+					pos += gn;
+					lv++;
 				}
-				pos += gn;
+				else
+				{
+					next += gn;
+				}
 			}
 		}
 	}
