@@ -51,7 +51,9 @@ struct Backend {
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
 // of a mapped page.
 constexpr size_t ALLOC_SLACK = 4096;
-constexpr size_t TRACE_WORDS_PER_BLOCK_HOST = 1024;   // = TRACE_WORDS_PER_BLOCK (wave_ctx.h), ASTC_TRACE builds
+#if defined(ASTC_TRACE)
+constexpr size_t TRACE_WORDS_PER_BLOCK_HOST = 1024;   // = TRACE_WORDS_PER_BLOCK (wave_ctx.h)
+#endif
 
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
 	fprintf(stderr, "astcenc_amd: %s -> %s\n", #expr, hipGetErrorString(e_)); fail; } } while (0)

@@ -983,9 +983,9 @@ WV_OUT int stage_partition_select(int search_limit, int requested_trials)
 }
 
 /* (ref: find_best_partition_candidates :551) candidates -> PartScratch::best[], returns how many */
-WV_FN int stage_partition_search(int partition_count, int requested_indices, int requested_trials)
+WV_FN int stage_partition_search(const Ctx& c, int partition_count, int requested_indices, int requested_trials)
 {
-	const Ctx c = ctx_make();
+	(void)c;      // (read by DUP_STAGE in instruction-count builds)
 	int sequence_len;
 	DUP_STAGE(c, DUP_PART_ORDER, sequence_len = wv_uniform(stage_partition_order(partition_count)));
 	const int search_limit = i_min(requested_indices, sequence_len);
@@ -1110,7 +1110,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			requested_trials = i_min(requested_trials, requested_indices);
 
 			int actual_trials;
-			actual_trials = wv_uniform(stage_partition_search(partition_count, requested_indices, requested_trials));
+			actual_trials = wv_uniform(stage_partition_search(c, partition_count, requested_indices, requested_trials));
 			// copy out of the scratch region (the trials below reuse it): candidate i sits in lane i
 			LaneArray128 partition_indices;
 			partition_indices.clear();
