@@ -516,7 +516,7 @@ WV_OUT float refine_difference(int partition_count, int partition_packed, int de
 	return errorval;
 }
 
-WV_OUT bool refine_realign(int partition_count, int partition_packed, int decimation_mode)
+__attribute__((always_inline)) WV_FN bool refine_realign(int partition_count, int partition_packed, int decimation_mode)
 {
 	const Ctx c = ctx_make();
 	partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed); decimation_mode = wv_uniform(decimation_mode);
@@ -842,7 +842,7 @@ WV_FN float stage_refine(int partition_count, int partition_packed, int plane2_c
 }
 
 /* One trial of the search (ref: compress_symbolic_block_for_partition_1plane :353, _2planes :715). */
-WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune_errorval_threshold,
+__attribute__((always_inline)) WV_FN float compress_trial(const Ctx& c, bool dual, bool only_always, float tune_errorval_threshold,
                            int partition_count, int partition_packed, int plane2_component, int quant_limit)
 {
 	PROF_SCOPE(c, PS_X3);

@@ -746,7 +746,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			int lv = 0, pos = 0;                          // LEVELS: next group of the schedule
 			int next = 0;                                 // SPEC_ALL: next weight to evaluate; SPEC_LATER: next entry of the mover's list
 			int start = 0, later_count = 0;               // SPEC_LATER: verdicts below `start` are final
-			const uint8_t* later = di.later;
+			uint8_t* later = reinterpret_cast<uint8_t*>(&tr.ibox[56]);    // [REALIGN_LATER_MAX] the mover's list, copied to LDS
 			for (;;)
 			{
 				// ---- which weights next: `gn` of them, weight of slot s = src[s] (kind 0, 2) or base + s (kind 1) ----
@@ -785,7 +785,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						}
 						WV_SYNC();
 						// the later weights that share a texel with the mover see different infilled weights now
-						later = di.later + mover * REALIGN_LATER_MAX;
+						{
+							const uint32_t* list = reinterpret_cast<const uint32_t*>(di.later + mover * REALIGN_LATER_MAX);
+							WV_FOR(k, REALIGN_LATER_MAX / 4) { reinterpret_cast<uint32_t*>(later)[k] = list[k]; }
+							WV_SYNC();
+						}
 						later_count = 0;
 						while (later_count < REALIGN_LATER_MAX && later[later_count] != 255) later_count++;
 						start = mover + 1;
