@@ -417,7 +417,7 @@ WV_OUT void refine_recompute_2planes(int decimation_mode, int plane2_component)
 
 /* Part 2: pack the endpoints (one lane per partition), retry at the higher quant level that matched
  * formats allow (ref: :561-598), and fill in the header of the working block. */
-WV_OUT void refine_pack(bool dual, int partition_count, int partition_packed, int plane2_component,
+__attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_count, int partition_packed, int plane2_component,
                         int candidate, int quant_level, int quant_level_mod, int block_mode_packed)
 {
 	const Ctx c = ctx_make();
@@ -875,13 +875,13 @@ __attribute__((always_inline)) WV_FN float compress_trial(const Ctx& c, bool dua
 	return wv_uniform(stage_refine(partition_count, partition_packed, dual ? plane2_component : -1, tune_errorval_threshold));
 }
 
-WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_errorval_threshold,
+__attribute__((always_inline)) WV_FN float compress_block_1plane(const Ctx& c, bool only_always, float tune_errorval_threshold,
                                   int partition_count, int partition_packed, int quant_limit)
 {
 	return compress_trial(c, false, only_always, tune_errorval_threshold, partition_count, partition_packed, -1, quant_limit);
 }
 
-WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, int plane2_component, int quant_limit)
+__attribute__((always_inline)) WV_FN float compress_block_2planes(const Ctx& c, float tune_errorval_threshold, int plane2_component, int quant_limit)
 {
 	return compress_trial(c, true, false, tune_errorval_threshold, 1, 0, plane2_component, quant_limit);
 }
