@@ -33,6 +33,7 @@ int astc_decode_launch(const DecodeLaunch& d)
 	img.blocks_y = (d.dim_y + d.block_y - 1) / d.block_y;
 	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
+	decode_image_prepare(img);
 	const uint32_t n = img.blocks_x * img.blocks_y * img.blocks_z;
 	hipLaunchKernelGGL(astc_decompress_blocks, dim3((n + (uint32_t)DECODE_BATCH - 1) / (uint32_t)DECODE_BATCH), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, n);
 	return (int)hipGetLastError();

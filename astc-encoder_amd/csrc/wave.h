@@ -131,6 +131,24 @@ WV_FN void wv_all_minmax(float& mn0, float& mx0)
 #endif
 }
 
+/* Maximum over the wave of a per-lane partial (same usage as wv_all_minmax): ballot-free butterfly through DPP. */
+WV_FN int wv_all_imax(int v)
+{
+#if WV_DEVICE
+	asm volatile("s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+	    "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1\n"
+	    : "+v"(v));
+	return __builtin_amdgcn_readlane(v, 63);
+#else
+	return v;
+#endif
+}
+
 /* A small array with one element per lane index 0..127, written from WV_FOR bodies (element i by
  * the lane that runs iteration i) and read back with a wave-uniform index.  On the device it is two
  * VGPRs and a v_readlane, i.e. no memory at all; on the CPU it is an array. */

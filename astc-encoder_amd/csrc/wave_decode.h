@@ -27,7 +27,24 @@ struct DecodeImage {
 	uint32_t blocks_x, blocks_y, blocks_z;
 	uint32_t block_x, block_y, block_z;
 	uint32_t profile;         // astcenc_profile
+	// multiply-shift inverses (the device has no integer divide); filled by decode_image_prepare()
+	uint32_t t_inv24;         // ceil(2^24 / texels per block):   j / T == (j * t_inv24) >> 24
+	uint32_t bx_inv16;        // ceil(2^16 / block_x):            t / block_x == (t * bx_inv16) >> 16 for t < 256
+	uint32_t bxy_inv16;       // ceil(2^16 / (block_x * block_y))
+	uint32_t ds, dt, dr;      // texel -> grid scale factors (1024 + block / 2) / (block - 1) (ref: astcenc_block_sizes.cpp:261-262)
 };
+
+/* Derived fields of a DecodeImage (host side, once per launch). */
+inline void decode_image_prepare(DecodeImage& img)
+{
+	const uint32_t T = img.block_x * img.block_y * img.block_z;
+	img.t_inv24 = ((1u << 24) + T - 1u) / T;
+	img.bx_inv16 = (65536u + img.block_x - 1u) / img.block_x;
+	img.bxy_inv16 = (65536u + img.block_x * img.block_y - 1u) / (img.block_x * img.block_y);
+	img.ds = img.block_x > 1 ? (1024u + img.block_x / 2u) / (img.block_x - 1u) : 0u;
+	img.dt = img.block_y > 1 ? (1024u + img.block_y / 2u) / (img.block_y - 1u) : 0u;
+	img.dr = img.block_z > 1 ? (1024u + img.block_z / 2u) / (img.block_z - 1u) : 0u;
+}
 
 /* Per-wave scratch (LDS). */
 struct DecodeScratch {
@@ -560,15 +577,16 @@ WV_FN void endpoint_lns_flags(int profile, int f, bool& rgb_lns, bool& alpha_lns
 }
 
 /* Weights of one texel from the grid (format rule "weight infill"; ref: unpack_weights :89). */
-WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int block_x, int block_y, int block_z, int tx, int ty, int tz, int wp[2])
+WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
 {
+	// ds, dt, dr = (1024 + block / 2) / (block - 1) per axis
 	if (block_z > 1)
 	{
 		// 3D: simplex interpolation inside the grid cell -- from the low corner step along the axes in
 		// descending order of fraction (ref: init_decimation_info_3d, astcenc_block_sizes.cpp:483-600)
-		const int gs = (((1024 + block_x / 2) / (block_x - 1)) * tx * (h.wx - 1) + 32) >> 6;
-		const int gt = (((1024 + block_y / 2) / (block_y - 1)) * ty * (h.wy - 1) + 32) >> 6;
-		const int gr = (((1024 + block_z / 2) / (block_z - 1)) * tz * (h.wz - 1) + 32) >> 6;
+		const int gs = (ds * tx * (h.wx - 1) + 32) >> 6;
+		const int gt = (dt * ty * (h.wy - 1) + 32) >> 6;
+		const int gr = (dr * tz * (h.wz - 1) + 32) >> 6;
 		const int fs = gs & 0xF, ft = gt & 0xF, fp = gr & 0xF;
 		const int N = h.wx, NM = h.wx * h.wy;
 		const int cas = ((fs > ft) << 2) + ((ft > fp) << 1) + (fs > fp);
@@ -596,8 +614,7 @@ WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], i
 		}
 		return;
 	}
-	const int ds = (1024 + block_x / 2) / (block_x - 1);
-	const int dt = (1024 + block_y / 2) / (block_y - 1);
+	wp[1] = 0;
 	const int cs = ds * tx, ct = dt * ty;
 	const int gs = (cs * (h.wx - 1) + 32) >> 6;
 	const int gt = (ct * (h.wy - 1) + 32) >> 6;
@@ -606,7 +623,7 @@ WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], i
 	const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
 	const int v0 = js + jt * h.wx;
 	const int wcount = h.wx * h.wy;
-	for (int pl = 0; pl < 2; pl++)
+	for (int pl = 0; pl < (h.dual ? 2 : 1); pl++)
 	{
 		const uint8_t* g = gw[pl];
 		int sum = 8;
@@ -725,7 +742,8 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 		else
 		{
 			int wp[2];
-			infill_texel_weights(h, s.weights, block_x, block_y, block_z, tx, ty, tz, wp);
+			infill_texel_weights(h, s.weights, (1024 + block_x / 2) / (block_x - 1), (1024 + block_y / 2) / (block_y - 1),
+			                     block_z > 1 ? (1024 + block_z / 2) / (block_z - 1) : 0, block_z, tx, ty, tz, wp);
 			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
 			const int* e = s.ep[p];
 			float out[4];
@@ -755,6 +773,7 @@ struct DecodeBatch {
 	Bits128     rev[DECODE_BATCH];        // the same bits reversed: the weight stream
 	float       constant[DECODE_BATCH][4];
 	int         error[DECODE_BATCH];
+	uint32_t    origin[DECODE_BATCH][4];  // texel coordinates of the block's first texel
 	DecodeScratch payload[DECODE_BATCH];
 };
 
@@ -798,6 +817,15 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 				}
 			}
 		}
+		{
+			// (one lane per block: the two divides here replace two per texel)
+			const uint32_t b = first + (uint32_t)k;
+			const uint32_t row = b / img.blocks_x;
+			const uint32_t bxi = b - row * img.blocks_x;
+			const uint32_t bzi = row / img.blocks_y;
+			const uint32_t byi = row - bzi * img.blocks_y;
+			s.origin[k][0] = bxi * (uint32_t)block_x; s.origin[k][1] = byi * (uint32_t)block_y; s.origin[k][2] = bzi * (uint32_t)block_z;
+		}
 		s.hdr[k] = h;
 		s.bits[k] = blk;
 		s.rev[k] = bits_reversed(blk);
@@ -806,28 +834,47 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 	}
 	WV_SYNC();
 
-	// ---- weights: one lane per (block, weight) ----
-	WV_FOR(j, count * 64)
+	// ---- weights and colour values: one lane per (block, element), as many lanes per block as the fullest block needs ----
+	int wmax_part = 0, cmax_part = 0;                 // per-lane partial maxima (lane k looked at block k), folded below
+	WV_FOR(k, count)
 	{
-		const int k = j >> 6, i = j & 63;
 		const BlockHeader& h = s.hdr[k];
-		if (s.error[k] || h.constant) continue;
-		const int wcount = h.wx * h.wy * h.wz;
-		const int real_wcount = h.dual ? 2 * wcount : wcount;
-		if (i >= real_wcount) continue;
-		int sym = ise_symbol(s.rev[k], 0, h.wquant, real_wcount, i);
-		int w = unquant_weight_symbol(sym, h.wquant);
-		if (h.dual) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
-		else s.payload[k].weights[0][i] = (uint8_t)w;
+		if (!(s.error[k] || h.constant))
+		{
+			const int wcount = h.wx * h.wy * h.wz;
+			wmax_part = i_max(wmax_part, h.dual ? 2 * wcount : wcount);
+			cmax_part = i_max(cmax_part, h.nvals);
+		}
 	}
-	// ---- colour values: one lane per (block, value) ----
-	WV_FOR(j, count * 32)
+	const int wmax = wv_all_imax(wmax_part), cmax = wv_all_imax(cmax_part);
+	if (wmax > 0)
 	{
-		const int k = j >> 5, i = j & 31;
-		const BlockHeader& h = s.hdr[k];
-		if (s.error[k] || h.constant || i >= h.nvals) continue;
-		int sym = ise_symbol(s.bits[k], h.color_start, h.cquant, h.nvals, i);
-		s.payload[k].colors[i] = (uint8_t)unquant_color_symbol(sym, h.cquant);
+		const uint32_t winv = (65536u + (uint32_t)wmax - 1u) / (uint32_t)wmax;      // (one divide per batch)
+		WV_FOR(j, count * wmax)
+		{
+			const int k = (int)(((uint32_t)j * winv) >> 16), i = j - k * wmax;
+			const BlockHeader& h = s.hdr[k];
+			if (s.error[k] || h.constant) continue;
+			const int wcount = h.wx * h.wy * h.wz;
+			const int real_wcount = h.dual ? 2 * wcount : wcount;
+			if (i >= real_wcount) continue;
+			int sym = ise_symbol(s.rev[k], 0, h.wquant, real_wcount, i);
+			int w = unquant_weight_symbol(sym, h.wquant);
+			if (h.dual) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
+			else s.payload[k].weights[0][i] = (uint8_t)w;
+		}
+	}
+	if (cmax > 0)
+	{
+		const uint32_t cinv = (65536u + (uint32_t)cmax - 1u) / (uint32_t)cmax;
+		WV_FOR(j, count * cmax)
+		{
+			const int k = (int)(((uint32_t)j * cinv) >> 16), i = j - k * cmax;
+			const BlockHeader& h = s.hdr[k];
+			if (s.error[k] || h.constant || i >= h.nvals) continue;
+			int sym = ise_symbol(s.bits[k], h.color_start, h.cquant, h.nvals, i);
+			s.payload[k].colors[i] = (uint8_t)unquant_color_symbol(sym, h.cquant);
+		}
 	}
 	WV_SYNC();
 	// ---- endpoints: one lane per (block, partition) ----
@@ -857,21 +904,22 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 
 	// ---- texels: one lane per (block, texel) ----
 	const bool small_block = T < 31;
-	const uint32_t t_inv = ((1u << 24) + (uint32_t)T - 1u) / (uint32_t)T;     // j / T == (j * t_inv) >> 24 for j < 2^24 / T
+	const uint32_t t_inv = img.t_inv24;
+	// RGBA8 output whose swizzle only picks channels or constants: a decoded UNORM16 value v leaves as the byte
+	// v >> 8 (exact: for every byte b, b * 257 -> FP16 -> float -> * 255 + 0.5 -> int gives b back, which is the
+	// reference's route, astcenc_image.cpp:345-420 after decompress_symbolic.cpp:66-120), so the texel is built
+	// from integers alone; LNS (HDR) endpoints, error and constant blocks and the Z swizzle take the general route.
+	const bool bytes_out = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
 	WV_FOR(j, count * T)
 	{
 		const int k = (int)(((uint32_t)j * t_inv) >> 24), t = j - k * T;
-		const uint32_t b = first + (uint32_t)k;
-		const uint32_t row = b / img.blocks_x;
-		const uint32_t bx = b - row * img.blocks_x;
-		const uint32_t bz = row / img.blocks_y;
-		const uint32_t by = row - bz * img.blocks_y;
-		const int tz = block_z > 1 ? t / (block_x * block_y) : 0;
+		const uint32_t bx = s.origin[k][0], by = s.origin[k][1], bz = s.origin[k][2];
+		const int tz = block_z > 1 ? (int)(((uint32_t)t * img.bxy_inv16) >> 16) : 0;
 		const int trem = t - tz * (block_x * block_y);
-		const int ty = trem / block_x, tx = trem - ty * block_x;
-		const uint32_t xi = bx * (uint32_t)block_x + (uint32_t)tx;
-		const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
-		const uint32_t zi = bz * (uint32_t)block_z + (uint32_t)tz;
+		const int ty = (int)(((uint32_t)trem * img.bx_inv16) >> 16), tx = trem - ty * block_x;
+		const uint32_t xi = bx + (uint32_t)tx;
+		const uint32_t yi = by + (uint32_t)ty;
+		const uint32_t zi = bz + (uint32_t)tz;
 		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
 
 		const BlockHeader& h = s.hdr[k];
@@ -888,14 +936,32 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 		{
 			const DecodeScratch& ps = s.payload[k];
 			int wp[2];
-			infill_texel_weights(h, ps.weights, block_x, block_y, block_z, tx, ty, tz, wp);
+			infill_texel_weights(h, ps.weights, (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
 			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
 			const int* e = ps.ep[p];
-			float out[4];
+			int cv[4];
 			for (int q = 0; q < 4; q++)
 			{
 				const int wk = (h.dual && q == h.plane2) ? wp[1] : wp[0];
-				int cval = (e[q] * (64 - wk) + e[4 + q] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
+				cv[q] = (e[q] * (64 - wk) + e[4 + q] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
+			}
+			if (bytes_out && !(ps.lns[p][0] | ps.lns[p][1]))
+			{
+				uint32_t px = 0;
+				for (int q = 0; q < 4; q++)
+				{
+					const uint32_t sw = img.swz[q];
+					const uint32_t v = sw == 4 ? 0u : sw == 5 ? 255u : (uint32_t)(cv[sw & 3] >> 8);
+					px |= v << (8 * q);
+				}
+				const size_t at = (((size_t)zi * img.dim_y + yi) * img.dim_x + xi) * 4;
+				__builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
+				continue;
+			}
+			float out[4];
+			for (int q = 0; q < 4; q++)
+			{
+				int cval = cv[q];
 				if (u8_out) cval = (cval >> 8) * 257;
 				const bool lns = ps.lns[p][q == 3 ? 1 : 0] != 0;
 				const int hf = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
@@ -954,7 +1020,8 @@ WV_FN void describe_block(const uint8_t* pcb, int block_x, int block_y, int bloc
 		const int tz = t / (block_x * block_y), trem = t - tz * (block_x * block_y);
 		const int ty = trem / block_x, tx = trem - ty * block_x;
 		int wp[2];
-		infill_texel_weights(h, s.weights, block_x, block_y, block_z, tx, ty, tz, wp);
+		infill_texel_weights(h, s.weights, (1024 + block_x / 2) / (block_x - 1), (1024 + block_y / 2) / (block_y - 1),
+		                     block_z > 1 ? (1024 + block_z / 2) / (block_z - 1) : 0, block_z, tx, ty, tz, wp);
 		info->weight_values_plane1[t] = (float)wp[0] * (1.0f / 16.0f);
 		if (h.dual) info->weight_values_plane2[t] = (float)wp[1] * (1.0f / 16.0f);
 		info->partition_assignment[t] = (uint8_t)(h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block));

@@ -155,6 +155,7 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	img.blocks_y = (job.dim_y + root->dim_y - 1) / root->dim_y;
 	img.blocks_z = (dim_z + root->dim_z - 1) / root->dim_z;
 	img.profile = b->cfg.profile;
+	decode_image_prepare(img);
 	// the same batched routine the kernel runs (decode_block_batch), DECODE_BATCH blocks at a time
 	std::vector<DecodeBatch> batch(1);
 	memset(static_cast<void*>(batch.data()), 0xCD, sizeof(DecodeBatch));
