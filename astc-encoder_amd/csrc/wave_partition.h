@@ -399,10 +399,10 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		{
 			int t = tix[i];
 			f4 d = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], n == 4 ? c.data(3)[t] : 0.0f) - average;
-			if (d.x > 0.0f) sum[0] = sum[0] + d;
-			if (d.y > 0.0f) sum[1] = sum[1] + d;
-			if (d.z > 0.0f) sum[2] = sum[2] + d;
-			if (n == 4 && d.w > 0.0f) sum[3] = sum[3] + d;
+			sum[0] = select4(d.x > 0.0f, sum[0] + d, sum[0]);
+			sum[1] = select4(d.y > 0.0f, sum[1] + d, sum[1]);
+			sum[2] = select4(d.z > 0.0f, sum[2] + d, sum[2]);
+			if (n == 4) sum[3] = select4(d.w > 0.0f, sum[3] + d, sum[3]);
 		}
 		f4 best_vector = sum[0];
 		float best_sum = dot_s(sum[0], sum[0]);
@@ -411,7 +411,9 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		{
 			if (k >= n) break;
 			float prod = dot_s(sum[k], sum[k]);
-			if (prod > best_sum) { best_vector = sum[k]; best_sum = prod; }
+			const bool better = prod > best_sum;
+			best_vector = select4(better, sum[k], best_vector);
+			best_sum = better ? prod : best_sum;
 		}
 
 		f4 ub = normalize_safe4(best_vector, n == 4 ? unit4() : unit3());
