@@ -46,7 +46,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	c.cfg = reinterpret_cast<const DeviceConfig*>(tab - CTX_CONFIG_BACK);
 	c.lds = lds;
 	c.L = reinterpret_cast<const LdsLayout*>(tab - CTX_LAYOUT_BACK);
-	c.T = c.root->texel_count;
+	c.T = wv_uniform((int)c.root->texel_count);
 	c.Tp = (c.T + 3) & ~3;
 #if defined(ASTC_TRACE)
 	// trace builds: `prof` is the search trace buffer, one slice per block of the image (wave_ctx.h: TRACE_PUT)
@@ -60,6 +60,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 		LdsHeader* h = reinterpret_cast<LdsHeader*>(lds);
 		h->tab = tab;
 		h->prof = prof;
+		c.blk().block_index = b;
 	}
 	WV_SYNC();
 
@@ -69,7 +70,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 		if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
 		else DUP_STAGE(c, DUP_LOAD, load_block(c, img, bx, by, bz));
 	}
-	compress_block(c, out + (size_t)b * 16);
+	compress_block(c, out);
 }
 
 int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes)

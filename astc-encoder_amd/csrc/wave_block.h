@@ -846,23 +846,24 @@ __attribute__((always_inline)) WV_FN float compress_trial(const Ctx& c, bool dua
                            int partition_count, int partition_packed, int plane2_component, int quant_limit)
 {
 	PROF_SCOPE(c, PS_X3);
+	tune_errorval_threshold = wv_uniform(tune_errorval_threshold);
 	TRACE_PUT(c, TR_PASS, (float)(partition_count * 64 + (dual ? 2 : 1) * 8 + (plane2_component + 1)));
 #if defined(ASTC_TRACE)
 	if (partition_count > 1) TRACE_PUT(c, TR_PARTITION_INDEX, (float)part_view(c, partition_count, partition_packed).h->partition_index);
 #endif
 	const int max_weight_quant = i_min((int)QUANT_32, quant_limit);
-	const int max_decimation_modes = only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected;
+	const int max_decimation_modes = wv_uniform(only_always ? (int)c.root->decimation_mode_count_always : (int)c.root->decimation_mode_count_selected);
 	const int ref_mask = (int)((1u << (max_weight_quant + 1)) - 1);
 	int mode_start, mode_end;
 	if (dual)
 	{
-		mode_start = (int)c.root->block_mode_count_1plane_selected;
-		mode_end = (int)c.root->block_mode_count_1plane_2plane_selected;
+		mode_start = wv_uniform((int)c.root->block_mode_count_1plane_selected);
+		mode_end = wv_uniform((int)c.root->block_mode_count_1plane_2plane_selected);
 	}
 	else
 	{
 		mode_start = 0;
-		mode_end = only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected;
+		mode_end = wv_uniform(only_always ? (int)c.root->block_mode_count_1plane_always : (int)c.root->block_mode_count_1plane_selected);
 	}
 
 	DUP_STAGE(c, DUP_IDEAL, stage_ideal(dual, partition_count, partition_packed, plane2_component));
@@ -1002,8 +1003,9 @@ WV_OUT float stage_block_statistics()
 	return prepare_block_statistics(c);
 }
 
-/* Compress the block currently loaded in LDS and write 16 bytes to pcb. (ref: compress_block :1162) */
-WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
+/* The search of compress_block for a block that is not one constant colour: leaves the best encoding found in
+ * c.scb(), or block_type SYM_BTYPE_ERROR.  (ref: compress_block :1247-1430) */
+__attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 {
 	const BlkInfo& blk = c.blk();
 	const DeviceConfig& cfg = *c.cfg;
@@ -1015,34 +1017,10 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	bool block_is_la = blk_is_luminancealpha(blk);
 	float block_is_la_scale = block_is_la ? 1.0f / 1.05f : 1.0f;
 
-	// constant colour -> void extent (ref: :1216-1245)
-	if (blk.data_min[0] == blk.data_max[0] && blk.data_min[1] == blk.data_max[1] &&
-	    blk.data_min[2] == blk.data_max[2] && blk.data_min[3] == blk.data_max[3])
-	{
-		WV_ONE
-		{
-			scb.partition_count = 0;
-			if (cfg.profile == 3 || cfg.profile == 2)
-			{
-				scb.block_type = SYM_BTYPE_CONST_F16;
-				for (int k = 0; k < 4; k++) scb.constant_color[k] = float_to_half(blk.origin[k]);
-			}
-			else
-			{
-				scb.block_type = SYM_BTYPE_CONST_U16;
-				for (int k = 0; k < 4; k++)
-				{
-					float v = v_clamp(0.0f, 1.0f, blk.origin[k]) * 65535.0f;
-					scb.constant_color[k] = (int)(v + 0.5f);
-				}
-			}
-			symbolic_to_physical(c, scb, pcb);
-		}
-		return;
-	}
-
 	float error_weight_sum = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) * (float)T;
-	float error_threshold = cfg.tune_db_limit * error_weight_sum * block_is_l_scale * block_is_la_scale;
+	// (driver state of the whole block: wave-uniform, kept in scalar registers -- values derived from LDS or table
+	//  loads look lane-variant to the compiler and would be carried, and spilled, as vector registers)
+	const float error_threshold = wv_uniform(cfg.tune_db_limit * error_weight_sum * block_is_l_scale * block_is_la_scale);
 
 	TRACE_PUT(c, TR_THRESHOLD, error_threshold);
 	WV_ONE
@@ -1057,7 +1035,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	// (the reference's best_errorvals_for_pcount[] / exit_thresholds_for_pcount[] / errorval_mult[] as scalars:
 	//  run-time indexed local arrays would live in scratch memory)
 	float best_errorval_prev_pcount = ERROR_CALC_DEFAULT;      // best error with one partition fewer
-	const float errorval_overshoot = 1.0f / cfg.tune_mse_overshoot;
+	const float errorval_overshoot = wv_uniform(1.0f / cfg.tune_mse_overshoot);
 
 	int start_trial = 1;
 	if (cfg.tune_search_mode0_enable >= 0.85f && c.root->dim_z == 1) start_trial = 0;   // ref: compress_symbolic.cpp:1287
@@ -1073,9 +1051,9 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 		WV_SYNC();
 		if (scb.block_type != SYM_BTYPE_ERROR)
 		{
-			quant_limit = c.block_mode(scb.block_mode).quant_mode;
+			quant_limit = wv_uniform((int)c.block_mode(scb.block_mode).quant_mode);
 		}
-		best_errorval_prev_pcount = f_min(best_errorval_prev_pcount, errorval);
+		best_errorval_prev_pcount = wv_uniform(f_min(best_errorval_prev_pcount, errorval));
 		if (errorval < (error_threshold * errorval_mult)) done = true;
 	}
 
@@ -1102,11 +1080,11 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 	// trial C: 2..4 partitions (ref: :1372-1429)
 	if (!done)
 	{
-		const int max_partitions = (int)cfg.tune_partition_count_limit;
+		const int max_partitions = wv_uniform((int)cfg.tune_partition_count_limit);
 		for (int partition_count = 2; partition_count <= max_partitions && !done; partition_count++)
 		{
-			int requested_indices = (int)cfg.tune_partition_index_limit[partition_count - 2];
-			int requested_trials = (int)cfg.tune_partitioning_candidate_limit[partition_count - 2];
+			int requested_indices = wv_uniform((int)cfg.tune_partition_index_limit[partition_count - 2]);
+			int requested_trials = wv_uniform((int)cfg.tune_partitioning_candidate_limit[partition_count - 2]);
 			requested_trials = i_min(requested_trials, requested_indices);
 
 			int actual_trials;
@@ -1121,8 +1099,8 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 			WV_SYNC();
 
 			const float best_error_in_prev = best_errorval_prev_pcount;
-			const float exit_threshold = partition_count == 2 ? cfg.tune_partition_early_out_limit_factor[0]
-			                           : partition_count == 3 ? cfg.tune_partition_early_out_limit_factor[1] : 0.0f;
+			const float exit_threshold = wv_uniform(partition_count == 2 ? cfg.tune_partition_early_out_limit_factor[0]
+			                           : partition_count == 3 ? cfg.tune_partition_early_out_limit_factor[1] : 0.0f);
 			float best_error = ERROR_CALC_DEFAULT;               // best error with this partition count
 
 			for (int i = 0; i < actual_trials; i++)
@@ -1130,7 +1108,7 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 				float errorval = compress_block_1plane(c, false, error_threshold * errorval_overshoot,
 				                                       partition_count, partition_indices.get(i), quant_limit);
 				WV_SYNC();
-				best_error = f_min(best_error, errorval);
+				best_error = wv_uniform(f_min(best_error, errorval));
 
 				if (best_error > (best_error_in_prev * (exit_threshold * 1.85f))) { done = true; break; }
 				if (errorval < error_threshold) { done = true; break; }
@@ -1142,10 +1120,49 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 		}
 	}
 
+}
+
+/* Compress the block currently loaded in LDS and write its 16 bytes. (ref: compress_block :1162)
+ * `out`: the launch's output array; the block's index in it is blk.block_index (kept in LDS rather than in a
+ * register pair across the whole search). */
+WV_FN void compress_block(const Ctx& c, uint8_t* out)
+{
+	bool constant_color;
+	{
+		const BlkInfo& blk = c.blk();
+		constant_color = blk.data_min[0] == blk.data_max[0] && blk.data_min[1] == blk.data_max[1] &&
+		                 blk.data_min[2] == blk.data_max[2] && blk.data_min[3] == blk.data_max[3];
+	}
+	if (!wv_uniform(constant_color)) search_block(c);
+
+	// (the context is rebuilt from the LDS header here, like in an out-of-line stage: anything derived from `c`
+	//  above would have to stay in registers across the whole search)
 	WV_SYNC();
 	WV_ONE
 	{
-		if (scb.block_type == SYM_BTYPE_ERROR)
+		const Ctx ce = ctx_make();
+		Scb& scb = ce.scb();
+		const BlkInfo& blk = ce.blk();
+		if (constant_color)
+		{
+			// constant colour -> void extent (ref: :1216-1245)
+			scb.partition_count = 0;
+			if (ce.cfg->profile == 3 || ce.cfg->profile == 2)
+			{
+				scb.block_type = SYM_BTYPE_CONST_F16;
+				for (int k = 0; k < 4; k++) scb.constant_color[k] = float_to_half(blk.origin[k]);
+			}
+			else
+			{
+				scb.block_type = SYM_BTYPE_CONST_U16;
+				for (int k = 0; k < 4; k++)
+				{
+					float v = v_clamp(0.0f, 1.0f, blk.origin[k]) * 65535.0f;
+					scb.constant_color[k] = (int)(v + 0.5f);
+				}
+			}
+		}
+		else if (scb.block_type == SYM_BTYPE_ERROR)
 		{
 			// no valid encoding found: constant colour of texel 0 (ref: :1436-1452)
 			scb.block_type = SYM_BTYPE_CONST_U16;
@@ -1155,8 +1172,9 @@ WV_FN void compress_block(const Ctx& c, uint8_t* pcb)
 				scb.constant_color[k] = (int)(v + 0.5f);
 			}
 		}
-		PROF_SCOPE(c, PS_X1);
-		DUP_STAGE(c, DUP_PHYSICAL, symbolic_to_physical(c, scb, pcb));
+		PROF_SCOPE(ce, PS_X1);
+		uint8_t* pcb = out + (size_t)blk.block_index * 16;
+		DUP_STAGE(ce, DUP_PHYSICAL, symbolic_to_physical(ce, scb, pcb));
 	}
 }
 

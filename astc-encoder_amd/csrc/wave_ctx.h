@@ -20,7 +20,7 @@ struct BlkInfo {
 	int   grayscale;
 	int   rgb_lns;        // blk.rgb_lns[0]
 	int   alpha_lns;      // blk.alpha_lns[0]
-	int   pad;
+	uint32_t block_index; // which 16 bytes of the output this block writes (read back when the block is written)
 };
 
 /* Symbolic block. (ref: symbolic_compressed_block :1077).  block_mode / partition_index hold PACKED
@@ -118,6 +118,8 @@ struct LdsLayout {
 	uint32_t tsc_p;      // partition search: f32 [2][Tp] k-means rows
 	uint32_t part_tabs;  // partition search: staged records (header + texel lists) of the candidates being scored
 	uint32_t part_chunk; // candidates per staging pass
+	uint32_t part_rec_words;   // 32-bit words of one staged record
+	uint32_t part_rec_inv24;   // ceil(2^24 / part_rec_words): k / words == (k * inv) >> 24 for k < chunk * words
 	uint32_t uni_bytes;  // size of the `uni` region
 	uint32_t tsc_stride; // floats between tsc rows
 	uint32_t t_inv24;    // ceil(2^24 / texel_count): k / T == (k * t_inv24) >> 24 for k < 2^24 / T (no integer divide on the device)
@@ -214,6 +216,8 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		if (chunk > 64) chunk = 64;
 		if (chunk > lim) chunk = lim < 1 ? 1 : lim;
 		L.part_chunk = chunk;
+		L.part_rec_words = rec >> 2;
+		L.part_rec_inv24 = ((1u << 24) + (rec >> 2) - 1u) / (rec >> 2);
 		L.part_tabs = take(chunk * rec);
 	}
 	if (o > end) end = o;
@@ -280,6 +284,10 @@ WV_FN uint32_t wv_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfi
 WV_FN int wv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 WV_FN bool wv_uniform(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
 WV_FN float wv_uniform(float v) { return int_as_float(__builtin_amdgcn_readfirstlane(float_as_int(v))); }
+/* The same value, but the optimiser cannot see through it: an expression built on wv_opaque(lane) is not loop
+ * invariant, so it is computed where it is used instead of being hoisted to the top of the kernel and carried (or
+ * spilled to scratch memory) across every stage in between.  No instruction is emitted. */
+WV_FN int wv_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 WV_FN uint64_t wv_uniform(uint64_t v)
 {
 	uint32_t lo = wv_uniform((uint32_t)v), hi = wv_uniform((uint32_t)(v >> 32));
@@ -299,13 +307,14 @@ WV_FN Ctx ctx_make()
 	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
 	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
 	c.lds = astc_lds;
-	c.T = c.root->texel_count;
+	c.T = wv_uniform((int)c.root->texel_count);
 	c.Tp = (c.T + 3) & ~3;
 	return c;
 }
 #else
 WV_FN uint32_t wv_uniform(uint32_t v) { return v; }
 WV_FN int wv_uniform(int v) { return v; }
+WV_FN int wv_opaque(int v) { return v; }
 WV_FN bool wv_uniform(bool v) { return v; }
 WV_FN float wv_uniform(float v) { return v; }
 extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block

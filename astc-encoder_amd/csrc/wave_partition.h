@@ -546,13 +546,14 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 	if (T <= 20) weight_imprecision_estim = 0.03f;
 	else if (T <= 31) weight_imprecision_estim = 0.04f;
 	else if (T <= 41) weight_imprecision_estim = 0.05f;
-	weight_imprecision_estim = weight_imprecision_estim * weight_imprecision_estim;
+	weight_imprecision_estim = wv_uniform(weight_imprecision_estim * weight_imprecision_estim);
 
-	bool uses_alpha = !(blk.data_min[3] == blk.data_max[3]);
+	const bool uses_alpha = wv_uniform(!(blk.data_min[3] == blk.data_max[3]));
 
 	{ PROF_SCOPE(c, PS_PSCORE);
-	const int rec_words = (int)(((uint32_t)sizeof(PartitionHeader) + 2u * (uint32_t)T + 3u) >> 2);
-	const int chunk = (int)c.L->part_chunk;
+	const int rec_words = wv_uniform((int)c.L->part_rec_words);        // (sizeof(PartitionHeader) + 2 T + 3) / 4
+	const uint32_t rec_inv24 = wv_uniform(c.L->part_rec_inv24);
+	const int chunk = wv_uniform((int)c.L->part_chunk);
 	uint32_t* staged = reinterpret_cast<uint32_t*>(c.lds + c.L->part_tabs);
 	for (int first = 0; first < partition_search_limit; first += chunk)
 	{
@@ -560,7 +561,7 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 		// stage the records of candidates [first, first + nn) (coalesced word copies)
 		WV_FOR(k, nn * rec_words)
 		{
-			int sl = k / rec_words, w = k - sl * rec_words;
+			int sl = (int)(((uint32_t)k * rec_inv24) >> 24), w = k - sl * rec_words;
 			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.part_rec(pc, ps.ordering()[first + sl]));
 			staged[k] = src[w];
 		}

@@ -857,7 +857,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					const int we = src ? (int)src[slot] : base + slot;
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
-					const float* sm = rt + slot * 12 * rs;
+					const float* sm = rt + wv_opaque(slot * 12) * rs;
 					float error_base = hadd_s(mk4(sm[0], sm[rs], sm[2 * rs], sm[3 * rs]) * error_weight);
 					float error_down = hadd_s(mk4(sm[4 * rs], sm[5 * rs], sm[6 * rs], sm[7 * rs]) * error_weight);
 					float error_up = hadd_s(mk4(sm[8 * rs], sm[9 * rs], sm[10 * rs], sm[11 * rs]) * error_weight);

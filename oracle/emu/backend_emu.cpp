@@ -36,6 +36,14 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(b->blob.data(), &b->layout, sizeof(LdsLayout));
 	memcpy(b->blob.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &cfg, sizeof(cfg));
 	memcpy(b->blob.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
+	if (getenv("ASTC_EMU_DUMP_LAYOUT"))
+	{
+		const LdsLayout& L = b->layout;
+		const TableRoot& r = *reinterpret_cast<const TableRoot*>(blob);
+		fprintf(stderr, "lds layout: total %u | data %u blk %u scb %u trial %u ei_w %u ei_wes %u ptab %u candw %u | phase begin %u | search: dwi %u lowhigh %u modes %u uni %u (+%u) | refine: dtab %u ctab %u qtab %u rsc %u tsc_r %u wsc %u | part: part %u tsc_p %u part_tabs %u (chunk %u) | max_dec_table %u realign_rt %u\n",
+		        L.total, L.data, L.blk, L.scb, L.trial, L.ei_w, L.ei_wes, L.ptab, L.candw, L.dwi, L.dwi, L.lowhigh, L.modes, L.uni, L.uni_bytes,
+		        L.dtab, L.ctab, L.qtab, L.rsc, L.tsc_r, L.wsc, L.part, L.tsc_p, L.part_tabs, L.part_chunk, r.max_decimation_table_bytes, r.realign_rt_floats);
+	}
 	*status = 0;
 	return b;
 }
@@ -127,7 +135,8 @@ int backend_compress(Backend* b, const CompressJob& job)
 #endif
 			if (img.alpha_avg && !block_has_visible_alpha(c, img, bx, by)) load_transparent_block(c);
 			else load_block(c, img, bx, by, bz);
-			compress_block(c, out + idx * 16);
+			c.blk().block_index = (uint32_t)idx;
+			compress_block(c, out);
 		}
 		if (job.progress) job.progress(100.0f * (float)(row + 1) / (float)(img.blocks_y * img.blocks_z));
 	}
