@@ -287,6 +287,79 @@ WV_FN int unquant_color_symbol(int v, int quant)
 	return (A & 0x80) | (t >> 2);
 }
 
+#if !defined(ASTC_DECODE_NO_LUTS)
+// ---------------------------------------------------------------------------------------------
+// Table-driven symbol decode of the batched decoder.  The four tables are generated from the arithmetic
+// routines above (tools/gen_decode_luts.cpp -> decode_luts.inc); they hold format constants, nothing that
+// depends on a block size or preset.
+// ---------------------------------------------------------------------------------------------
+#include "decode_luts.inc"
+
+WV_FN uint32_t trit_group_lut(uint32_t t8) { const uint16_t t[256] = { ASTC_TRIT_LUT_VALUES }; return t[t8]; }
+WV_FN uint32_t quint_group_lut(uint32_t q7) { const uint16_t t[128] = { ASTC_QUINT_LUT_VALUES }; return t[q7]; }
+WV_FN int weight_unquant_lut(int quant, int sym) { const uint8_t t[12 * 32] = { ASTC_WEIGHT_UNQUANT_LUT_VALUES }; return t[quant * 32 + sym]; }
+WV_FN int color_unquant_lut(int quant, int sym) { const uint8_t t[21 * 256] = { ASTC_COLOR_UNQUANT_LUT_VALUES }; return t[quant * 256 + sym]; }
+
+/* (hi:lo) >> sh, low 32 bits; sh in 0..31. */
+WV_FN uint32_t funnel_shift_right(uint32_t hi, uint32_t lo, int sh)
+{
+#if WV_DEVICE
+	return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+#else
+	return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+#endif
+}
+
+/* 64 bits of a 128-bit stream from bit `at` on.  `w` = the four words followed by two zero words (bits past
+ * 127 read as zeros, like the reference's padded buffer). */
+WV_FN uint64_t bits_window(const uint32_t* w, int at)
+{
+	if (at >= 128) return 0ull;
+	const int word = at >> 5, sh = at & 31;
+	const uint32_t w0 = w[word], w1 = w[word + 1], w2 = w[word + 2];
+	return ((uint64_t)funnel_shift_right(w2, w1, sh) << 32) | funnel_shift_right(w1, w0, sh);
+}
+
+/* ise_symbol() with the group fetched as one bit window and the trits / quints looked up.
+ * bits / kind = btq_of(quant) (kind 0 plain bits, 1 trits, 2 quints). */
+WV_FN int ise_symbol_lut(const uint32_t* w, int offset, int bits, int kind, int count, int index)
+{
+	const uint32_t low_mask = (1u << bits) - 1u;
+	if (kind == 0)
+	{
+		return (int)((uint32_t)bits_window(w, offset + index * bits) & low_mask);
+	}
+	if (kind == 1)
+	{
+		// element k of a group starts at bit k * bits + {0, 2, 4, 5, 7}[k]; a group of n elements is n * bits + {0, 2, 4, 5, 7, 8}[n] bits long
+		const int group = (index * 205) >> 10, pos = index - group * 5;          // index / 5 (index < 1024)
+		const int in_group = i_min(5, count - group * 5);
+		const int glen = in_group * bits + (int)((0x875420u >> (4 * in_group)) & 0xFu);
+		uint64_t g = bits_window(w, offset + group * (5 * bits + 8));
+		g &= (1ull << glen) - 1ull;                                               // (the missing elements of a short last group read as zeros)
+		const uint32_t t8 = ((uint32_t)(g >> bits) & 3u) | (((uint32_t)(g >> (2 * bits + 2)) & 3u) << 2) |
+		                    (((uint32_t)(g >> (3 * bits + 4)) & 1u) << 4) | (((uint32_t)(g >> (4 * bits + 5)) & 3u) << 5) |
+		                    (((uint32_t)(g >> (5 * bits + 7)) & 1u) << 7);
+		const uint32_t m = (uint32_t)(g >> (pos * bits + (int)((0x75420u >> (4 * pos)) & 0xFu))) & low_mask;
+		const uint32_t trit = (trit_group_lut(t8) >> (2 * pos)) & 3u;
+		return (int)((trit << bits) | m);
+	}
+	{
+		// quints: element k starts at bit k * bits + {0, 3, 5}[k]; n elements are n * bits + {0, 3, 5, 7}[n] bits
+		const int group = (index * 171) >> 9, pos = index - group * 3;            // index / 3 (index < 512)
+		const int in_group = i_min(3, count - group * 3);
+		const int glen = in_group * bits + (int)((0x7530u >> (4 * in_group)) & 0xFu);
+		uint64_t g = bits_window(w, offset + group * (3 * bits + 7));
+		g &= (1ull << glen) - 1ull;
+		const uint32_t q7 = ((uint32_t)(g >> bits) & 7u) | (((uint32_t)(g >> (2 * bits + 3)) & 3u) << 3) |
+		                    (((uint32_t)(g >> (3 * bits + 5)) & 3u) << 5);
+		const uint32_t m = (uint32_t)(g >> (pos * bits + (int)((0x530u >> (4 * pos)) & 0xFu))) & low_mask;
+		const uint32_t quint = (quint_group_lut(q7) >> (3 * pos)) & 7u;
+		return (int)((quint << bits) | m);
+	}
+}
+#endif // !ASTC_DECODE_NO_LUTS
+
 /* Block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.
  * (ref: decode_block_mode_2d / _3d, astcenc_block_sizes.cpp:37-243 + the checks in construct_block_size_descriptor_2d / _3d) */
 WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int block_z, int& wx, int& wy, int& wz, bool& dual, int& wquant)
@@ -577,18 +650,18 @@ WV_FN void endpoint_lns_flags(int profile, int f, bool& rgb_lns, bool& alpha_lns
 }
 
 /* Weights of one texel from the grid (format rule "weight infill"; ref: unpack_weights :89). */
-WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
+WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
 {
 	// ds, dt, dr = (1024 + block / 2) / (block - 1) per axis
 	if (block_z > 1)
 	{
 		// 3D: simplex interpolation inside the grid cell -- from the low corner step along the axes in
 		// descending order of fraction (ref: init_decimation_info_3d, astcenc_block_sizes.cpp:483-600)
-		const int gs = (ds * tx * (h.wx - 1) + 32) >> 6;
-		const int gt = (dt * ty * (h.wy - 1) + 32) >> 6;
-		const int gr = (dr * tz * (h.wz - 1) + 32) >> 6;
+		const int gs = (ds * tx * (wx - 1) + 32) >> 6;
+		const int gt = (dt * ty * (wy - 1) + 32) >> 6;
+		const int gr = (dr * tz * (wz - 1) + 32) >> 6;
 		const int fs = gs & 0xF, ft = gt & 0xF, fp = gr & 0xF;
-		const int N = h.wx, NM = h.wx * h.wy;
+		const int N = wx, NM = wx * wy;
 		const int cas = ((fs > ft) << 2) + ((ft > fp) << 1) + (fs > fp);
 		int s1, s2, w0, w1, w2, w3;
 		switch (cas)
@@ -600,7 +673,7 @@ WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], i
 		case 2: s1 = N;  s2 = NM; w0 = 16 - ft; w1 = ft - fp; w2 = fp - fs; w3 = fs; break;
 		default: s1 = NM; s2 = N; w0 = 16 - fp; w1 = fp - ft; w2 = ft - fs; w3 = fs; break;
 		}
-		const int v0 = ((gr >> 4) * h.wy + (gt >> 4)) * h.wx + (gs >> 4);
+		const int v0 = ((gr >> 4) * wy + (gt >> 4)) * wx + (gs >> 4);
 		const int v1 = v0 + s1, v2 = v1 + s2, v3 = v0 + NM + N + 1;
 		for (int pl = 0; pl < 2; pl++)
 		{
@@ -616,23 +689,28 @@ WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], i
 	}
 	wp[1] = 0;
 	const int cs = ds * tx, ct = dt * ty;
-	const int gs = (cs * (h.wx - 1) + 32) >> 6;
-	const int gt = (ct * (h.wy - 1) + 32) >> 6;
+	const int gs = (cs * (wx - 1) + 32) >> 6;
+	const int gt = (ct * (wy - 1) + 32) >> 6;
 	const int js = gs >> 4, fs = gs & 0xF, jt = gt >> 4, ft = gt & 0xF;
 	const int w11 = (fs * ft + 8) >> 4;
 	const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
-	const int v0 = js + jt * h.wx;
-	const int wcount = h.wx * h.wy;
-	for (int pl = 0; pl < (h.dual ? 2 : 1); pl++)
+	const int v0 = js + jt * wx;
+	const int wcount = wx * wy;
+	for (int pl = 0; pl < (dual ? 2 : 1); pl++)
 	{
 		const uint8_t* g = gw[pl];
 		int sum = 8;
 		sum += w00 ? g[v0] * w00 : 0;
 		sum += (w01 && v0 + 1 < wcount) ? g[v0 + 1] * w01 : 0;
-		sum += (w10 && v0 + h.wx < wcount) ? g[v0 + h.wx] * w10 : 0;
-		sum += (w11 && v0 + h.wx + 1 < wcount) ? g[v0 + h.wx + 1] * w11 : 0;
+		sum += (w10 && v0 + wx < wcount) ? g[v0 + wx] * w10 : 0;
+		sum += (w11 && v0 + wx + 1 < wcount) ? g[v0 + wx + 1] * w11 : 0;
 		wp[pl] = sum >> 4;
 	}
+}
+
+WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
+{
+	infill_texel_weights(h.wx, h.wy, h.wz, h.dual, gw, ds, dt, dr, block_z, tx, ty, tz, wp);
 }
 
 /* Unpack weights, colour values and endpoints of a non-constant, legal block into the scratch. */
@@ -762,18 +840,32 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 	}
 }
 
+#if !defined(ASTC_DECODE_NO_LUTS)
 /* A batch of consecutive blocks decoded together by one wavefront.  Decoding one block keeps few lanes
  * busy (a header, <= 64 weights, <= 18 colour values, <= 4 endpoint pairs, T texels, one after the other);
  * over a batch every phase is one flat loop over (block, element) pairs, so the lanes stay filled and
  * the per-block phases cost one pass per batch instead of one per block. */
-constexpr int DECODE_BATCH = 8;
+#ifndef ASTC_DECODE_BATCH
+#define ASTC_DECODE_BATCH 16
+#endif
+constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
+
+/* What the element and texel phases need to know about a block, packed so that one 16-byte LDS read fetches it. */
+struct DecodeBlockRec {
+	uint32_t a;          // flags (1 = no payload, 2 = error block, 4 = constant colour) | weight bits << 8 | weight kind << 16 | weight quant << 24
+	uint32_t b;          // colour bits | colour kind << 8 | colour quant << 16 | colour value count << 24
+	uint32_t c;          // weight count over both planes | dual << 8 | first colour bit << 16 | partition count << 24
+	uint32_t d;          // grid x | y << 8 | z << 16 | second plane's component (255 = none) << 24
+	uint32_t seed;
+	uint32_t origin[3];  // texel coordinates of the block's first texel
+};
+
 struct DecodeBatch {
-	BlockHeader hdr[DECODE_BATCH];
-	Bits128     bits[DECODE_BATCH];
-	Bits128     rev[DECODE_BATCH];        // the same bits reversed: the weight stream
+	DecodeBlockRec rec[DECODE_BATCH];
+	uint32_t    bits[DECODE_BATCH][6];    // the block, then two zero words (see bits_window)
+	uint32_t    rev[DECODE_BATCH][6];     // the same bits reversed: the weight stream
 	float       constant[DECODE_BATCH][4];
-	int         error[DECODE_BATCH];
-	uint32_t    origin[DECODE_BATCH][4];  // texel coordinates of the block's first texel
+	uint8_t     fmt[DECODE_BATCH][4];     // colour endpoint mode per partition
 	DecodeScratch payload[DECODE_BATCH];
 };
 
@@ -824,69 +916,87 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 			const uint32_t bxi = b - row * img.blocks_x;
 			const uint32_t bzi = row / img.blocks_y;
 			const uint32_t byi = row - bzi * img.blocks_y;
-			s.origin[k][0] = bxi * (uint32_t)block_x; s.origin[k][1] = byi * (uint32_t)block_y; s.origin[k][2] = bzi * (uint32_t)block_z;
+			s.rec[k].origin[0] = bxi * (uint32_t)block_x; s.rec[k].origin[1] = byi * (uint32_t)block_y; s.rec[k].origin[2] = bzi * (uint32_t)block_z;
 		}
-		s.hdr[k] = h;
-		s.bits[k] = blk;
-		s.rev[k] = bits_reversed(blk);
-		for (int q = 0; q < 4; q++) s.constant[k][q] = cc[q];
-		s.error[k] = error ? 1 : 0;
+		{
+			const Btq wq = btq_of(h.wquant), cq = btq_of(h.cquant);
+			const int wcount = h.wx * h.wy * h.wz;
+			const uint32_t skip = ((error || h.constant) ? 1u : 0u) | (error ? 2u : 0u) | (h.constant ? 4u : 0u);
+			DecodeBlockRec& r = s.rec[k];
+			r.a = skip | ((uint32_t)wq.bits << 8) | ((wq.trits ? 1u : wq.quints ? 2u : 0u) << 16) | ((uint32_t)h.wquant << 24);
+			r.b = (uint32_t)cq.bits | ((cq.trits ? 1u : cq.quints ? 2u : 0u) << 8) | ((uint32_t)h.cquant << 16) | ((uint32_t)h.nvals << 24);
+			r.c = (uint32_t)(h.dual ? 2 * wcount : wcount) | ((h.dual ? 1u : 0u) << 8) | ((uint32_t)h.color_start << 16) | ((uint32_t)h.parts << 24);
+			r.d = (uint32_t)h.wx | ((uint32_t)h.wy << 8) | ((uint32_t)h.wz << 16) | (((uint32_t)h.plane2 & 0xFFu) << 24);
+			r.seed = (uint32_t)h.seed;
+		}
+		{
+			const Bits128 rv = bits_reversed(blk);
+			for (int q = 0; q < 4; q++) { s.bits[k][q] = blk.w[q]; s.rev[k][q] = rv.w[q]; }
+			s.bits[k][4] = 0u; s.bits[k][5] = 0u; s.rev[k][4] = 0u; s.rev[k][5] = 0u;
+		}
+		for (int q = 0; q < 4; q++) { s.constant[k][q] = cc[q]; s.fmt[k][q] = (uint8_t)h.fmt[q]; }
 	}
 	WV_SYNC();
 
+	// (profiling builds only: -DDEC_EXP=3 / 2 / 1 stop after the headers / the symbol phases / the endpoints, which
+	//  is how the phase split quoted in DESIGN.md was measured)
+#if defined(DEC_EXP) && DEC_EXP >= 3
+	return;
+#endif
 	// ---- weights and colour values: one lane per (block, element), as many lanes per block as the fullest block needs ----
 	int wmax_part = 0, cmax_part = 0;                 // per-lane partial maxima (lane k looked at block k), folded below
 	WV_FOR(k, count)
 	{
-		const BlockHeader& h = s.hdr[k];
-		if (!(s.error[k] || h.constant))
+		const DecodeBlockRec& r = s.rec[k];
+		if (!(r.a & 1u))
 		{
-			const int wcount = h.wx * h.wy * h.wz;
-			wmax_part = i_max(wmax_part, h.dual ? 2 * wcount : wcount);
-			cmax_part = i_max(cmax_part, h.nvals);
+			wmax_part = i_max(wmax_part, (int)(r.c & 0xFFu));
+			cmax_part = i_max(cmax_part, (int)(r.b >> 24));
 		}
 	}
 	const int wmax = wv_all_imax(wmax_part), cmax = wv_all_imax(cmax_part);
 	if (wmax > 0)
 	{
-		const uint32_t winv = (65536u + (uint32_t)wmax - 1u) / (uint32_t)wmax;      // (one divide per batch)
+		const uint32_t winv = ((1u << 20) + (uint32_t)wmax - 1u) / (uint32_t)wmax;      // j / wmax == (j * winv) >> 20 for j < count * wmax (one divide per batch)
 		WV_FOR(j, count * wmax)
 		{
-			const int k = (int)(((uint32_t)j * winv) >> 16), i = j - k * wmax;
-			const BlockHeader& h = s.hdr[k];
-			if (s.error[k] || h.constant) continue;
-			const int wcount = h.wx * h.wy * h.wz;
-			const int real_wcount = h.dual ? 2 * wcount : wcount;
-			if (i >= real_wcount) continue;
-			int sym = ise_symbol(s.rev[k], 0, h.wquant, real_wcount, i);
-			int w = unquant_weight_symbol(sym, h.wquant);
-			if (h.dual) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
+			const int k = (int)(((uint32_t)j * winv) >> 20), i = j - k * wmax;
+			const uint32_t ra = s.rec[k].a, rc = s.rec[k].c;
+			const int real_wcount = (int)(rc & 0xFFu);
+			if ((ra & 1u) || i >= real_wcount) continue;
+			const int sym = ise_symbol_lut(s.rev[k], 0, (int)((ra >> 8) & 0xFFu), (int)((ra >> 16) & 0xFFu), real_wcount, i);
+			const int w = weight_unquant_lut((int)(ra >> 24), sym);
+			if (rc & 0x100u) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
 			else s.payload[k].weights[0][i] = (uint8_t)w;
 		}
 	}
 	if (cmax > 0)
 	{
-		const uint32_t cinv = (65536u + (uint32_t)cmax - 1u) / (uint32_t)cmax;
+		const uint32_t cinv = ((1u << 20) + (uint32_t)cmax - 1u) / (uint32_t)cmax;
 		WV_FOR(j, count * cmax)
 		{
-			const int k = (int)(((uint32_t)j * cinv) >> 16), i = j - k * cmax;
-			const BlockHeader& h = s.hdr[k];
-			if (s.error[k] || h.constant || i >= h.nvals) continue;
-			int sym = ise_symbol(s.bits[k], h.color_start, h.cquant, h.nvals, i);
-			s.payload[k].colors[i] = (uint8_t)unquant_color_symbol(sym, h.cquant);
+			const int k = (int)(((uint32_t)j * cinv) >> 20), i = j - k * cmax;
+			const uint32_t ra = s.rec[k].a, rb = s.rec[k].b, rc = s.rec[k].c;
+			const int nvals = (int)(rb >> 24);
+			if ((ra & 1u) || i >= nvals) continue;
+			const int sym = ise_symbol_lut(s.bits[k], (int)((rc >> 16) & 0xFFu), (int)(rb & 0xFFu), (int)((rb >> 8) & 0xFFu), nvals, i);
+			s.payload[k].colors[i] = (uint8_t)color_unquant_lut((int)((rb >> 16) & 0xFFu), sym);
 		}
 	}
 	WV_SYNC();
+#if defined(DEC_EXP) && DEC_EXP >= 2
+	return;
+#endif
 	// ---- endpoints: one lane per (block, partition) ----
 	WV_FOR(j, count * 4)
 	{
 		const int k = j >> 2, p = j & 3;
-		const BlockHeader& h = s.hdr[k];
-		if (s.error[k] || h.constant || p >= h.parts) continue;
+		const DecodeBlockRec& r = s.rec[k];
+		if ((r.a & 1u) || p >= (int)(r.c >> 24)) continue;
 		DecodeScratch& ps = s.payload[k];
 		int start = 0;
-		for (int i = 0; i < 4; i++) start += i < p ? 2 * (h.fmt[i] >> 2) + 2 : 0;
-		const int f = p == 0 ? h.fmt[0] : p == 1 ? h.fmt[1] : p == 2 ? h.fmt[2] : h.fmt[3];
+		for (int i = 0; i < 4; i++) start += i < p ? 2 * (s.fmt[k][i] >> 2) + 2 : 0;
+		const int f = s.fmt[k][p];
 		uint8_t in[8];
 		const int n = 2 * (f >> 2) + 2;
 		for (int q = 0; q < 8; q++) in[q] = q < n ? ps.colors[start + q] : 0;
@@ -902,6 +1012,9 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 	}
 	WV_SYNC();
 
+#if defined(DEC_EXP) && DEC_EXP >= 1
+	return;
+#endif
 	// ---- texels: one lane per (block, texel) ----
 	const bool small_block = T < 31;
 	const uint32_t t_inv = img.t_inv24;
@@ -910,69 +1023,111 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 	// reference's route, astcenc_image.cpp:345-420 after decompress_symbolic.cpp:66-120), so the texel is built
 	// from integers alone; LNS (HDR) endpoints, error and constant blocks and the Z swizzle take the general route.
 	const bool bytes_out = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
+	const bool identity_swz = img.swz[0] == 0 && img.swz[1] == 1 && img.swz[2] == 2 && img.swz[3] == 3;
+	const bool halves_out = img.data_type == 1 && identity_swz;
+	// 2D blocks: lanes in (texel row, block, column) order, so that consecutive lanes write consecutive pixels of
+	// an image row across the blocks of the batch (which are neighbours in x unless the batch wraps a block row)
+	const int row_len = count * block_x;
+	const uint32_t row_inv22 = block_z == 1 ? ((1u << 22) + (uint32_t)row_len - 1u) / (uint32_t)row_len : 0u;   // (one divide per batch)
 	WV_FOR(j, count * T)
 	{
-		const int k = (int)(((uint32_t)j * t_inv) >> 24), t = j - k * T;
-		const uint32_t bx = s.origin[k][0], by = s.origin[k][1], bz = s.origin[k][2];
-		const int tz = block_z > 1 ? (int)(((uint32_t)t * img.bxy_inv16) >> 16) : 0;
-		const int trem = t - tz * (block_x * block_y);
-		const int ty = (int)(((uint32_t)trem * img.bx_inv16) >> 16), tx = trem - ty * block_x;
-		const uint32_t xi = bx + (uint32_t)tx;
-		const uint32_t yi = by + (uint32_t)ty;
-		const uint32_t zi = bz + (uint32_t)tz;
+		int k, tx, ty, tz;
+		if (block_z == 1)
+		{
+			ty = (int)(((uint32_t)j * row_inv22) >> 22);
+			const int rem = j - ty * row_len;
+			k = (int)(((uint32_t)rem * img.bx_inv16) >> 16);
+			tx = rem - k * block_x;
+			tz = 0;
+		}
+		else
+		{
+			k = (int)(((uint32_t)j * t_inv) >> 24);
+			const int t = j - k * T;
+			tz = (int)(((uint32_t)t * img.bxy_inv16) >> 16);
+			const int trem = t - tz * (block_x * block_y);
+			ty = (int)(((uint32_t)trem * img.bx_inv16) >> 16);
+			tx = trem - ty * block_x;
+		}
+		const DecodeBlockRec& rec = s.rec[k];
+		const uint32_t xi = rec.origin[0] + (uint32_t)tx;
+		const uint32_t yi = rec.origin[1] + (uint32_t)ty;
+		const uint32_t zi = rec.origin[2] + (uint32_t)tz;
 		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
+		const size_t texel_index = ((size_t)zi * img.dim_y + yi) * img.dim_x + xi;
 
-		const BlockHeader& h = s.hdr[k];
 		float r, g, bl, a;
-		if (s.error[k])
+		const uint32_t flags = rec.a;
+		if (flags & 2u)
 		{
 			r = g = bl = a = error_nan;
 		}
-		else if (h.constant)
+		else if (flags & 4u)
 		{
 			r = s.constant[k][0]; g = s.constant[k][1]; bl = s.constant[k][2]; a = s.constant[k][3];
 		}
 		else
 		{
 			const DecodeScratch& ps = s.payload[k];
+			const uint32_t rc = rec.c, rd = rec.d;
+			const bool dual = (rc & 0x100u) != 0;
+			const int parts = (int)(rc >> 24);
+			const int plane2 = dual ? (int)(rd >> 24) : -1;
 			int wp[2];
-			infill_texel_weights(h, ps.weights, (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
-			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
+			infill_texel_weights((int)(rd & 0xFFu), (int)((rd >> 8) & 0xFFu), (int)((rd >> 16) & 0xFFu), dual, ps.weights,
+			                     (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
+			const int p = parts == 1 ? 0 : partition_of_texel((int)rec.seed, tx, ty, tz, parts, small_block);
 			const int* e = ps.ep[p];
 			int cv[4];
 			for (int q = 0; q < 4; q++)
 			{
-				const int wk = (h.dual && q == h.plane2) ? wp[1] : wp[0];
+				const int wk = q == plane2 ? wp[1] : wp[0];
 				cv[q] = (e[q] * (64 - wk) + e[4 + q] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
 			}
 			if (bytes_out && !(ps.lns[p][0] | ps.lns[p][1]))
 			{
 				uint32_t px = 0;
-				for (int q = 0; q < 4; q++)
+				if (identity_swz)
 				{
-					const uint32_t sw = img.swz[q];
-					const uint32_t v = sw == 4 ? 0u : sw == 5 ? 255u : (uint32_t)(cv[sw & 3] >> 8);
-					px |= v << (8 * q);
+					px = (uint32_t)(cv[0] >> 8) | ((uint32_t)(cv[1] >> 8) << 8) | ((uint32_t)(cv[2] >> 8) << 16) | ((uint32_t)(cv[3] >> 8) << 24);
 				}
-				const size_t at = (((size_t)zi * img.dim_y + yi) * img.dim_x + xi) * 4;
-				__builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
+				else
+				{
+					for (int q = 0; q < 4; q++)
+					{
+						const uint32_t sw = img.swz[q];
+						const uint32_t v = sw == 4 ? 0u : sw == 5 ? 255u : (uint32_t)(cv[sw & 3] >> 8);
+						px |= v << (8 * q);
+					}
+				}
+				__builtin_memcpy(static_cast<uint8_t*>(img.data) + texel_index * 4, &px, 4);
 				continue;
 			}
-			float out[4];
+			int hf[4];
 			for (int q = 0; q < 4; q++)
 			{
 				int cval = cv[q];
 				if (u8_out) cval = (cval >> 8) * 257;
 				const bool lns = ps.lns[p][q == 3 ? 1 : 0] != 0;
-				const int hf = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
-				out[q] = half_to_float((uint16_t)hf);
+				hf[q] = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
 			}
-			r = out[0]; g = out[1]; bl = out[2]; a = out[3];
+			// FP16 output through the identity swizzle: binary16 -> float -> binary16 gives every finite value back
+			// unchanged, so the four halves are stored as they are (infinities / NaNs take the general route)
+			if (halves_out && ((hf[0] & 0x7C00) != 0x7C00) && ((hf[1] & 0x7C00) != 0x7C00) && ((hf[2] & 0x7C00) != 0x7C00) && ((hf[3] & 0x7C00) != 0x7C00))
+			{
+				const uint32_t lo = (uint32_t)(hf[0] & 0xFFFF) | ((uint32_t)hf[1] << 16), hi = (uint32_t)(hf[2] & 0xFFFF) | ((uint32_t)hf[3] << 16);
+				const uint64_t px = ((uint64_t)hi << 32) | lo;
+				__builtin_memcpy(static_cast<uint8_t*>(img.data) + texel_index * 8, &px, 8);
+				continue;
+			}
+			r = half_to_float((uint16_t)hf[0]); g = half_to_float((uint16_t)hf[1]); bl = half_to_float((uint16_t)hf[2]); a = half_to_float((uint16_t)hf[3]);
 		}
 		store_texel(img, xi, yi, zi, r, g, bl, a);
 	}
 	WV_SYNC();          // the batch scratch is reused by the next call
 }
+
+#endif // !ASTC_DECODE_NO_LUTS
 
 /* astcenc_get_block_info for one block, as plain sequential code (runs on the host).
  * (ref: astcenc_get_block_info, astcenc_entry.cpp:1401-1517)  `info` is a struct astcenc_block_info. */
