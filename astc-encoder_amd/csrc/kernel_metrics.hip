@@ -2,8 +2,8 @@
 // Image comparison kernel: squared-error sums of two images resident in HBM, for PSNR without a host
 // round trip (ref: compute_error_metrics, Source/astcenccli_error_metrics.cpp:110).  Streaming and
 // HBM-bound: every lane walks texels with a grid stride (coalesced 4 / 8 / 16-byte texel loads), keeps
-// fp64 partial sums, the workgroup folds them in a fixed order and a one-workgroup second pass adds the
-// workgroups' partials in index order (no atomics: the totals are reproducible).
+// fp64 partial sums, the workgroup folds them in a fixed order and a second pass (one wavefront per quantity)
+// adds the workgroups' partials in a fixed order (no atomics: the totals are reproducible).
 #define ASTC_VARIANT v_metrics
 #include "backend.h"
 #include "wave_metrics.h"
@@ -67,19 +67,26 @@ astc_compare_images(const void* __restrict__ a, uint32_t type_a, const void* __r
 	}
 }
 
-/* Pass 2: one thread per quantity adds the workgroups' partials in index order. */
+/* Pass 2: one wavefront per quantity.  Lane l adds the partials of workgroups l, l + 64, ... in index order, then
+ * the 64 lane sums are folded with a fixed shuffle tree: the same totals on every run, whatever the scheduling. */
 __global__ void __launch_bounds__(64)
 astc_compare_finish(const double* __restrict__ partials, uint32_t groups, int hdr, double* __restrict__ sums)
 {
-	const int k = threadIdx.x;
+	const int k = (int)blockIdx.x;
 	if (k >= (hdr ? METRIC_SUMS_HDR : 9) || k == 9) return;
-	double v = partials[k];
-	for (uint32_t g = 1; g < groups; g++)
+	const bool is_peak = k == 8;
+	double v = 0.0;                                         // (every quantity is a sum of squares or a peak of non-negative values)
+	for (uint32_t g = threadIdx.x; g < groups; g += 64)
 	{
 		const double p = partials[(size_t)g * METRIC_STRIDE + k];
-		v = k != 8 ? v + p : (p > v ? p : v);
+		v = !is_peak ? v + p : (p > v ? p : v);
 	}
-	sums[k] = v;
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const double o = __shfl_down(v, off);
+		v = !is_peak ? v + o : (o > v ? o : v);
+	}
+	if (threadIdx.x == 0) sums[k] = v;
 }
 
 int astc_compare_launch(const CompareLaunch& c)
@@ -94,7 +101,7 @@ int astc_compare_launch(const CompareLaunch& c)
 	else
 		hipLaunchKernelGGL(astc_compare_images<false>, dim3((uint32_t)groups), dim3(256), 0, static_cast<hipStream_t>(c.stream),
 		                   c.d_a, c.type_a, c.d_b, c.type_b, c.texels, 0, 0, partials);
-	hipLaunchKernelGGL(astc_compare_finish, dim3(1), dim3(64), 0, static_cast<hipStream_t>(c.stream), partials, (uint32_t)groups, c.hdr, c.d_sums);
+	hipLaunchKernelGGL(astc_compare_finish, dim3(METRIC_SUMS_HDR), dim3(64), 0, static_cast<hipStream_t>(c.stream), partials, (uint32_t)groups, c.hdr, c.d_sums);
 	return (int)hipGetLastError();
 }
 
