@@ -41,6 +41,11 @@ WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, ui
 	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]);
 }
 
+// taps of a weight fetched per round trip in the decimation sweeps (table loads in flight per lane = 2x this)
+#ifndef ASTC_DWI_GROUP
+#define ASTC_DWI_GROUP 4
+#endif
+
 /* Row of the sin/cos tables an ideal weight selects in the angular search (ref: compute_angular_offsets,
  * weight_align.cpp:110-118).  It depends on the weight only, not on the angular step, so it is computed once when
  * the weight is final instead of once per (weight, step) in the search. */
@@ -196,7 +201,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
 			const DwiSlot sl = slots[k];
 			if (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask))) continue;
-			const float w0 = dwi_initial_weight<4>(c, sl);
+			const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
 			dwi_base[k] = w0;
 			if (sl.flags & 1) isamp[k] = angular_sample_row(w0);     // copied weights are final here
 		}
@@ -222,7 +227,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
 			const DwiSlot sl = slots[k];
 			if ((sl.flags & 1) || (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)))) continue;
-			const float w1 = dwi_refined_weight<4>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+			const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
 			dwi_base[k] = w1;
 			isamp[k] = angular_sample_row(w1);
 		}

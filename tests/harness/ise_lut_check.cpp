@@ -1,0 +1,58 @@
+// SPDX-License-Identifier: Apache-2.0
+// Test infrastructure: the batched decoder's table-driven BISE symbol decode (ise_symbol_lut, *_unquant_lut) against
+// the arithmetic per-element routines it replaces (ise_symbol, unquant_*_symbol), which are the ones the single-block
+// decoder and astcenc_get_block_info use and which are pinned to the reference decoder by tests/test_decode.py.
+//   g++ -std=c++17 -O1 -DASTC_WAVE_EMU=1 -I astc-encoder_amd/csrc tests/harness/ise_lut_check.cpp -o ise_lut_check
+#define ASTC_VARIANT v_check
+#define ASTC_ENABLE_HDR 1
+#include "backend.h"
+#include "wave_decode.h"
+#include <cstdio>
+#include <cstdint>
+
+using namespace astcd;
+
+int main()
+{
+	uint64_t x = 0x9E3779B97F4A7C15ull;
+	auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 16); };
+	long checked = 0, bad = 0;
+	for (int quant = 0; quant <= 20; quant++)
+	{
+		const Btq q = btq_of(quant);
+		const int kind = q.trits ? 1 : q.quints ? 2 : 0;
+		for (int rep = 0; rep < 400; rep++)
+		{
+			Bits128 b;
+			uint32_t w[6];
+			for (int k = 0; k < 4; k++) { b.w[k] = rnd(); if (rep % 5 == 0) b.w[k] &= rnd(); w[k] = b.w[k]; }
+			w[4] = 0; w[5] = 0;
+			const int offsets[4] = { 0, 17, 29, (int)(rnd() % 100) };
+			for (int oi = 0; oi < 4; oi++)
+			{
+				const int count = 1 + (int)(rnd() % 64);
+				for (int index = 0; index < count; index++)
+				{
+					const int want = ise_symbol(b, offsets[oi], quant, count, index);
+					const int got = ise_symbol_lut(w, offsets[oi], q.bits, kind, count, index);
+					checked++;
+					if (want != got)
+					{
+						if (bad++ < 10) fprintf(stderr, "quant %d offset %d count %d index %d: %d != %d\n", quant, offsets[oi], count, index, got, want);
+					}
+				}
+			}
+		}
+		// unquantization tables: every symbol the level can produce
+		for (int v = 0; v < 256; v++)
+		{
+			const int top = v >> q.bits;
+			const bool valid = q.trits ? top < 3 : q.quints ? top < 5 : v < (1 << q.bits);
+			if (!valid) continue;
+			if (quant <= 11 && v < 32) { checked++; if (weight_unquant_lut(quant, v) != unquant_weight_symbol(v, quant)) { bad++; fprintf(stderr, "weight unquant %d %d\n", quant, v); } }
+			if (quant >= 4) { checked++; if (color_unquant_lut(quant, v) != unquant_color_symbol(v, quant)) { bad++; fprintf(stderr, "colour unquant %d %d\n", quant, v); } }
+		}
+	}
+	printf("%ld checks, %ld mismatches\n", checked, bad);
+	return bad ? 1 : 0;
+}

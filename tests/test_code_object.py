@@ -1,0 +1,52 @@
+"""Static properties of the kernels inside the shipped library (no GPU needed): the code objects are pulled out of
+libastcenc_amd.so's fat binary and their kernel descriptors read with the ROCm LLVM tools.
+
+The LDR compression kernel is required to run without scratch memory: every scratch store of a spilled register is
+256 B of HBM write traffic per wavefront (round 1: 177 such stores per block, 136x the algorithmic traffic)."""
+import os, re, shutil, subprocess, sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
+import astcenc_amd as A  # noqa: E402
+
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+
+def kernel_descriptors(lib, tmp):
+    """{kernel name: {descriptor field: int}} of every gfx950 kernel in the library."""
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), data)] + [len(data)]
+    kernels = {}
+    for n in range(len(starts) - 1):
+        bundle, co = os.path.join(tmp, "b%d.bin" % n), os.path.join(tmp, "k%d.co" % n)
+        open(bundle, "wb").write(data[starts[n]:starts[n + 1]])
+        subprocess.run([BUNDLER, "--unbundle", "--type=o", "--input=" + bundle, "--targets=" + TARGET, "--output=" + co], check=True)
+        notes = subprocess.run([READELF, "--notes", co], capture_output=True, text=True, check=True).stdout
+        # one YAML map per kernel under amdhsa.kernels; the fields of a kernel precede the next "- .agpr_count" / "- .args"
+        for block in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            kernels[name] = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", block, re.M)}
+    return kernels
+
+
+@pytest.mark.skipif(not (os.path.exists(A.LIB_PRODUCT) and os.path.exists(BUNDLER) and os.path.exists(READELF) and shutil.which("objcopy")),
+                    reason="needs the built product library and the ROCm LLVM tools")
+def test_kernel_descriptors(tmp_path):
+    k = kernel_descriptors(A.LIB_PRODUCT, str(tmp_path))
+    by_short = {re.sub(r"^_ZN5astcd\d+", "", n): d for n, d in k.items()}
+    ldr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_ldr"))
+    hdr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_hdr"))
+    assert any(n.startswith("astc_decompress_blocks") for n in by_short)
+    assert any(n.startswith("astc_alpha_averages") for n in by_short)
+    assert sum(n.startswith("astc_compare_") for n in by_short) == 3
+    # the headline kernel: no scratch memory at all, the register budget of four wavefronts per SIMD
+    assert ldr["private_segment_fixed_size"] == 0 and ldr["vgpr_spill_count"] == 0, ldr
+    assert ldr["vgpr_count"] <= 128 and ldr["max_flat_workgroup_size"] == 64, ldr
+    # the HDR variant still saves a few callee-saved registers in two stage functions: bounded, not zero
+    assert hdr["private_segment_fixed_size"] <= 128 and hdr["vgpr_count"] <= 128, hdr
