@@ -249,6 +249,22 @@ WV_FN float std_max(float a, float b) { return a < b ? b : a; }
 WV_FN float hmin4(float a, float b, float c, float d) { return std_min(std_min(a, b), std_min(c, d)); }
 WV_FN float hmax4(float a, float b, float c, float d) { return std_max(std_max(a, b), std_max(c, d)); }
 
+/* base[index] for a table in HBM with a lane-variant index: the byte offset is formed in 32 bits (every table is far
+ * smaller than 4 GB), which lets the load use the scalar-base + 32-bit vector offset addressing mode; plain
+ * `base[index]` with an unsigned index makes the compiler build a 64-bit address per access (shift + add pairs). */
+template <typename T>
+WV_FN const T& table_at(const T* base, uint32_t index)
+{
+	return *reinterpret_cast<const T*>(reinterpret_cast<const uint8_t*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+}
+
+/* The T at byte offset `offset` of a table (same addressing as table_at). */
+template <typename T>
+WV_FN const T& table_at_byte(const uint8_t* base, uint32_t offset)
+{
+	return *reinterpret_cast<const T*>(base + offset);
+}
+
 // ---- a 4-lane value type for the strictly scalar sections ----
 struct f4 {
 	float x, y, z, w;

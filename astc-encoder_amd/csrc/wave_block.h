@@ -363,7 +363,7 @@ WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_co
 		if (stage_dm >= 0)
 		{
 			const DecimationInfo& dinfo = c.dec_info(stage_dm);
-			stage_words_nosync(c.lds + c.L->dtab, c.tab + dinfo.off_texel_weights, (int)((dinfo.table_bytes + 3) / 4));
+			stage_words_nosync(c.lds + c.L->dtab, c.table(dinfo.off_texel_weights), (int)((dinfo.table_bytes + 3) / 4));
 		}
 		if (stage_wq >= 0)
 		{
@@ -438,6 +438,7 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 	{
 		const bool to_scratch = pass == 1;
 		const int q = to_scratch ? quant_level_mod : quant_level;
+		if (to_scratch) stage_color_rows(c, q);        // (rare: the retry level's rows replace the candidate's, put back below)
 		WV_FOR(j, partition_count)
 		{
 			uint8_t* vals = to_scratch ? colorvals + j * 8 : workscb.color_values[j];
@@ -447,7 +448,8 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 			if (to_scratch) fmts[j] = f; else workscb.color_formats[j] = f;
 		}
 		WV_SYNC();
-		if (pass == 1 || dual || partition_count < 2 || quant_level == quant_level_mod) break;
+		if (pass == 1) { stage_color_rows(c, quant_level); break; }
+		if (dual || partition_count < 2 || quant_level == quant_level_mod) break;
 		bool all_same = true;
 		for (int j = 1; j < partition_count; j++) all_same = all_same && workscb.color_formats[j] == workscb.color_formats[0];
 		if (!wv_uniform(all_same)) break;
@@ -743,7 +745,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 
 	}
 	// list of the grids this trial uses, largest weight count first (the order the search batches them in)
-	const uint8_t* by_weights = c.tab + c.root->off_dm_by_weights;
+	const uint8_t* by_weights = c.table(c.root->off_dm_by_weights);
 	const int all_dms = (int)c.root->decimation_mode_count_selected;
 #if WV_DEVICE
 	{

@@ -12,23 +12,25 @@ struct ColorTabs {
 	const uint8_t* unq_to_uq;   // [512] for the current quant level
 };
 
-/* Rows staged in LDS by stage_color_rows() are preferred: pack_color_endpoints does ~50 dependent
- * lookups per call. */
+/* The rows of the colour quant level staged in LDS by stage_color_rows(): pack_color_endpoints does ~50 dependent
+ * lookups per call, and a pointer that could be LDS or HBM would make each of them a flat load with 64-bit address
+ * arithmetic.  The caller stages the level it packs at (refine_candidate_setup; refine_pack for its retry level). */
 WV_FN ColorTabs color_tabs(const Ctx& c, int quant_level)
 {
 	ColorTabs t;
-	const TrialInfo& tr = c.tr();
-	if (quant_level == tr.staged_color_quant[0]) t.unq_to_uq = c.lds + c.L->ctab;
-	else t.unq_to_uq = c.tab + c.root->off_color_unquant_to_uquant + (quant_level - QUANT_6) * 512;
+#if !WV_DEVICE
+	if (quant_level != c.tr().staged_color_quant[0]) __builtin_trap();
+#endif
+	(void)quant_level;
+	t.unq_to_uq = c.lds + c.L->ctab;
 	return t;
 }
 
-/* Stage the rows of the candidate's colour quant level (the rarely used "matched formats" retry at
- * the next level reads the table in global memory). */
+/* Stage the rows of a colour quant level. */
 WV_FN void stage_color_rows(const Ctx& c, int q0)
 {
 	TrialInfo& tr = c.tr();
-	const uint32_t* s0 = reinterpret_cast<const uint32_t*>(c.tab + c.root->off_color_unquant_to_uquant + (q0 - QUANT_6) * 512);
+	const uint32_t* s0 = reinterpret_cast<const uint32_t*>(c.table(c.root->off_color_unquant_to_uquant) + (q0 - QUANT_6) * 512);
 	stage_words_nosync(c.lds + c.L->ctab, reinterpret_cast<const uint8_t*>(s0), 128);
 	WV_ONE { tr.staged_color_quant[0] = q0; tr.staged_color_quant[1] = -1; }
 	WV_SYNC();

@@ -227,6 +227,32 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.total = end;
 }
 
+/* wv_uniform(v): `v` is the same on every lane (a value read from LDS or from a table looks lane-variant to the
+ * compiler); returns it in a scalar register, so that control flow on it runs on the scalar unit and addresses built
+ * on it use the scalar-base addressing mode. */
+#if WV_DEVICE
+WV_FN uint32_t wv_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+WV_FN int wv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+WV_FN bool wv_uniform(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
+WV_FN float wv_uniform(float v) { return int_as_float(__builtin_amdgcn_readfirstlane(float_as_int(v))); }
+/* The same value, but the optimiser cannot see through it: an expression built on wv_opaque(lane) is not loop
+ * invariant, so it is computed where it is used instead of being hoisted to the top of the kernel and carried (or
+ * spilled to scratch memory) across every stage in between.  No instruction is emitted. */
+WV_FN int wv_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+WV_FN uint64_t wv_uniform(uint64_t v)
+{
+	uint32_t lo = wv_uniform((uint32_t)v), hi = wv_uniform((uint32_t)(v >> 32));
+	return ((uint64_t)hi << 32) | lo;
+}
+#else
+WV_FN uint32_t wv_uniform(uint32_t v) { return v; }
+WV_FN int wv_uniform(int v) { return v; }
+WV_FN int wv_opaque(int v) { return v; }
+WV_FN bool wv_uniform(bool v) { return v; }
+WV_FN float wv_uniform(float v) { return v; }
+WV_FN uint64_t wv_uniform(uint64_t v) { return v; }
+#endif
+
 /* Uniform per-wave context. */
 struct Ctx {
 	const uint8_t* tab;          // table blob (HBM, read-only)
@@ -238,6 +264,9 @@ struct Ctx {
 	int Tp;                      // T rounded up to 4
 	unsigned long long* prof;    // stage cycle counters (profiling builds only), else null
 
+	// a table of the blob at byte offset `off` (an offset read from the blob): scalar base pointer, so that lane-variant
+	// indexing costs one 32-bit offset per access instead of 64-bit pointer arithmetic
+	WV_FN const uint8_t* table(uint32_t off) const { return tab + wv_uniform(off); }
 	// typed views
 	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L->data) + c * Tp; }
 	WV_FN BlkInfo& blk() const { return *reinterpret_cast<BlkInfo*>(lds + L->blk); }
@@ -266,11 +295,11 @@ struct Ctx {
 	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
-	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(tab + root->off_block_modes)[i]; }
-	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(tab + root->off_decimation_modes)[i]; }
-	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(tab + root->off_decimation_infos)[i]; }
-	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return tab + root->off_partitions[pcount - 1] + (uint32_t)packed * root->partition_stride; }
-	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(tab + root->off_quant_xfer)[q]; }
+	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(table(root->off_block_modes))[i]; }
+	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(table(root->off_decimation_modes))[i]; }
+	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(table(root->off_decimation_infos))[i]; }
+	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return table(root->off_partitions[pcount - 1]) + (uint32_t)packed * root->partition_stride; }
+	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(table(root->off_quant_xfer))[q]; }
 };
 
 /* Rebuild the wave's context inside an out-of-line stage function.  On the device everything comes
@@ -280,19 +309,6 @@ struct Ctx {
 extern __shared__ __attribute__((aligned(16))) uint8_t astc_lds[];
 #endif
 #if WV_DEVICE
-WV_FN uint32_t wv_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-WV_FN int wv_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-WV_FN bool wv_uniform(bool v) { return __builtin_amdgcn_readfirstlane(v ? 1 : 0) != 0; }
-WV_FN float wv_uniform(float v) { return int_as_float(__builtin_amdgcn_readfirstlane(float_as_int(v))); }
-/* The same value, but the optimiser cannot see through it: an expression built on wv_opaque(lane) is not loop
- * invariant, so it is computed where it is used instead of being hoisted to the top of the kernel and carried (or
- * spilled to scratch memory) across every stage in between.  No instruction is emitted. */
-WV_FN int wv_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-WV_FN uint64_t wv_uniform(uint64_t v)
-{
-	uint32_t lo = wv_uniform((uint32_t)v), hi = wv_uniform((uint32_t)(v >> 32));
-	return ((uint64_t)hi << 32) | lo;
-}
 WV_FN Ctx ctx_make()
 {
 	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(astc_lds);
@@ -312,11 +328,6 @@ WV_FN Ctx ctx_make()
 	return c;
 }
 #else
-WV_FN uint32_t wv_uniform(uint32_t v) { return v; }
-WV_FN int wv_uniform(int v) { return v; }
-WV_FN int wv_opaque(int v) { return v; }
-WV_FN bool wv_uniform(bool v) { return v; }
-WV_FN float wv_uniform(float v) { return v; }
 extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block
 WV_FN Ctx ctx_make() { return *g_wave_ctx; }
 #endif
@@ -535,14 +546,14 @@ WV_FN DecView dec_view_at(const DecimationInfo& di, const uint8_t* base /* addre
 WV_FN DecView dec_view_global(const Ctx& c, int dm)
 {
 	const DecimationInfo& di = c.dec_info(dm);
-	return dec_view_at(di, c.tab + di.off_texel_weights);
+	return dec_view_at(di, c.table(di.off_texel_weights));
 }
 
 WV_FN DecView dec_view_staged(const Ctx& c, int dm)
 {
 	const DecimationInfo& di = c.dec_info(dm);
 	uint8_t* dst = c.lds + c.L->dtab;
-	stage_words(dst, c.tab + di.off_texel_weights, (int)((di.table_bytes + 3) / 4));
+	stage_words(dst, c.table(di.off_texel_weights), (int)((di.table_bytes + 3) / 4));
 	return dec_view_at(di, dst);
 }
 
@@ -551,7 +562,7 @@ WV_FN DecView dec_view_lds(const Ctx& c, int dm)
 {
 	const DecimationInfo& di = c.dec_info(dm);
 	DecView v = dec_view_at(di, c.lds + c.L->dtab);
-	if (di.realign_speculative) v.later = c.tab + di.off_realign_later;
+	if (di.realign_speculative) v.later = c.table(di.off_realign_later);
 	return v;
 }
 

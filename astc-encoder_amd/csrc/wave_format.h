@@ -452,7 +452,7 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
  * :905-957, :1041-1093) */
 WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available, ModeRec& m)
 {
-	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.tab + c.root->off_quant_mode_table);
+	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.table(c.root->off_quant_mode_table));
 	float best_integer_count_error = ERROR_CALC_DEFAULT;
 
 	if (pc == 1)

@@ -56,8 +56,8 @@ WV_FN void encode_ise(const Ctx& c, int quant, unsigned int count, const uint8_t
 	Btq b = btq_of(quant);
 	unsigned int bits = b.bits;
 	unsigned int mask = (1u << bits) - 1;
-	const uint8_t* trit_tab = c.tab + c.root->off_integer_of_trits;
-	const uint8_t* quint_tab = c.tab + c.root->off_integer_of_quints;
+	const uint8_t* trit_tab = c.table(c.root->off_integer_of_trits);
+	const uint8_t* quint_tab = c.table(c.root->off_integer_of_quints);
 
 	if (b.trits)
 	{
@@ -238,7 +238,7 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 	}
 
 	int valuecount = 0;
-	const uint8_t* pack_table = c.tab + c.root->off_color_uquant_to_pquant + (scb.quant_mode - QUANT_6) * 256;
+	const uint8_t* pack_table = c.table(c.root->off_color_uquant_to_pquant) + (scb.quant_mode - QUANT_6) * 256;
 	for (unsigned int i = 0; i < partition_count; i++)
 	{
 		int vals = 2 * (scb.color_formats[i] >> 2) + 2;

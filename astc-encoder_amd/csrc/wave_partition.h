@@ -209,7 +209,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 
 	// ---- bitmaps over the k-means texel subset (ref: :483-490) ----
 	const int texels_to_process = i_min(T, MAX_KMEANS_TEXELS);
-	const uint8_t* km = c.tab + c.root->off_kmeans_texels;
+	const uint8_t* km = c.table(c.root->off_kmeans_texels);
 	WV_FOR(p, pc)
 	{
 		uint64_t bm = 0;
@@ -223,7 +223,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 
 	// ---- mismatch counts against every selected partitioning (ref: :365-401) ----
 	const int count = (int)c.root->partitioning_count_selected[pc - 1];
-	const uint64_t* cov = reinterpret_cast<const uint64_t*>(c.tab + c.root->off_coverage[pc - 1]);
+	const uint64_t* cov = reinterpret_cast<const uint64_t*>(c.table(c.root->off_coverage[pc - 1]));
 	WV_FOR(i, count)
 	{
 		int m;
@@ -555,6 +555,8 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 	const uint32_t rec_inv24 = wv_uniform(c.L->part_rec_inv24);
 	const int chunk = wv_uniform((int)c.L->part_chunk);
 	uint32_t* staged = reinterpret_cast<uint32_t*>(c.lds + c.L->part_tabs);
+	const uint8_t* part_base = c.table(c.root->off_partitions[pc - 1]);
+	const uint32_t part_stride = wv_uniform(c.root->partition_stride);
 	for (int first = 0; first < partition_search_limit; first += chunk)
 	{
 		const int nn = i_min(chunk, partition_search_limit - first);
@@ -562,8 +564,8 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 		WV_FOR(k, nn * rec_words)
 		{
 			int sl = (int)(((uint32_t)k * rec_inv24) >> 24), w = k - sl * rec_words;
-			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.part_rec(pc, ps.ordering()[first + sl]));
-			staged[k] = src[w];
+			// (word w of the record of partitioning ordering[first + sl]: scalar table base + a 32-bit byte offset)
+			staged[k] = table_at_byte<uint32_t>(part_base, (uint32_t)ps.ordering()[first + sl] * part_stride + (uint32_t)w * 4u);
 		}
 		WV_SYNC();
 		WV_FOR(i, nn)

@@ -31,14 +31,14 @@ WV_FN float infill4_at(const float* wts, const uint8_t* tab, uint32_t tw_off, ui
 {
 	const float* tabf = reinterpret_cast<const float*>(tab);
 	const uint32_t a = tw_off + t, b = tcf_off + t;
-	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]) +
-	       (wts[tab[a + 2 * T]] * tabf[b + 2 * T] + wts[tab[a + 3 * T]] * tabf[b + 3 * T]);
+	return (wts[tab[a]] * table_at(tabf, b) + wts[tab[a + T]] * table_at(tabf, b + T)) +
+	       (wts[tab[a + 2 * T]] * table_at(tabf, b + 2 * T) + wts[tab[a + 3 * T]] * table_at(tabf, b + 3 * T));
 }
 WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, uint32_t tcf_off, uint32_t T, uint32_t t)
 {
 	const float* tabf = reinterpret_cast<const float*>(tab);
 	const uint32_t a = tw_off + t, b = tcf_off + t;
-	return (wts[tab[a]] * tabf[b] + wts[tab[a + T]] * tabf[b + T]);
+	return (wts[tab[a]] * table_at(tabf, b) + wts[tab[a + T]] * table_at(tabf, b + T));
 }
 
 // taps of a weight fetched per round trip in the decimation sweeps (table loads in flight per lane = 2x this)
@@ -81,7 +81,7 @@ WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 		{
 			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
 			tx[u] = tab[wt + j * uW];
-			wv[u] = tabf[wc + j * uW];
+			wv[u] = table_at(tabf, wc + j * uW);
 		}
 		#pragma unroll
 		for (int u = 0; u < GROUP; u++)
@@ -126,7 +126,7 @@ WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf
 		{
 			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
 			tx[u] = tab[wt + j * uW];
-			wv[u] = tabf[wc + j * uW];
+			wv[u] = table_at(tabf, wc + j * uW);
 		}
 		#pragma unroll
 		for (int u = 0; u < GROUP; u++)
@@ -162,8 +162,8 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const TableRoot& r = *c.root;
 	const int T = c.T, Tp = c.Tp;
 	const int cls = nplanes == 2 ? 1 : 0;          // trial class: selects the packing of the dwi region
-	const DwiSlot* slots = reinterpret_cast<const DwiSlot*>(c.tab + r.off_dwi_slots[cls]);
-	const InfillSet* isets = reinterpret_cast<const InfillSet*>(c.tab + r.off_infill_sets[cls]);
+	const DwiSlot* slots = reinterpret_cast<const DwiSlot*>(c.table(r.off_dwi_slots[cls]));
+	const InfillSet* isets = reinterpret_cast<const InfillSet*>(c.table(r.off_infill_sets[cls]));
 	float* dwi_base = reinterpret_cast<float*>(c.lds + c.L->dwi);
 	uint8_t* isamp = c.isample();
 	float* infilled = c.uni_f();
@@ -176,9 +176,9 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const bool all_grids = max_dm >= (int)r.decimation_mode_count_selected;
 	const int nsets_used = all_grids ? (int)r.dwi_used_sets[cls][quant_limit] : nsets_all;
 	const uint32_t t_inv = c.L->t_inv24;                                       // k / T == (k * t_inv) >> 24
-	const DwiOrderDir& dir = reinterpret_cast<const DwiOrderDir*>(c.tab + r.off_dwi_order[cls])[quant_limit];
+	const DwiOrderDir& dir = reinterpret_cast<const DwiOrderDir*>(c.table(r.off_dwi_order[cls]))[quant_limit];
 	const bool sorted = all_grids && dir.chunks != 0;
-	const uint16_t* order = reinterpret_cast<const uint16_t*>(c.tab + dir.list_off);
+	const uint16_t* order = reinterpret_cast<const uint16_t*>(c.table(dir.list_off));
 
 	// chunks of (grid, plane) sets whose texel-resolution infill fits the scratch region
 	int p0 = 0, chunk = 0;
@@ -198,8 +198,8 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		{ PROF_SCOPE(c, PS_DEC1);
 		WV_FOR(j, n_items)
 		{
-			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
-			const DwiSlot sl = slots[k];
+			const int k = sorted ? (int)table_at(order, (uint32_t)(o_begin + j)) : k_begin + j;
+			const DwiSlot sl = table_at(slots, (uint32_t)k);
 			if (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask))) continue;
 			const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
 			dwi_base[k] = w0;
@@ -212,7 +212,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		WV_FOR(k, nsets * T)
 		{
 			int set = (int)(((uint32_t)k * t_inv) >> 24), t = k - set * T;
-			const InfillSet is = isets[p0 + set];
+			const InfillSet is = table_at(isets, (uint32_t)(p0 + set));
 			if (is.direct || (int)is.dm >= max_dm || !(is.refprec & ref_mask)) continue;
 			const float* wts = dwi_base + is.dwi_offset;
 			infilled[set * Tp + t] = is.taps <= 2 ? infill2_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t)
@@ -224,8 +224,8 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		{ PROF_SCOPE(c, PS_DEC3);
 		WV_FOR(j, n_items)
 		{
-			const int k = sorted ? (int)order[o_begin + j] : k_begin + j;
-			const DwiSlot sl = slots[k];
+			const int k = sorted ? (int)table_at(order, (uint32_t)(o_begin + j)) : k_begin + j;
+			const DwiSlot sl = table_at(slots, (uint32_t)k);
 			if ((sl.flags & 1) || (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)))) continue;
 			const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
 			dwi_base[k] = w1;
@@ -267,8 +267,8 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 {
 	float* ang = c.ang();               // [64][8]: offset, lowest, span, err, cut_low, cut_high
 	TrialInfo& tr = c.tr();
-	const float* sin_table = reinterpret_cast<const float*>(c.tab + c.root->off_sin_table);
-	const float* cos_table = reinterpret_cast<const float*>(c.tab + c.root->off_cos_table);
+	const float* sin_table = reinterpret_cast<const float*>(c.table(c.root->off_sin_table));
+	const float* cos_table = reinterpret_cast<const float*>(c.table(c.root->off_cos_table));
 
 	// steps of every set, one per lane: the batching below then needs no memory access per set
 	LaneArray128 steps_of;
@@ -326,8 +326,8 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				for (int u = 0; u < 8; u++)
 				{
 					const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
-					cs[u] = cos_table[at];
-					sn[u] = sin_table[at];
+					cs[u] = table_at(cos_table, at);
+					sn[u] = table_at(sin_table, at);
 				}
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
