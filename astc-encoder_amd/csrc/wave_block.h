@@ -220,7 +220,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				if (h.taps == 4)
 				{
 					const int i0 = tab[tw], i1 = tab[tw + uT], i2 = tab[tw + 2 * uT], i3 = tab[tw + 3 * uT];
-					const float c0 = tabf[tcf], c1 = tabf[tcf + uT], c2 = tabf[tcf + 2 * uT], c3 = tabf[tcf + 3 * uT];
+					const float c0 = table_at(tabf, tcf), c1 = table_at(tabf, tcf + uT), c2 = table_at(tabf, tcf + 2 * uT), c3 = table_at(tabf, tcf + 3 * uT);
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
@@ -238,7 +238,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				else if (h.taps == 2)
 				{
 					const int i0 = tab[tw], i1 = tab[tw + uT];
-					const float c0 = tabf[tcf], c1 = tabf[tcf + uT];
+					const float c0 = table_at(tabf, tcf), c1 = table_at(tabf, tcf + uT);
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];

@@ -295,11 +295,11 @@ struct Ctx {
 	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
-	WV_FN const BlockMode& block_mode(int i) const { return reinterpret_cast<const BlockMode*>(table(root->off_block_modes))[i]; }
-	WV_FN const DecimationMode& dec_mode(int i) const { return reinterpret_cast<const DecimationMode*>(table(root->off_decimation_modes))[i]; }
-	WV_FN const DecimationInfo& dec_info(int i) const { return reinterpret_cast<const DecimationInfo*>(table(root->off_decimation_infos))[i]; }
+	WV_FN const BlockMode& block_mode(int i) const { return table_at(reinterpret_cast<const BlockMode*>(table(root->off_block_modes)), (uint32_t)i); }
+	WV_FN const DecimationMode& dec_mode(int i) const { return table_at(reinterpret_cast<const DecimationMode*>(table(root->off_decimation_modes)), (uint32_t)i); }
+	WV_FN const DecimationInfo& dec_info(int i) const { return table_at(reinterpret_cast<const DecimationInfo*>(table(root->off_decimation_infos)), (uint32_t)i); }
 	WV_FN const uint8_t* part_rec(int pcount, int packed) const { return table(root->off_partitions[pcount - 1]) + (uint32_t)packed * root->partition_stride; }
-	WV_FN const QuantXfer& qxfer(int q) const { return reinterpret_cast<const QuantXfer*>(table(root->off_quant_xfer))[q]; }
+	WV_FN const QuantXfer& qxfer(int q) const { return table_at(reinterpret_cast<const QuantXfer*>(table(root->off_quant_xfer)), (uint32_t)q); }
 };
 
 /* Rebuild the wave's context inside an out-of-line stage function.  On the device everything comes
