@@ -324,24 +324,10 @@ WV_FN i4 operator-(i4 a, i4 b) { return mki4(a.x - b.x, a.y - b.y, a.z - b.z, a.
 WV_FN i4 operator*(i4 a, int b) { return mki4(a.x * b, a.y * b, a.z * b, a.w * b); }
 WV_FN f4 int_to_float4(i4 a) { return mk4((float)a.x, (float)a.y, (float)a.z, (float)a.w); }
 
-/* c ? a : b on all four lanes of an f4 with ONE condition.  The compiler turns such a select into one v_cmp and four
- * back-to-back VOP2 v_cndmask_b32 on VCC -- and on gfx950 the third and every further v_cndmask_b32_e32 in a row costs
- * ~22 cycles instead of ~4 (tools/valu_microbench2.hip).  The VOP3 encoding with the lane mask in
- * an SGPR pair does not have that penalty, so hot per-texel loops that select whole vectors go through this. */
-WV_FN f4 select4(bool c, f4 a, f4 b)
-{
-#if WV_DEVICE
-	const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
-	f4 r;
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.x) : "v"(b.x), "v"(a.x), "s"(m));
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.y) : "v"(b.y), "v"(a.y), "s"(m));
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.z) : "v"(b.z), "v"(a.z), "s"(m));
-	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r.w) : "v"(b.w), "v"(a.w), "s"(m));
-	return r;
-#else
-	return c ? a : b;
-#endif
-}
+/* c ? a : b on all four components of an f4 with one condition.  (A VOP3 v_cndmask_b32_e64 version on a ballot mask,
+ * tried because runs of three or more VOP2 v_cndmask_b32 cost ~22 cycles each in tools/valu_microbench2.hip, made no
+ * difference in the kernel in two same-call A/B runs and cost ~1.4 k instructions per block: dropped.) */
+WV_FN f4 select4(bool c, f4 a, f4 b) { return c ? a : b; }
 
 /* atan2 approximation (ref: vecmathlib.h:275-306) */
 WV_FN float ref_change_sign(float a, float b)
