@@ -1038,6 +1038,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 	//  run-time indexed local arrays would live in scratch memory)
 	float best_errorval_prev_pcount = ERROR_CALC_DEFAULT;      // best error with one partition fewer
 	const float errorval_overshoot = wv_uniform(1.0f / cfg.tune_mse_overshoot);
+	const float trial_threshold = wv_uniform(error_threshold * errorval_overshoot);     // what the 2-plane and partitioned trials aim for
 
 	int start_trial = 1;
 	if (cfg.tune_search_mode0_enable >= 0.85f && c.root->dim_z == 1) start_trial = 0;   // ref: compress_symbolic.cpp:1287
@@ -1072,7 +1073,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 			if (blk.grayscale && i != 3) continue;
 			if (is_constant_channel(blk, i)) continue;
 
-			float errorval = compress_block_2planes(c, error_threshold * errorval_overshoot, i, quant_limit);
+			float errorval = compress_block_2planes(c, trial_threshold, i, quant_limit);
 			WV_SYNC();
 			if (errorval > (best_errorval_prev_pcount * 1.85f)) break;
 			if (errorval < error_threshold) done = true;
@@ -1107,7 +1108,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 
 			for (int i = 0; i < actual_trials; i++)
 			{
-				float errorval = compress_block_1plane(c, false, error_threshold * errorval_overshoot,
+				float errorval = compress_block_1plane(c, false, trial_threshold,
 				                                       partition_count, partition_indices.get(i), quant_limit);
 				WV_SYNC();
 				best_error = wv_uniform(f_min(best_error, errorval));

@@ -279,22 +279,26 @@ WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, 
 		int cc = (int)f_clamp(cf, 0.0f, 65536.0f);
 		int d = (int)f_clamp(df, 0.0f, 65536.0f);
 
+		// (each comparison is turned into a 0 / 1 integer at once: as thirteen && chains the compiler keeps some twenty
+		//  lane masks alive at the same time, more scalar registers than an out-of-line stage has without parking
+		//  some in a vector register -- which costs a scratch frame)
+		auto below = [](int v, int limit) { return wv_opaque(v < limit ? 1 : 0); };
 		int rgbo_mode = 5;
-		if (b < 32768 && cc < 16384) rgbo_mode = 4;
-		if (b < 8192 && cc < 16384) rgbo_mode = 3;
-		if (b < 2048 && cc < 16384) rgbo_mode = 2;
-		if (b < 2048 && cc < 1024) rgbo_mode = 1;
-		if (b < 1024 && cc < 4096) rgbo_mode = 0;
+		if (below(b, 32768) & below(cc, 16384)) rgbo_mode = 4;
+		if (below(b, 8192) & below(cc, 16384)) rgbo_mode = 3;
+		if (below(b, 2048) & below(cc, 16384)) rgbo_mode = 2;
+		if (below(b, 2048) & below(cc, 1024)) rgbo_mode = 1;
+		if (below(b, 1024) & below(cc, 4096)) rgbo_mode = 0;
 
 		int rgb_mode = 8;
-		if (b < 16384 && cc < 8192 && d < 8192) rgb_mode = 0;
-		if (b < 32768 && cc < 8192 && d < 4096) rgb_mode = 1;
-		if (b < 4096 && cc < 8192 && d < 4096) rgb_mode = 2;
-		if (b < 8192 && cc < 8192 && d < 2048) rgb_mode = 3;
-		if (b < 8192 && cc < 2048 && d < 512) rgb_mode = 4;
-		if (b < 2048 && cc < 8192 && d < 1024) rgb_mode = 5;
-		if (b < 2048 && cc < 2048 && d < 256) rgb_mode = 6;
-		if (b < 1024 && cc < 2048 && d < 512) rgb_mode = 7;
+		if (below(b, 16384) & below(cc, 8192) & below(d, 8192)) rgb_mode = 0;
+		if (below(b, 32768) & below(cc, 8192) & below(d, 4096)) rgb_mode = 1;
+		if (below(b, 4096) & below(cc, 8192) & below(d, 4096)) rgb_mode = 2;
+		if (below(b, 8192) & below(cc, 8192) & below(d, 2048)) rgb_mode = 3;
+		if (below(b, 8192) & below(cc, 2048) & below(d, 512)) rgb_mode = 4;
+		if (below(b, 2048) & below(cc, 8192) & below(d, 1024)) rgb_mode = 5;
+		if (below(b, 2048) & below(cc, 2048) & below(d, 256)) rgb_mode = 6;
+		if (below(b, 1024) & below(cc, 2048) & below(d, 512)) rgb_mode = 7;
 
 		const float rgbo_error_scales[6] = { 4.0f, 4.0f, 16.0f, 64.0f, 256.0f, 1024.0f };
 		const float rgb_error_scales[9] = { 64.0f, 64.0f, 16.0f, 16.0f, 4.0f, 4.0f, 1.0f, 1.0f, 384.0f };

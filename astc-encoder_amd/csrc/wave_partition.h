@@ -565,7 +565,7 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 		{
 			int sl = (int)(((uint32_t)k * rec_inv24) >> 24), w = k - sl * rec_words;
 			// (word w of the record of partitioning ordering[first + sl]: scalar table base + a 32-bit byte offset)
-			staged[k] = table_at_byte<uint32_t>(part_base, (uint32_t)ps.ordering()[first + sl] * part_stride + (uint32_t)w * 4u);
+			staged[wv_opaque(k)] = table_at_byte<uint32_t>(part_base, (uint32_t)ps.ordering()[first + sl] * part_stride + (uint32_t)w * 4u);
 		}
 		WV_SYNC();
 		WV_FOR(i, nn)

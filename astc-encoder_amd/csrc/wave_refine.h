@@ -459,9 +459,26 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 			}
 		}
 
-		if (kHdr && (blk.rgb_lns || blk.alpha_lns))
+		store4(tr.wep0[0], ep0);
+		store4(tr.wep1[0], ep1);
+		store4(tr.rgbs[0], rgbs);
+	}
+	WV_SYNC();
+
+	// HDR endpoints: the rgbo vector (ref: :1614-1640).  Its inputs are read back from the sums in LDS instead of being
+	// kept in registers across the two solves above (the HDR build of this function needed callee-saved registers,
+	// i.e. a scratch frame, for them).
+	if (kHdr && (blk.rgb_lns || blk.alpha_lns))
+	{
+		WV_ONE
 		{
-			weight_weight_sum = weight_weight_sum * color_weight;
+			const float* s = tr.fbox;
+			const f4 color_weight = load4(blk.cw);
+			const f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
+			const f4 right1_sum = splat4(s[8]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
+			const f4 color_vec_x = load4(&s[12]) * color_weight;
+			const f4 color_vec_y = load4(&s[16]) * color_weight;
+			const f4 weight_weight_sum = load4(&s[22]) * color_weight;
 			f4 sel = mk4(plane2_component == 0 ? right2_sum.x : right1_sum.x, plane2_component == 1 ? right2_sum.y : right1_sum.y,
 			             plane2_component == 2 ? right2_sum.z : right1_sum.z, plane2_component == 3 ? right2_sum.w : right1_sum.w);
 			float psum = dot3_s(sel, color_weight);
@@ -470,7 +487,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
 			if (f_isnan(dot_s(rgbovec, rgbovec)))
 			{
-				f4 v0 = ep0, v1 = ep1;
+				f4 v0 = load4(tr.wep0[0]), v1 = load4(tr.wep1[0]);
 				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
 				avgdif = f_max(avgdif, 0.0f);
 				f4 avg = (v0 + v1) * 0.5f;
@@ -479,12 +496,8 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 			}
 			store4(tr.rgbo[0], rgbovec);
 		}
-
-		store4(tr.wep0[0], ep0);
-		store4(tr.wep1[0], ep1);
-		store4(tr.rgbs[0], rgbs);
+		WV_SYNC();
 	}
-	WV_SYNC();
 }
 
 // ---------------------------------------------------------------------------------------------
