@@ -6,12 +6,13 @@
 //        unpack_weights / lerp_color_int / decode_texel       :37-155
 //        store_image_block           Source/astcenc_image.cpp:345-573
 //
-// One wavefront decodes one block.  Unlike the reference (and unlike the encoder) nothing here reads
-// a table: the decoder must accept every legal block mode and partitioning, not just the ones a
-// compression preset selects, so grid weights are infilled with the format's arithmetic rule, BISE
-// symbols are unpacked per element straight from the bit stream, and texels are assigned to
-// partitions with the hash function.  Lanes own weights / colour values while unpacking and texels
-// while interpolating.
+// One wavefront decodes a batch of consecutive blocks (decode_block_batch).  Unlike the reference (and unlike the
+// encoder) nothing here depends on tables built for a block size or a preset: the decoder must accept every legal
+// block mode and partitioning, not just the ones a compression preset selects, so grid weights are infilled with the
+// format's arithmetic rule and texels are assigned to partitions with the hash function.  BISE symbols are unpacked per
+// element straight from the bit stream; the batched path looks trit / quint groups and unquantized values up in four
+// tables of format constants generated from the arithmetic routines below (decode_luts.inc).  Lanes own weights /
+// colour values while unpacking and texels while interpolating.
 #pragma once
 #include "wave_color.h"
 #include "wave_load.h"
