@@ -239,6 +239,7 @@ WV_FN float wv_uniform(float v) { return int_as_float(__builtin_amdgcn_readfirst
  * invariant, so it is computed where it is used instead of being hoisted to the top of the kernel and carried (or
  * spilled to scratch memory) across every stage in between.  No instruction is emitted. */
 WV_FN int wv_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+WV_FN float wv_opaque_f(float v) { asm volatile("" : "+v"(v)); return v; }
 WV_FN uint64_t wv_uniform(uint64_t v)
 {
 	uint32_t lo = wv_uniform((uint32_t)v), hi = wv_uniform((uint32_t)(v >> 32));
@@ -248,6 +249,7 @@ WV_FN uint64_t wv_uniform(uint64_t v)
 WV_FN uint32_t wv_uniform(uint32_t v) { return v; }
 WV_FN int wv_uniform(int v) { return v; }
 WV_FN int wv_opaque(int v) { return v; }
+WV_FN float wv_opaque_f(float v) { return v; }
 WV_FN bool wv_uniform(bool v) { return v; }
 WV_FN float wv_uniform(float v) { return v; }
 WV_FN uint64_t wv_uniform(uint64_t v) { return v; }

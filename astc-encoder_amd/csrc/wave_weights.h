@@ -332,13 +332,15 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
 				{
-					if (j0 + u < W)
-					{
-						anglesum_x += cs[u];
-						anglesum_y += sn[u];
-						min_weight = wj[u] < min_weight ? wj[u] : min_weight;
-						max_weight = wj[u] > max_weight ? wj[u] : max_weight;
-					}
+					// past the set's last weight: wj is a copy of weight 0 (no effect on min / max) and the table values
+					// are replaced by +0.0, which leaves the sums as they are (they are never -0.0: they start at +0.0)
+					// as a multiplication by 1.0 / 0.0 (exact: the products are cs, sn or a signed zero), so that what stays
+					// live across the table loads is a vector register per slot, not a lane mask in a scalar register pair
+					const float keep = wv_opaque_f(j0 + u < W ? 1.0f : 0.0f);
+					anglesum_x += cs[u] * keep;
+					anglesum_y += sn[u] * keep;
+					min_weight = wj[u] < min_weight ? wj[u] : min_weight;
+					max_weight = wj[u] > max_weight ? wj[u] : max_weight;
 				}
 			}
 			float angle = ref_atan2(anglesum_y, anglesum_x);
@@ -358,15 +360,18 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				#pragma unroll
 				for (int u = 0; u < 8; u++)
 				{
-					if (j0 + u < W)
-					{
-						float sval = wj[u] * rcp_stepsize - offset;
-						float svalrte = f_round(sval);
-						float diff = sval - svalrte;
-						errval += diff * diff;
-						if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
-						if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
-					}
+					// past the set's last weight (wj is a copy of weight 0 there): the squared difference is multiplied by 0.0
+					// (+0.0 added to a sum that is >= +0.0: exact) and the rounded value is pushed out of the index range so
+					// that neither cut test fires -- arithmetic on a 1.0 / 0.0 flag in a vector register instead of a branch
+					// or a lane mask per slot (eight of those do not fit the scalar registers of an out-of-line stage)
+					const float keep = wv_opaque_f(j0 + u < W ? 1.0f : 0.0f);
+					float sval = wj[u] * rcp_stepsize - offset;
+					float svalrte = f_round(sval);
+					float diff = sval - svalrte;
+					errval += (diff * diff) * keep;
+					const float key = svalrte + (1.0f - keep) * 1e30f;       // == svalrte for a real weight
+					if (key == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
+					if (key == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
 				}
 			}
 			int max_quant_steps = steps;
