@@ -404,7 +404,6 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 		f4 color_vec_x = load4(&s[12]) * color_weight;
 		f4 color_vec_y = load4(&s[16]) * color_weight;
 		float scale_vec0 = s[20], scale_vec1 = s[21];
-		f4 weight_weight_sum = load4(&s[22]);
 
 		float scalediv = scale_min / f_max(scale_max, 1e-10f);
 		scalediv = f_clamp1(scalediv);
