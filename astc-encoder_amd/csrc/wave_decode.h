@@ -438,10 +438,14 @@ WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int block_
 	return wbits >= 24 && wbits <= 96;
 }
 
-/* (ref: select_partition / hash52, astcenc_partition_tables.cpp:66-245) */
-WV_FN int partition_of_texel(int seed, int x, int y, int z, int partition_count, bool small_block)
+/* The partition hash (ref: select_partition / hash52, astcenc_partition_tables.cpp:66-245) in two steps: everything
+ * that depends on the block only -- the scrambled seed, its twelve 4-bit multipliers after squaring and shifting, the
+ * four offsets -- is packed into four words (x | y << 8 | z << 16 multipliers and the offset << 24 of the a, b, c, d
+ * terms; the terms a partition count does not use are zero), then a texel needs three multiply-adds per term. */
+struct PartitionHash { uint32_t term[4]; };
+
+WV_FN PartitionHash partition_hash_setup(int seed, int partition_count)
 {
-	if (small_block) { x <<= 1; y <<= 1; z <<= 1; }
 	seed += (partition_count - 1) * 1024;
 	uint32_t rnum = (uint32_t)seed;
 	rnum ^= rnum >> 15; rnum -= rnum << 17; rnum += rnum << 7; rnum += rnum << 4;
@@ -461,17 +465,34 @@ WV_FN int partition_of_texel(int seed, int x, int y, int z, int partition_count,
 	s1 >>= sh1; s2 >>= sh2; s3 >>= sh1; s4 >>= sh2; s5 >>= sh1; s6 >>= sh2; s7 >>= sh1; s8 >>= sh2;
 	s9 >>= sh3; s10 >>= sh3; s11 >>= sh3; s12 >>= sh3;
 
-	int a = (int)(s1 * (uint32_t)x + s2 * (uint32_t)y + s11 * (uint32_t)z + (rnum >> 14));
-	int b = (int)(s3 * (uint32_t)x + s4 * (uint32_t)y + s12 * (uint32_t)z + (rnum >> 10));
-	int c = (int)(s5 * (uint32_t)x + s6 * (uint32_t)y + s9 * (uint32_t)z + (rnum >> 6));
-	int d = (int)(s7 * (uint32_t)x + s8 * (uint32_t)y + s10 * (uint32_t)z + (rnum >> 2));
-	a &= 0x3F; b &= 0x3F; c &= 0x3F; d &= 0x3F;
-	if (partition_count <= 3) d = 0;
-	if (partition_count <= 2) c = 0;
+	// only the low six bits of a term matter, so the offsets are kept modulo 64
+	PartitionHash h;
+	h.term[0] = s1 | (s2 << 8) | (s11 << 16) | (((rnum >> 14) & 0x3Fu) << 24);
+	h.term[1] = s3 | (s4 << 8) | (s12 << 16) | (((rnum >> 10) & 0x3Fu) << 24);
+	h.term[2] = partition_count <= 2 ? 0u : s5 | (s6 << 8) | (s9 << 16) | (((rnum >> 6) & 0x3Fu) << 24);
+	h.term[3] = partition_count <= 3 ? 0u : s7 | (s8 << 8) | (s10 << 16) | (((rnum >> 2) & 0x3Fu) << 24);
+	return h;
+}
+
+WV_FN int partition_from_hash(const PartitionHash& h, int x, int y, int z, bool small_block)
+{
+	if (small_block) { x <<= 1; y <<= 1; z <<= 1; }
+	int v[4];
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t t = h.term[k];
+		v[k] = (int)(((t & 0xFFu) * (uint32_t)x + ((t >> 8) & 0xFFu) * (uint32_t)y + ((t >> 16) & 0xFFu) * (uint32_t)z + (t >> 24)) & 0x3Fu);
+	}
+	const int a = v[0], b = v[1], c = v[2], d = v[3];
 	if (a >= b && a >= c && a >= d) return 0;
 	if (b >= c && b >= d) return 1;
 	if (c >= d) return 2;
 	return 3;
+}
+
+WV_FN int partition_of_texel(int seed, int x, int y, int z, int partition_count, bool small_block)
+{
+	return partition_from_hash(partition_hash_setup(seed, partition_count), x, y, z, small_block);
 }
 
 /* (ref: unorm16_to_sf16, astcenc_vecmathlib.h:503) */
@@ -857,8 +878,9 @@ struct DecodeBlockRec {
 	uint32_t b;          // colour bits | colour kind << 8 | colour quant << 16 | colour value count << 24
 	uint32_t c;          // weight count over both planes | dual << 8 | first colour bit << 16 | partition count << 24
 	uint32_t d;          // grid x | y << 8 | z << 16 | second plane's component (255 = none) << 24
-	uint32_t seed;
 	uint32_t origin[3];  // texel coordinates of the block's first texel
+	uint32_t pad;
+	PartitionHash hash;  // multi-partition blocks: the per-block part of the partition hash
 };
 
 struct DecodeBatch {
@@ -928,7 +950,9 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 			r.b = (uint32_t)cq.bits | ((cq.trits ? 1u : cq.quints ? 2u : 0u) << 8) | ((uint32_t)h.cquant << 16) | ((uint32_t)h.nvals << 24);
 			r.c = (uint32_t)(h.dual ? 2 * wcount : wcount) | ((h.dual ? 1u : 0u) << 8) | ((uint32_t)h.color_start << 16) | ((uint32_t)h.parts << 24);
 			r.d = (uint32_t)h.wx | ((uint32_t)h.wy << 8) | ((uint32_t)h.wz << 16) | (((uint32_t)h.plane2 & 0xFFu) << 24);
-			r.seed = (uint32_t)h.seed;
+			r.pad = 0u;
+			if (!skip && h.parts > 1) r.hash = partition_hash_setup(h.seed, h.parts);
+			else { r.hash.term[0] = 0u; r.hash.term[1] = 0u; r.hash.term[2] = 0u; r.hash.term[3] = 0u; }
 		}
 		{
 			const Bits128 rv = bits_reversed(blk);
@@ -1077,7 +1101,7 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 			int wp[2];
 			infill_texel_weights((int)(rd & 0xFFu), (int)((rd >> 8) & 0xFFu), (int)((rd >> 16) & 0xFFu), dual, ps.weights,
 			                     (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
-			const int p = parts == 1 ? 0 : partition_of_texel((int)rec.seed, tx, ty, tz, parts, small_block);
+			const int p = parts == 1 ? 0 : partition_from_hash(rec.hash, tx, ty, tz, small_block);
 			const int* e = ps.ep[p];
 			int cv[4];
 			for (int q = 0; q < 4; q++)
