@@ -51,8 +51,8 @@ inline void decode_image_prepare(DecodeImage& img)
 struct DecodeScratch {
 	uint8_t weights[2][64];   // unquantized grid weights per plane, 0..64
 	uint8_t colors[32];       // unquantized colour values, 0..255
-	int     ep[4][8];         // endpoint0.rgba, endpoint1.rgba per partition (16-bit domain)
-	int     lns[4][2];        // rgb / alpha are LNS encoded, per partition
+	uint16_t ep[4][8];        // endpoint0.rgba, endpoint1.rgba per partition (16-bit domain)
+	uint8_t  lns[4][2];       // rgb / alpha are LNS encoded, per partition
 };
 
 /* 128-bit block held as four dwords, bit 0 = LSB of byte 0. */
@@ -71,11 +71,15 @@ WV_FN uint32_t bits_get(const Bits128& b, int off, int n)
 
 WV_FN uint32_t rev32(uint32_t v)
 {
+#if WV_DEVICE
+	return __builtin_bitreverse32(v);       // v_bfrev_b32
+#else
 	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
 	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
 	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
 	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
 	return (v >> 16) | (v << 16);
+#endif
 }
 
 /* The weight stream is stored from the top of the block downwards: bit i of it is bit 127 - i. */
@@ -764,9 +768,9 @@ WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int pr
 		for (int j = 0; j < 8; j++) in[j] = j < n ? s.colors[first + j] : 0;
 		i4 e0, e1;
 		unpack_color_endpoints(profile, f, in, e0, e1);
-		int* o = s.ep[p];
-		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
-		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+		uint16_t* o = s.ep[p];
+		o[0] = (uint16_t)e0.x; o[1] = (uint16_t)e0.y; o[2] = (uint16_t)e0.z; o[3] = (uint16_t)e0.w;
+		o[4] = (uint16_t)e1.x; o[5] = (uint16_t)e1.y; o[6] = (uint16_t)e1.z; o[7] = (uint16_t)e1.w;
 		bool rgb_lns, alpha_lns;
 		endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
 		s.lns[p][0] = rgb_lns ? 1 : 0;
@@ -845,7 +849,7 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 			infill_texel_weights(h, s.weights, (1024 + block_x / 2) / (block_x - 1), (1024 + block_y / 2) / (block_y - 1),
 			                     block_z > 1 ? (1024 + block_z / 2) / (block_z - 1) : 0, block_z, tx, ty, tz, wp);
 			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
-			const int* e = s.ep[p];
+			const uint16_t* e = s.ep[p];
 			float out[4];
 			for (int k = 0; k < 4; k++)
 			{
@@ -1027,9 +1031,9 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 		for (int q = 0; q < 8; q++) in[q] = q < n ? ps.colors[start + q] : 0;
 		i4 e0, e1;
 		unpack_color_endpoints(profile, f, in, e0, e1);
-		int* o = ps.ep[p];
-		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
-		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+		uint16_t* o = ps.ep[p];
+		o[0] = (uint16_t)e0.x; o[1] = (uint16_t)e0.y; o[2] = (uint16_t)e0.z; o[3] = (uint16_t)e0.w;
+		o[4] = (uint16_t)e1.x; o[5] = (uint16_t)e1.y; o[6] = (uint16_t)e1.z; o[7] = (uint16_t)e1.w;
 		bool rgb_lns, alpha_lns;
 		endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
 		ps.lns[p][0] = rgb_lns ? 1 : 0;
@@ -1102,7 +1106,7 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 			infill_texel_weights((int)(rd & 0xFFu), (int)((rd >> 8) & 0xFFu), (int)((rd >> 16) & 0xFFu), dual, ps.weights,
 			                     (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
 			const int p = parts == 1 ? 0 : partition_from_hash(rec.hash, tx, ty, tz, small_block);
-			const int* e = ps.ep[p];
+			const uint16_t* e = ps.ep[p];
 			int cv[4];
 			for (int q = 0; q < 4; q++)
 			{
