@@ -363,6 +363,56 @@ WV_FN int ise_symbol_lut(const uint32_t* w, int offset, int bits, int kind, int 
 		return (int)((quint << bits) | m);
 	}
 }
+/* Symbols per lane in the batched decoder: one BISE group (five trits or three quints share packed bits, so the
+ * group is the natural unit: its window and its table entry are fetched once), four symbols for plain bit fields. */
+WV_FN int ise_group_size(int kind) { return kind == 1 ? 5 : kind == 2 ? 3 : 4; }
+
+/* The symbols of group `group` of a BISE sequence (same results as ise_symbol_lut for each of them); returns how many
+ * of out[0..4] are real (the last group may be short). */
+WV_FN int ise_group_lut(const uint32_t* w, int offset, int bits, int kind, int count, int group, int out[5])
+{
+	const uint32_t low_mask = (1u << bits) - 1u;
+	const int per = ise_group_size(kind);
+	const int n = i_min(per, count - group * per);
+	if (kind == 0)
+	{
+		const uint64_t g = bits_window(w, offset + group * 4 * bits);              // 4 * bits <= 32
+		for (int e = 0; e < 4; e++) out[e] = (int)((uint32_t)(g >> (e * bits)) & low_mask);
+		out[4] = 0;
+		return n;
+	}
+	if (kind == 1)
+	{
+		const int glen = n * bits + (int)((0x875420u >> (4 * n)) & 0xFu);
+		uint64_t g = bits_window(w, offset + group * (5 * bits + 8));
+		g &= (1ull << glen) - 1ull;
+		const uint32_t t8 = ((uint32_t)(g >> bits) & 3u) | (((uint32_t)(g >> (2 * bits + 2)) & 3u) << 2) |
+		                    (((uint32_t)(g >> (3 * bits + 4)) & 1u) << 4) | (((uint32_t)(g >> (4 * bits + 5)) & 3u) << 5) |
+		                    (((uint32_t)(g >> (5 * bits + 7)) & 1u) << 7);
+		const uint32_t trits = trit_group_lut(t8);
+		for (int e = 0; e < 5; e++)
+		{
+			const uint32_t m = (uint32_t)(g >> (e * bits + (int)((0x75420u >> (4 * e)) & 0xFu))) & low_mask;
+			out[e] = (int)((((trits >> (2 * e)) & 3u) << bits) | m);
+		}
+		return n;
+	}
+	{
+		const int glen = n * bits + (int)((0x7530u >> (4 * n)) & 0xFu);
+		uint64_t g = bits_window(w, offset + group * (3 * bits + 7));
+		g &= (1ull << glen) - 1ull;
+		const uint32_t q7 = ((uint32_t)(g >> bits) & 7u) | (((uint32_t)(g >> (2 * bits + 3)) & 3u) << 3) |
+		                    (((uint32_t)(g >> (3 * bits + 5)) & 3u) << 5);
+		const uint32_t quints = quint_group_lut(q7);
+		for (int e = 0; e < 3; e++)
+		{
+			const uint32_t m = (uint32_t)(g >> (e * bits + (int)((0x530u >> (4 * e)) & 0xFu))) & low_mask;
+			out[e] = (int)((((quints >> (3 * e)) & 7u) << bits) | m);
+		}
+		out[3] = 0; out[4] = 0;
+		return n;
+	}
+}
 #endif // !ASTC_DECODE_NO_LUTS
 
 /* Block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.
@@ -972,31 +1022,39 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 #if defined(DEC_EXP) && DEC_EXP >= 3
 	return;
 #endif
-	// ---- weights and colour values: one lane per (block, element), as many lanes per block as the fullest block needs ----
+	// ---- weights and colour values: one lane per (block, BISE group), as many lanes per block as the fullest block needs ----
 	int wmax_part = 0, cmax_part = 0;                 // per-lane partial maxima (lane k looked at block k), folded below
 	WV_FOR(k, count)
 	{
 		const DecodeBlockRec& r = s.rec[k];
 		if (!(r.a & 1u))
 		{
-			wmax_part = i_max(wmax_part, (int)(r.c & 0xFFu));
-			cmax_part = i_max(cmax_part, (int)(r.b >> 24));
+			const int wper = ise_group_size((int)((r.a >> 16) & 0xFFu)), cper = ise_group_size((int)((r.b >> 8) & 0xFFu));
+			wmax_part = i_max(wmax_part, ((int)(r.c & 0xFFu) + wper - 1) / wper);
+			cmax_part = i_max(cmax_part, ((int)(r.b >> 24) + cper - 1) / cper);
 		}
 	}
-	const int wmax = wv_all_imax(wmax_part), cmax = wv_all_imax(cmax_part);
+	const int wmax = wv_all_imax(wmax_part), cmax = wv_all_imax(cmax_part);      // groups per block, at most 32 / 8
 	if (wmax > 0)
 	{
 		const uint32_t winv = ((1u << 20) + (uint32_t)wmax - 1u) / (uint32_t)wmax;      // j / wmax == (j * winv) >> 20 for j < count * wmax (one divide per batch)
 		WV_FOR(j, count * wmax)
 		{
-			const int k = (int)(((uint32_t)j * winv) >> 20), i = j - k * wmax;
+			const int k = (int)(((uint32_t)j * winv) >> 20), g = j - k * wmax;
 			const uint32_t ra = s.rec[k].a, rc = s.rec[k].c;
 			const int real_wcount = (int)(rc & 0xFFu);
-			if ((ra & 1u) || i >= real_wcount) continue;
-			const int sym = ise_symbol_lut(s.rev[k], 0, (int)((ra >> 8) & 0xFFu), (int)((ra >> 16) & 0xFFu), real_wcount, i);
-			const int w = weight_unquant_lut((int)(ra >> 24), sym);
-			if (rc & 0x100u) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
-			else s.payload[k].weights[0][i] = (uint8_t)w;
+			const int kind = (int)((ra >> 16) & 0xFFu), per = ise_group_size(kind);
+			if ((ra & 1u) || g * per >= real_wcount) continue;
+			int sym[5];
+			const int n = ise_group_lut(s.rev[k], 0, (int)((ra >> 8) & 0xFFu), kind, real_wcount, g, sym);
+			for (int e = 0; e < 5; e++)
+			{
+				if (e >= n) break;
+				const int i = g * per + e;
+				const int w = weight_unquant_lut((int)(ra >> 24), sym[e]);
+				if (rc & 0x100u) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
+				else s.payload[k].weights[0][i] = (uint8_t)w;
+			}
 		}
 	}
 	if (cmax > 0)
@@ -1004,12 +1062,18 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 		const uint32_t cinv = ((1u << 20) + (uint32_t)cmax - 1u) / (uint32_t)cmax;
 		WV_FOR(j, count * cmax)
 		{
-			const int k = (int)(((uint32_t)j * cinv) >> 20), i = j - k * cmax;
+			const int k = (int)(((uint32_t)j * cinv) >> 20), g = j - k * cmax;
 			const uint32_t ra = s.rec[k].a, rb = s.rec[k].b, rc = s.rec[k].c;
 			const int nvals = (int)(rb >> 24);
-			if ((ra & 1u) || i >= nvals) continue;
-			const int sym = ise_symbol_lut(s.bits[k], (int)((rc >> 16) & 0xFFu), (int)(rb & 0xFFu), (int)((rb >> 8) & 0xFFu), nvals, i);
-			s.payload[k].colors[i] = (uint8_t)color_unquant_lut((int)((rb >> 16) & 0xFFu), sym);
+			const int kind = (int)((rb >> 8) & 0xFFu), per = ise_group_size(kind);
+			if ((ra & 1u) || g * per >= nvals) continue;
+			int sym[5];
+			const int n = ise_group_lut(s.bits[k], (int)((rc >> 16) & 0xFFu), (int)(rb & 0xFFu), kind, nvals, g, sym);
+			for (int e = 0; e < 5; e++)
+			{
+				if (e >= n) break;
+				s.payload[k].colors[g * per + e] = (uint8_t)color_unquant_lut((int)((rb >> 16) & 0xFFu), sym[e]);
+			}
 		}
 	}
 	WV_SYNC();

@@ -41,6 +41,22 @@ int main()
 						if (bad++ < 10) fprintf(stderr, "quant %d offset %d count %d index %d: %d != %d\n", quant, offsets[oi], count, index, got, want);
 					}
 				}
+				// the same sequence group by group (what a lane of the batched decoder does)
+				const int per = ise_group_size(kind);
+				for (int group = 0; group * per < count; group++)
+				{
+					int sym[5];
+					const int n = ise_group_lut(w, offsets[oi], q.bits, kind, count, group, sym);
+					if (n != (count - group * per < per ? count - group * per : per)) { bad++; fprintf(stderr, "group size\n"); }
+					for (int e = 0; e < n; e++)
+					{
+						checked++;
+						if (sym[e] != ise_symbol(b, offsets[oi], quant, count, group * per + e))
+						{
+							if (bad++ < 10) fprintf(stderr, "group: quant %d offset %d count %d group %d element %d\n", quant, offsets[oi], count, group, e);
+						}
+					}
+				}
 			}
 		}
 		// unquantization tables: every symbol the level can produce
