@@ -772,14 +772,14 @@ WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t
 	const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
 	const int v0 = js + jt * wx;
 	const int wcount = wx * wy;
+	// A tap whose factor is zero may lie past the grid (the last row / column interpolates with factor 0): its product is
+	// zero whatever is read there, and v0 + wx + 1 <= 76 stays inside the scratch record the weights are the first 128
+	// bytes of -- so the four taps are read unconditionally instead of behind eight tests.
+	(void)wcount;
 	for (int pl = 0; pl < (dual ? 2 : 1); pl++)
 	{
 		const uint8_t* g = gw[pl];
-		int sum = 8;
-		sum += w00 ? g[v0] * w00 : 0;
-		sum += (w01 && v0 + 1 < wcount) ? g[v0 + 1] * w01 : 0;
-		sum += (w10 && v0 + wx < wcount) ? g[v0 + wx] * w10 : 0;
-		sum += (w11 && v0 + wx + 1 < wcount) ? g[v0 + wx + 1] * w11 : 0;
+		const int sum = 8 + g[v0] * w00 + g[v0 + 1] * w01 + g[v0 + wx] * w10 + g[v0 + wx + 1] * w11;
 		wp[pl] = sum >> 4;
 	}
 }
