@@ -41,9 +41,15 @@ WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, ui
 	return (wts[tab[a]] * table_at(tabf, b) + wts[tab[a + T]] * table_at(tabf, b + T));
 }
 
+// weights per round trip in the angular search's two per-(grid, step) loops.  Measured on config 2: 8 -> 4 +1.2 %
+// (the tail of a group is padded work for the whole wavefront, and four weights are eight table loads in flight)
+#ifndef ASTC_ANG_GROUP
+#define ASTC_ANG_GROUP 4
+#endif
 // taps of a weight fetched per round trip in the decimation sweeps (table loads in flight per lane = 2x this)
+// (measured on config 2: 8 -1.5 %, 4 = baseline, 3 +-0, 2 +0.5 %)
 #ifndef ASTC_DWI_GROUP
-#define ASTC_DWI_GROUP 4
+#define ASTC_DWI_GROUP 2
 #endif
 
 /* Row of the sin/cos tables an ideal weight selects in the angular search (ref: compute_angular_offsets,
@@ -315,22 +321,22 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
 			float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
-			// groups of 8 weights: LDS reads, then all table loads, then the ordered accumulation
-			for (int j0 = 0; j0 < W; j0 += 8)
+			// groups of ASTC_ANG_GROUP weights: LDS reads, then all table loads, then the ordered accumulation
+			for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
 			{
-				float wj[8], cs[8], sn[8];
-				uint32_t row[8];
+				float wj[ASTC_ANG_GROUP], cs[ASTC_ANG_GROUP], sn[ASTC_ANG_GROUP];
+				uint32_t row[ASTC_ANG_GROUP];
 				#pragma unroll
-				for (int u = 0; u < 8; u++) { const int j = j0 + u < W ? j0 + u : 0; wj[u] = wv[j]; row[u] = rows[j]; }
+				for (int u = 0; u < ASTC_ANG_GROUP; u++) { const int j = j0 + u < W ? j0 + u : 0; wj[u] = wv[j]; row[u] = rows[j]; }
 				#pragma unroll
-				for (int u = 0; u < 8; u++)
+				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
 					const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
 					cs[u] = table_at(cos_table, at);
 					sn[u] = table_at(sin_table, at);
 				}
 				#pragma unroll
-				for (int u = 0; u < 8; u++)
+				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
 					// past the set's last weight: wj is a copy of weight 0 (no effect on min / max) and the table values
 					// are replaced by +0.0, which leaves the sums as they are (they are never -0.0: they start at +0.0)
@@ -352,13 +358,13 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			float errval = 0.0f, cut_low = 0.0f, cut_high = 0.0f;
 			float minidx = f_round(min_weight * rcp_stepsize - offset);
 			float maxidx = f_round(max_weight * rcp_stepsize - offset);
-			for (int j0 = 0; j0 < W; j0 += 8)
+			for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
 			{
-				float wj[8];
+				float wj[ASTC_ANG_GROUP];
 				#pragma unroll
-				for (int u = 0; u < 8; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
+				for (int u = 0; u < ASTC_ANG_GROUP; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
 				#pragma unroll
-				for (int u = 0; u < 8; u++)
+				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
 					// past the set's last weight (wj is a copy of weight 0 there): the squared difference is multiplied by 0.0
 					// (+0.0 added to a sum that is >= +0.0: exact) and the rounded value is pushed out of the index range so
