@@ -242,7 +242,7 @@ struct astcenc_context {
 	int dstate;                       // same protocol for decompress (ref: manage_decompress)
 	astcenc_error dresult;
 	std::atomic<int> cancel_flag;     // (ref: ParallelManager::m_is_cancelled, astcenc_internal_entry.h:104)
-	bool per_slice_fast_load;         // ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD
+	int per_slice_fast_load;          // ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD: -1 not set (each entry point's default), 0, 1
 };
 
 extern "C" {
@@ -401,7 +401,7 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 	ctx->dstate = astcenc_context::IDLE;
 	ctx->result = ASTCENC_SUCCESS;
 	ctx->cancel_flag.store(0);
-	ctx->per_slice_fast_load = false;
+	ctx->per_slice_fast_load = -1;
 
 	// NB: like the reference, a child context re-validates (and below re-converts) the parent's
 	// already processed config (ref: astcenc_entry.cpp:761-777, :811-821).
@@ -581,7 +581,8 @@ astcenc_error astcenc_compress_image(astcenc_context* ctx, astcenc_image* imagep
 	job.swz[0] = swizzle->r; job.swz[1] = swizzle->g; job.swz[2] = swizzle->b; job.swz[3] = swizzle->a;
 	job.host_out = data_out;
 	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
-	job.fast_load_slice0 = ctx->per_slice_fast_load ? 0u : 1u;
+	// default: the reference's bytes (its fast loader reads slice 0 for every slice, astcenc_image.cpp:304)
+	job.fast_load_slice0 = ctx->per_slice_fast_load == 1 ? 0u : 1u;
 	return run_job(ctx, job);
 }
 
@@ -616,12 +617,16 @@ astcenc_error astcenc_amd_compress_volume_device(astcenc_context* ctx, const voi
 	job.stream = hip_stream;
 	job.kernel_ms = kernel_ms;
 	job.a_scale_radius = alpha_scale ? ctx->config.a_scale_radius : 0u;
-	job.fast_load_slice0 = ctx->per_slice_fast_load ? 0u : 1u;
+	// default of this entry point (which has no reference counterpart to match): every slice from its own data
+	job.fast_load_slice0 = ctx->per_slice_fast_load == 0 ? 1u : 0u;
 
-	// A device-resident call is a single-caller operation: like a thread_count == 1 compress it starts from a
-	// clean state (a cancel issued before the call is forgotten; one issued while it runs stops it at the next
-	// chunk).  Calls on one context are serialised per device inside the backend.
-	ctx->cancel_flag.store(0);
+	// A device-resident call is a single-caller operation.  On a thread_count == 1 context it starts from a clean
+	// state like astcenc_compress_image does there (a cancel issued before the call is forgotten; one issued while
+	// it runs stops it at the next chunk).  On a multi-thread context a cancel is sticky until
+	// astcenc_compress_reset -- a device call must not swallow the cancel of a concurrent or later
+	// astcenc_compress_image -- so a pending one stops this call as well.  Calls on one context are serialised per
+	// device inside the backend.
+	if (ctx->thread_count == 1) ctx->cancel_flag.store(0);
 	job.cancel_flag = &ctx->cancel_flag;
 	job.progress = ctx->config.progress_callback;
 	int rc = backend_compress(ctx->backend, job);
@@ -679,7 +684,7 @@ static astcenc_error compare_images(astcenc_context* ctx, const void* device_ima
 	job.sums = raw;
 	job.hdr = hdr_sums ? 1 : 0; job.fstop_lo = fstop_lo; job.fstop_hi = fstop_hi;
 	int rc = backend_compare(ctx->backend, job);
-	if (rc != 0) return rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : ASTCENC_ERR_BAD_CONTEXT;
+	if (rc != 0) return rc == 1 ? ASTCENC_ERR_OUT_OF_MEM : rc == 3 ? ASTCENC_ERR_BAD_PARAM : ASTCENC_ERR_BAD_CONTEXT;
 	for (int k = 0; k < 4; k++) { sums->squared_error[k] = raw[k]; sums->alpha_scaled_squared_error[k] = raw[4 + k]; }
 	sums->rgb_peak = raw[8];
 	sums->texels = (double)texel_count;
@@ -725,7 +730,7 @@ astcenc_error astcenc_amd_context_set_option(astcenc_context* ctx, astcenc_amd_o
 	switch ((int)option)
 	{
 	case ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD:
-		ctx->per_slice_fast_load = value != 0;
+		ctx->per_slice_fast_load = value != 0 ? 1 : 0;
 		return ASTCENC_SUCCESS;
 	default:
 		return ASTCENC_ERR_BAD_PARAM;

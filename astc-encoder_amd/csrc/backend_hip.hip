@@ -39,8 +39,9 @@ struct DeviceSlot {
 };
 
 struct Backend {
-	std::vector<DeviceSlot*> slots;   // slot 0 is the default device of the context
-	std::mutex slots_mu;              // guards `slots` (slots for further devices are added on first use)
+	std::vector<DeviceSlot*> slots;   // the devices host images are sharded over; fixed at backend_create (slot 0 = default device)
+	std::vector<DeviceSlot*> extra;   // slots created on first use for device pointers that live on other GPUs; never sharded over
+	std::mutex slots_mu;              // guards `extra`
 	std::vector<uint8_t> full;        // host copy of [LdsLayout][DeviceConfig][table blob], uploaded to every slot
 	DeviceConfig cfg;
 	uint32_t lds_bytes;
@@ -132,14 +133,17 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	return s;
 }
 
-/* Device list of a context.  ASTCENC_AMD_DEVICES = "all" (default: every visible device) or a comma
- * separated list of device ordinals; an ordinal may repeat ("0,0": two slots on one GPU, which is how the
- * multi-device path is tested on a one-GPU box). */
+/* Device list of a context.  Default: the calling thread's current device only (a rank-per-GPU process must not
+ * initialise, or contend for, its neighbours' GPUs).  The N-device split of host images is opt-in:
+ * ASTCENC_AMD_DEVICES = "all" (every visible device, the current one first) or a comma separated list of device
+ * ordinals; an ordinal may repeat ("0,0": two slots on one GPU, which is how the multi-device path is tested on a
+ * one-GPU box). */
 std::vector<int> device_list(int ndev)
 {
 	std::vector<int> out;
 	const char* env = getenv("ASTCENC_AMD_DEVICES");
-	if (env && *env && strcmp(env, "all") != 0)
+	const bool all = env && strcmp(env, "all") == 0;
+	if (env && *env && !all)
 	{
 		const char* p = env;
 		while (*p)
@@ -159,7 +163,7 @@ std::vector<int> device_list(int ndev)
 		int cur = 0;
 		if (hipGetDevice(&cur) != hipSuccess) cur = 0;
 		out.push_back(cur);
-		if (!(env && *env && strcmp(env, "all") != 0)) for (int d = 0; d < ndev; d++) if (d != cur) out.push_back(d);
+		if (all) for (int d = 0; d < ndev; d++) if (d != cur) out.push_back(d);
 	}
 	return out;
 }
@@ -175,11 +179,30 @@ DeviceSlot* slot_for_pointer(Backend* b, const void* ptr, int* status)
 		(void)hipGetLastError();
 		return b->slots[0];
 	}
+	for (DeviceSlot* s : b->slots) if (s->device == attr.device) return s;     // (immutable after backend_create: no lock)
 	std::lock_guard<std::mutex> lk(b->slots_mu);
-	for (DeviceSlot* s : b->slots) if (s->device == attr.device) return s;
+	for (DeviceSlot* s : b->extra) if (s->device == attr.device) return s;
 	DeviceSlot* s = slot_create(b, attr.device, status);
-	if (s) b->slots.push_back(s);
+	if (s) b->extra.push_back(s);
 	return s;
+}
+
+/* The stream a device-resident call runs on: the caller's, which must belong to the device the buffers (and the
+ * slot's tables) live on, or the slot's own.  Returns false (-> rc 3, a bad argument) on a foreign stream. */
+bool pick_stream(const DeviceSlot* s, void* caller_stream, hipStream_t* out)
+{
+	*out = s->stream;
+	if (!caller_stream) return true;
+	hipStream_t stream = static_cast<hipStream_t>(caller_stream);
+	hipDevice_t sdev = -1;
+	if (hipStreamGetDevice(stream, &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = s->device; }
+	if ((int)sdev != s->device)
+	{
+		fprintf(stderr, "astcenc_amd: the stream belongs to device %d, the buffers to device %d\n", (int)sdev, s->device);
+		return false;
+	}
+	*out = stream;
+	return true;
 }
 
 /* Completed-block counter shared by the slots of one call; the callback sees a monotonic percentage
@@ -261,6 +284,7 @@ void backend_destroy(Backend* b)
 	if (!b) return;
 	DeviceGuard guard;
 	for (DeviceSlot* s : b->slots) slot_destroy(s);
+	for (DeviceSlot* s : b->extra) slot_destroy(s);
 	delete b;
 }
 
@@ -283,19 +307,8 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 	const size_t image_bytes = slice_bytes * dim_z;
 	const size_t out_bytes = nblocks * 16;
 
-	hipStream_t stream = s->stream;
-	if (job.stream)
-	{
-		// a caller's stream must belong to the device the buffers (and this slot's tables) live on
-		stream = static_cast<hipStream_t>(job.stream);
-		hipDevice_t sdev = -1;
-		if (hipStreamGetDevice(stream, &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = s->device; }
-		if ((int)sdev != s->device)
-		{
-			fprintf(stderr, "astcenc_amd: the stream belongs to device %d, the buffers to device %d\n", (int)sdev, s->device);
-			return 3;
-		}
-	}
+	hipStream_t stream;
+	if (!pick_stream(s, job.stream, &stream)) return 3;
 
 	const void* d_image = job.device_data;
 	uint8_t* d_out = job.device_out;
@@ -525,6 +538,9 @@ int backend_compress(Backend* b, const CompressJob& job)
 	const size_t by_size = progress.total / MIN_BLOCKS_PER_DEVICE;
 	if (ndev > by_size) ndev = by_size < 1 ? 1 : by_size;
 	if (ndev > blocks_y) ndev = blocks_y;
+#if defined(ASTC_TRACE)
+	ndev = 1;      // (debug build: every shard would write the same trace file)
+#endif
 	if (ndev <= 1) return compress_on_slot(b, b->slots[0], job, &progress);
 
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
@@ -548,10 +564,17 @@ int backend_compress(Backend* b, const CompressJob& job)
 		shards.push_back(sh);
 	}
 	for (Shard& sh : shards) sh.job.host_slices = &sh.slice;      // (after the vector stopped growing)
+	// one host thread per further shard; a shard whose thread cannot be created (std::system_error must not cross the
+	// C ABI, and the earlier workers must still be joined) runs on the calling thread after its own
 	std::vector<std::thread> workers;
+	std::vector<size_t> inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
-		workers.emplace_back([&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); });
+	{
+		try { workers.emplace_back([&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); }); }
+		catch (...) { inline_shards.push_back(g); }
+	}
 	shards[0].rc = compress_on_slot(b, b->slots[0], shards[0].job, &progress);
+	for (size_t g : inline_shards) shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress);
 	for (std::thread& t : workers) t.join();
 	int rc = 0;
 	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
@@ -610,7 +633,8 @@ int backend_decompress_device(Backend* bk, const DecompressDeviceJob& job)
 	if (!b) return st ? st : 2;
 	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
-	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+	hipStream_t stream;
+	if (!pick_stream(b, job.stream, &stream)) return 3;
 	DecodeLaunch d;
 	d.d_blocks = job.device_blocks;
 	d.d_image = job.device_image;
@@ -633,7 +657,8 @@ int backend_compare(Backend* bk, const CompareJob& job)
 	if (!b) return st ? st : 2;
 	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
-	hipStream_t stream = job.stream ? static_cast<hipStream_t>(job.stream) : b->stream;
+	hipStream_t stream;
+	if (!pick_stream(b, job.stream, &stream)) return 3;
 	if (!b->d_sums) HIP_TRY(hipMalloc(&b->d_sums, astc_compare_scratch_doubles() * sizeof(double)), return 1);
 	CompareLaunch c;
 	c.d_a = job.device_a; c.type_a = job.type_a; c.d_b = job.device_b; c.type_b = job.type_b;

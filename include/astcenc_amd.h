@@ -36,7 +36,12 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_image_device(
 
 /* The same for a volume or 2D array image: dim_z slices of dim_x * dim_y texels back to back at
  * device_volume, compressed with the context's 2D or 3D footprint into blocks in x, y, z raster order
- * (ref: the z loop of compress_image, Source/astcenc_entry.cpp:961-966, and astcenc_image::data[z]). */
+ * (ref: the z loop of compress_image, Source/astcenc_entry.cpp:961-966, and astcenc_image::data[z]).
+ * Every slice is compressed from its own data (see ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD below for the one case in
+ * which astcenc_compress_image deliberately does not).
+ * The context's progress_callback, if any, is called from the calling thread here; astcenc_compress_image on a
+ * context that shards over several devices (ASTCENC_AMD_DEVICES) calls it from library-created threads as well,
+ * serialised, with a monotonic percentage. */
 ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compress_volume_device(
 	struct astcenc_context* context,
 	const void* device_volume,
@@ -109,20 +114,23 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_hdr_device(
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 
-/* Number of GPUs the context runs on.  astcenc_context_alloc() prepares every visible device (or the
- * ordinals listed in the environment variable ASTCENC_AMD_DEVICES, e.g. "0,1,2,3"); astcenc_compress_image()
- * then deals contiguous ranges of block rows of the host image to those devices -- each with its own
- * tables, streams and PCIe pipeline -- and joins them, the way the reference deals blocks to its N worker
- * threads (ref: Source/astcenc_entry.cpp:1009-1038).  Buffers that already live on a device (the *_device
- * entry points) are processed on the device that owns them. */
+/* Number of GPUs the context shards host images over.  By default astcenc_context_alloc() prepares the calling
+ * thread's current device only (one process per GPU is the usual deployment, and a context must not touch its
+ * neighbours' GPUs).  With the environment variable ASTCENC_AMD_DEVICES = "all" or a list of ordinals ("0,1,2,3")
+ * it prepares those devices, and astcenc_compress_image() / astcenc_decompress_image() then deal contiguous ranges
+ * of block rows of the host image to them -- each with its own tables, streams and PCIe pipeline -- and join them,
+ * the way the reference deals blocks to its N worker threads (ref: Source/astcenc_entry.cpp:1009-1038, :1340-1385).
+ * Buffers that already live on a device (the *_device entry points) are processed on the device that owns them,
+ * whatever the list says. */
 ASTCENC_PUBLIC int astcenc_amd_context_device_count(const struct astcenc_context* context);
 
 /* Behaviour switches that have no counterpart in the reference API. */
 enum astcenc_amd_option {
 	/* Multi-slice RGBA8 input (image.dim_z > 1) with a 2D footprint, LDR profile and identity swizzle: the
 	 * reference's fast block loader reads slice 0 for every slice (Source/astcenc_image.cpp:304), so it emits
-	 * slice 0's blocks dim_z times.  0 (default): do exactly that, byte for byte.  1: every slice is loaded
-	 * from its own data (the output equals compressing the slices one by one). */
+	 * slice 0's blocks dim_z times.  0: do exactly that, byte for byte (the default of astcenc_compress_image, which
+	 * promises the reference's bytes).  1: every slice is loaded from its own data, the output equals compressing the
+	 * slices one by one (the default of astcenc_amd_compress_volume_device, which has no reference counterpart). */
 	ASTCENC_AMD_OPT_PER_SLICE_FAST_LOAD = 1
 };
 
