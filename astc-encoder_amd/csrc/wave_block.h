@@ -6,6 +6,7 @@
 //        prepare_block_statistics                        :1047-1159
 // All control flow here is wave-uniform: every decision is taken on values read back from LDS.
 #pragma once
+#include <stddef.h>
 #include "wave_ctx.h"
 #include "wave_load.h"
 #include "wave_ideal.h"
@@ -415,6 +416,27 @@ WV_OUT void refine_recompute_2planes(int decimation_mode, int plane2_component)
 	recompute_ideal_colors_2planes(c, dec_view_lds(c, decimation_mode), plane2_component);
 }
 
+#if ASTC_ENABLE_HDR
+/* The HDR endpoint formats of the candidate's partitions (sub-modes side by side, wave_color_hdr.h), out of line: the
+ * LDR-profile kernel has none of it, and the HDR kernel's refinement loop should not carry its registers. */
+WV_OUT void refine_pack_hdr(int partition_count, int candidate, int to_scratch, int quant_level)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); candidate = wv_uniform(candidate);
+	to_scratch = wv_uniform(to_scratch); quant_level = wv_uniform(quant_level);
+	TrialInfo& tr = c.tr();
+	Scb& workscb = c.wscb();
+	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);    // (the retry buffers of refine_pack)
+	uint8_t* fmts = colorvals + 32;
+	uint8_t* have_decoded = fmts + 4;
+	uint8_t* tries = reinterpret_cast<uint8_t*>(tr.fbox);             // (the re-fit's sums are consumed by now)
+	static_assert(sizeof(tr.fbox) >= 4 * HDR_TRY_LANES * HDR_TRY_BYTES, "sub-mode records do not fit the mailbox");
+	WV_FOR(j, partition_count) { if (!to_scratch && endpoint_format_is_hdr(tr.cand_formats[candidate][j])) have_decoded[j] = 0; }
+	pack_endpoints_hdr(c, partition_count, tr.cand_formats[candidate], to_scratch ? colorvals : &workscb.color_values[0][0],
+	                   to_scratch ? fmts : workscb.color_formats, quant_level, tries);
+}
+#endif
+
 /* Part 2: pack the endpoints (one lane per partition), retry at the higher quant level that matched
  * formats allow (ref: :561-598), and fill in the header of the working block. */
 __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_count, int partition_packed, int plane2_component,
@@ -430,7 +452,9 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 
 	uint8_t* colorvals = reinterpret_cast<uint8_t*>(&tr.ibox[32]);   // [4][8] scratch copy for the matched-format retry
 	uint8_t* fmts = colorvals + 32;                                   // [4]
+	uint8_t* have_decoded = fmts + 4;                                 // [4] the pack left partition p's decoded endpoints in tr.ibox
 	int formats_matched = 0;
+	const int profile = c.cfg->profile;
 	{ PROF_SCOPE(c, PS_PACK);
 	// pass 0 packs into the working block; pass 1 (only when every partition got the same format and a
 	// higher quant level is then possible) packs again at that level into the retry buffer
@@ -439,14 +463,30 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 		const bool to_scratch = pass == 1;
 		const int q = to_scratch ? quant_level_mod : quant_level;
 		if (to_scratch) stage_color_rows(c, q);        // (rare: the retry level's rows replace the candidate's, put back below)
-		WV_FOR(j, partition_count)
+		// four lanes per partition, one colour channel each (wave_quad.h)
+		WV_QUADS(j, partition_count)
 		{
+			const int requested = tr.cand_formats[candidate][j];
+			if (kHdr && endpoint_format_is_hdr(requested)) continue;
 			uint8_t* vals = to_scratch ? colorvals + j * 8 : workscb.color_values[j];
-			uint8_t f = (uint8_t)pack_color_endpoints(
-			    c, load4(tr.wep0[j]), load4(tr.wep1[j]), load4(tr.rgbs[j]), load4(tr.rgbo[j]),
-			    tr.cand_formats[candidate][j], vals, q);
-			if (to_scratch) fmts[j] = f; else workscb.color_formats[j] = f;
+			const QPacked r = pack_endpoints_quad(c, q_load(tr.wep0[j]), q_load(tr.wep1[j]), q_load(tr.rgbs[j]), requested, vals, q);
+			Q_ONCE
+			{
+				if (to_scratch) fmts[j] = (uint8_t)r.format;
+				else { workscb.color_formats[j] = (uint8_t)r.format; have_decoded[j] = r.decoded_valid ? 1 : 0; }
+			}
+			if (!to_scratch && r.decoded_valid)
+			{
+				// the 8-bit endpoints a decoder sees, expanded to the 16 bits the scoring works in
+				// (ref: unpack_color_endpoints, color_unquantize.cpp:980-1022: LDR formats in every profile)
+				auto widen = [profile](int v) { return profile == 0 ? (v << 8) | 0x80 : v * 257; };
+				q_store_i32(&tr.ibox[j * 8], q_mapi(r.decoded.e0, widen));
+				q_store_i32(&tr.ibox[j * 8 + 4], q_mapi(r.decoded.e1, widen));
+			}
 		}
+#if ASTC_ENABLE_HDR
+		refine_pack_hdr(partition_count, candidate, to_scratch ? 1 : 0, q);
+#endif
 		WV_SYNC();
 		if (pass == 1) { stage_color_rows(c, quant_level); break; }
 		if (dual || partition_count < 2 || quant_level == quant_level_mod) break;
@@ -469,15 +509,17 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 			{
 				formats_matched = 1;
 				WV_FOR(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
-				WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; }
+				WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; have_decoded[j] = 0; }
 			}
 			WV_SYNC();
 		}
 	}
 	// The decoded endpoints of what was just packed: the scoring and weight realignment steps that follow (up to three
-	// of them before the next packing) all start from these, so they are unpacked once, here (tr.ibox[p * 8 ..]).
+	// of them before the next packing) all start from these (tr.ibox[p * 8 ..]).  The direct and base + offset formats
+	// left them there while packing; the others (and a retry that replaced the values) are decoded here.
 	WV_FOR(p, partition_count)
 	{
+		if (have_decoded[p]) continue;
 		i4 e0, e1;
 		unpack_color_endpoints(c.cfg->profile, workscb.color_formats[p], workscb.color_values[p], e0, e1);
 		int* o = &tr.ibox[p * 8];
@@ -486,13 +528,13 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 	}
 	WV_ONE
 	{
-		workscb.color_formats_matched = (uint8_t)formats_matched;
-		workscb.partition_count = (uint8_t)partition_count;
-		workscb.partition_index = (uint16_t)partition_packed;
-		workscb.plane2_component = (int8_t)plane2_component;
+		// the header of the working block: its first eight bytes as two words, then the colour quant level
+		static_assert(offsetof(Scb, block_type) == 0 && offsetof(Scb, partition_count) == 1 && offsetof(Scb, color_formats_matched) == 2 &&
+		              offsetof(Scb, plane2_component) == 3 && offsetof(Scb, block_mode) == 4 && offsetof(Scb, partition_index) == 6, "Scb header layout");
+		uint32_t* head = reinterpret_cast<uint32_t*>(&workscb);
+		head[0] = (uint32_t)SYM_BTYPE_NONCONST | ((uint32_t)partition_count << 8) | ((uint32_t)formats_matched << 16) | ((uint32_t)(plane2_component & 0xFF) << 24);
+		head[1] = (uint32_t)block_mode_packed | ((uint32_t)partition_packed << 16);
 		workscb.quant_mode = (uint8_t)(formats_matched ? quant_level_mod : quant_level);
-		workscb.block_mode = (uint16_t)block_mode_packed;
-		workscb.block_type = SYM_BTYPE_NONCONST;
 	}
 	WV_SYNC();
 }
@@ -562,8 +604,8 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 	{
 		const int bm_packed_index = wv_uniform(tr.cand_block_mode[i]);
 		const BlockMode& qw_bm = c.block_mode(bm_packed_index);
-		const int color_quant_level = wv_uniform(tr.cand_quant[i]);
-		const int color_quant_level_mod = wv_uniform(tr.cand_quant_mod[i]);
+		const int color_quant_level = wv_uniform((int)tr.cand_quant[i]);
+		const int color_quant_level_mod = wv_uniform((int)tr.cand_quant_mod[i]);
 		const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
 		const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
 
@@ -670,16 +712,28 @@ WV_OUT void stage_ideal(bool dual, int partition_count, int partition_packed, in
 	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count);
 	partition_packed = wv_uniform(partition_packed); plane2_component = wv_uniform(plane2_component);
 	PROF_SCOPE(c, PS_IDEAL);
+	TrialInfo& tr = c.tr();
 	if (partition_count == 1)
 	{
 		PartView pv = part_view_staged(c, 1, 0);
 		if (dual) ideal_colors_and_weights_2planes(c, pv, plane2_component);
-		else ideal_colors_and_weights_1plane(c, pv);
+		else
+		{
+			// the second run of trial A (ref: compress_symbolic.cpp:1292-1318: both runs call
+			// compute_ideal_colors_and_weights_1plane on the same block and partitioning) finds the first run's result
+			// still in place: nothing in between writes plane 0 of ei_w / ei_wes / ep0 / ep1
+			if (wv_uniform(tr.ideal_1p1p_valid) != 0) return;
+			ideal_colors_and_weights_1plane(c, pv);
+		}
+		WV_ONE { tr.ideal_1p1p_valid = dual ? 0 : 1; }
+		WV_SYNC();
 	}
 	else
 	{
 		PartView pv = part_view_staged(c, partition_count, partition_packed);
 		ideal_colors_and_weights_1plane(c, pv);
+		WV_ONE { tr.ideal_1p1p_valid = 0; }
+		WV_SYNC();
 	}
 }
 
@@ -1031,6 +1085,8 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 		scb.block_type = SYM_BTYPE_ERROR;
 		c.tr().staged_color_quant[0] = -1;
 		c.tr().staged_color_quant[1] = -1;
+		c.tr().eci1_valid = 0;
+		c.tr().ideal_1p1p_valid = 0;
 	}
 	WV_SYNC();
 

@@ -2,9 +2,11 @@
 // Colour endpoint quantization (pack) and its inverse (unpack) for the LDR endpoint formats.
 //   ref: quantize_* / try_quantize_* / pack_color_endpoints   Source/astcenc_color_quantize.cpp:53-839, :1909-2147
 //        *_unpack / unpack_color_endpoints                    Source/astcenc_color_unquantize.cpp:35-301, :844-1023
-// These are short, branchy, strictly scalar routines: one lane handles one partition's endpoint pair.
+// The quantizers are quad code (wave_quad.h): four lanes per partition, one colour channel each.  The decoder of an
+// endpoint pair (unpack_color_endpoints, shared with the decompression kernel) is scalar code on one lane.
 #pragma once
 #include "wave_ctx.h"
+#include "wave_quad.h"
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
@@ -266,416 +268,371 @@ WV_FN void unpack_color_endpoints(int profile, int format, const uint8_t* in, i4
 }
 
 // ---------------------------------------------------------------------------------------------
-// Quantizers
+// Quantizers: quad code (wave_quad.h) -- partition p of the block on lanes 4p .. 4p+3, one colour channel per lane
 // ---------------------------------------------------------------------------------------------
 
-/* (ref: get_rgba_encoding_error :53) */
-WV_FN float rgba_encoding_error(f4 uquant0, f4 uquant1, i4 quant0, i4 quant1)
+WV_FN qi q_quant(const ColorTabs& t, qi value) { return q_mapi(value, [&t](int v) { return quant_color(t, v); }); }
+WV_FN qi q_quant(const ColorTabs& t, qi value, qf valuef) { return q_zip_if(value, valuef, [&t](int v, float f) { return quant_color(t, v, f); }); }
+
+/* Two decoded or encoded endpoints. */
+struct QPair { qi e0, e1; };
+
+/* The blue-contracted colour: R and G move away from B, B and A stay (ref: try_quantize_rgb_blue_contract :248-252). */
+WV_FN qf q_blue_contract(qf colour)
 {
-	f4 error0 = uquant0 - int_to_float4(quant0);
-	f4 error1 = uquant1 - int_to_float4(quant1);
-	return hadd_s(error0 * error0 + error1 * error1);
+	const float blue = q_get<2>(colour);
+	return colour + q_map_ch(colour, [blue](int ch, float x) { return x - (ch == 3 ? x : blue); });
 }
 
-/* (ref: quantize_rgb :169) */
-WV_FN void quantize_rgb(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
+/* (ref: uncontract_color, color_unquantize.cpp:35) */
+WV_FN qi q_uncontract(qi in)
 {
-	i4 color0i, color1i;
-	f4 nudge = splat4(0.2f);
-	do
+	const int blue = q_get<2>(in);
+	return q_mapi_ch(in, [blue](int ch, int x) { return ch < 2 ? (x + blue) >> 1 : x; });
+}
+
+/* Direct endpoints -> decoded pair: a pair stored in descending RGB-sum order means blue contraction
+ * (ref: rgba_unpack, color_unquantize.cpp:105). */
+WV_FN QPair q_decode_direct(QPair in)
+{
+	QPair out = in;
+	if (q_sum_rgb(in.e0) > q_sum_rgb(in.e1))
 	{
-		i4 q0 = float_to_int_rtn4(color0);
-		q0 = mki4(i_max(q0.x, 0), i_max(q0.y, 0), i_max(q0.z, 0), i_max(q0.w, 0));
-		color0i = quant_color3(t, q0, color0);
-		color0 = color0 - nudge;
-
-		i4 q1 = float_to_int_rtn4(color1);
-		q1 = mki4(i_min(q1.x, 255), i_min(q1.y, 255), i_min(q1.z, 255), i_min(q1.w, 255));
-		color1i = quant_color3(t, q1, color1);
-		color1 = color1 + nudge;
-	} while (hadd_rgb_i(color0i) > hadd_rgb_i(color1i));
-	color0_out = color0i;
-	color1_out = color1i;
-}
-
-/* (ref: quantize_rgba :208) */
-WV_FN void quantize_rgba(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
-{
-	quantize_rgb(t, color0, color1, color0_out, color1_out);
-	color0_out.w = quant_color(t, flt2int_rtn(color0.w), color0.w);
-	color1_out.w = quant_color(t, flt2int_rtn(color1.w), color1.w);
-}
-
-WV_FN bool out_of_byte_range(f4 a)
-{
-	return (a.x < 0.0f) || (a.x > 255.0f) || (a.y < 0.0f) || (a.y > 255.0f) ||
-	       (a.z < 0.0f) || (a.z > 255.0f) || (a.w < 0.0f) || (a.w > 255.0f);
-}
-
-/* (ref: try_quantize_rgb_blue_contract :237) */
-WV_FN bool try_quantize_rgb_blue_contract(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
-{
-	color0 = color0 + (color0 - mk4(color0.z, color0.z, color0.z, color0.w));
-	color1 = color1 + (color1 - mk4(color1.z, color1.z, color1.z, color1.w));
-	if (out_of_byte_range(color0) || out_of_byte_range(color1)) return false;
-
-	i4 color0i = quant_color3(t, float_to_int_rtn4(color0), color0);
-	i4 color1i = quant_color3(t, float_to_int_rtn4(color1), color1);
-	if (hadd_rgb_i(color1i) <= hadd_rgb_i(color0i)) return false;
-
-	color0_out = color1i;
-	color1_out = color0i;
-	return true;
-}
-
-/* (ref: try_quantize_rgba_blue_contract :285) */
-WV_FN bool try_quantize_rgba_blue_contract(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
-{
-	if (try_quantize_rgb_blue_contract(t, color0, color1, color0_out, color1_out))
-	{
-		float a0 = color0.w, a1 = color1.w;
-		color0_out.w = quant_color(t, flt2int_rtn(a1), a1);
-		color1_out.w = quant_color(t, flt2int_rtn(a0), a0);
-		return true;
+		out.e0 = q_uncontract(in.e1);
+		out.e1 = q_uncontract(in.e0);
 	}
-	return false;
+	return out;
 }
 
-/* Shared tail of the two RGB delta encoders (ref: :329-387, :426-484). want_negative_sum selects the
- * blue-contracted flavour. */
-WV_FN bool quantize_rgb_delta_core(const ColorTabs& t, f4 color0, f4 color1, bool want_negative_sum, i4& color0_out, i4& color1_out)
+/* Base + offset endpoints -> decoded pair (ref: rgba_delta_unpack, color_unquantize.cpp:61 with bit_transfer_signed). */
+WV_FN QPair q_decode_delta(QPair in)
 {
-	i4 color0a = float_to_int_rtn4(color0);
-	color0a = mki4(color0a.x << 1, color0a.y << 1, color0a.z << 1, color0a.w << 1);
-	i4 color0b = mki4(color0a.x & 0xFF, color0a.y & 0xFF, color0a.z & 0xFF, color0a.w & 0xFF);
-	i4 color0be = quant_color3(t, color0b);
-	color0b = mki4(color0be.x | (color0a.x & 0x100), color0be.y | (color0a.y & 0x100), color0be.z | (color0a.z & 0x100), color0be.w | (color0a.w & 0x100));
-
-	i4 color1d = float_to_int_rtn4(color1);
-	color1d = mki4(color1d.x << 1, color1d.y << 1, color1d.z << 1, 0);
-	color1d = mki4(color1d.x - color0b.x, color1d.y - color0b.y, color1d.z - color0b.z, 0);
-
-	if (color1d.x > 63 || color1d.x < -64 || color1d.y > 63 || color1d.y < -64 || color1d.z > 63 || color1d.z < -64)
+	// the offset's top bit is the base's ninth bit; what is left of the offset is a 6-bit signed number
+	qi base = (in.e0 >> 1) | (in.e1 & 0x80);
+	qi offset = q_mapi((in.e1 >> 1) & 0x3F, [](int x) { return (x & 0x20) ? x - 0x40 : x; });
+	const int offset_sum = q_sum_rgb(offset);
+	qi other = offset + base;
+	if (offset_sum < 0)
 	{
-		return false;
+		const qi t = q_uncontract(base);
+		base = q_uncontract(other);
+		other = t;
 	}
+	QPair out;
+	out.e0 = q_clamp(0, 255, base);
+	out.e1 = q_clamp(0, 255, other);
+	return out;
+}
 
-	color1d = mki4((color1d.x & 0x7F) | ((color0b.x & 0x100) >> 1),
-	               (color1d.y & 0x7F) | ((color0b.y & 0x100) >> 1),
-	               (color1d.z & 0x7F) | ((color0b.z & 0x100) >> 1), 0);
+/* Squared distance of a decoded pair to the real-valued endpoints (ref: get_rgba_encoding_error :53). */
+WV_FN float q_encoding_error(qf colour0, qf colour1, QPair decoded)
+{
+	const qf d0 = colour0 - q_to_float(decoded.e0);
+	const qf d1 = colour1 - q_to_float(decoded.e1);
+	return q_hadd(d0 * d0 + d1 * d1);
+}
 
-	i4 color1de = quant_color3(t, color1d);
-	if (((color1d.x ^ color1de.x) & 0xC0) || ((color1d.y ^ color1de.y) & 0xC0) || ((color1d.z ^ color1de.z) & 0xC0))
+/* Base + offset encoding of (colour0, colour1): 8.1-bit base, 7-bit signed offset.  `alpha`: the alpha lane takes part
+ * (its own validity rule; ref: try_quantize_alpha_delta :504), otherwise it computes along and is ignored.
+ * `contracted`: the decoder must see a negative offset sum, i.e. the pair is the swapped, blue-contracted one; else a
+ * non-negative sum.  (ref: try_quantize_rgb_delta :321, try_quantize_rgb_delta_blue_contract :403) */
+WV_FN bool q_encode_delta(const ColorTabs& t, qf colour0, qf colour1, bool contracted, bool alpha, QPair& out)
+{
+	auto any = [alpha](qb test) { return alpha ? q_any(test) : q_any_rgb(test); };
+
+	const qi base9 = q_round_to_int(colour0) << 1;
+	const qi base_q = q_quant(t, base9 & 0xFF);
+	const qi base = base_q | (base9 & 0x100);
+
+	qi offset = (q_round_to_int(colour1) << 1) - base;
+	if (any(q_test(offset, [](int x) { return x > 63 || x < -64; }))) return false;
+	offset = (offset & 0x7F) | ((base & 0x100) >> 1);
+	const qi offset_q = q_quant(t, offset);
+	// quantization must not touch the sign bit nor the base's ninth bit
+	if (any(q_test((offset ^ offset_q) & 0xC0, [](int x) { return x != 0; }))) return false;
+
+	// what a decoder makes of it: colour lanes must stay within a byte and show the right contraction flag; the alpha
+	// lane, decoded at 9 bits, must stay within 0 .. 0x1FF
+	QPair in; in.e0 = base_q; in.e1 = offset_q;
+	const qi dec_base = (base_q >> 1) | (offset_q & 0x80);
+	const qi dec_offset = q_mapi((offset_q >> 1) & 0x3F, [](int x) { return (x & 0x20) ? x - 0x40 : x; });
+	const int offset_sum = q_sum_rgb(dec_offset);
+	if (contracted ? offset_sum >= 0 : offset_sum < 0) return false;
+	if (q_any_rgb_outside(dec_base + dec_offset, 0, 0xFF)) return false;
+	if (alpha)
 	{
-		return false;
+		const qi alpha9 = q_mapi(offset_q & 0x7F, [](int x) { return (x & 0x40) ? x - 0x80 : x; }) + base;
+		if (q_get<3>(q_test(alpha9, [](int x) { return x < 0 || x > 0x1FF; }))) return false;
 	}
-
-	i4 ep0 = color0be;
-	i4 ep1 = color1de;
-	ep0.w = 0; ep1.w = 0;
-	bit_transfer_signed4(ep1, ep0);
-	int s = hadd_rgb_i(ep1);
-	if (want_negative_sum ? (s >= 0) : (s < 0)) return false;
-
-	ep0 = ep0 + ep1;
-	if (ep0.x < 0 || ep0.x > 0xFF || ep0.y < 0 || ep0.y > 0xFF || ep0.z < 0 || ep0.z > 0xFF) return false;
-
-	color0_out = color0be;
-	color1_out = color1de;
+	out = in;
 	return true;
 }
 
-/* (ref: try_quantize_rgb_delta :321) */
-WV_FN bool try_quantize_rgb_delta(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
+/* Blue-contracted direct encoding of the (already contracted, range-checked) pair: stored in descending order
+ * (ref: try_quantize_rgb[a]_blue_contract :237, :285). */
+WV_FN bool q_encode_contracted(const ColorTabs& t, qf contracted0, qf contracted1, QPair& out)
 {
-	return quantize_rgb_delta_core(t, color0, color1, false, color0_out, color1_out);
-}
-
-/* (ref: try_quantize_rgb_delta_blue_contract :403) */
-WV_FN bool try_quantize_rgb_delta_blue_contract(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
-{
-	f4 tmp = color0; color0 = color1; color1 = tmp;
-	color0 = color0 + (color0 - mk4(color0.z, color0.z, color0.z, color0.w));
-	color1 = color1 + (color1 - mk4(color1.z, color1.z, color1.z, color1.w));
-	if (out_of_byte_range(color0) || out_of_byte_range(color1)) return false;
-	return quantize_rgb_delta_core(t, color0, color1, true, color0_out, color1_out);
-}
-
-/* (ref: try_quantize_alpha_delta :504) */
-WV_FN bool try_quantize_alpha_delta(const ColorTabs& t, f4 color0, f4 color1, i4& color0_out, i4& color1_out)
-{
-	float a0 = color0.w, a1 = color1.w;
-	int a0a = flt2int_rtn(a0);
-	a0a <<= 1;
-	int a0b = a0a & 0xFF;
-	int a0be = quant_color(t, a0b);
-	a0b = a0be;
-	a0b |= a0a & 0x100;
-	int a1d = flt2int_rtn(a1);
-	a1d <<= 1;
-	a1d -= a0b;
-	if (a1d > 63 || a1d < -64) return false;
-	a1d &= 0x7F;
-	a1d |= (a0b & 0x100) >> 1;
-	int a1de = quant_color(t, a1d);
-	int a1du = a1de;
-	if ((a1d ^ a1du) & 0xC0) return false;
-	a1du &= 0x7F;
-	if (a1du & 0x40) a1du -= 0x80;
-	a1du += a0b;
-	if (a1du < 0 || a1du > 0x1FF) return false;
-	color0_out.w = a0be;
-	color1_out.w = a1de;
+	const qi q0 = q_quant(t, q_round_to_int(contracted0), contracted0);
+	const qi q1 = q_quant(t, q_round_to_int(contracted1), contracted1);
+	if (q_sum_rgb(q1) <= q_sum_rgb(q0)) return false;
+	out.e0 = q1;
+	out.e1 = q0;
 	return true;
 }
 
-/* (ref: try_quantize_luminance_alpha_delta :573) */
-WV_FN bool try_quantize_luminance_alpha_delta(const ColorTabs& t, f4 color0, f4 color1, uint8_t* output)
+/* Plain direct encoding; the colour lanes are nudged apart until they are stored in ascending order, alpha is
+ * quantized as it is (ref: quantize_rgb :169, quantize_rgba :208). */
+WV_FN QPair q_encode_direct(const ColorTabs& t, qf colour0, qf colour1)
 {
-	float l0 = hadd_rgb_s(color0) * (1.0f / 3.0f);
-	float l1 = hadd_rgb_s(color1) * (1.0f / 3.0f);
-	float a0 = color0.w, a1 = color1.w;
-
-	int l0a = flt2int_rtn(l0), a0a = flt2int_rtn(a0);
-	l0a <<= 1; a0a <<= 1;
-	int l0b = l0a & 0xFF, a0b = a0a & 0xFF;
-	int l0be = quant_color(t, l0b), a0be = quant_color(t, a0b);
-	l0b = l0be; a0b = a0be;
-	l0b |= l0a & 0x100; a0b |= a0a & 0x100;
-
-	int l1d = flt2int_rtn(l1), a1d = flt2int_rtn(a1);
-	l1d <<= 1; a1d <<= 1;
-	l1d -= l0b; a1d -= a0b;
-	if (l1d > 63 || l1d < -64) return false;
-	if (a1d > 63 || a1d < -64) return false;
-
-	l1d &= 0x7F; a1d &= 0x7F;
-	l1d |= (l0b & 0x100) >> 1;
-	a1d |= (a0b & 0x100) >> 1;
-
-	int l1de = quant_color(t, l1d), a1de = quant_color(t, a1d);
-	int l1du = l1de, a1du = a1de;
-	if ((l1d ^ l1du) & 0xC0) return false;
-	if ((a1d ^ a1du) & 0xC0) return false;
-
-	l1du &= 0x7F; a1du &= 0x7F;
-	if (l1du & 0x40) l1du -= 0x80;
-	if (a1du & 0x40) a1du -= 0x80;
-	l1du += l0b; a1du += a0b;
-	if (l1du < 0 || l1du > 0x1FF) return false;
-	if (a1du < 0 || a1du > 0x1FF) return false;
-
-	output[0] = (uint8_t)l0be; output[1] = (uint8_t)l1de;
-	output[2] = (uint8_t)a0be; output[3] = (uint8_t)a1de;
-	return true;
-}
-
-/* (ref: quantize_rgbs :734) */
-WV_FN void quantize_rgbs(const ColorTabs& t, f4 color, uint8_t* output)
-{
-	float scale = 1.0f / 257.0f;
-	float r = f_clamp255(color.x * scale);
-	float g = f_clamp255(color.y * scale);
-	float b = f_clamp255(color.z * scale);
-
-	int ri = quant_color(t, flt2int_rtn(r), r);
-	int gi = quant_color(t, flt2int_rtn(g), g);
-	int bi = quant_color(t, flt2int_rtn(b), b);
-
-	float oldcolorsum = hadd_rgb_s(color) * scale;
-	float newcolorsum = (float)(ri + gi + bi);
-
-	float scalea = f_clamp1(color.w * (oldcolorsum + 1e-10f) / (newcolorsum + 1e-10f));
-	int scale_idx = flt2int_rtn(scalea * 256.0f);
-	scale_idx = i_clamp(scale_idx, 0, 255);
-
-	output[0] = (uint8_t)ri; output[1] = (uint8_t)gi; output[2] = (uint8_t)bi;
-	output[3] = (uint8_t)quant_color(t, scale_idx);
-}
-
-/* (ref: pack_color_endpoints :1909).  Returns the format actually used. */
-WV_FN int pack_color_endpoints(const Ctx& c, f4 color0, f4 color1, f4 rgbs_color, f4 rgbo_color, int format, uint8_t* output, int quant_level)
-{
-	(void)rgbo_color;
-	ColorTabs t = color_tabs(c, quant_level);
-
-	color0 = v4_clamp(0.0f, 65535.0f, color0);
-	color1 = v4_clamp(0.0f, 65535.0f, color1);
-	f4 color0_ldr = color0 * (1.0f / 257.0f);
-	f4 color1_ldr = color1 * (1.0f / 257.0f);
-
-	int retval = 0;
-	float best_error = ERROR_CALC_DEFAULT;
-	i4 c0 = mki4(0, 0, 0, 0), c1 = mki4(0, 0, 0, 0), c0b = c0, c1b = c1, u0, u1;
-
-	switch (format)
+	// The first round quantizes all four lanes of the values as they are (they lie within 0 .. 255, so the clamps of
+	// the rounded index do nothing yet): that is the alpha lane's result, whatever the colour lanes go on to do.
+	QPair first;
+	first.e0 = q_quant(t, q_round_to_int(colour0), colour0);
+	first.e1 = q_quant(t, q_round_to_int(colour1), colour1);
+	QPair out = first;
+	while (q_sum_rgb(out.e0) > q_sum_rgb(out.e1))
 	{
-	case FMT_RGB:
-	case FMT_RGBA:
+		colour0 = colour0 - 0.2f;
+		colour1 = colour1 + 0.2f;
+		out.e0 = q_quant(t, q_mapi(q_round_to_int(colour0), [](int x) { return i_max(x, 0); }), colour0);
+		out.e1 = q_quant(t, q_mapi(q_round_to_int(colour1), [](int x) { return i_min(x, 255); }), colour1);
+	}
+	out.e0 = q_with_w(out.e0, first.e0);
+	out.e1 = q_with_w(out.e1, first.e1);
+	return out;
+}
+
+/* RGB + scale (ref: quantize_rgbs :734): components 0..2 = colour, 3 = scale -> four bytes */
+WV_FN qi q_encode_rgb_scale(const ColorTabs& t, qf rgbs)
+{
+	const qf c = q_map(rgbs * (1.0f / 257.0f), [](float x) { return f_clamp255(x); });
+	const qi cq = q_quant(t, q_round_to_int(c), c);
+	const float old_sum = q_hadd_rgb(rgbs) * (1.0f / 257.0f);
+	const float new_sum = (float)q_sum_rgb(cq);
+	const float scale = f_clamp1(q_get<3>(rgbs) * (old_sum + 1e-10f) / (new_sum + 1e-10f));
+	const int scale_index = i_clamp(flt2int_rtn(scale * 256.0f), 0, 255);
+	return q_with_w(cq, quant_color(t, scale_index));
+}
+
+/* What pack_endpoints_quad found. */
+struct QPacked {
+	int format;          // the format actually used (same value on the quad's lanes)
+	bool decoded_valid;  // `decoded` holds the 8-bit endpoints a decoder reconstructs (the direct and base + offset formats)
+	QPair decoded;
+};
+
+/* One partition's endpoints -> bytes, LDR formats (ref: pack_color_endpoints :1909; the HDR formats are coded by
+ * pack_endpoints_hdr in wave_color_hdr.h).  colour0 / colour1 are the real-valued endpoints (0 .. 65535), rgbs the
+ * RGB + scale vector.  output: 8 bytes. */
+WV_FN QPacked pack_endpoints_quad(const Ctx& c, qf colour0, qf colour1, qf rgbs, int format, uint8_t* output, int quant_level)
+{
+	const ColorTabs t = color_tabs(c, quant_level);
+	QPacked r;
+	r.format = format;
+	r.decoded_valid = false;
+	r.decoded.e0 = q_splat(0); r.decoded.e1 = q_splat(0);
+
+	colour0 = q_clamp(0.0f, 65535.0f, colour0) * (1.0f / 257.0f);
+	colour1 = q_clamp(0.0f, 65535.0f, colour1) * (1.0f / 257.0f);
+
+	if (format == FMT_RGB || format == FMT_RGBA)
+	{
+		// Up to four encodings in the reference's order of preference; a later one replaces an earlier one only if its
+		// decoded endpoints are strictly closer (ref: :1936-1999, :2010-2073).
+		const bool alpha = format == FMT_RGBA;
+		const int format_delta = alpha ? FMT_RGBA_DELTA : FMT_RGB_DELTA;
+		float best_error = ERROR_CALC_DEFAULT;
+		QPair best, trial;
+		best.e0 = q_splat(0); best.e1 = q_splat(0);
+		auto consider = [&](QPair enc, bool delta) {
+			if (!alpha) { enc.e0 = q_with_w(enc.e0, 0); enc.e1 = q_with_w(enc.e1, 0); }
+			const QPair dec = delta ? q_decode_delta(enc) : q_decode_direct(enc);
+			const float error = q_encoding_error(colour0, colour1, dec);
+			if (error < best_error)
+			{
+				best_error = error;
+				best = enc;
+				r.format = delta ? format_delta : format;
+				r.decoded = dec;
+			}
+		};
+		// both blue-contracting encodings start from the same contracted pair, and fall together if it leaves the byte range
+		const qf contracted0 = q_blue_contract(colour0), contracted1 = q_blue_contract(colour1);
+		const bool contractible = quant_level < QUANT_256 &&
+		    !q_any(q_zipb(q_testf(contracted0, [](float x) { return x < 0.0f || x > 255.0f; }), q_testf(contracted1, [](float x) { return x < 0.0f || x > 255.0f; })));
+		if (quant_level <= QUANT_160)
 		{
-			const bool al = format == FMT_RGBA;
-			const int fmt_delta = al ? FMT_RGBA_DELTA : FMT_RGB_DELTA;
-			if (quant_level <= QUANT_160)
-			{
-				bool ok = try_quantize_rgb_delta_blue_contract(t, color0_ldr, color1_ldr, c0, c1);
-				if (ok && al) ok = try_quantize_alpha_delta(t, color1_ldr, color0_ldr, c0, c1);
-				if (ok)
-				{
-					rgba_delta_unpack(c0, c1, u0, u1);
-					retval = fmt_delta;
-					best_error = rgba_encoding_error(color0_ldr, color1_ldr, u0, u1);
-				}
-
-				ok = try_quantize_rgb_delta(t, color0_ldr, color1_ldr, c0b, c1b);
-				if (ok && al) ok = try_quantize_alpha_delta(t, color0_ldr, color1_ldr, c0b, c1b);
-				if (ok)
-				{
-					rgba_delta_unpack(c0b, c1b, u0, u1);
-					float error = rgba_encoding_error(color0_ldr, color1_ldr, u0, u1);
-					if (error < best_error)
-					{
-						retval = fmt_delta;
-						best_error = error;
-						c0 = c0b; c1 = c1b;
-					}
-				}
-			}
-
-			if (quant_level < QUANT_256)
-			{
-				bool ok = al ? try_quantize_rgba_blue_contract(t, color0_ldr, color1_ldr, c0b, c1b)
-				             : try_quantize_rgb_blue_contract(t, color0_ldr, color1_ldr, c0b, c1b);
-				if (ok)
-				{
-					rgba_unpack(c0b, c1b, u0, u1);
-					float error = rgba_encoding_error(color0_ldr, color1_ldr, u0, u1);
-					if (error < best_error)
-					{
-						retval = format;
-						best_error = error;
-						c0 = c0b; c1 = c1b;
-					}
-				}
-			}
-
-			{
-				if (al) quantize_rgba(t, color0_ldr, color1_ldr, c0b, c1b);
-				else quantize_rgb(t, color0_ldr, color1_ldr, c0b, c1b);
-				rgba_unpack(c0b, c1b, u0, u1);
-				float error = rgba_encoding_error(color0_ldr, color1_ldr, u0, u1);
-				if (error < best_error)
-				{
-					retval = format;
-					c0 = c0b; c1 = c1b;
-				}
-			}
-
-			output[0] = (uint8_t)c0.x; output[1] = (uint8_t)c1.x;
-			output[2] = (uint8_t)c0.y; output[3] = (uint8_t)c1.y;
-			output[4] = (uint8_t)c0.z; output[5] = (uint8_t)c1.z;
-			if (al) { output[6] = (uint8_t)c0.w; output[7] = (uint8_t)c1.w; }
+			if (contractible && q_encode_delta(t, contracted1, contracted0, true, alpha, trial)) consider(trial, true);
+			if (q_encode_delta(t, colour0, colour1, false, alpha, trial)) consider(trial, true);
 		}
-		break;
+		if (contractible && q_encode_contracted(t, contracted0, contracted1, trial)) consider(trial, false);
+		consider(q_encode_direct(t, colour0, colour1), false);
 
-	case FMT_RGB_SCALE:
-		quantize_rgbs(t, rgbs_color, output);
-		retval = FMT_RGB_SCALE;
-		break;
+		q_store_u8(output, 2, best.e0, alpha ? 4 : 3);
+		q_store_u8(output + 1, 2, best.e1, alpha ? 4 : 3);
+		if (!alpha) { r.decoded.e0 = q_with_w(r.decoded.e0, 255); r.decoded.e1 = q_with_w(r.decoded.e1, 255); }
+		r.decoded_valid = true;
+		return r;
+	}
 
-	case FMT_RGB_SCALE_ALPHA:
+	if (format == FMT_RGB_SCALE || format == FMT_RGB_SCALE_ALPHA)
+	{
+		q_store_u8(output, 1, q_encode_rgb_scale(t, rgbs), 4);
+		if (format == FMT_RGB_SCALE_ALPHA)
 		{
-			float a0 = color0_ldr.w, a1 = color1_ldr.w;
-			output[4] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
-			output[5] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
-			quantize_rgbs(t, rgbs_color, output);
-			retval = FMT_RGB_SCALE_ALPHA;
+			// alpha of both endpoints behind the four bytes: lane 3 computes both
+			const float a0 = q_get<3>(colour0), a1 = q_get<3>(colour1);
+			Q_ONCE
+			{
+				output[4] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
+				output[5] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
+			}
 		}
-		break;
+		return r;
+	}
 
-	case FMT_LUMINANCE:
+	if (format == FMT_LUMINANCE || format == FMT_LUMINANCE_ALPHA)
+	{
+		// (luminance, alpha) of both endpoints: two values per endpoint, the same arithmetic on every lane of the quad
+		float lum0 = q_hadd_rgb(colour0) * (1.0f / 3.0f);
+		float lum1 = q_hadd_rgb(colour1) * (1.0f / 3.0f);
+		const float a0 = q_get<3>(colour0), a1 = q_get<3>(colour1);
+		if (format == FMT_LUMINANCE)
 		{
-			float lum0 = hadd_rgb_s(color0_ldr) * (1.0f / 3.0f);
-			float lum1 = hadd_rgb_s(color1_ldr) * (1.0f / 3.0f);
 			if (lum0 > lum1)
 			{
-				float avg = (lum0 + lum1) * 0.5f;
+				const float avg = (lum0 + lum1) * 0.5f;
 				lum0 = avg;
 				lum1 = avg;
 			}
-			output[0] = (uint8_t)quant_color(t, flt2int_rtn(lum0), lum0);
-			output[1] = (uint8_t)quant_color(t, flt2int_rtn(lum1), lum1);
-			retval = FMT_LUMINANCE;
-		}
-		break;
-
-	case FMT_LUMINANCE_ALPHA:
-		{
-			if (quant_level <= 18)
+			Q_ONCE
 			{
-				if (try_quantize_luminance_alpha_delta(t, color0_ldr, color1_ldr, output))
-				{
-					retval = FMT_LUMINANCE_ALPHA_DELTA;
-					break;
-				}
+				output[0] = (uint8_t)quant_color(t, flt2int_rtn(lum0), lum0);
+				output[1] = (uint8_t)quant_color(t, flt2int_rtn(lum1), lum1);
 			}
-			float lum0 = hadd_rgb_s(color0_ldr) * (1.0f / 3.0f);
-			float lum1 = hadd_rgb_s(color1_ldr) * (1.0f / 3.0f);
-			float a0 = color0_ldr.w, a1 = color1_ldr.w;
+			return r;
+		}
+		if (quant_level <= 18)
+		{
+			// base + offset form of the (luminance, alpha) pair (ref: try_quantize_luminance_alpha_delta :573): components
+			// 0 and 1 of a quad vector, coded like the alpha lane of q_encode_delta
+			const qf v0 = q_make(lum0, a0, 0.0f, 0.0f), v1 = q_make(lum1, a1, 0.0f, 0.0f);
+			const qi base9 = q_round_to_int(v0) << 1;
+			const qi base_q = q_quant(t, base9 & 0xFF);
+			const qi base = base_q | (base9 & 0x100);
+			qi offset = (q_round_to_int(v1) << 1) - base;
+			bool ok = !q_any(q_test(offset, [](int x) { return x > 63 || x < -64; }));
+			offset = (offset & 0x7F) | ((base & 0x100) >> 1);
+			const qi offset_q = q_quant(t, offset);
+			ok = ok && !q_any(q_test((offset ^ offset_q) & 0xC0, [](int x) { return x != 0; }));
+			const qi value9 = q_mapi(offset_q & 0x7F, [](int x) { return (x & 0x40) ? x - 0x80 : x; }) + base;
+			ok = ok && !q_any(q_test(value9, [](int x) { return x < 0 || x > 0x1FF; }));
+			if (ok)
+			{
+				// bytes: l0 l1 a0 a1
+				q_store_u8(output, 2, base_q, 2);
+				q_store_u8(output + 1, 2, offset_q, 2);
+				r.format = FMT_LUMINANCE_ALPHA_DELTA;
+				return r;
+			}
+		}
+		Q_ONCE
+		{
 			output[0] = (uint8_t)quant_color(t, flt2int_rtn(lum0), lum0);
 			output[1] = (uint8_t)quant_color(t, flt2int_rtn(lum1), lum1);
 			output[2] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
 			output[3] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
-			retval = FMT_LUMINANCE_ALPHA;
 		}
-		break;
+		return r;
+	}
+	return r;
+}
+
+/* The endpoint formats coded by pack_endpoints_hdr. */
+WV_FN bool endpoint_format_is_hdr(int format)
+{
+	return ((1u << format) & ((1u << FMT_HDR_LUMINANCE_LARGE_RANGE) | (1u << FMT_HDR_LUMINANCE_SMALL_RANGE) | (1u << FMT_HDR_RGB_SCALE) |
+	                          (1u << FMT_HDR_RGB) | (1u << FMT_HDR_RGB_LDR_ALPHA) | (1u << FMT_HDR_RGBA))) != 0;
+}
 
 #if ASTC_ENABLE_HDR
-	case FMT_HDR_RGB_SCALE:
-		quantize_hdr_rgbo(t, rgbo_color, output);
-		retval = FMT_HDR_RGB_SCALE;
-		break;
-
-	case FMT_HDR_RGB:
-		quantize_hdr_rgb(t, color0, color1, output);
-		retval = FMT_HDR_RGB;
-		break;
-
-	case FMT_HDR_LUMINANCE_SMALL_RANGE:
-	case FMT_HDR_LUMINANCE_LARGE_RANGE:
-		if (try_quantize_hdr_luminance_small_range(t, color0, color1, output))
+/* HDR endpoint formats of all partitions of the candidate being refined (ref: the HDR cases of pack_color_endpoints
+ * :2076-2140).  requested[p] = format asked for; values + 8 p receives the bytes, formats_out[p] the format used.
+ * Partitions with an LDR format are left alone (pack_endpoints_quad codes those).  `tries`: LDS scratch,
+ * 4 * HDR_TRY_LANES * HDR_TRY_BYTES bytes. */
+WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* requested, uint8_t* values, uint8_t* formats_out,
+                              int quant_level, uint8_t* tries)
+{
+	const TrialInfo& tr = c.tr();
+	const ColorTabs t = color_tabs(c, quant_level);
+	// the sub-modes, side by side
+	WV_FOR(k, partition_count * HDR_TRY_LANES)
+	{
+		const int p = k / HDR_TRY_LANES, lane = k % HDR_TRY_LANES;
+		const int format = requested[p];
+		uint8_t* rec = tries + k * HDR_TRY_BYTES;
+		const f4 low = v4_clamp(0.0f, 65535.0f, load4(tr.wep0[p])), high = v4_clamp(0.0f, 65535.0f, load4(tr.wep1[p]));
+		if (format == FMT_HDR_RGB_SCALE)
 		{
-			retval = FMT_HDR_LUMINANCE_SMALL_RANGE;
-			break;
+			if (lane < 5) hdr_try_rgbo(t, load4(tr.rgbo[p]), lane, rec);                       // preference: sub-mode 0 first
 		}
-		quantize_hdr_luminance_large_range(t, color0, color1, output);
-		retval = FMT_HDR_LUMINANCE_LARGE_RANGE;
-		break;
-
-	case FMT_HDR_RGB_LDR_ALPHA:
+		else if (format == FMT_HDR_RGB || format == FMT_HDR_RGB_LDR_ALPHA || format == FMT_HDR_RGBA)
 		{
-			float scale = 1.0f / 257.0f;
-			float a0 = f_clamp255(color0.w * scale);
-			float a1 = f_clamp255(color1.w * scale);
-			output[6] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
-			output[7] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
-			quantize_hdr_rgb(t, color0, color1, output);
-			retval = FMT_HDR_RGB_LDR_ALPHA;
+			if (lane < 8) hdr_try_rgb(t, low, high, 7 - lane, rec);                             // preference: sub-mode 7 first
+			else if (lane < 11 && format == FMT_HDR_RGBA) hdr_try_alpha(t, low.w, high.w, 10 - lane, rec);   // finest first
 		}
-		break;
-
-	case FMT_HDR_RGBA:
-		quantize_hdr_rgb(t, color0, color1, output);
-		quantize_hdr_alpha(t, color0.w, color1.w, output + 6);
-		retval = FMT_HDR_RGBA;
-		break;
-#endif
-
-	default:
-		retval = format;
-		break;
 	}
-
-	return retval;
+	WV_SYNC();
+	// first sub-mode that fits, else the escape layout
+	WV_FOR(p, partition_count)
+	{
+		const int format = requested[p];
+		if (!endpoint_format_is_hdr(format)) continue;
+		uint8_t* out = values + p * 8;
+		const uint8_t* recs = tries + p * HDR_TRY_LANES * HDR_TRY_BYTES;
+		const f4 low = v4_clamp(0.0f, 65535.0f, load4(tr.wep0[p])), high = v4_clamp(0.0f, 65535.0f, load4(tr.wep1[p]));
+		auto first_fit = [recs](int begin, int end) {
+			for (int m = begin; m < end; m++) if (recs[m * HDR_TRY_BYTES]) return m;
+			return -1;
+		};
+		int used = format;
+		if (format == FMT_HDR_RGB_SCALE)
+		{
+			const int m = first_fit(0, 5);
+			if (m >= 0) { for (int i = 0; i < 4; i++) out[i] = recs[m * HDR_TRY_BYTES + 1 + i]; }
+			else hdr_escape_rgbo(t, load4(tr.rgbo[p]), out);
+		}
+		else if (format == FMT_HDR_LUMINANCE_SMALL_RANGE || format == FMT_HDR_LUMINANCE_LARGE_RANGE)
+		{
+			used = hdr_code_luminance(t, low, high, out);
+		}
+		else
+		{
+			const int m = first_fit(0, 8);
+			if (m >= 0) { for (int i = 0; i < 6; i++) out[i] = recs[m * HDR_TRY_BYTES + 1 + i]; }
+			else hdr_escape_rgb(t, low, high, out);
+			if (format == FMT_HDR_RGB_LDR_ALPHA)
+			{
+				const float a0 = f_clamp255(low.w * (1.0f / 257.0f)), a1 = f_clamp255(high.w * (1.0f / 257.0f));
+				out[6] = (uint8_t)quant_color(t, flt2int_rtn(a0), a0);
+				out[7] = (uint8_t)quant_color(t, flt2int_rtn(a1), a1);
+			}
+			else if (format == FMT_HDR_RGBA)
+			{
+				const int ma = first_fit(8, 11);
+				if (ma >= 0) { out[6] = recs[ma * HDR_TRY_BYTES + 1]; out[7] = recs[ma * HDR_TRY_BYTES + 2]; }
+				else
+				{
+					// plain 7-bit alphas (ref: :1890-1906)
+					const int a0 = flt2int_rtn(f_clamp(low.w, 0.0f, 65280.0f)), a1 = flt2int_rtn(f_clamp(high.w, 0.0f, 65280.0f));
+					out[6] = (uint8_t)quant_color(t, ((a0 + 256) >> 9) | 0x80);
+					out[7] = (uint8_t)quant_color(t, ((a1 + 256) >> 9) | 0x80);
+				}
+			}
+		}
+		formats_out[p] = (uint8_t)used;
+	}
 }
+#endif
 
 } } // namespace astcd::ASTC_VARIANT

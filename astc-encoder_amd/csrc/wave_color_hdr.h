@@ -1,7 +1,6 @@
 // SPDX-License-Identifier: Apache-2.0
-// HDR endpoint formats: quantizers (pack) and decoders (unpack).
-//   ref: quantize_and_unquantize_retain_top_{two,four}_bits, quantize_hdr_rgbo, quantize_hdr_rgb,
-//        quantize_hdr_rgb_ldr_alpha, quantize_hdr_luminance_large_range,
+// HDR endpoint formats: coders (sub-modes side by side on lanes, driven by width / spare-bit tables) and decoders.
+//   ref (behaviour): quantize_hdr_rgbo, quantize_hdr_rgb, quantize_hdr_rgb_ldr_alpha, quantize_hdr_luminance_large_range,
 //        try_quantize_hdr_luminance_small_range, quantize_hdr_alpha, quantize_hdr_rgb_alpha
 //                                   Source/astcenc_color_quantize.cpp:848-1906
 //        hdr_rgbo_unpack, hdr_rgb_unpack, hdr_rgb_ldr_alpha_unpack, hdr_luminance_*_unpack,
@@ -17,479 +16,264 @@ struct ColorTabs;
 WV_FN int quant_color(const ColorTabs& t, int value);
 WV_FN int quant_color(const ColorTabs& t, int value, float valuef);
 
-/* Quantize `value` so that its top bits survive the quantize/unquantize round trip.
- * (ref: color_quantize.cpp:848-916; keep_mask = 0xC0 or 0xF0) */
-WV_FN uint8_t quant_retain_top_bits(const ColorTabs& t, uint8_t value, int keep_mask)
+// ---- coders ------------------------------------------------------------------------------------------------
+//
+// An HDR endpoint format is a family of sub-modes -- different splits of the available bits between a base value
+// and its offsets -- and the coder's job is to find the first sub-mode of a fixed preference order in which every
+// field fits (ref: the mode loops of quantize_hdr_rgbo :1002 and quantize_hdr_rgb :1353, the three tries of
+// quantize_hdr_alpha :1838).  The tries are independent of each other, so they run SIDE BY SIDE: sixteen lanes per
+// partition, one sub-mode per lane (lanes 0..7 colour, 8..10 alpha), each leaving "fits" and its bytes in a small
+// LDS record; one lane per partition then takes the first record that fits, or codes the format's escape layout.
+// The sub-modes are data: field widths per sub-mode (every cut-off and scale follows from them) and, per spare bit
+// of the byte layout, which field's which bit it carries (spec tables 26, 28: "Endpoint Unquantization" of modes
+// 7 and 11).
+
+/* Largest value <= `value` whose bits under `keep` survive the quantize / unquantize round trip, quantized
+ * (ref: quantize_and_unquantize_retain_top_{two,four}_bits :848-916). */
+WV_FN int quant_keeping(const ColorTabs& t, int value, int keep)
 {
-	bool perform_loop;
-	uint8_t quantval;
-	do
+	for (;;)
 	{
-		quantval = (uint8_t)quant_color(t, value);
-		perform_loop = (value & keep_mask) != (quantval & keep_mask);
-		if ((quantval & keep_mask) > (value & keep_mask)) value--;
-		else if ((quantval & keep_mask) < (value & keep_mask)) value--;
-	} while (perform_loop);
-	return quantval;
-}
-
-/* (ref: quantize_hdr_rgbo :925) */
-WV_FN void quantize_hdr_rgbo(const ColorTabs& t, f4 color, uint8_t* output)
-{
-	color.x = color.x + color.w;
-	color.y = color.y + color.w;
-	color.z = color.z + color.w;
-	color = v4_clamp(0.0f, 65535.0f, color);
-	f4 color_bak = color;
-
-	int majcomp;
-	if (color.x > color.y && color.x > color.z) majcomp = 0;
-	else if (color.y > color.z) majcomp = 1;
-	else majcomp = 2;
-
-	if (majcomp == 1) color = mk4(color.y, color.x, color.z, color.w);
-	else if (majcomp == 2) color = mk4(color.z, color.y, color.x, color.w);
-
-	const int mode_bits[5][3] = { {11, 5, 7}, {11, 6, 5}, {10, 5, 8}, {9, 6, 7}, {8, 7, 6} };
-	const float mode_cutoffs[5][2] = { {1024, 4096}, {2048, 1024}, {2048, 16384}, {8192, 16384}, {32768, 16384} };
-	const float mode_rscales[5] = { 32.0f, 32.0f, 64.0f, 128.0f, 256.0f };
-	const float mode_scales[5] = { 1.0f / 32.0f, 1.0f / 32.0f, 1.0f / 64.0f, 1.0f / 128.0f, 1.0f / 256.0f };
-
-	float r_base = color.x;
-	float g_base = color.x - color.y;
-	float b_base = color.x - color.z;
-	float s_base = color.w;
-
-	for (int mode = 0; mode < 5; mode++)
-	{
-		if (g_base > mode_cutoffs[mode][0] || b_base > mode_cutoffs[mode][0] || s_base > mode_cutoffs[mode][1]) continue;
-
-		int mode_enc = mode < 4 ? (mode | (majcomp << 2)) : (majcomp | 0xC);
-		float mode_scale = mode_scales[mode];
-		float mode_rscale = mode_rscales[mode];
-		int gb_intcutoff = 1 << mode_bits[mode][1];
-		int s_intcutoff = 1 << mode_bits[mode][2];
-
-		int r_intval = flt2int_rtn(r_base * mode_scale);
-		int r_lowbits = r_intval & 0x3f;
-		r_lowbits |= (mode_enc & 3) << 6;
-		uint8_t r_quantval = quant_retain_top_bits(t, (uint8_t)r_lowbits, 0xC0);
-		r_intval = (r_intval & ~0x3f) | (r_quantval & 0x3f);
-		float r_fval = (float)r_intval * mode_rscale;
-
-		float g_fval = r_fval - color.y;
-		float b_fval = r_fval - color.z;
-		g_fval = f_clamp(g_fval, 0.0f, 65535.0f);
-		b_fval = f_clamp(b_fval, 0.0f, 65535.0f);
-		int g_intval = flt2int_rtn(g_fval * mode_scale);
-		int b_intval = flt2int_rtn(b_fval * mode_scale);
-		if (g_intval >= gb_intcutoff || b_intval >= gb_intcutoff) continue;
-
-		int g_lowbits = g_intval & 0x1f;
-		int b_lowbits = b_intval & 0x1f;
-
-		int bit0 = 0, bit1 = 0, bit2 = 0, bit3 = 0;
-		switch (mode)
-		{
-		case 0: case 2: bit0 = (r_intval >> 9) & 1; break;
-		case 1: case 3: bit0 = (r_intval >> 8) & 1; break;
-		default: bit0 = (g_intval >> 6) & 1; break;
-		}
-		switch (mode)
-		{
-		case 0: case 1: case 2: case 3: bit2 = (r_intval >> 7) & 1; break;
-		default: bit2 = (b_intval >> 6) & 1; break;
-		}
-		switch (mode)
-		{
-		case 0: case 2: bit1 = (r_intval >> 8) & 1; break;
-		default: bit1 = (g_intval >> 5) & 1; break;
-		}
-		switch (mode)
-		{
-		case 0: bit3 = (r_intval >> 10) & 1; break;
-		case 2: bit3 = (r_intval >> 6) & 1; break;
-		default: bit3 = (b_intval >> 5) & 1; break;
-		}
-
-		g_lowbits |= (mode_enc & 0x4) << 5;
-		b_lowbits |= (mode_enc & 0x8) << 4;
-		g_lowbits |= bit0 << 6;
-		g_lowbits |= bit1 << 5;
-		b_lowbits |= bit2 << 6;
-		b_lowbits |= bit3 << 5;
-
-		uint8_t g_quantval = quant_retain_top_bits(t, (uint8_t)g_lowbits, 0xF0);
-		uint8_t b_quantval = quant_retain_top_bits(t, (uint8_t)b_lowbits, 0xF0);
-
-		g_intval = (g_intval & ~0x1f) | (g_quantval & 0x1f);
-		b_intval = (b_intval & ~0x1f) | (b_quantval & 0x1f);
-		g_fval = (float)g_intval * mode_rscale;
-		b_fval = (float)b_intval * mode_rscale;
-
-		float rgb_errorsum = (r_fval - color.x) + (r_fval - g_fval - color.y) + (r_fval - b_fval - color.z);
-		float s_fval = s_base + rgb_errorsum * (1.0f / 3.0f);
-		s_fval = f_clamp(s_fval, 0.0f, 1e9f);
-		int s_intval = flt2int_rtn(s_fval * mode_scale);
-		if (s_intval >= s_intcutoff) continue;
-
-		int s_lowbits = s_intval & 0x1f;
-		int bit4, bit5, bit6;
-		bit6 = mode == 1 ? (r_intval >> 9) & 1 : (s_intval >> 5) & 1;
-		bit5 = mode == 4 ? (r_intval >> 7) & 1 : mode == 1 ? (r_intval >> 10) & 1 : (s_intval >> 6) & 1;
-		bit4 = mode == 2 ? (s_intval >> 7) & 1 : (r_intval >> 6) & 1;
-
-		s_lowbits |= bit6 << 5;
-		s_lowbits |= bit5 << 6;
-		s_lowbits |= bit4 << 7;
-		uint8_t s_quantval = quant_retain_top_bits(t, (uint8_t)s_lowbits, 0xF0);
-
-		output[0] = r_quantval; output[1] = g_quantval; output[2] = b_quantval; output[3] = s_quantval;
-		return;
-	}
-
-	// no sub-mode fits: flat 7/7/7/7-bit layout ("mode 5")
-	float vals[4] = { color_bak.x, color_bak.y, color_bak.z, color_bak.w };
-	int ivals[4];
-	float cvals[3];
-	for (int i = 0; i < 3; i++)
-	{
-		vals[i] = f_clamp(vals[i], 0.0f, 65020.0f);
-		ivals[i] = flt2int_rtn(vals[i] * (1.0f / 512.0f));
-		cvals[i] = (float)ivals[i] * 512.0f;
-	}
-	float rgb_errorsum = (cvals[0] - vals[0]) + (cvals[1] - vals[1]) + (cvals[2] - vals[2]);
-	vals[3] += rgb_errorsum * (1.0f / 3.0f);
-	vals[3] = f_clamp(vals[3], 0.0f, 65020.0f);
-	ivals[3] = flt2int_rtn(vals[3] * (1.0f / 512.0f));
-
-	int encvals[4];
-	encvals[0] = (ivals[0] & 0x3f) | 0xC0;
-	encvals[1] = (ivals[1] & 0x7f) | 0x80;
-	encvals[2] = (ivals[2] & 0x7f) | 0x80;
-	encvals[3] = (ivals[3] & 0x7f) | ((ivals[0] & 0x40) << 1);
-	for (int i = 0; i < 4; i++) output[i] = quant_retain_top_bits(t, (uint8_t)encvals[i], 0xF0);
-}
-
-/* (ref: quantize_hdr_rgb :1253) */
-WV_FN void quantize_hdr_rgb(const ColorTabs& t, f4 color0, f4 color1, uint8_t* output)
-{
-	color0 = v4_clamp(0.0f, 65535.0f, color0);
-	color1 = v4_clamp(0.0f, 65535.0f, color1);
-	f4 color0_bak = color0, color1_bak = color1;
-
-	int majcomp;
-	if (color1.x > color1.y && color1.x > color1.z) majcomp = 0;
-	else if (color1.y > color1.z) majcomp = 1;
-	else majcomp = 2;
-
-	if (majcomp == 1)
-	{
-		color0 = mk4(color0.y, color0.x, color0.z, color0.w);
-		color1 = mk4(color1.y, color1.x, color1.z, color1.w);
-	}
-	else if (majcomp == 2)
-	{
-		color0 = mk4(color0.z, color0.y, color0.x, color0.w);
-		color1 = mk4(color1.z, color1.y, color1.x, color1.w);
-	}
-
-	float a_base = color1.x;
-	a_base = f_clamp(a_base, 0.0f, 65535.0f);
-	float b0_base = a_base - color1.y;
-	float b1_base = a_base - color1.z;
-	float c_base = a_base - color0.x;
-	float d0_base = a_base - b0_base - c_base - color0.y;
-	float d1_base = a_base - b1_base - c_base - color0.z;
-
-	const int mode_bits[8][4] = { {9, 7, 6, 7}, {9, 8, 6, 6}, {10, 6, 7, 7}, {10, 7, 7, 6}, {11, 8, 6, 5}, {11, 6, 8, 6}, {12, 7, 7, 5}, {12, 6, 7, 6} };
-	const float mode_cutoffs[8][3] = { {16384, 8192, 8192}, {32768, 8192, 4096}, {4096, 8192, 4096}, {8192, 8192, 2048},
-	                                   {8192, 2048, 512}, {2048, 8192, 1024}, {2048, 2048, 256}, {1024, 2048, 512} };
-	const float mode_scales[8] = { 1.0f / 128.0f, 1.0f / 128.0f, 1.0f / 64.0f, 1.0f / 64.0f, 1.0f / 32.0f, 1.0f / 32.0f, 1.0f / 16.0f, 1.0f / 16.0f };
-	const float mode_rscales[8] = { 128.0f, 128.0f, 64.0f, 64.0f, 32.0f, 32.0f, 16.0f, 16.0f };
-
-	for (int mode = 7; mode >= 0; mode--)
-	{
-		float b_cutoff = mode_cutoffs[mode][0], c_cutoff = mode_cutoffs[mode][1], d_cutoff = mode_cutoffs[mode][2];
-		if (b0_base > b_cutoff || b1_base > b_cutoff || c_base > c_cutoff || f_abs(d0_base) > d_cutoff || f_abs(d1_base) > d_cutoff) continue;
-
-		float mode_scale = mode_scales[mode];
-		float mode_rscale = mode_rscales[mode];
-		int b_intcutoff = 1 << mode_bits[mode][1];
-		int c_intcutoff = 1 << mode_bits[mode][2];
-		int d_intcutoff = 1 << (mode_bits[mode][3] - 1);
-
-		int a_intval = flt2int_rtn(a_base * mode_scale);
-		int a_lowbits = a_intval & 0xFF;
-		int a_quantval = quant_color(t, a_lowbits);
-		int a_uquantval = a_quantval;
-		a_intval = (a_intval & ~0xFF) | a_uquantval;
-		float a_fval = (float)a_intval * mode_rscale;
-
-		float c_fval = a_fval - color0.x;
-		c_fval = f_clamp(c_fval, 0.0f, 65535.0f);
-		int c_intval = flt2int_rtn(c_fval * mode_scale);
-		if (c_intval >= c_intcutoff) continue;
-
-		int c_lowbits = c_intval & 0x3f;
-		c_lowbits |= (mode & 1) << 7;
-		c_lowbits |= (a_intval & 0x100) >> 2;
-		uint8_t c_quantval = quant_retain_top_bits(t, (uint8_t)c_lowbits, 0xC0);
-		c_intval = (c_intval & ~0x3F) | (c_quantval & 0x3F);
-		c_fval = (float)c_intval * mode_rscale;
-
-		float b0_fval = a_fval - color1.y;
-		float b1_fval = a_fval - color1.z;
-		b0_fval = f_clamp(b0_fval, 0.0f, 65535.0f);
-		b1_fval = f_clamp(b1_fval, 0.0f, 65535.0f);
-		int b0_intval = flt2int_rtn(b0_fval * mode_scale);
-		int b1_intval = flt2int_rtn(b1_fval * mode_scale);
-		if (b0_intval >= b_intcutoff || b1_intval >= b_intcutoff) continue;
-
-		int b0_lowbits = b0_intval & 0x3f;
-		int b1_lowbits = b1_intval & 0x3f;
-
-		int bit0 = 0, bit1 = 0;
-		switch (mode)
-		{
-		case 0: case 1: case 3: case 4: case 6: bit0 = (b0_intval >> 6) & 1; break;
-		default: bit0 = (a_intval >> 9) & 1; break;
-		}
-		switch (mode)
-		{
-		case 0: case 1: case 3: case 4: case 6: bit1 = (b1_intval >> 6) & 1; break;
-		case 2: bit1 = (c_intval >> 6) & 1; break;
-		default: bit1 = (a_intval >> 10) & 1; break;
-		}
-
-		b0_lowbits |= bit0 << 6;
-		b1_lowbits |= bit1 << 6;
-		b0_lowbits |= ((mode >> 1) & 1) << 7;
-		b1_lowbits |= ((mode >> 2) & 1) << 7;
-
-		uint8_t b0_quantval = quant_retain_top_bits(t, (uint8_t)b0_lowbits, 0xC0);
-		uint8_t b1_quantval = quant_retain_top_bits(t, (uint8_t)b1_lowbits, 0xC0);
-
-		b0_intval = (b0_intval & ~0x3f) | (b0_quantval & 0x3f);
-		b1_intval = (b1_intval & ~0x3f) | (b1_quantval & 0x3f);
-		b0_fval = (float)b0_intval * mode_rscale;
-		b1_fval = (float)b1_intval * mode_rscale;
-
-		float d0_fval = a_fval - b0_fval - c_fval - color0.y;
-		float d1_fval = a_fval - b1_fval - c_fval - color0.z;
-		d0_fval = f_clamp(d0_fval, -65535.0f, 65535.0f);
-		d1_fval = f_clamp(d1_fval, -65535.0f, 65535.0f);
-		int d0_intval = flt2int_rtn(d0_fval * mode_scale);
-		int d1_intval = flt2int_rtn(d1_fval * mode_scale);
-		int ad0 = d0_intval < 0 ? -d0_intval : d0_intval;
-		int ad1 = d1_intval < 0 ? -d1_intval : d1_intval;
-		if (ad0 >= d_intcutoff || ad1 >= d_intcutoff) continue;
-
-		int d0_lowbits = d0_intval & 0x1f;
-		int d1_lowbits = d1_intval & 0x1f;
-
-		int bit2 = 0, bit3 = 0, bit4, bit5;
-		switch (mode)
-		{
-		case 0: case 2: bit2 = (d0_intval >> 6) & 1; break;
-		case 1: case 4: bit2 = (b0_intval >> 7) & 1; break;
-		case 3: bit2 = (a_intval >> 9) & 1; break;
-		case 5: bit2 = (c_intval >> 7) & 1; break;
-		default: bit2 = (a_intval >> 11) & 1; break;
-		}
-		switch (mode)
-		{
-		case 0: case 2: bit3 = (d1_intval >> 6) & 1; break;
-		case 1: case 4: bit3 = (b1_intval >> 7) & 1; break;
-		default: bit3 = (c_intval >> 6) & 1; break;
-		}
-		if (mode == 4 || mode == 6)
-		{
-			bit4 = (a_intval >> 9) & 1;
-			bit5 = (a_intval >> 10) & 1;
-		}
-		else
-		{
-			bit4 = (d0_intval >> 5) & 1;
-			bit5 = (d1_intval >> 5) & 1;
-		}
-
-		d0_lowbits |= bit2 << 6;
-		d1_lowbits |= bit3 << 6;
-		d0_lowbits |= bit4 << 5;
-		d1_lowbits |= bit5 << 5;
-		d0_lowbits |= (majcomp & 1) << 7;
-		d1_lowbits |= ((majcomp >> 1) & 1) << 7;
-
-		uint8_t d0_quantval = quant_retain_top_bits(t, (uint8_t)d0_lowbits, 0xF0);
-		uint8_t d1_quantval = quant_retain_top_bits(t, (uint8_t)d1_lowbits, 0xF0);
-
-		output[0] = (uint8_t)a_quantval;
-		output[1] = c_quantval;
-		output[2] = b0_quantval;
-		output[3] = b1_quantval;
-		output[4] = d0_quantval;
-		output[5] = d1_quantval;
-		return;
-	}
-
-	// no sub-mode fits: direct 8/8/7-bit endpoints (majcomp == 3 encoding)
-	float vals[6] = { color0_bak.x, color1_bak.x, color0_bak.y, color1_bak.y, color0_bak.z, color1_bak.z };
-	for (int i = 0; i < 6; i++) vals[i] = f_clamp(vals[i], 0.0f, 65020.0f);
-	for (int i = 0; i < 4; i++)
-	{
-		int idx = flt2int_rtn(vals[i] * 1.0f / 256.0f);
-		output[i] = (uint8_t)quant_color(t, idx);
-	}
-	for (int i = 4; i < 6; i++)
-	{
-		int idx = flt2int_rtn(vals[i] * 1.0f / 512.0f) + 128;
-		output[i] = quant_retain_top_bits(t, (uint8_t)idx, 0xC0);
+		const int q = quant_color(t, value & 0xFF);
+		if ((((value & 0xFF) ^ q) & keep) == 0) return q;
+		value--;
 	}
 }
 
-/* (ref: quantize_hdr_luminance_large_range :1644) */
-WV_FN void quantize_hdr_luminance_large_range(const ColorTabs& t, f4 color0, f4 color1, uint8_t* output)
+/* One spare bit of a byte layout: bit `shift` of field `field`. */
+struct SpareBit { uint8_t field, shift; };
+WV_FN int spare_bit(SpareBit s, int f0, int f1, int f2, int f3, int f4, int f5)
+{
+	const int v = s.field == 0 ? f0 : s.field == 1 ? f1 : s.field == 2 ? f2 : s.field == 3 ? f3 : s.field == 4 ? f4 : f5;
+	return (v >> s.shift) & 1;
+}
+
+/* The record a sub-mode lane leaves: [0] fits, [1..6] bytes. */
+constexpr int HDR_TRY_BYTES = 8;
+constexpr int HDR_TRY_LANES = 16;       // per partition: 0..7 colour sub-modes, 8..10 alpha sub-modes
+
+/* Colour with its largest component moved to x (ties: the reference's comparison order). */
+WV_FN int major_component(f4 v)
+{
+	if (v.x > v.y && v.x > v.z) return 0;
+	return v.y > v.z ? 1 : 2;
+}
+WV_FN f4 major_first(f4 v, int major) { return major == 1 ? mk4(v.y, v.x, v.z, v.w) : major == 2 ? mk4(v.z, v.y, v.x, v.w) : v; }
+
+/* RGB + offset format, sub-mode `mode` 0..4: base R (the major component), G and B as differences from it, the
+ * offset S as the last field.  (ref: quantize_hdr_rgbo :925, one iteration of its mode loop) */
+WV_FN void hdr_try_rgbo(const ColorTabs& t, f4 rgbo, int mode, uint8_t* rec)
+{
+	// widths of R, G/B, S per sub-mode
+	const uint8_t widths[5][3] = { { 11, 5, 7 }, { 11, 6, 5 }, { 10, 5, 8 }, { 9, 6, 7 }, { 8, 7, 6 } };
+	// spare bits 0..6 of bytes 1..3 (fields: 0 R, 1 G, 2 B, 3 S)
+	const SpareBit spare[5][7] = {
+		{ { 0, 9 }, { 0, 8 }, { 0, 7 }, { 0, 10 }, { 0, 6 }, { 3, 6 }, { 3, 5 } },
+		{ { 0, 8 }, { 1, 5 }, { 0, 7 }, { 2, 5 },  { 0, 6 }, { 0, 10 }, { 0, 9 } },
+		{ { 0, 9 }, { 0, 8 }, { 0, 7 }, { 0, 6 },  { 3, 7 }, { 3, 6 }, { 3, 5 } },
+		{ { 0, 8 }, { 1, 5 }, { 0, 7 }, { 2, 5 },  { 0, 6 }, { 3, 6 }, { 3, 5 } },
+		{ { 1, 6 }, { 1, 5 }, { 2, 6 }, { 2, 5 },  { 0, 6 }, { 0, 7 }, { 3, 5 } } };
+	rec[0] = 0;
+
+	f4 v = v4_clamp(0.0f, 65535.0f, mk4(rgbo.x + rgbo.w, rgbo.y + rgbo.w, rgbo.z + rgbo.w, rgbo.w));
+	const int major = major_component(v);
+	v = major_first(v, major);
+
+	const int wr = widths[mode][0], wgb = widths[mode][1], ws = widths[mode][2];
+	const float step = (float)(1 << (16 - wr)), rstep = 1.0f / step;
+	if (v.x - v.y > (float)(1 << wgb) * step || v.x - v.z > (float)(1 << wgb) * step || v.w > (float)(1 << ws) * step) return;
+	const int tag = mode < 4 ? (mode | (major << 2)) : (major | 0xC);
+
+	int r = flt2int_rtn(v.x * rstep);
+	const int byte0 = quant_keeping(t, (r & 0x3F) | ((tag & 3) << 6), 0xC0);
+	r = (r & ~0x3F) | (byte0 & 0x3F);
+	const float rf = (float)r * step;
+
+	int g = flt2int_rtn(f_clamp(rf - v.y, 0.0f, 65535.0f) * rstep);
+	int b = flt2int_rtn(f_clamp(rf - v.z, 0.0f, 65535.0f) * rstep);
+	if (g >= (1 << wgb) || b >= (1 << wgb)) return;
+	const SpareBit* sp = spare[mode];
+	const int byte1 = quant_keeping(t, (g & 0x1F) | ((tag & 4) << 5) | (spare_bit(sp[0], r, g, b, 0, 0, 0) << 6) | (spare_bit(sp[1], r, g, b, 0, 0, 0) << 5), 0xF0);
+	const int byte2 = quant_keeping(t, (b & 0x1F) | ((tag & 8) << 4) | (spare_bit(sp[2], r, g, b, 0, 0, 0) << 6) | (spare_bit(sp[3], r, g, b, 0, 0, 0) << 5), 0xF0);
+	g = (g & ~0x1F) | (byte1 & 0x1F);
+	b = (b & ~0x1F) | (byte2 & 0x1F);
+	const float gf = (float)g * step, bf = (float)b * step;
+
+	// the offset absorbs a third of the colour's coding error
+	const float drift = (rf - v.x) + (rf - gf - v.y) + (rf - bf - v.z);
+	const int sv = flt2int_rtn(f_clamp(v.w + drift * (1.0f / 3.0f), 0.0f, 1e9f) * rstep);
+	if (sv >= (1 << ws)) return;
+	const int byte3 = quant_keeping(t, (sv & 0x1F) | (spare_bit(sp[6], r, g, b, sv, 0, 0) << 5) | (spare_bit(sp[5], r, g, b, sv, 0, 0) << 6) |
+	                                   (spare_bit(sp[4], r, g, b, sv, 0, 0) << 7), 0xF0);
+	rec[1] = (uint8_t)byte0; rec[2] = (uint8_t)byte1; rec[3] = (uint8_t)byte2; rec[4] = (uint8_t)byte3;
+	rec[0] = 1;
+}
+
+/* ... no sub-mode fits: four plain 7-bit fields (ref: :1179-1240). */
+WV_FN void hdr_escape_rgbo(const ColorTabs& t, f4 rgbo, uint8_t* output)
+{
+	const f4 v = v4_clamp(0.0f, 65535.0f, mk4(rgbo.x + rgbo.w, rgbo.y + rgbo.w, rgbo.z + rgbo.w, rgbo.w));
+	const float cr = f_clamp(v.x, 0.0f, 65020.0f), cg = f_clamp(v.y, 0.0f, 65020.0f), cb = f_clamp(v.z, 0.0f, 65020.0f);
+	const int ir = flt2int_rtn(cr * (1.0f / 512.0f)), ig = flt2int_rtn(cg * (1.0f / 512.0f)), ib = flt2int_rtn(cb * (1.0f / 512.0f));
+	const float drift = ((float)ir * 512.0f - cr) + ((float)ig * 512.0f - cg) + ((float)ib * 512.0f - cb);
+	const int is = flt2int_rtn(f_clamp(v.w + drift * (1.0f / 3.0f), 0.0f, 65020.0f) * (1.0f / 512.0f));
+	output[0] = (uint8_t)quant_keeping(t, (ir & 0x3F) | 0xC0, 0xF0);
+	output[1] = (uint8_t)quant_keeping(t, (ig & 0x7F) | 0x80, 0xF0);
+	output[2] = (uint8_t)quant_keeping(t, (ib & 0x7F) | 0x80, 0xF0);
+	output[3] = (uint8_t)quant_keeping(t, (is & 0x7F) | ((ir & 0x40) << 1), 0xF0);
+}
+
+/* Direct RGB format, sub-mode `mode` 0..7: A = the major component of the high endpoint, B0 / B1 the other two as
+ * differences from it, C the step down to the low endpoint, D0 / D1 what the low endpoint's minor components still
+ * differ by.  (ref: quantize_hdr_rgb :1253, one iteration of its mode loop) */
+WV_FN void hdr_try_rgb(const ColorTabs& t, f4 low, f4 high, int mode, uint8_t* rec)
+{
+	// widths of A, B, C, D per sub-mode
+	const uint8_t widths[8][4] = { { 9, 7, 6, 7 }, { 9, 8, 6, 6 }, { 10, 6, 7, 7 }, { 10, 7, 7, 6 }, { 11, 8, 6, 5 }, { 11, 6, 8, 6 }, { 12, 7, 7, 5 }, { 12, 6, 7, 6 } };
+	// spare bits 0..5 of bytes 2..5 (fields: 0 A, 1 B0, 2 B1, 3 C, 4 D0, 5 D1)
+	const SpareBit spare[8][6] = {
+		{ { 1, 6 }, { 2, 6 },  { 4, 6 },  { 5, 6 }, { 4, 5 }, { 5, 5 } },
+		{ { 1, 6 }, { 2, 6 },  { 1, 7 },  { 2, 7 }, { 4, 5 }, { 5, 5 } },
+		{ { 0, 9 }, { 3, 6 },  { 4, 6 },  { 5, 6 }, { 4, 5 }, { 5, 5 } },
+		{ { 1, 6 }, { 2, 6 },  { 0, 9 },  { 3, 6 }, { 4, 5 }, { 5, 5 } },
+		{ { 1, 6 }, { 2, 6 },  { 1, 7 },  { 2, 7 }, { 0, 9 }, { 0, 10 } },
+		{ { 0, 9 }, { 0, 10 }, { 3, 7 },  { 3, 6 }, { 4, 5 }, { 5, 5 } },
+		{ { 1, 6 }, { 2, 6 },  { 0, 11 }, { 3, 6 }, { 0, 9 }, { 0, 10 } },
+		{ { 0, 9 }, { 0, 10 }, { 0, 11 }, { 3, 6 }, { 4, 5 }, { 5, 5 } } };
+	rec[0] = 0;
+
+	low = v4_clamp(0.0f, 65535.0f, low);
+	high = v4_clamp(0.0f, 65535.0f, high);
+	const int major = major_component(high);
+	low = major_first(low, major);
+	high = major_first(high, major);
+
+	const int wa = widths[mode][0], wb = widths[mode][1], wc = widths[mode][2], wd = widths[mode][3];
+	const float step = (float)(1 << (16 - wa)), rstep = 1.0f / step;
+	{
+		// coarse test on the real-valued fields
+		const float fa = f_clamp(high.x, 0.0f, 65535.0f);
+		const float fb0 = fa - high.y, fb1 = fa - high.z, fc = fa - low.x;
+		const float fd0 = fa - fb0 - fc - low.y, fd1 = fa - fb1 - fc - low.z;
+		const float bmax = (float)(1 << wb) * step, cmax = (float)(1 << wc) * step, dmax = (float)(1 << (wd - 1)) * step;
+		if (fb0 > bmax || fb1 > bmax || fc > cmax || f_abs(fd0) > dmax || f_abs(fd1) > dmax) return;
+	}
+
+	int a = flt2int_rtn(f_clamp(high.x, 0.0f, 65535.0f) * rstep);
+	const int byte0 = quant_color(t, a & 0xFF);
+	a = (a & ~0xFF) | byte0;
+	const float af = (float)a * step;
+
+	int cv = flt2int_rtn(f_clamp(af - low.x, 0.0f, 65535.0f) * rstep);
+	if (cv >= (1 << wc)) return;
+	const int byte1 = quant_keeping(t, (cv & 0x3F) | ((mode & 1) << 7) | ((a & 0x100) >> 2), 0xC0);
+	cv = (cv & ~0x3F) | (byte1 & 0x3F);
+	const float cf = (float)cv * step;
+
+	int b0 = flt2int_rtn(f_clamp(af - high.y, 0.0f, 65535.0f) * rstep);
+	int b1 = flt2int_rtn(f_clamp(af - high.z, 0.0f, 65535.0f) * rstep);
+	if (b0 >= (1 << wb) || b1 >= (1 << wb)) return;
+	const SpareBit* sp = spare[mode];
+	const int byte2 = quant_keeping(t, (b0 & 0x3F) | (spare_bit(sp[0], a, b0, b1, cv, 0, 0) << 6) | (((mode >> 1) & 1) << 7), 0xC0);
+	const int byte3 = quant_keeping(t, (b1 & 0x3F) | (spare_bit(sp[1], a, b0, b1, cv, 0, 0) << 6) | (((mode >> 2) & 1) << 7), 0xC0);
+	b0 = (b0 & ~0x3F) | (byte2 & 0x3F);
+	b1 = (b1 & ~0x3F) | (byte3 & 0x3F);
+	const float b0f = (float)b0 * step, b1f = (float)b1 * step;
+
+	const int d0 = flt2int_rtn(f_clamp(af - b0f - cf - low.y, -65535.0f, 65535.0f) * rstep);
+	const int d1 = flt2int_rtn(f_clamp(af - b1f - cf - low.z, -65535.0f, 65535.0f) * rstep);
+	if ((d0 < 0 ? -d0 : d0) >= (1 << (wd - 1)) || (d1 < 0 ? -d1 : d1) >= (1 << (wd - 1))) return;
+	const int byte4 = quant_keeping(t, (d0 & 0x1F) | (spare_bit(sp[2], a, b0, b1, cv, d0, d1) << 6) | (spare_bit(sp[4], a, b0, b1, cv, d0, d1) << 5) | ((major & 1) << 7), 0xF0);
+	const int byte5 = quant_keeping(t, (d1 & 0x1F) | (spare_bit(sp[3], a, b0, b1, cv, d0, d1) << 6) | (spare_bit(sp[5], a, b0, b1, cv, d0, d1) << 5) | (((major >> 1) & 1) << 7), 0xF0);
+
+	rec[1] = (uint8_t)byte0; rec[2] = (uint8_t)byte1; rec[3] = (uint8_t)byte2; rec[4] = (uint8_t)byte3; rec[5] = (uint8_t)byte4; rec[6] = (uint8_t)byte5;
+	rec[0] = 1;
+}
+
+/* ... no sub-mode fits: both endpoints as plain 8 / 8 / 7-bit values, flagged by major component "3" (ref: :1571-1610). */
+WV_FN void hdr_escape_rgb(const ColorTabs& t, f4 low, f4 high, uint8_t* output)
+{
+	low = v4_clamp(0.0f, 65020.0f, v4_clamp(0.0f, 65535.0f, low));
+	high = v4_clamp(0.0f, 65020.0f, v4_clamp(0.0f, 65535.0f, high));
+	output[0] = (uint8_t)quant_color(t, flt2int_rtn(low.x * 1.0f / 256.0f));
+	output[1] = (uint8_t)quant_color(t, flt2int_rtn(high.x * 1.0f / 256.0f));
+	output[2] = (uint8_t)quant_color(t, flt2int_rtn(low.y * 1.0f / 256.0f));
+	output[3] = (uint8_t)quant_color(t, flt2int_rtn(high.y * 1.0f / 256.0f));
+	output[4] = (uint8_t)quant_keeping(t, flt2int_rtn(low.z * 1.0f / 512.0f) + 128, 0xC0);
+	output[5] = (uint8_t)quant_keeping(t, flt2int_rtn(high.z * 1.0f / 512.0f) + 128, 0xC0);
+}
+
+/* HDR alpha pair, sub-mode `fine` 2..0: a 7-bit base at (9 - fine)-bit precision and a signed offset of 6 - fine
+ * bits (ref: quantize_hdr_alpha :1820, one iteration of its loop). */
+WV_FN void hdr_try_alpha(const ColorTabs& t, float alpha0, float alpha1, int fine, uint8_t* rec)
+{
+	rec[0] = 0;
+	const int a0 = flt2int_rtn(f_clamp(alpha0, 0.0f, 65280.0f)), a1 = flt2int_rtn(f_clamp(alpha1, 0.0f, 65280.0f));
+	int base = (a0 + (128 >> fine)) >> (8 - fine);
+	const int other = (a1 + (128 >> fine)) >> (8 - fine);
+	const int byte0_in = (base & 0x7F) | ((fine & 1) << 7);
+	const int byte0 = quant_color(t, byte0_in);
+	if ((byte0_in ^ byte0) & 0x80) return;
+	base = (base & ~0x7F) | (byte0 & 0x7F);
+	const int reach = 32 >> fine;
+	const int offset = other - base;
+	if (offset < -reach || offset >= reach) return;
+	const int byte1_in = ((fine & 2) << 6) | ((base >> 7) << (6 - fine)) | (offset & (2 * reach - 1));
+	const int byte1 = quant_color(t, byte1_in);
+	// everything but the offset's own bits must survive
+	if ((byte1_in ^ byte1) & (0xFF & ~(reach - 1))) return;
+	rec[1] = (uint8_t)byte0; rec[2] = (uint8_t)byte1;
+	rec[0] = 1;
+}
+
+/* HDR luminance pair (ref: try_quantize_hdr_luminance_small_range :1718, quantize_hdr_luminance_large_range :1644):
+ * returns the format used. */
+WV_FN int hdr_code_luminance(const ColorTabs& t, f4 color0, f4 color1, uint8_t* output)
 {
 	float lum0 = hadd_rgb_s(color0) * (1.0f / 3.0f);
 	float lum1 = hadd_rgb_s(color1) * (1.0f / 3.0f);
 	if (lum1 < lum0)
 	{
-		float avg = (lum0 + lum1) * 0.5f;
+		const float avg = (lum0 + lum1) * 0.5f;
 		lum0 = avg;
 		lum1 = avg;
 	}
-	int ilum1 = flt2int_rtn(lum1);
-	int ilum0 = flt2int_rtn(lum0);
+	const int y0 = flt2int_rtn(lum0), y1 = flt2int_rtn(lum1);
 
-	int upper_v0 = i_clamp((ilum0 + 128) >> 8, 0, 255);
-	int upper_v1 = i_clamp((ilum1 + 128) >> 8, 0, 255);
-	int lower_v0 = i_clamp((ilum1 + 256) >> 8, 0, 255);
-	int lower_v1 = i_clamp(ilum0 >> 8, 0, 255);
-
-	int upper0_dec = upper_v0 << 8;
-	int upper1_dec = upper_v1 << 8;
-	int lower0_dec = (lower_v1 << 8) + 128;
-	int lower1_dec = (lower_v0 << 8) - 128;
-
-	int upper0_diff = upper0_dec - ilum0, upper1_diff = upper1_dec - ilum1;
-	int lower0_diff = lower0_dec - ilum0, lower1_diff = lower1_dec - ilum1;
-	int upper_error = (upper0_diff * upper0_diff) + (upper1_diff * upper1_diff);
-	int lower_error = (lower0_diff * lower0_diff) + (lower1_diff * lower1_diff);
-
-	int v0, v1;
-	if (upper_error < lower_error) { v0 = upper_v0; v1 = upper_v1; }
-	else { v0 = lower_v0; v1 = lower_v1; }
-	output[0] = (uint8_t)quant_color(t, v0);
-	output[1] = (uint8_t)quant_color(t, v1);
-}
-
-/* (ref: try_quantize_hdr_luminance_small_range :1718) */
-WV_FN bool try_quantize_hdr_luminance_small_range(const ColorTabs& t, f4 color0, f4 color1, uint8_t* output)
-{
-	float lum0 = hadd_rgb_s(color0) * (1.0f / 3.0f);
-	float lum1 = hadd_rgb_s(color1) * (1.0f / 3.0f);
-	if (lum1 < lum0)
+	// small range: a base with `wb` bits and a `wo`-bit unsigned offset -- (11, 4) first, then (10, 5)
+	if (y1 - y0 <= 2048)
 	{
-		float avg = (lum0 + lum1) * 0.5f;
-		lum0 = avg;
-		lum1 = avg;
-	}
-	int ilum1 = flt2int_rtn(lum1);
-	int ilum0 = flt2int_rtn(lum0);
-	if (ilum1 - ilum0 > 2048) return false;
-
-	int lowval, highval, diffval, v0, v1, v0e, v1e, v0d, v1d;
-
-	// sub-mode with 11-bit base, 4-bit offset
-	lowval = i_clamp((ilum0 + 16) >> 5, 0, 2047);
-	highval = i_clamp((ilum1 + 16) >> 5, 0, 2047);
-	v0 = lowval & 0x7F;
-	v0e = quant_color(t, v0);
-	v0d = v0e;
-	if (v0d < 0x80)
-	{
-		lowval = (lowval & ~0x7F) | v0d;
-		diffval = highval - lowval;
-		if (diffval >= 0 && diffval <= 15)
+		for (int wo = 4; wo <= 5; wo++)
 		{
-			v1 = ((lowval >> 3) & 0xF0) | diffval;
-			v1e = quant_color(t, v1);
-			v1d = v1e;
-			if ((v1d & 0xF0) == (v1 & 0xF0))
-			{
-				output[0] = (uint8_t)v0e;
-				output[1] = (uint8_t)v1e;
-				return true;
-			}
+			const int drop = wo + 1;                       // 16 -> 15 - wo bits
+			int base = i_clamp((y0 + (1 << (drop - 1))) >> drop, 0, (1 << (15 - wo)) - 1);
+			const int top = i_clamp((y1 + (1 << (drop - 1))) >> drop, 0, (1 << (15 - wo)) - 1);
+			const int flag = wo == 5 ? 0x80 : 0;
+			const int b0 = quant_color(t, (base & 0x7F) | flag);
+			if ((b0 & 0x80) != flag) { if (wo == 5) break; continue; }
+			base = (base & ~0x7F) | (b0 & 0x7F);
+			const int offset = top - base;
+			if (offset < 0 || offset >= (1 << wo)) { if (wo == 5) break; continue; }
+			const int high_mask = 0xFF & ~((1 << wo) - 1);
+			const int b1_in = ((base >> (7 - wo)) & high_mask) | offset;
+			const int b1 = quant_color(t, b1_in);
+			if ((b1 & high_mask) != (b1_in & high_mask)) { if (wo == 5) break; continue; }
+			output[0] = (uint8_t)b0;
+			output[1] = (uint8_t)b1;
+			return FMT_HDR_LUMINANCE_SMALL_RANGE;
 		}
 	}
 
-	// sub-mode with 10-bit base, 5-bit offset
-	lowval = i_clamp((ilum0 + 32) >> 6, 0, 1023);
-	highval = i_clamp((ilum1 + 32) >> 6, 0, 1023);
-	v0 = (lowval & 0x7F) | 0x80;
-	v0e = quant_color(t, v0);
-	v0d = v0e;
-	if ((v0d & 0x80) == 0) return false;
-
-	lowval = (lowval & ~0x7F) | (v0d & 0x7F);
-	diffval = highval - lowval;
-	if (diffval < 0 || diffval > 31) return false;
-
-	v1 = ((lowval >> 2) & 0xE0) | diffval;
-	v1e = quant_color(t, v1);
-	v1d = v1e;
-	if ((v1d & 0xE0) != (v1 & 0xE0)) return false;
-
-	output[0] = (uint8_t)v0e;
-	output[1] = (uint8_t)v1e;
-	return true;
-}
-
-/* (ref: quantize_hdr_alpha :1820) */
-WV_FN void quantize_hdr_alpha(const ColorTabs& t, float alpha0, float alpha1, uint8_t* output)
-{
-	alpha0 = f_clamp(alpha0, 0.0f, 65280.0f);
-	alpha1 = f_clamp(alpha1, 0.0f, 65280.0f);
-	int ialpha0 = flt2int_rtn(alpha0);
-	int ialpha1 = flt2int_rtn(alpha1);
-
-	int val0, val1, diffval, v6, v7, v6e, v7e, v6d, v7d;
-	const int testbits[3] = { 0xE0, 0xF0, 0xF8 };
-
-	for (int i = 2; i >= 0; i--)
-	{
-		val0 = (ialpha0 + (128 >> i)) >> (8 - i);
-		val1 = (ialpha1 + (128 >> i)) >> (8 - i);
-
-		v6 = (val0 & 0x7F) | ((i & 1) << 7);
-		v6e = quant_color(t, v6);
-		v6d = v6e;
-		if ((v6 ^ v6d) & 0x80) continue;
-
-		val0 = (val0 & ~0x7f) | (v6d & 0x7f);
-		diffval = val1 - val0;
-		int cutoff = 32 >> i;
-		int mask = 2 * cutoff - 1;
-		if (diffval < -cutoff || diffval >= cutoff) continue;
-
-		v7 = ((i & 2) << 6) | ((val0 >> 7) << (6 - i)) | (diffval & mask);
-		v7e = quant_color(t, v7);
-		v7d = v7e;
-		if ((v7 ^ v7d) & testbits[i]) continue;
-
-		output[0] = (uint8_t)v6e;
-		output[1] = (uint8_t)v7e;
-		return;
-	}
-
-	val0 = (ialpha0 + 256) >> 9;
-	val1 = (ialpha1 + 256) >> 9;
-	v6 = val0 | 0x80;
-	v7 = val1 | 0x80;
-	output[0] = (uint8_t)quant_color(t, v6);
-	output[1] = (uint8_t)quant_color(t, v7);
+	// large range: two 8-bit values, either rounded (stored ascending) or offset by half a step (stored descending);
+	// take the layout with the smaller squared error
+	const int up0 = i_clamp((y0 + 128) >> 8, 0, 255), up1 = i_clamp((y1 + 128) >> 8, 0, 255);
+	const int dn0 = i_clamp((y1 + 256) >> 8, 0, 255), dn1 = i_clamp(y0 >> 8, 0, 255);
+	const int eu0 = (up0 << 8) - y0, eu1 = (up1 << 8) - y1;
+	const int ed0 = ((dn1 << 8) + 128) - y0, ed1 = ((dn0 << 8) - 128) - y1;
+	const bool rounded = eu0 * eu0 + eu1 * eu1 < ed0 * ed0 + ed1 * ed1;
+	output[0] = (uint8_t)quant_color(t, rounded ? up0 : dn0);
+	output[1] = (uint8_t)quant_color(t, rounded ? up1 : dn1);
+	return FMT_HDR_LUMINANCE_LARGE_RANGE;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,8 +52,8 @@ struct TrialInfo {
 	// candidate search results (ref: compute_ideal_endpoint_formats outputs)
 	int   cand_count;
 	int   cand_block_mode[MAX_TRIAL_CANDIDATES];
-	int   cand_quant[MAX_TRIAL_CANDIDATES];
-	int   cand_quant_mod[MAX_TRIAL_CANDIDATES];
+	uint8_t cand_quant[MAX_TRIAL_CANDIDATES];
+	uint8_t cand_quant_mod[MAX_TRIAL_CANDIDATES];
 	uint8_t cand_formats[MAX_TRIAL_CANDIDATES][4];
 	// working endpoints of the candidate being refined
 	float wep0[4][4];
@@ -66,6 +66,13 @@ struct TrialInfo {
 	// encoding choice errors per partition (ref: encoding_choice_errors :922)
 	float eci_rgb_scale[4], eci_rgb_luma[4], eci_luminance[4], eci_alpha_drop[4];
 	int   eci_can_offset[4], eci_can_blue_contract[4];
+	// Block-lifetime cache of what the single-partition trials share (search_block clears the flags): the four
+	// encoding choice errors depend on the block and the partitioning only, so the two runs of trial A and the four
+	// two-plane trials (all with the one-partition "partitioning") compute them once; the ideal endpoints and weights
+	// of the one-plane trial are identical in both runs of trial A.
+	int   eci1_valid;
+	float eci1[4];            // rgb_scale, rgb_luma, luminance, alpha_drop of partition 0 of 1
+	int   ideal_1p1p_valid;   // ei_w / ei_wes / ep0 / ep1 / is_constant_wes hold the 1-partition 1-plane result
 	// generic small uniform mailboxes
 	float fbox[128];
 	int   ibox[64];

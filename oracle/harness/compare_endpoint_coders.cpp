@@ -1,0 +1,146 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+// Differential test of the endpoint coders (astc-encoder_amd/csrc/wave_color.h: the quad-lane LDR coders,
+// wave_color_hdr.h: the sub-mode-lane HDR coders; here in their sequential CPU build) against the reference's own
+// pack_color_endpoints / unpack_color_endpoints, linked from the objects oracle/Makefile builds out of
+// /root/reference/Source.  Random and adversarial endpoint pairs, every requested format, every colour quant level.
+//
+// usage: compare_endpoint_coders [cases per (format, level)] [seed]      exit code 0 = identical
+#include "astcenc_internal.h"
+
+#define ASTC_WAVE_EMU 1
+#include "wave_color.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace astcd { inline namespace ASTC_VARIANT { thread_local const Ctx* g_wave_ctx = nullptr; } }
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd()
+{
+	rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+	return (uint32_t)(rng_state >> 32);
+}
+static float frand(float lo, float hi) { return lo + (hi - lo) * (float)(rnd() & 0xFFFFFF) / 16777215.0f; }
+
+/* An endpoint component: mostly in range, sometimes on a byte boundary (x * 257), sometimes outside 0 .. 65535. */
+static float component(float centre, float spread)
+{
+	switch (rnd() % 8)
+	{
+	case 0: return (float)(rnd() % 256) * 257.0f;
+	case 1: return frand(-3000.0f, 69000.0f);
+	case 2: return centre;
+	default: return centre + frand(-spread, spread);
+	}
+}
+
+int main(int argc, char** argv)
+{
+	const int per_case = argc > 1 ? atoi(argv[1]) : 20000;
+	if (argc > 2) rng_state ^= (uint64_t)atoll(argv[2]) * 0x2545F4914F6CDD1Dull;
+
+	// a context that holds exactly what the coders touch: the staged colour row and the trial mailboxes
+	astcd::LdsLayout L; memset(&L, 0, sizeof(L));
+	L.trial = 0;
+	L.ctab = (uint32_t)((sizeof(astcd::TrialInfo) + 15) & ~15u);
+	std::vector<uint8_t> lds(L.ctab + 512 + 64);
+	astcd::DeviceConfig cfg; memset(&cfg, 0, sizeof(cfg));
+	astcd::TableRoot root; memset(&root, 0, sizeof(root));
+	astcd::Ctx c; memset(&c, 0, sizeof(c));
+	c.lds = lds.data(); c.L = &L; c.cfg = &cfg; c.root = &root; c.T = 16; c.Tp = 16;
+	astcd::g_wave_ctx = &c;
+	astcd::TrialInfo& tr = c.tr();
+
+	const int formats[] = { ::FMT_LUMINANCE, ::FMT_LUMINANCE_ALPHA, ::FMT_RGB_SCALE, ::FMT_RGB, ::FMT_RGB_SCALE_ALPHA, ::FMT_RGBA,
+	                        ::FMT_HDR_LUMINANCE_LARGE_RANGE, ::FMT_HDR_LUMINANCE_SMALL_RANGE, ::FMT_HDR_RGB_SCALE, ::FMT_HDR_RGB,
+	                        ::FMT_HDR_RGB_LDR_ALPHA, ::FMT_HDR_RGBA };
+	long long cases = 0, bad = 0;
+	long long used_format[16] = { 0 };
+	long long fit_rgbo[6] = { 0 }, fit_rgb[9] = { 0 }, fit_alpha[4] = { 0 };     // winning sub-mode, last = escape layout
+	for (int q = ::QUANT_6; q <= ::QUANT_256; q++)
+	{
+		memcpy(lds.data() + L.ctab, color_unquant_to_uquant_tables[q - ::QUANT_6], 512);
+		tr.staged_color_quant[0] = q;
+		for (int format : formats)
+		{
+			const bool hdr = astcd::endpoint_format_is_hdr(format);
+			for (int n = 0; n < per_case; n++)
+			{
+				// endpoint pairs: far apart, close (base + offset territory), grey-ish (luminance), dark (HDR fine sub-modes)
+				const int kind = rnd() % 6;
+				float e0[4], e1[4], rgbs[4], rgbo[4];
+				const float centre = kind == 4 ? frand(0.0f, 3000.0f) : frand(0.0f, 65535.0f);
+				const float spread = kind == 0 ? 65535.0f : kind == 1 ? 6000.0f : kind == 2 ? 1200.0f : kind == 3 ? 200.0f : kind == 4 ? 2500.0f : 20000.0f;
+				for (int k = 0; k < 4; k++)
+				{
+					const float ck = kind == 3 || (rnd() & 3) == 0 ? centre : frand(0.0f, 65535.0f);
+					e0[k] = component(ck, spread);
+					e1[k] = component(ck + ((rnd() & 1) ? spread * 0.5f : 0.0f), spread);
+					rgbs[k] = k < 3 ? component(ck, spread) : frand(-0.2f, 1.3f);
+					rgbo[k] = k < 3 ? component(ck, spread) : ((rnd() & 3) ? frand(0.0f, spread) : frand(-1000.0f, 70000.0f));
+				}
+				if (rnd() % 16 == 0) for (int k = 0; k < 4; k++) e1[k] = e0[k];
+
+				uint8_t want[8] = { 0 }, got[8] = { 0 };
+				const int want_format = pack_color_endpoints(vfloat4(e0[0], e0[1], e0[2], e0[3]), vfloat4(e1[0], e1[1], e1[2], e1[3]),
+				                                             vfloat4(rgbs[0], rgbs[1], rgbs[2], rgbs[3]), vfloat4(rgbo[0], rgbo[1], rgbo[2], rgbo[3]),
+				                                             format, want, (quant_method)q);
+				int got_format;
+				bool decoded_ok = true;
+				if (!hdr)
+				{
+					const astcd::QPacked r = astcd::pack_endpoints_quad(c, astcd::q_load(e0), astcd::q_load(e1), astcd::q_load(rgbs), format, got, q);
+					got_format = r.format;
+					if (r.decoded_valid)
+					{
+						bool rgb_hdr, alpha_hdr; vint4 o0, o1;
+						unpack_color_endpoints(ASTCENC_PRF_LDR, want_format, want, rgb_hdr, alpha_hdr, o0, o1);
+						int w0[4], w1[4]; storea(o0, w0); storea(o1, w1);
+						for (int k = 0; k < 4; k++) decoded_ok = decoded_ok && r.decoded.e0.v[k] * 257 == w0[k] && r.decoded.e1.v[k] * 257 == w1[k];
+					}
+				}
+				else
+				{
+					for (int k = 0; k < 4; k++) { tr.wep0[0][k] = e0[k]; tr.wep1[0][k] = e1[k]; tr.rgbo[0][k] = rgbo[k]; }
+					uint8_t requested[4] = { (uint8_t)format, 0, 0, 0 }, formats_out[4] = { 0 };
+					uint8_t tries[4 * astcd::HDR_TRY_LANES * astcd::HDR_TRY_BYTES];
+					astcd::pack_endpoints_hdr(c, 1, requested, got, formats_out, q, tries);
+					got_format = formats_out[0];
+					// coverage: which sub-mode record won
+					auto first = [&tries](int begin, int end) { for (int m = begin; m < end; m++) if (tries[m * astcd::HDR_TRY_BYTES]) return m - begin; return end - begin; };
+					if (format == ::FMT_HDR_RGB_SCALE) fit_rgbo[first(0, 5)]++;
+					else if (format == ::FMT_HDR_RGB || format == ::FMT_HDR_RGB_LDR_ALPHA || format == ::FMT_HDR_RGBA) fit_rgb[first(0, 8)]++;
+					if (format == ::FMT_HDR_RGBA) fit_alpha[first(8, 11)]++;
+				}
+				const int count = 2 * ((want_format >> 2) + 1);
+				cases++;
+				used_format[want_format & 15]++;
+				if (got_format != want_format || memcmp(want, got, (size_t)count) != 0 || !decoded_ok)
+				{
+					if (bad < 12)
+					{
+						printf("MISMATCH q=%d format=%d: reference -> %d [", q, format, want_format);
+						for (int k = 0; k < count; k++) printf(" %02x", want[k]);
+						printf(" ], coder -> %d [", got_format);
+						for (int k = 0; k < count; k++) printf(" %02x", got[k]);
+						printf(" ]%s  e0=(%g %g %g %g) e1=(%g %g %g %g)\n", decoded_ok ? "" : " (decoded endpoints differ)", e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]);
+					}
+					bad++;
+				}
+			}
+		}
+	}
+	printf("formats produced:");
+	for (int f = 0; f < 16; f++) printf(" %d:%lld", f, used_format[f]);
+	printf("\nHDR sub-mode that fitted first (last column: escape layout): RGB+offset");
+	for (long long v : fit_rgbo) printf(" %lld", v);
+	printf("; direct RGB");
+	for (long long v : fit_rgb) printf(" %lld", v);
+	printf("; alpha");
+	for (long long v : fit_alpha) printf(" %lld", v);
+	printf("\n%s (%lld mismatches in %lld cases)\n", bad == 0 ? "OK" : "FAILED", bad, cases);
+	return bad == 0 ? 0 : 1;
+}
