@@ -58,7 +58,8 @@ ASTC_HD inline uint32_t fmt_comb_cols(uint32_t partition_limit) { return partiti
 ASTC_HD inline uint32_t fmt_scratch_bytes(uint32_t partition_limit)
 {
 	uint32_t P = partition_limit < 1 ? 1u : partition_limit > 4 ? 4u : partition_limit;
-	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 4);
+	// best_error f32 [P][17][4], format_of_choice u8 [P][17][4]; comb_error f32 [17][cols], comb_format u16 [17][cols] (four 4-bit formats)
+	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 2);
 }
 ASTC_HD inline uint32_t uni_region_bytes(uint32_t texel_count, uint32_t partition_limit)
 {
@@ -94,7 +95,7 @@ struct DecimationMode {
 	// slots 1 / 2 = plane 0 / 1 of a 2-plane trial.  Within a class the grids are packed by ascending
 	// lowest quant level of their block modes (TableRoot::dwi_used_sets); grids the class cannot use have no slot.
 	uint16_t dwi_offset[3];      // float offset of the ideal weights in the packed dwi region
-	uint16_t lowhigh_offset[3];  // float offset of the angular (low, high) pairs, one per quant level 0..min(maxprec, 7)
+	uint16_t lowhigh_offset[3];  // float offset of the angular (low, high) pairs: one per quant level <= QUANT_12 in refprec, in ascending order
 };
 
 // Everything the decimation sweeps need about one packed ideal-weight slot (TableRoot::off_dwi_slots):

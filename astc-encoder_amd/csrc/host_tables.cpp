@@ -252,10 +252,12 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	uint32_t o_tcf = blob.alloc(4 * T * sizeof(float), 4);
 	uint32_t o_wtc = blob.alloc(W, 4);
 	uint32_t o_wt  = blob.alloc(rows * W, 4);
-	uint32_t o_wc  = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_tcw = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_ro  = blob.alloc(W, 4);          // realign schedule, filled by build_realign_schedules()
 	uint32_t o_rc  = blob.alloc(W, 4);
+	// (the weight contributions feed the decimation sweeps only, which read them from HBM / L2: behind the range that a
+	//  refined candidate stages into LDS, DecimationInfo::table_bytes)
+	uint32_t o_wc  = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_later = blob.alloc((size_t)W * REALIGN_LATER_MAX, 4);   // later neighbours (not part of the staged range), see build_realign_schedule()
 
 	uint8_t* p_tw = blob.at<uint8_t>(o_tw);
@@ -889,7 +891,12 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 				dms[i].dwi_offset[cls + plane] = (uint16_t)dwi_total[cls];
 				dms[i].lowhigh_offset[cls + plane] = (uint16_t)lh_total[cls];
 				dwi_total[cls] += wc4;
-				lh_total[cls] += 2u * (uint32_t)(std::min<int>(maxprec, 7) + 1);
+				// one (low, high) pair per angular quant level (<= QUANT_12) that a block mode of this grid uses in this class
+				// (at least one: the angular search parks the set's weight range there); the pair of level q sits at the rank
+				// of q among the used levels (mode_weight_bounds, angular_endpoints)
+				(void)maxprec;
+				const uint32_t used = (cls == 0 ? dms[i].refprec_1plane : dms[i].refprec_2planes) & 0xFFu;
+				lh_total[cls] += 2u * std::max<uint32_t>(1u, (uint32_t)__builtin_popcount(used));
 			}
 		}
 	}

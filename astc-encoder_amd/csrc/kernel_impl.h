@@ -9,6 +9,7 @@
 #include "wave_block.h"
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdlib>
 
 #ifndef ASTC_WAVES_PER_EU
 #define ASTC_WAVES_PER_EU 4
@@ -77,6 +78,10 @@ int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* 
 {
 	LdsLayout L;
 	make_lds_layout(root, cfg, L);
+#if defined(ASTC_DUPSTAGE)
+	// instrumentation builds only: extra LDS per block at run time, to find where the occupancy steps are
+	if (const char* pad = getenv("ASTC_LDS_PAD_RT")) L.total += (uint32_t)atoi(pad);
+#endif
 	*lds_bytes = L.total;
 	static_assert(sizeof(LdsLayout) <= 256, "layout record grew past the space the backend reserves");
 	memcpy(layout_out, &L, sizeof(L));

@@ -362,6 +362,15 @@ WV_FN int popcount64(uint64_t v)
 #endif
 }
 
+WV_FN int popcount32(uint32_t v)
+{
+#if WV_DEVICE
+	return __popc(v);
+#else
+	return __builtin_popcount(v);
+#endif
+}
+
 /* IEEE binary16 -> binary32 (exact). (ref semantics: sf16_to_float, mathlib_softfloat.cpp) */
 WV_FN float half_to_float(uint16_t h)
 {

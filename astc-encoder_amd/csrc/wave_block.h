@@ -32,9 +32,13 @@ WV_FN void mode_weight_bounds(const Ctx& c, const BlockMode& bm, int plane, floa
 {
 	if (bm.quant_mode <= MAX_ANGULAR_QUANT)
 	{
+		// the pair of quant level q is stored at the rank of q among the levels this grid's block modes use
+		const DecimationMode& m = c.dec_mode(bm.decimation_mode);
+		const uint32_t used = bm.is_dual_plane ? m.refprec_2planes : m.refprec_1plane;
+		const int rank = popcount32(used & ((1u << bm.quant_mode) - 1u));
 		const float* lh = c.lowhigh(plane, bm.decimation_mode, bm.is_dual_plane != 0);
-		low = lh[bm.quant_mode * 2];
-		high = lh[bm.quant_mode * 2 + 1];
+		low = lh[rank * 2];
+		high = lh[rank * 2 + 1];
 	}
 	else
 	{
@@ -848,6 +852,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		a.out = c.lowhigh(plane, dm, dual);
 		a.wcount = c.dec_info(dm).weight_count;
 		a.maxq = max_precision;
+		a.used = (uint16_t)((dual ? m.refprec_2planes : m.refprec_1plane) & 0xFFu);
 		return a;
 	};
 	PROF_SCOPE(c, PS_ANGULAR);

@@ -82,13 +82,12 @@ struct TrialInfo {
 	uint8_t dm_list[96];
 };
 
-/* Per block mode record of one trial. */
+/* Per block mode record of one trial: the weight quantization error, then (in place) + the error of the best colour
+ * combination.  Only the error is kept per mode: the quant levels and endpoint formats that go with it are recomputed
+ * for the handful of modes that become candidates (compute_ideal_endpoint_formats) -- at 217 one-plane modes (8x8
+ * -thorough) eight more bytes per mode were 1.7 KB of every block's LDS. */
 struct ModeRec {
-	float error;              // weight quantization error, then (in place) + error of the best colour combination
-	uint8_t quant_level;
-	uint8_t quant_level_mod;
-	uint8_t formats[4];
-	uint8_t pad[2];
+	float error;
 };
 
 /* First bytes of every workgroup's LDS: what an out-of-line stage function needs to rebuild its Ctx. */

@@ -50,20 +50,20 @@ WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
 
 /* Endpoint-format tables of one trial, laid out in the `uni` LDS region (fmt_scratch_bytes()):
  *   best_error[P][17][4], format_of_choice[P][17][4]   per partition x quant level x integer count
- *   comb_error[17][cols], comb_format[17][cols][4]       best combination over partitions
+ *   comb_error[17][cols], comb_format[17][cols] (4 x 4 bits) best combination over partitions
  * Quant rows are indexed by (quant - QUANT_6): lower levels are never legal for colour endpoints
  * (the reference fills them with ERROR_CALC_DEFAULT and never reads them back, ref :328-346). */
 struct FmtView {
 	float*   best_error_;
 	uint8_t* format_of_choice_;
 	float*   comb_error_;
-	uint8_t* comb_format_;
+	uint16_t* comb_format_;      // four 4-bit endpoint formats per cell, partition p in bits 4p .. 4p+3
 	int      cols;
 
 	WV_FN float* best_error(int p, int quant) const { return best_error_ + (p * (int)FMT_QUANT_ROWS + (quant - QUANT_6)) * 4; }
 	WV_FN uint8_t* format_of_choice(int p, int quant) const { return format_of_choice_ + (p * (int)FMT_QUANT_ROWS + (quant - QUANT_6)) * 4; }
 	WV_FN float* comb_error(int quant) const { return comb_error_ + (quant - QUANT_6) * cols; }
-	WV_FN uint8_t* comb_format(int quant, int col) const { return comb_format_ + ((quant - QUANT_6) * cols + col) * 4; }
+	WV_FN uint16_t& comb_format(int quant, int col) const { return comb_format_[(quant - QUANT_6) * cols + col]; }
 };
 
 WV_FN FmtView fmt_view(const Ctx& c)
@@ -76,7 +76,7 @@ WV_FN FmtView fmt_view(const Ctx& c)
 	v.format_of_choice_ = base + P * FMT_QUANT_ROWS * 16;
 	v.cols = (int)fmt_comb_cols(P);
 	v.comb_error_ = reinterpret_cast<float*>(base + P * FMT_QUANT_ROWS * 20);
-	v.comb_format_ = base + P * FMT_QUANT_ROWS * 20 + FMT_QUANT_ROWS * (uint32_t)v.cols * 4;
+	v.comb_format_ = reinterpret_cast<uint16_t*>(base + P * FMT_QUANT_ROWS * 20 + FMT_QUANT_ROWS * (uint32_t)v.cols * 4);
 	return v;
 }
 
@@ -430,8 +430,7 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 				if (errorterm <= fs.comb_error(quant)[intcnt])
 				{
 					fs.comb_error(quant)[intcnt] = errorterm;
-					fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
-					fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
+					fs.comb_format(quant, intcnt) = (uint16_t)(fs.format_of_choice(0, quant)[i] | (fs.format_of_choice(1, quant)[j] << 4));
 				}
 				continue;
 			}
@@ -446,9 +445,8 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 					if (errorterm <= fs.comb_error(quant)[intcnt])
 					{
 						fs.comb_error(quant)[intcnt] = errorterm;
-						fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
-						fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
-						fs.comb_format(quant, intcnt)[2] = fs.format_of_choice(2, quant)[k];
+						fs.comb_format(quant, intcnt) = (uint16_t)(fs.format_of_choice(0, quant)[i] | (fs.format_of_choice(1, quant)[j] << 4) |
+						                                           (fs.format_of_choice(2, quant)[k] << 8));
 					}
 					continue;
 				}
@@ -461,10 +459,8 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 					if (errorterm <= fs.comb_error(quant)[intcnt])
 					{
 						fs.comb_error(quant)[intcnt] = errorterm;
-						fs.comb_format(quant, intcnt)[0] = fs.format_of_choice(0, quant)[i];
-						fs.comb_format(quant, intcnt)[1] = fs.format_of_choice(1, quant)[j];
-						fs.comb_format(quant, intcnt)[2] = fs.format_of_choice(2, quant)[k];
-						fs.comb_format(quant, intcnt)[3] = fs.format_of_choice(3, quant)[l];
+						fs.comb_format(quant, intcnt) = (uint16_t)(fs.format_of_choice(0, quant)[i] | (fs.format_of_choice(1, quant)[j] << 4) |
+						                                           (fs.format_of_choice(2, quant)[k] << 8) | (fs.format_of_choice(3, quant)[l] << 12));
 					}
 				}
 			}
@@ -474,7 +470,10 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 
 /* Best (quant level, formats) for one block mode's colour bit budget. (ref: :678-718, :780-832,
  * :905-957, :1041-1093) */
-WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available, ModeRec& m)
+/* `quant` receives the colour quant level, `quant_mod` the level that matched formats would allow, `formats` [4] the
+ * endpoint formats; all three null in the scoring pass, which only wants the error. */
+WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available,
+                                          uint8_t* quant, uint8_t* quant_mod, uint8_t* formats)
 {
 	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.table(c.root->off_quant_mode_table));
 	float best_integer_count_error = ERROR_CALC_DEFAULT;
@@ -493,11 +492,13 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 				best_integer_count = integer_count - 1;
 			}
 		}
-		int ql = qmt[(best_integer_count + 1) * 128 + bits_available];
-		m.quant_level = (uint8_t)ql;
-		m.quant_level_mod = (uint8_t)ql;
-		m.formats[0] = FMT_LUMINANCE;
-		if (ql >= QUANT_6) m.formats[0] = fs.format_of_choice(0, ql)[best_integer_count];
+		if (quant)
+		{
+			int ql = qmt[(best_integer_count + 1) * 128 + bits_available];
+			*quant = (uint8_t)ql;
+			*quant_mod = (uint8_t)ql;
+			formats[0] = ql >= QUANT_6 ? fs.format_of_choice(0, ql)[best_integer_count] : (uint8_t)FMT_LUMINANCE;
+		}
 		return best_integer_count_error;
 	}
 
@@ -516,13 +517,16 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 			best_integer_count = integer_count;
 		}
 	}
-	int ql = qmt[best_integer_count * 128 + bits_available];
-	int ql_mod = qmt[best_integer_count * 128 + bits_available + mod_bits];
-	m.quant_level = (uint8_t)ql;
-	m.quant_level_mod = (uint8_t)ql_mod;
-	for (int i = 0; i < pc; i++)
+	if (quant)
 	{
-		m.formats[i] = ql >= QUANT_6 ? fs.comb_format(ql, best_integer_count - lo)[i] : (uint8_t)FMT_LUMINANCE;
+		int ql = qmt[best_integer_count * 128 + bits_available];
+		int ql_mod = qmt[best_integer_count * 128 + bits_available + mod_bits];
+		*quant = (uint8_t)ql;
+		*quant_mod = (uint8_t)ql_mod;
+		for (int i = 0; i < pc; i++)
+		{
+			formats[i] = ql >= QUANT_6 ? (uint8_t)((fs.comb_format(ql, best_integer_count - lo) >> (4 * i)) & 0xF) : (uint8_t)FMT_LUMINANCE;
+		}
 	}
 	return best_integer_count_error;
 }
@@ -573,7 +577,7 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 		else
 		{
 			int bitcount = mode_bitcount(pc, c.block_mode(start_block_mode + i));
-			float error_of_best = best_combination_for_bitcount(c, pc, fs, bitcount, m);
+			float error_of_best = best_combination_for_bitcount(c, pc, fs, bitcount, nullptr, nullptr, nullptr);
 			m.error = error_of_best + m.error;
 		}
 	}
@@ -590,13 +594,18 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 		WV_ONE
 		{
 			tr.cand_block_mode[n] = best;
-			tr.cand_quant[n] = modes[best].quant_level;
-			tr.cand_quant_mod[n] = modes[best].quant_level_mod;
-			for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = modes[best].formats[j];
 			modes[best].error = ERROR_CALC_DEFAULT;
 		}
 		WV_SYNC();
 		count++;
+	}
+	// the quant levels and formats of the winners: the same pick as in the scoring pass, now with its outputs, one lane
+	// per winner (the table lookups of all of them in flight together)
+	WV_FOR(n, count)
+	{
+		const int mode = tr.cand_block_mode[n];
+		for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = 0;
+		(void)best_combination_for_bitcount(c, pc, fs, mode_bitcount(pc, c.block_mode(mode)), &tr.cand_quant[n], &tr.cand_quant_mod[n], tr.cand_formats[n]);
 	}
 	WV_ONE { tr.cand_count = count; }
 	WV_SYNC();

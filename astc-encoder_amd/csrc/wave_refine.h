@@ -503,11 +503,14 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 // Decode-and-score
 // ---------------------------------------------------------------------------------------------
 
-/* Integer texel weights of one plane (ref: unpack_weights :89). */
-WV_FN int unpack_texel_weight(const uint8_t* uq, const uint8_t* tw, const uint8_t* tci, int T, int t)
+/* Integer texel weights of one plane (ref: unpack_weights :89).  `taps`: how many grid weights a texel of this grid
+ * interpolates at most (1, 2 or 4); the taps beyond that have contribution 0, so leaving them out changes nothing. */
+WV_FN int unpack_texel_weight(const uint8_t* uq, const uint8_t* tw, const uint8_t* tci, int T, int t, int taps)
 {
+	if (taps == 1) return uq[t];                  // an undecimated grid: one tap of weight 16, (8 + 16 w) >> 4 = w
 	int sum = 8;
-	for (int j = 0; j < 4; j++) sum += uq[tw[j * T + t]] * tci[j * T + t];
+	sum += uq[tw[t]] * tci[t] + uq[tw[T + t]] * tci[T + t];
+	if (taps > 2) sum += uq[tw[2 * T + t]] * tci[2 * T + t] + uq[tw[3 * T + t]] * tci[3 * T + t];
 	return sum >> 4;
 }
 
@@ -539,6 +542,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	const bool rgbm = (c.cfg->flags & (1u << 6)) != 0;
 	const bool fast_1p = !dual && pc == 1 && !rgbm;
 	const int p2c = wv_uniform((int)scb.plane2_component);
+	const int taps = di.W == T ? 1 : di.max_texel_weight_count <= 2 ? 2 : 4;
 
 	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
 
@@ -550,8 +554,8 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 		int t = (!dual && !fast_1p) ? pv.sorted[i] : i;
 		int p = pv.of_texel[t];
 		const int* e = &tr.ibox[p * 8];
-		int w1 = unpack_texel_weight(scb.weights, tw, tci, T, t);
-		int w2 = dual ? unpack_texel_weight(scb.weights + PLANE2_OFFSET, tw, tci, T, t) : w1;
+		int w1 = unpack_texel_weight(scb.weights, tw, tci, T, t, taps);
+		int w2 = dual ? unpack_texel_weight(scb.weights + PLANE2_OFFSET, tw, tci, T, t, taps) : w1;
 
 		float col[4], old[4];
 		for (int k = 0; k < 4; k++)
@@ -597,7 +601,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 
 	if (fast_1p)
 	{
-		return sum4(term, T);
+		return wv_sum4(term, T);
 	}
 
 	float summa = 0.0f;
@@ -727,7 +731,9 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			WV_SYNC();
 			// The reference re-infills a texel's weight every time it looks at it; the value only changes
 			// when one of its grid weights moves, so it is kept here and refreshed on moves.
-			WV_FOR(t, T) { wb[t] = infill4(uqf, tw, tcf, T, t); }
+			// (grids decimated in one dimension only: two taps; the other two would add 0.0 * weight, i.e. nothing)
+			const bool two_taps = di.max_texel_weight_count <= 2;
+			WV_FOR(t, T) { wb[t] = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t); }
 			WV_SYNC();
 
 			// with one partition the endpoint base / step are the same for every texel
@@ -793,7 +799,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						WV_FOR(te, (int)wtc[mover])
 						{
 							const int texel = wt[te * W + mover];
-							wb[texel] = infill4(uqf, tw, tcf, T, texel);
+							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
 						}
 						WV_SYNC();
 						// the later weights that share a texel with the mover see different infilled weights now
@@ -898,7 +904,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 							const int we = order[pos + slot];
 							if (verdict[we] == 255 || te >= (int)wtc[we]) continue;
 							int texel = wt[te * W + we];
-							wb[texel] = infill4(uqf, tw, tcf, T, texel);
+							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
 						}
 						WV_SYNC();
 					}

@@ -263,9 +263,10 @@ WV_FN int steps_for_quant_level(int q)
 struct AngSet {
 	const float* weights;
 	const uint8_t* rows;    // sin/cos table row per weight (angular_sample_row)
-	float* out;
+	float* out;             // (low, high) pairs of the quant levels in `used`, ascending
 	int wcount;
 	int maxq;
+	uint16_t used;          // quant levels <= QUANT_12 that a block mode of this grid uses (bit mask)
 };
 
 template <typename SetFn>
@@ -282,6 +283,24 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 	WV_FOR(s, nsets) { steps_of.set(s, steps_for_quant_level(get_set(s).maxq)); }
 	uint8_t* pair_set = reinterpret_cast<uint8_t*>(&tr.ibox[32]);      // [64] batch-local set of each (set, step) pair
 	uint8_t* set_steps = reinterpret_cast<uint8_t*>(&tr.ibox[48]);     // [32] steps of each set of the batch
+
+	// Lowest and highest weight of every set (ref: compute_angular_offsets keeps them per step, :104-127: they are the same
+	// for every step of a set), one lane per set, parked in the first two floats of the set's output row until the
+	// set's own phase 2 overwrites them with the bounds of quant level 0.
+	WV_FOR(s, nsets)
+	{
+		const AngSet a = get_set(s);
+		float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
+		for (int j = 0; j < a.wcount; j++)
+		{
+			const float w = a.weights[j];
+			min_weight = w < min_weight ? w : min_weight;
+			max_weight = w > max_weight ? w : max_weight;
+		}
+		a.out[0] = min_weight;
+		a.out[1] = max_weight;
+	}
+	WV_SYNC();
 
 	int s0 = 0;
 	while (s0 < nsets)
@@ -317,17 +336,17 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			const int W = a.wcount;
 			const float* wv = a.weights;
 			const uint8_t* rows = a.rows;
+			const float min_weight = a.out[0], max_weight = a.out[1];
 
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
-			float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
 			// groups of ASTC_ANG_GROUP weights: LDS reads, then all table loads, then the ordered accumulation
 			for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
 			{
-				float wj[ASTC_ANG_GROUP], cs[ASTC_ANG_GROUP], sn[ASTC_ANG_GROUP];
+				float cs[ASTC_ANG_GROUP], sn[ASTC_ANG_GROUP];
 				uint32_t row[ASTC_ANG_GROUP];
 				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++) { const int j = j0 + u < W ? j0 + u : 0; wj[u] = wv[j]; row[u] = rows[j]; }
+				for (int u = 0; u < ASTC_ANG_GROUP; u++) { const int j = j0 + u < W ? j0 + u : 0; row[u] = rows[j]; }
 				#pragma unroll
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
@@ -338,15 +357,13 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				#pragma unroll
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
-					// past the set's last weight: wj is a copy of weight 0 (no effect on min / max) and the table values
-					// are replaced by +0.0, which leaves the sums as they are (they are never -0.0: they start at +0.0)
-					// as a multiplication by 1.0 / 0.0 (exact: the products are cs, sn or a signed zero), so that what stays
-					// live across the table loads is a vector register per slot, not a lane mask in a scalar register pair
+					// past the set's last weight the table values are replaced by +0.0, which leaves the sums as they are (they
+					// are never -0.0: they start at +0.0), as a multiplication by 1.0 / 0.0 (exact: the products are cs, sn or a
+					// signed zero), so that what stays live across the table loads is a vector register per slot, not a lane mask
+					// in a scalar register pair
 					const float keep = wv_opaque_f(j0 + u < W ? 1.0f : 0.0f);
 					anglesum_x += cs[u] * keep;
 					anglesum_y += sn[u] * keep;
-					min_weight = wj[u] < min_weight ? wj[u] : min_weight;
-					max_weight = wj[u] > max_weight ? wj[u] : max_weight;
 				}
 			}
 			float angle = ref_atan2(anglesum_y, anglesum_x);
@@ -401,7 +418,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		{
 			int s = s0 + (k >> 3), qi = k & 7;
 			AngSet a = get_set(s);
-			if (qi <= a.maxq)
+			if (qi <= a.maxq && ((a.used >> qi) & 1u))
 			{
 				int steps = steps_for_quant_level(a.maxq);
 				const float* base = ang + tr.ibox[s - s0] * 8;
@@ -441,8 +458,9 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				float lwi = r[1] + best_cut;
 				float hwi = lwi + (float)q - 1.0f;
 				float stepsize = 1.0f / (1.0f + (float)bsi);
-				a.out[qi * 2 + 0] = (r[0] + lwi) * stepsize;
-				a.out[qi * 2 + 1] = (r[0] + hwi) * stepsize;
+				const int slot = popcount32((uint32_t)a.used & ((1u << qi) - 1u));
+				a.out[slot * 2 + 0] = (r[0] + lwi) * stepsize;
+				a.out[slot * 2 + 1] = (r[0] + hwi) * stepsize;
 			}
 		}
 		WV_SYNC();
@@ -513,6 +531,23 @@ WV_FN float sum4(const float* v, int n)
 	if (i + 1 < n) a1 += v[i + 1];
 	if (i + 2 < n) a2 += v[i + 2];
 	return (a0 + a2) + (a1 + a3);
+}
+
+/* The same sum as a wave-level operation: the four accumulators run side by side on lanes 0..3 (a quarter of the
+ * dependent additions of the one-lane form), then (acc0 + acc2) + (acc1 + acc3).  Uniform result; v must be visible to
+ * all lanes (a WV_SYNC() after it was written). */
+WV_FN float wv_sum4(const float* v, int n)
+{
+#if WV_DEVICE
+	float acc = 0.0f;
+	if (WV_LANE < 4) for (int i = WV_LANE; i < n; i += 4) acc += v[i];
+	const int bits = float_as_int(acc);
+	const float a0 = int_as_float(__builtin_amdgcn_readlane(bits, 0)), a1 = int_as_float(__builtin_amdgcn_readlane(bits, 1));
+	const float a2 = int_as_float(__builtin_amdgcn_readlane(bits, 2)), a3 = int_as_float(__builtin_amdgcn_readlane(bits, 3));
+	return (a0 + a2) + (a1 + a3);
+#else
+	return sum4(v, n);
+#endif
 }
 
 } } // namespace astcd::ASTC_VARIANT

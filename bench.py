@@ -15,14 +15,19 @@ the rank barrier only; the work is libastcenc_amd.so called through its C ABI
 
 Rank 0 prints ONE JSON line with the driver's fields plus:
   roofline       : algorithmic HBM bytes per launch / mean kernel time (HIP events recorded by the library on
-                   the launch stream) vs the 8 TB/s HBM peak; `traffic` and the VALU figures come from the
-                   latest committed rocprofv3 PMC passes of this same workload (profiles/*/traffic.json,
-                   named in traffic_source: rocprofv3 cannot run inside this process).
+                   the launch stream) vs the 8 TB/s HBM peak; `traffic` (HBM bytes per launch from the PMC passes) and
+                   `valu` (the bound that actually binds: wave instructions per block, active lanes, and the issue rate
+                   of THIS run = committed instruction count x blocks / measured kernel time, against the chip's
+                   1.23e12 wave-instructions/s) come from the latest committed rocprofv3 PMC passes of the same
+                   workload (profiles/*/traffic.json, named in traffic_source: rocprofv3 cannot run inside this process).
+  parity_full    : config 2 only: the WHOLE 8192^2 image through the reference's AVX2 build, every one of the
+                   1 865 956 blocks compared with the GPU's (ref: the block loop of astcenc_entry.cpp:1009-1038).
   value_host_api : the same image through astcenc_compress_image (host pointers, PCIe both ways included).
-  cpu_baseline   : the reference encoder's AVX2 build (oracle/_ref/libastcenc-avx2.so) on this box's host
-                   cores: thread-count sweep on a 2048^2 crop, best of 3 with astcenc_compress_reset in
-                   between, plus the 1-thread rate and the host's CPU model / cgroup quota / load; then a
-                   byte comparison of a larger crop against the GPU output.  N = 1 only.
+  cpu_baseline   : the reference encoder's AVX2 build (oracle/_ref/libastcenc-avx2.so; the build with
+                   ASTCENC_X86_GATHERS=1, the reference's x86 default, is timed too and the faster one reported) on this
+                   box's host cores: thread-count sweep on a 2048^2 crop, best of 3 with astcenc_compress_reset in
+                   between, plus the 1-thread rate, the rate per host core-second, and the host's CPU model / cgroup
+                   quota / load; then a byte comparison of the crop against the GPU output.  N = 1 only.
   extra_configs  : BASELINE configs[2] (8192^2 8x8 -thorough) and configs[3] (4096^2 RGBA16F HDR 6x6 -medium):
                    kernel time, Mtexels/s, roofline, byte parity of a block-aligned crop and of the clamped image
                    tail against the reference, and (HDR) mPSNR / log RMSE from the on-device comparison.
@@ -45,6 +50,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle_libs as O  # noqa: E402  (checker libraries: used by the cpu_baseline / parity legs only, never inside the timed region)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# VALU issue peak of the chip in wave-instructions per second: 1024 SIMDs x 2.4 GHz / 2 clocks per wave64 instruction
+# (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 32 lanes per clock; packed / dual-issue forms aside)
+VALU_PEAK_WAVE_INSTS_S = 1024 * 2.4e9 / 2.0
 
 # BASELINE.json configs (C1..C4); `index` = position in BASELINE.json's list
 CONFIGS = {
@@ -182,14 +190,42 @@ def cpu_reference_baseline(cfg, img, gpu_blocks, budget_s=30.0):
             best_rate, best_threads, out_best = rate, threads, out
     want = crop_blocks(gpu_blocks, cfg, 0, 0, side, side)
     mismatch = int((want != out_best.reshape(-1, 16)).any(axis=1).sum())
+    # the same crop, same thread count, through the build with hardware gathers (the reference's x86 default,
+    # CMakeLists.txt:55); the faster of the two is the baseline
+    gathers = {"0": round(best_rate, 3)}
+    used_gathers = 0
+    if os.path.exists(O.LIB_REF_AVX2_GATHERS):
+        dt, out_g = reference_threads(A.Library(O.LIB_REF_AVX2_GATHERS), cfg, crop, best_threads, 3)
+        gathers["1"] = round(side * side / dt / 1e6, 3)
+        mismatch += int((want != out_g.reshape(-1, 16)).any(axis=1).sum())
+        if gathers["1"] > best_rate:
+            best_rate, used_gathers = gathers["1"], 1
+    quota = host.get("cgroup_cpu_max", "").split()
+    cpus_allowed = min(cores, float(quota[0]) / float(quota[1])) if len(quota) == 2 and quota[0] != "max" else float(cores)
     return {"value": round(best_rate, 3), "unit": "Mtexels/s", "cores": best_threads, "kind": "reference",
             "sample": "astcenc-avx2 (oracle/_ref), %dx%d top-left crop of the bench image, best of 3 per thread count with "
                       "astcenc_compress_reset in between; 1-thread figure on a %dx%d crop" % (side, side, small.shape[1], small.shape[0]),
+            "x86_gathers_mtexels_s": gathers, "x86_gathers_used": used_gathers,
+            "cpus_allowed": round(cpus_allowed, 2), "mtexels_per_core_second": round(best_rate / max(min(cpus_allowed, best_threads), 1e-9), 4),
             "threads_at_best": best_threads, "value_1thread": round(rate1, 4), "per_thread_at_best": round(best_rate / best_threads, 4),
             "thread_sweep_mtexels_s": sweep, "cpu_model": host.get("cpu_model"), "nproc": host["nproc"], "affinity": host["affinity"],
             "cgroup_cpu_max": host.get("cgroup_cpu_max"), "loadavg": host.get("loadavg"),
             "blocks_compared_with_gpu": int(want.shape[0]), "blocks_mismatching_gpu": mismatch,
             "seconds": round(time.perf_counter() - t_start, 1)}
+
+
+def parity_full(cfg, img, gpu_blocks, threads, gathers):
+    """Every block of the whole image against the reference (AVX2 build, byte-identical to the scalar build by the
+    reference's invariance mode -- tests/ pin that) at the thread count the baseline sweep found best."""
+    path = O.LIB_REF_AVX2_GATHERS if gathers and os.path.exists(O.LIB_REF_AVX2_GATHERS) else O.LIB_REF_AVX2
+    if not os.path.exists(path):
+        return None
+    dt, out = reference_threads(A.Library(path), cfg, img, threads, 1)
+    want, got = out.reshape(-1, 16), gpu_blocks.reshape(-1, 16)
+    bad = np.nonzero((want != got).any(axis=1))[0]
+    return {"blocks_compared": int(want.shape[0]), "mismatch": int(bad.size), "first_mismatching_blocks": [int(b) for b in bad[:8]],
+            "reference": os.path.basename(path), "threads": threads, "seconds": round(dt, 2),
+            "reference_mtexels_s_whole_image": round(img.shape[0] * img.shape[1] / dt / 1e6, 3)}
 
 
 def parity_crops(cfg, img, gpu_blocks, budget_s):
@@ -290,15 +326,17 @@ def device_quality(lib, ctx, cfg, d_img, d_blocks, dev):
             "definition": "astcenccli_error_metrics.cpp:60-107, :262-268, :389-403"}
 
 
-def measured_counters():
-    """HBM bytes per launch and the VALU figures from the latest committed PMC summary of the headline workload
-    (profiles/*/traffic.json, written by tools/gpu_profile.sh); {} when there is none."""
+def measured_counters(name="c2"):
+    """HBM bytes per launch and the VALU figures of config `name` from the latest committed PMC summary
+    (profiles/*/traffic.json, written by tools/gpu_evidence.sh); {} when there is none."""
     import glob
     # newest = highest round tag (profiles/r01a < r01b < ... < r02a); mtimes mean nothing in a fresh checkout
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))
-    if not files:
-        return {}, None
-    return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
+        data = json.load(open(path))
+        per_config = data.get("configs", {"c2": data} if "hbm_bytes_per_launch" in data else {})
+        if name in per_config:
+            return per_config[name], os.path.relpath(path, ROOT)
+    return {}, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -328,13 +366,31 @@ def time_device_resident(lib, ctx, cfg, d_img, d_out, dev, steps, warmup, barrie
     return time.perf_counter() - t0, kms
 
 
-def roofline_of(cfg, kernel_s, hdr_kernel):
+def roofline_of(cfg, kernel_s, hdr_kernel, name):
     algo = algorithmic_bytes(cfg)
     achieved = algo / kernel_s / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
             "kernel": "astcd::astc_compress_blocks_%s" % ("hdr" if hdr_kernel else "ldr"), "kernel_ms": round(kernel_s * 1e3, 3),
             "algorithmic_bytes_per_launch": algo}
+    counters, src = measured_counters(name)
+    if counters:
+        roof["traffic"] = counters.get("hbm_bytes_per_launch")
+        roof["traffic_unit"] = "bytes per launch"
+        roof["traffic_source"] = "%s (committed rocprofv3 --pmc summary of this workload, not measured in this run)" % src
+        if "valu_insts_per_block" in counters:
+            nbx, nby = block_grid(cfg)
+            # HBM is four orders of magnitude away; what binds the kernel is VALU issue.  Instructions per block are a
+            # property of (library, workload) and come from the committed counters; the rate is this run's.
+            roof["valu"] = {"insts_per_block": counters["valu_insts_per_block"], "active_lanes": counters.get("active_lanes_avg"),
+                            "issue_frac_spec": round(counters["valu_insts_per_block"] * nbx * nby / kernel_s / VALU_PEAK_WAVE_INSTS_S, 4),
+                            "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_S,
+                            "what": "wave-level VALU instructions per block x blocks / kernel time of this run, against 1024 SIMDs x 2.4 GHz / 2 "
+                                    "clocks; active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
+        for key in ("salu_insts_per_block", "lds_insts_per_block", "valu_issue_frac"):
+            if key in counters:
+                roof[key] = counters[key]
+    return roof
 
 
 def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
@@ -351,7 +407,7 @@ def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
     res = {"config": name, "baseline_config_index": cfg["index"], "workload": cfg["label"],
            "value": round(texels * steps / elapsed / 1e6, 3), "unit": "Mtexels/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "blocks_per_image": nbx * nby,
-           "roofline": roofline_of(cfg, kernel_s, cfg["hdr"]),
+           "roofline": roofline_of(cfg, kernel_s, cfg["hdr"], name),
            "parity_vs_reference": parity_crops(cfg, img, gpu_blocks, budget_s),
            "quality": device_quality(lib, ctx, cfg, d_img, d_out, dev)}
     lib.context_free(ctx)
@@ -392,6 +448,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config timed as the headline line (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-quality", action="store_true", help="skip decoding the output for PSNR")
+    ap.add_argument("--no-parity-full", action="store_true", help="skip the whole-image byte comparison with the reference (config 2, ~10 s of host time)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (BASELINE configs[2] and [3])")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--single-process", action="store_true",
@@ -451,16 +508,7 @@ def main():
         value = world * texels * args.steps / elapsed / 1e6
         kernel_s = sum(kms) / len(kms) / 1e3
         gpu_blocks = d_out.cpu().numpy()
-        roof = roofline_of(cfg, kernel_s, cfg["hdr"])
-        if args.config == "c2":
-            counters, src = measured_counters()
-            roof["traffic"] = counters.get("hbm_bytes_per_launch")
-            roof["traffic_unit"] = "bytes per launch"
-            roof["traffic_source"] = "%s (committed rocprofv3 --pmc summary of this workload, not measured in this run)" % src if src else None
-            for key in ("valu_insts_per_block", "active_lanes_avg", "valu_issue_frac", "salu_insts_per_block", "lds_insts_per_block",
-                        "scratch_bytes_per_lane", "sgpr_spills"):
-                if key in counters:
-                    roof[key] = counters[key]
+        roof = roofline_of(cfg, kernel_s, cfg["hdr"], args.config)
         out = {
             "metric": "Mtexels/s + PSNR-dB, 8192x8192 RGBA8 LDR 6x6 -medium" if args.config == "c2" else "Mtexels/s, " + cfg["label"],
             "value": round(value, 3), "unit": "Mtexels/s",
@@ -470,7 +518,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, one image per GPU (BASELINE configs[%d])" % (cfg["label"], cfg["index"]),
                        "blocks_per_image": nblocks, "block": "%dx%d" % cfg["block"], "sharding": "one image per rank, no collectives",
-                       "inputs": "resident in HBM (device API); value_host_api is the PCIe-inclusive rate of astcenc_compress_image"},
+                       "inputs": "resident in HBM when the timed region starts (device API, the timing rule of this benchmark); "
+                                 "value_host_api is the rate of the reference's own entry point astcenc_compress_image, "
+                                 "host pointers in and out, PCIe both ways inside the timing (SURVEY.md 8d)"},
             "roofline": roof,
         }
         if world == 1 and not args.no_host_api:
@@ -487,6 +537,8 @@ def main():
             if base:
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = round(value / base["value"], 2)
+                if args.config == "c2" and not args.no_parity_full:
+                    out["parity_full"] = parity_full(cfg, img_host, gpu_blocks, base["threads_at_best"], base["x86_gathers_used"])
         if world == 1 and not args.no_extra and args.config == "c2":
             del d_img, d_out
             extra = []

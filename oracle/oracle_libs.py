@@ -3,6 +3,7 @@
 
   oracle/_ref/libastcenc-none.so    the reference encoder (scalar build) compiled by oracle/Makefile: the authority
   oracle/_ref/libastcenc-avx2.so    the reference's AVX2 build: the timed CPU baseline (byte-identical by its invariance mode)
+  oracle/_ref/libastcenc-avx2-gathers.so   the same with ASTCENC_X86_GATHERS=1 (the reference's x86 default); bench.py times both
   oracle/_ref/libastcenc-diag.so    the reference with ASTCENC_DIAGNOSTICS (-dtrace JSON): stage-level error oracle
   oracle/emu/_build/libastcenc_emu.so   sequential CPU build of the kernel source (a debugging aid, not independent)
 
@@ -14,5 +15,6 @@ import os
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 LIB_REF_NONE = os.path.join(REPO, "oracle", "_ref", "libastcenc-none.so")
 LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
+LIB_REF_AVX2_GATHERS = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2-gathers.so")
 LIB_REF_DIAG = os.path.join(REPO, "oracle", "_ref", "libastcenc-diag.so")
 LIB_EMU = os.path.join(REPO, "oracle", "emu", "_build", "libastcenc_emu.so")
