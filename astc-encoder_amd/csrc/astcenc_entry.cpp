@@ -414,14 +414,8 @@ astcenc_error astcenc_context_alloc(const astcenc_config* configp, unsigned int 
 
 	const astcenc_config& config = ctx->config;
 
-	// Scope of this library: alpha-scale radii up to ALPHA_MAX_RADIUS_HOST.
 	bool is_hdr = config.profile == ASTCENC_PRF_HDR || config.profile == ASTCENC_PRF_HDR_RGB_LDR_A;
 	bool compress = !(config.flags & ASTCENC_FLG_DECOMPRESS_ONLY);
-	if (compress && config.block_z <= 1 && config.a_scale_radius > ALPHA_MAX_RADIUS_HOST)
-	{
-		delete ctx;
-		return ASTCENC_ERR_NOT_IMPLEMENTED;
-	}
 
 	if (!has_parent)
 	{
@@ -565,11 +559,10 @@ astcenc_error astcenc_compress_image(astcenc_context* ctx, astcenc_image* imagep
 	size_t block_count;
 	astcenc_error status = check_compress_args(ctx, image.dim_x, image.dim_y, image.dim_z, swizzle, data_len, thread_index, block_count);
 	if (status != ASTCENC_SUCCESS) return status;
-	// The alpha-scale test only exists for 2D footprints (ref: astcenc_entry.cpp:975).  On a multi-slice
-	// image the reference averages over a 3D box and then reads slice 0's averages for every slice;
-	// that combination is not reproduced.
+	// The alpha-scale test only exists for 2D footprints (ref: astcenc_entry.cpp:975).  On a multi-slice image the
+	// reference averages over a 3D box and then reads the averages around slice 0 for every slice; the pre-pass
+	// reproduces exactly that (wave_alpha.h).
 	const bool alpha_scale = ctx->config.a_scale_radius != 0 && ctx->config.block_z <= 1;
-	if (alpha_scale && image.dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;
 
 	CompressJob job;
 	memset(&job, 0, sizeof(job));
@@ -603,7 +596,6 @@ astcenc_error astcenc_amd_compress_volume_device(astcenc_context* ctx, const voi
 	astcenc_error status = check_compress_args(ctx, dim_x, dim_y, dim_z, swizzle, data_len, 0, block_count);
 	if (status != ASTCENC_SUCCESS) return status;
 	const bool alpha_scale = ctx->config.a_scale_radius != 0 && ctx->config.block_z <= 1;
-	if (alpha_scale && dim_z != 1) return ASTCENC_ERR_NOT_IMPLEMENTED;
 
 	CompressJob job;
 	memset(&job, 0, sizeof(job));

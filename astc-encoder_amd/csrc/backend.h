@@ -96,14 +96,18 @@ int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint
 int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
 
-/* Alpha-average pre-pass launch (kernel_alpha.hip); radius <= ALPHA_MAX_RADIUS_HOST. */
-constexpr uint32_t ALPHA_MAX_RADIUS_HOST = 80;
+/* Alpha-average pre-pass launch (kernel_alpha.hip).  The padded tile of a region lives in LDS while it fits
+ * (ALPHA_LDS_LIMIT) and otherwise in d_scratch: astc_alpha_scratch_bytes() says how much of it and for how many
+ * workgroups the launch needs (0 / 0: the LDS kernel is used). */
+constexpr size_t ALPHA_LDS_LIMIT = 160u * 1024u;
 struct AlphaLaunch {
 	const void* d_image;
 	float* d_averages;
-	uint32_t dim_x, dim_y, data_type, swz_a, radius;
+	uint32_t dim_x, dim_y, dim_z, data_type, swz_a, radius;
+	float* d_scratch; uint32_t scratch_workgroups;
 	void* stream;
 };
+size_t astc_alpha_scratch_bytes(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t radius, uint32_t* workgroups);
 int astc_alpha_launch(const AlphaLaunch& a);
 
 /* Decompression kernel launch (kernel_decode.hip). */

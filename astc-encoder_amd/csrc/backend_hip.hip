@@ -32,6 +32,7 @@ struct DeviceSlot {
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
 	float* d_alpha; size_t alpha_cap;   // alpha averages of the a_scale_radius pre-pass
+	float* d_alpha_scratch; size_t alpha_scratch_cap;   // padded tiles of the pre-pass when they outgrow LDS (large radii)
 	unsigned long long* d_prof;   // stage timers (ASTC_PROFILE builds) / search trace (ASTC_TRACE builds)
 	size_t trace_cap;             // bytes at d_prof in ASTC_TRACE builds
 	double* d_sums;               // totals of the image comparison kernel
@@ -78,6 +79,7 @@ void slot_destroy(DeviceSlot* s)
 	if (s->d_image) (void)hipFree(s->d_image);
 	if (s->d_out) (void)hipFree(s->d_out);
 	if (s->d_alpha) (void)hipFree(s->d_alpha);
+	if (s->d_alpha_scratch) (void)hipFree(s->d_alpha_scratch);
 	if (s->d_sums) (void)hipFree(s->d_sums);
 	if (s->d_prof) (void)hipFree(s->d_prof);
 	for (hipEvent_t e : { s->ev_copy[0], s->ev_copy[1], s->ev_band, s->ev_done[0], s->ev_done[1], s->ev_done[2], s->ev0, s->ev1 })
@@ -99,6 +101,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	s->ev0 = s->ev1 = s->ev_copy[0] = s->ev_copy[1] = s->ev_band = nullptr;
 	s->ev_done[0] = s->ev_done[1] = s->ev_done[2] = nullptr;
 	s->d_image = nullptr; s->image_cap = 0; s->d_out = nullptr; s->out_cap = 0; s->d_alpha = nullptr; s->alpha_cap = 0;
+	s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
 	s->d_prof = nullptr; s->trace_cap = 0; s->d_sums = nullptr;
 #define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
 	SLOT_TRY(hipSetDevice(device), 2);
@@ -372,8 +375,21 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		}
 		AlphaLaunch a;
 		a.d_image = d_image; a.d_averages = s->d_alpha;
-		a.dim_x = job.dim_x; a.dim_y = job.dim_y; a.data_type = job.data_type;
+		a.dim_x = job.dim_x; a.dim_y = job.dim_y; a.dim_z = dim_z; a.data_type = job.data_type;
 		a.swz_a = job.swz[3]; a.radius = job.a_scale_radius; a.stream = stream;
+		a.d_scratch = nullptr; a.scratch_workgroups = 0;
+		const size_t scratch = astc_alpha_scratch_bytes(job.dim_x, job.dim_y, dim_z, job.a_scale_radius, &a.scratch_workgroups);
+		if (scratch)
+		{
+			if (s->alpha_scratch_cap < scratch)
+			{
+				if (s->d_alpha_scratch) (void)hipFree(s->d_alpha_scratch);
+				s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
+				HIP_TRY(hipMalloc(&s->d_alpha_scratch, scratch + ALLOC_SLACK), return 1);
+				s->alpha_scratch_cap = scratch;
+			}
+			a.d_scratch = s->d_alpha_scratch;
+		}
 		int arc = astc_alpha_launch(a);
 		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
 		img.alpha_avg = s->d_alpha;

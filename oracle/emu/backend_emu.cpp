@@ -106,12 +106,12 @@ int backend_compress(Backend* b, const CompressJob& job)
 		averages.assign((size_t)job.dim_x * job.dim_y, 0.0f);
 		AlphaJob aj;
 		aj.image = img.data; aj.averages = averages.data();
-		aj.dim_x = job.dim_x; aj.dim_y = job.dim_y; aj.data_type = job.data_type;
+		aj.dim_x = job.dim_x; aj.dim_y = job.dim_y; aj.dim_z = dim_z; aj.data_type = job.data_type;
 		aj.swz_a = job.swz[3]; aj.radius = job.a_scale_radius;
-		const uint32_t pad = ALPHA_TILE + 2 * job.a_scale_radius + 1;
-		std::vector<float> buf((size_t)pad * pad);
-		for (uint32_t ty = 0; ty < (job.dim_y + ALPHA_TILE - 1) / ALPHA_TILE; ty++)
-			for (uint32_t tx = 0; tx < (job.dim_x + ALPHA_TILE - 1) / ALPHA_TILE; tx++)
+		const uint32_t tile = (uint32_t)alpha_tile_size(aj);
+		std::vector<float> buf(alpha_scratch_floats(aj));
+		for (uint32_t ty = 0; ty < (job.dim_y + tile - 1) / tile; ty++)
+			for (uint32_t tx = 0; tx < (job.dim_x + tile - 1) / tile; tx++)
 				alpha_average_tile(aj, tx, ty, buf.data());
 		img.alpha_avg = averages.data();
 	}

@@ -63,7 +63,36 @@ def test_alpha_scale_float_inputs_and_swizzle(lib, ref, A, dtype):
         assert len(images.mismatches(want, got)) == 0, swz
 
 
-def test_alpha_scale_radius_limit(lib, A):
-    err, cfg = lib.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, 0)
-    cfg.a_scale_radius = 81                              # beyond the LDS tile this library supports
-    assert lib.context_alloc(cfg, 1)[0] == A.ERR_NOT_IMPLEMENTED
+@pytest.mark.parametrize("radius", [81, 130])
+def test_alpha_scale_large_radius(lib, ref, radius):
+    """Radii whose padded 32x32 tile no longer fits the CU's LDS (the reference has no limit): the pre-pass keeps the tile
+    in a per-workgroup slice of device memory instead."""
+    img = holes(150, 70, 40 + radius)
+    img[:, 100:] = (9, 9, 9, 0)                          # transparent far beyond the reach of the filter on one side
+    img[20:40, 120:140, 3] = 0
+
+    def tweak(cfg):
+        cfg.a_scale_radius = radius
+    want = ref.compress(img, (6, 6), 10.0, tweak=tweak)
+    got = lib.compress(img, (6, 6), 10.0, tweak=tweak)
+    assert len(images.mismatches(want, got)) == 0
+
+
+@pytest.mark.parametrize("radius,slices", [(1, 2), (2, 5), (3, 20), (9, 3)])
+def test_alpha_scale_on_a_stack_of_slices(lib, ref, radius, slices):
+    """Multi-slice image, 2D footprint: the reference averages alpha over a (2r+1)^3 box in 16x16x16 regions and then
+    reads the averages around slice 0 for every slice (astcenc_entry.cpp:1001: `ay * dim_x + ax`); the same bytes
+    come out here.  F16 input: every slice is loaded from its own data, so the slices differ."""
+    w, h = 50, 37
+    vol = np.stack([holes(w, h, 70 + z, np.float16) for z in range(slices)])
+    vol[:, : h // 2, : w // 2, 3] = 0                     # transparent (but coloured) in every slice: skippable blocks
+    vol[slices - 1, 3, 3, 3] = 1.0                       # ... except one texel of the last slice (in reach for small stacks)
+
+    def tweak(cfg):
+        cfg.a_scale_radius = radius
+    want = ref.compress(vol, (5, 4), 10.0, tweak=tweak)
+    got = lib.compress(vol, (5, 4), 10.0, tweak=tweak)
+    assert len(images.mismatches(want, got)) == 0
+    if radius <= 3:
+        plain = ref.compress(vol, (5, 4), 10.0)
+        assert (plain != want).any(), "the test volume must contain blocks that the alpha test skips"
