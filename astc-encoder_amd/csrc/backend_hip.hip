@@ -540,46 +540,64 @@ int backend_compress(Backend* b, const CompressJob& job)
 		return compress_on_slot(b, s, job, &progress);
 	}
 
-	// Host images: contiguous ranges of block rows, one per device, each running its own banded pipeline
-	// on its own streams from its own host thread; the caller's thread takes the first shard and joins the
-	// rest (ref: the block loop of compress_image, astcenc_entry.cpp:1009-1038 -- blocks are independent,
-	// so the split needs no exchange).  Volumes and the alpha-scale pre-pass (which reads a halo around
-	// each block) stay on one device.
-	const uint32_t bsy = b->root.dim_y;
+	// Host images: contiguous ranges of block rows (2D) or of block layers (volumes, stacks of slices), one per device,
+	// each running its own pipeline on its own streams from its own host thread; the caller's thread takes the first
+	// shard and joins the rest (ref: the block loop of compress_image, astcenc_entry.cpp:1009-1038 -- blocks are
+	// independent, so the split needs no exchange).  The alpha-scale pre-pass (which reads a halo around each block)
+	// stays on one device.
+	const uint32_t bsy = b->root.dim_y, bsz = b->root.dim_z;
 	const uint32_t blocks_x = (job.dim_x + b->root.dim_x - 1) / b->root.dim_x;
 	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
-	size_t ndev = b->slots.size();
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
-	if (dim_z != 1 || job.a_scale_radius != 0 || !job.host_out) ndev = 1;
+	const uint32_t blocks_z = (dim_z + bsz - 1) / bsz;
+	size_t ndev = b->slots.size();
+	if (job.a_scale_radius != 0 || !job.host_out) ndev = 1;
 	const size_t by_size = progress.total / MIN_BLOCKS_PER_DEVICE;
 	if (ndev > by_size) ndev = by_size < 1 ? 1 : by_size;
-	if (ndev > blocks_y) ndev = blocks_y;
+	// a 2D image is cut into block rows, a volume / stack of slices into layers of blocks
+	const uint32_t units = dim_z == 1 ? blocks_y : blocks_z;
+	if (ndev > units) ndev = units;
 #if defined(ASTC_TRACE)
 	ndev = 1;      // (debug build: every shard would write the same trace file)
 #endif
 	if (ndev <= 1) return compress_on_slot(b, b->slots[0], job, &progress);
 
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
-	const uint32_t rows_per = (uint32_t)((blocks_y + ndev - 1) / ndev);
-	struct Shard { CompressJob job; const void* slice; int rc; };
+	const uint32_t units_per = (uint32_t)((units + ndev - 1) / ndev);
+	struct Shard { CompressJob job; std::vector<const void*> slices; int rc; };
 	std::vector<Shard> shards;
+	// The reference's fast loader reads slice 0 whatever the block's z (CompressJob::fast_load_slice0): a shard that
+	// starts further up the stack must then see the image's first slice as its own first slice.
+	const bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
+	const bool slice0_quirk = dim_z > 1 && job.fast_load_slice0 && !needs_swz && b->cfg.profile < 2 && job.data_type == 0 && bsz == 1;
 	for (size_t g = 0; g < ndev; g++)
 	{
-		const uint32_t r0 = (uint32_t)g * rows_per;
-		if (r0 >= blocks_y) break;
-		const uint32_t r1 = r0 + rows_per < blocks_y ? r0 + rows_per : blocks_y;
-		const uint32_t y0 = r0 * bsy;
-		const uint32_t y1 = r1 * bsy < job.dim_y ? r1 * bsy : job.dim_y;
+		const uint32_t u0 = (uint32_t)g * units_per;
+		if (u0 >= units) break;
+		const uint32_t u1 = u0 + units_per < units ? u0 + units_per : units;
 		Shard sh;
 		sh.job = job;
-		sh.slice = static_cast<const uint8_t*>(job.host_slices[0]) + (size_t)y0 * job.dim_x * texel_bytes;
-		sh.job.dim_y = y1 - y0;
-		sh.job.host_out = job.host_out + (size_t)r0 * blocks_x * 16;
 		sh.job.progress = nullptr;
 		sh.rc = 0;
-		shards.push_back(sh);
+		if (dim_z == 1)
+		{
+			const uint32_t y0 = u0 * bsy;
+			const uint32_t y1 = u1 * bsy < job.dim_y ? u1 * bsy : job.dim_y;
+			sh.slices.push_back(static_cast<const uint8_t*>(job.host_slices[0]) + (size_t)y0 * job.dim_x * texel_bytes);
+			sh.job.dim_y = y1 - y0;
+			sh.job.host_out = job.host_out + (size_t)u0 * blocks_x * 16;
+		}
+		else
+		{
+			const uint32_t z0 = u0 * bsz;
+			const uint32_t z1 = u1 * bsz < dim_z ? u1 * bsz : dim_z;
+			for (uint32_t z = z0; z < z1; z++) sh.slices.push_back(slice0_quirk ? job.host_slices[0] : job.host_slices[z]);
+			sh.job.dim_z = z1 - z0;
+			sh.job.host_out = job.host_out + (size_t)u0 * blocks_x * blocks_y * 16;
+		}
+		shards.push_back(std::move(sh));
 	}
-	for (Shard& sh : shards) sh.job.host_slices = &sh.slice;      // (after the vector stopped growing)
+	for (Shard& sh : shards) sh.job.host_slices = sh.slices.data();      // (after the vector stopped growing)
 	// one host thread per further shard; a shard whose thread cannot be created (std::system_error must not cross the
 	// C ABI, and the earlier workers must still be joined) runs on the calling thread after its own
 	std::vector<std::thread> workers;
@@ -597,10 +615,9 @@ int backend_compress(Backend* b, const CompressJob& job)
 	return rc;
 }
 
-int backend_decompress(Backend* bk, const DecompressJob& job)
+/* The blocks of `job` decoded on one slot. */
+static int decompress_on_slot(Backend* bk, DeviceSlot* b, const DecompressJob& job)
 {
-	DeviceGuard guard;
-	DeviceSlot* b = bk->slots[0];
 	std::lock_guard<std::mutex> busy(b->busy);
 	HIP_TRY(hipSetDevice(b->device), return 2);
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
@@ -639,6 +656,71 @@ int backend_decompress(Backend* bk, const DecompressJob& job)
 		HIP_TRY(hipMemcpyAsync(job.host_slices[z], static_cast<uint8_t*>(b->d_image) + z * slice_bytes, slice_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
 	HIP_TRY(hipStreamSynchronize(b->stream), return 2);
 	return 0;
+}
+
+/* Host blocks -> host image.  Like compression the work is dealt to the context's devices in contiguous ranges --
+ * block rows of a 2D image, layers of blocks of a volume -- each decoded into its own rows / slices of the caller's
+ * image (ref: the block loop of astcenc_decompress_image, astcenc_entry.cpp:1340-1385: blocks are independent). */
+int backend_decompress(Backend* bk, const DecompressJob& job)
+{
+	DeviceGuard guard;
+	const uint32_t bsx = bk->root.dim_x, bsy = bk->root.dim_y, bsz = bk->root.dim_z;
+	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
+	const uint32_t blocks_x = (job.dim_x + bsx - 1) / bsx, blocks_y = (job.dim_y + bsy - 1) / bsy, blocks_z = (dim_z + bsz - 1) / bsz;
+	const size_t total = (size_t)blocks_x * blocks_y * blocks_z;
+	size_t ndev = bk->slots.size();
+	const size_t by_size = total / MIN_BLOCKS_PER_DEVICE;
+	if (ndev > by_size) ndev = by_size < 1 ? 1 : by_size;
+	const uint32_t units = dim_z == 1 ? blocks_y : blocks_z;
+	if (ndev > units) ndev = units;
+	if (ndev <= 1) return decompress_on_slot(bk, bk->slots[0], job);
+
+	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
+	const uint32_t units_per = (uint32_t)((units + ndev - 1) / ndev);
+	struct Shard { DecompressJob job; std::vector<void*> slices; int rc; };
+	std::vector<Shard> shards;
+	for (size_t g = 0; g < ndev; g++)
+	{
+		const uint32_t u0 = (uint32_t)g * units_per;
+		if (u0 >= units) break;
+		const uint32_t u1 = u0 + units_per < units ? u0 + units_per : units;
+		Shard sh;
+		sh.job = job;
+		sh.rc = 0;
+		if (dim_z == 1)
+		{
+			const uint32_t y0 = u0 * bsy;
+			const uint32_t y1 = u1 * bsy < job.dim_y ? u1 * bsy : job.dim_y;
+			sh.slices.push_back(static_cast<uint8_t*>(job.host_slices[0]) + (size_t)y0 * job.dim_x * texel_bytes);
+			sh.job.dim_y = y1 - y0;
+			sh.job.host_blocks = job.host_blocks + (size_t)u0 * blocks_x * 16;
+			sh.job.block_bytes = (size_t)(u1 - u0) * blocks_x * 16;
+		}
+		else
+		{
+			const uint32_t z0 = u0 * bsz;
+			const uint32_t z1 = u1 * bsz < dim_z ? u1 * bsz : dim_z;
+			for (uint32_t z = z0; z < z1; z++) sh.slices.push_back(job.host_slices[z]);
+			sh.job.dim_z = z1 - z0;
+			sh.job.host_blocks = job.host_blocks + (size_t)u0 * blocks_x * blocks_y * 16;
+			sh.job.block_bytes = (size_t)(u1 - u0) * blocks_x * blocks_y * 16;
+		}
+		shards.push_back(std::move(sh));
+	}
+	for (Shard& sh : shards) sh.job.host_slices = sh.slices.data();
+	std::vector<std::thread> workers;
+	std::vector<size_t> inline_shards;
+	for (size_t g = 1; g < shards.size(); g++)
+	{
+		try { workers.emplace_back([&, g]() { shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); }); }
+		catch (...) { inline_shards.push_back(g); }
+	}
+	shards[0].rc = decompress_on_slot(bk, bk->slots[0], shards[0].job);
+	for (size_t g : inline_shards) shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job);
+	for (std::thread& t : workers) t.join();
+	int rc = 0;
+	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
+	return rc;
 }
 
 int backend_decompress_device(Backend* bk, const DecompressDeviceJob& job)

@@ -103,3 +103,118 @@ def test_device_buffers_follow_their_device_and_restore_the_callers(product, A):
         assert np.array_equal(out.cpu().numpy(), product.compress(img.cpu().numpy(), (6, 6), A.PRE_FAST))
     finally:
         product.context_free(ctx)
+
+
+class _Devices:
+    """ASTCENC_AMD_DEVICES for the contexts created inside the with-block."""
+    def __init__(self, devices):
+        self.devices = devices
+
+    def __enter__(self):
+        self.old = os.environ.get("ASTCENC_AMD_DEVICES")
+        os.environ["ASTCENC_AMD_DEVICES"] = self.devices
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            del os.environ["ASTCENC_AMD_DEVICES"]
+        else:
+            os.environ["ASTCENC_AMD_DEVICES"] = self.old
+
+
+def test_default_is_the_callers_device_only(product, A):
+    """Without ASTCENC_AMD_DEVICES a context touches one GPU: a rank-per-GPU process must not initialise its neighbours'."""
+    old = os.environ.pop("ASTCENC_AMD_DEVICES", None)
+    try:
+        err, cfg = product.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_FAST, 0)
+        err, ctx = product.context_alloc(cfg, 1)
+        assert err == A.SUCCESS
+        assert product.lib.astcenc_amd_context_device_count(ctx) == 1
+        product.context_free(ctx)
+    finally:
+        if old is not None:
+            os.environ["ASTCENC_AMD_DEVICES"] = old
+
+
+def test_eight_slots_on_the_baseline_image(product, ref, A):
+    """BASELINE's 8192^2 image dealt to eight slots (the 8-GPU node's code path on one GPU): the stream equals the
+    one-slot stream, the rows either side of all seven seams equal the reference, the progress callback is monotonic
+    although eight host threads feed it, and a cancel stops every shard within a few chunks."""
+    size, block = 8192, (6, 6)
+    img = A.synthetic_image(size, size)
+    seen = []
+    cb = A.PROGRESS_CB(lambda p: seen.append(p))
+    got, n = _compress(A, product, img, block, A.PRE_MEDIUM, "0,0,0,0,0,0,0,0", progress=cb)
+    assert n == 8
+    assert seen and seen == sorted(seen) and abs(seen[-1] - 100.0) < 1e-3
+    one, _ = _compress(A, product, img, block, A.PRE_MEDIUM, "0")
+    assert np.array_equal(got, one)
+    nb = (size + 5) // 6
+    per = (nb + 7) // 8
+    got = got.reshape(nb, nb, 16)
+    for g in range(1, 8):
+        r0 = g * per - 1                              # last row of shard g-1 and first row of shard g
+        y0, y1 = r0 * 6, (r0 + 2) * 6
+        want = ref.compress(np.ascontiguousarray(img[y0:y1, :1536]), block, A.PRE_MEDIUM).reshape(2, -1, 16)
+        assert np.array_equal(got[r0:r0 + 2, :256], want), g
+
+    # cancel from the progress callback: every shard stops at its next chunk boundary, the call still returns SUCCESS
+    # (ref: astcenc_compress_cancel, astcenc.h:820) and nothing past the cancelled chunks is written
+    with _Devices("0,0,0,0,0,0,0,0"):
+        err, cfg = product.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, 0)
+        holder = {}
+        calls = []
+
+        def on_progress(p):
+            calls.append(p)
+            if len(calls) == 2:
+                product.lib.astcenc_compress_cancel(holder["ctx"])
+        cb2 = A.PROGRESS_CB(on_progress)
+        cfg.progress_callback = cb2
+        err, ctx = product.context_alloc(cfg, 1)
+        assert err == A.SUCCESS
+    holder["ctx"] = ctx
+    try:
+        out = np.zeros(nb * nb * 16, dtype=np.uint8)
+        assert product.compress_raw(ctx, img, out) == A.SUCCESS
+        done = int(out.reshape(-1, 16).any(axis=1).sum())
+        assert 0 < done < nb * nb // 2, done          # eight shards x at most a few 2^18-block chunks each, of 1.87 M blocks
+        assert calls == sorted(calls) and calls[-1] < 100.0
+    finally:
+        product.context_free(ctx)
+
+
+def test_decompress_is_dealt_to_the_slots_too(product, A):
+    w, h, block = 2000, 1500, (5, 4)                   # 150 000 blocks: up to eight 16 384-block shards
+    img = A.synthetic_image(w, h, 4)
+    blocks = product.compress(img, block, A.PRE_FASTEST)
+    one = product.decompress(blocks, w, h, block)
+    for devices in ("0,0", "0,0,0,0,0,0,0,0"):
+        with _Devices(devices):
+            assert np.array_equal(product.decompress(blocks, w, h, block), one), devices
+    for t in (np.float16, np.float32):
+        with _Devices("0,0,0"):
+            assert np.array_equal(product.decompress(blocks, w, h, block, out_type=t), product.decompress(blocks, w, h, block, out_type=t))
+
+
+def test_volumes_and_slice_stacks_are_dealt_by_layers(product, ref, A):
+    rng = np.random.default_rng(5)
+    # a stack of 2D slices with a 2D footprint: F16 input (every slice from its own data) and RGBA8 input (the reference's
+    # fast loader reads slice 0 for every slice -- a shard further up the stack must still see slice 0)
+    stack8 = np.stack([A.synthetic_image(384, 256, 10 + z) for z in range(6)])            # 6 x 96 x 64 = 36 864 blocks
+    stackf = (stack8.astype(np.float32) / 255.0).astype(np.float16)
+    vol = rng.integers(0, 256, size=(40, 120, 120, 4), dtype=np.uint8)                    # 4x4x4: 10 x 30 x 30 = 9 000 ... 3x3x3 below
+    for pixels, block in ((stackf, (4, 4)), (stack8, (4, 4)), (vol, (3, 3, 3))):
+        with _Devices("0"):
+            one = product.compress(pixels, block, A.PRE_FASTEST)
+        with _Devices("0,0,0"):
+            got = product.compress(pixels, block, A.PRE_FASTEST)
+        assert np.array_equal(one, got), block
+        d = pixels.shape[0]
+        with _Devices("0"):
+            back1 = product.decompress(got, pixels.shape[2], pixels.shape[1], block, depth=d)
+        with _Devices("0,0,0"):
+            back3 = product.decompress(got, pixels.shape[2], pixels.shape[1], block, depth=d)
+        assert np.array_equal(back1, back3), block
+    want = ref.compress(stack8, (4, 4), A.PRE_FASTEST)
+    with _Devices("0,0,0"):
+        assert np.array_equal(product.compress(stack8, (4, 4), A.PRE_FASTEST), want)
