@@ -27,7 +27,10 @@ struct DeviceSlot {
 	uint8_t* d_tab;               // the blob inside it
 	hipStream_t stream;
 	hipStream_t copy_stream;      // PCIe traffic of the banded host-pointer path
-	hipEvent_t ev0, ev1, ev_copy[2], ev_band, ev_done[3];
+	hipEvent_t ev0, ev1, ev_copy[2], ev_band, ev_done[3], ev_out[2];
+	// pinned staging of the banded host-pointer path: two bands of input in flight, the blocks of two bands on their way back
+	uint8_t* h_in[2]; size_t h_in_cap;
+	uint8_t* h_out[2]; size_t h_out_cap;
 	// staging for the host-pointer API
 	void* d_image; size_t image_cap;
 	uint8_t* d_out; size_t out_cap;
@@ -82,7 +85,8 @@ void slot_destroy(DeviceSlot* s)
 	if (s->d_alpha_scratch) (void)hipFree(s->d_alpha_scratch);
 	if (s->d_sums) (void)hipFree(s->d_sums);
 	if (s->d_prof) (void)hipFree(s->d_prof);
-	for (hipEvent_t e : { s->ev_copy[0], s->ev_copy[1], s->ev_band, s->ev_done[0], s->ev_done[1], s->ev_done[2], s->ev0, s->ev1 })
+	for (int i = 0; i < 2; i++) { if (s->h_in[i]) (void)hipHostFree(s->h_in[i]); if (s->h_out[i]) (void)hipHostFree(s->h_out[i]); }
+	for (hipEvent_t e : { s->ev_copy[0], s->ev_copy[1], s->ev_band, s->ev_done[0], s->ev_done[1], s->ev_done[2], s->ev_out[0], s->ev_out[1], s->ev0, s->ev1 })
 		if (e) (void)hipEventDestroy(e);
 	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -100,6 +104,8 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	s->d_base = nullptr; s->d_tab = nullptr; s->stream = nullptr; s->copy_stream = nullptr;
 	s->ev0 = s->ev1 = s->ev_copy[0] = s->ev_copy[1] = s->ev_band = nullptr;
 	s->ev_done[0] = s->ev_done[1] = s->ev_done[2] = nullptr;
+	s->ev_out[0] = s->ev_out[1] = nullptr;
+	s->h_in[0] = s->h_in[1] = nullptr; s->h_in_cap = 0; s->h_out[0] = s->h_out[1] = nullptr; s->h_out_cap = 0;
 	s->d_image = nullptr; s->image_cap = 0; s->d_out = nullptr; s->out_cap = 0; s->d_alpha = nullptr; s->alpha_cap = 0;
 	s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
 	s->d_prof = nullptr; s->trace_cap = 0; s->d_sums = nullptr;
@@ -124,6 +130,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	SLOT_TRY(hipEventCreateWithFlags(&s->ev_copy[1], hipEventDisableTiming), 2);
 	SLOT_TRY(hipEventCreateWithFlags(&s->ev_band, hipEventDisableTiming), 2);
 	for (int i = 0; i < 3; i++) SLOT_TRY(hipEventCreateWithFlags(&s->ev_done[i], hipEventDisableTiming), 2);
+	for (int i = 0; i < 2; i++) SLOT_TRY(hipEventCreateWithFlags(&s->ev_out[i], hipEventDisableTiming), 2);
 	SLOT_TRY(hipEventCreate(&s->ev0), 2);
 	SLOT_TRY(hipEventCreate(&s->ev1), 2);
 #if defined(ASTC_PROFILE)
@@ -408,13 +415,47 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		chunk = rows * blocks_x;
 	}
 	const size_t row_bytes = (size_t)job.dim_x * texel_bytes;
+	if (banded)
+	{
+		// Pinned staging: a copy from or to the caller's pageable memory would hold the host thread until it is done (and the
+		// D2H one until the band's kernel is done), so the device would sit idle while the next band is queued.  The host
+		// copies a band into a pinned buffer (two of them: band k+1 is staged while band k's transfer is in flight) and the
+		// blocks come back through pinned buffers as well; every transfer is then a true asynchronous DMA.
+		const size_t band_rows = (chunk / blocks_x) * bsy;
+		const size_t in_need = band_rows * row_bytes, out_need = chunk * 16;
+		if (s->h_in_cap < in_need)
+		{
+			for (int i = 0; i < 2; i++) { if (s->h_in[i]) (void)hipHostFree(s->h_in[i]); s->h_in[i] = nullptr; }
+			s->h_in_cap = 0;
+			for (int i = 0; i < 2; i++) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_in[i]), in_need, hipHostMallocDefault), return 1);
+			s->h_in_cap = in_need;
+		}
+		if (s->h_out_cap < out_need)
+		{
+			for (int i = 0; i < 2; i++) { if (s->h_out[i]) (void)hipHostFree(s->h_out[i]); s->h_out[i] = nullptr; }
+			s->h_out_cap = 0;
+			for (int i = 0; i < 2; i++) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_out[i]), out_need, hipHostMallocDefault), return 1);
+			s->h_out_cap = out_need;
+		}
+	}
 	auto upload_band = [&](size_t band_first, size_t band_blocks) -> int {
+		const size_t band = band_first / chunk;
 		const size_t y0 = (band_first / blocks_x) * bsy;
 		size_t y1 = ((band_first + band_blocks) / blocks_x) * bsy;
 		if (y1 > job.dim_y) y1 = job.dim_y;
-		HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->d_image) + y0 * row_bytes, static_cast<const uint8_t*>(job.host_slices[0]) + y0 * row_bytes,
-		                       (y1 - y0) * row_bytes, hipMemcpyHostToDevice, s->copy_stream), return 2);
-		HIP_TRY(hipEventRecord(s->ev_copy[(band_first / chunk) & 1], s->copy_stream), return 2);
+		// the staging buffer's previous transfer (band - 2) must have left it
+		if (band >= 2) HIP_TRY(hipEventSynchronize(s->ev_copy[band & 1]), return 2);
+		memcpy(s->h_in[band & 1], static_cast<const uint8_t*>(job.host_slices[0]) + y0 * row_bytes, (y1 - y0) * row_bytes);
+		HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(s->d_image) + y0 * row_bytes, s->h_in[band & 1], (y1 - y0) * row_bytes, hipMemcpyHostToDevice, s->copy_stream), return 2);
+		HIP_TRY(hipEventRecord(s->ev_copy[band & 1], s->copy_stream), return 2);
+		return 0;
+	};
+	// a band's blocks, once its transfer has landed in the pinned buffer, go to the caller's memory (and to the progress count)
+	auto collect_band = [&](size_t band_first, size_t band_blocks) -> int {
+		const size_t band = band_first / chunk;
+		HIP_TRY(hipEventSynchronize(s->ev_out[band & 1]), return 2);
+		memcpy(job.host_out + band_first * 16, s->h_out[band & 1], band_blocks * 16);
+		if (progress) progress->add(band_blocks);
 		return 0;
 	};
 #if defined(ASTC_TRACE)
@@ -436,10 +477,9 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 	// (and reported to the progress callback) after chunk k has been queued, so the device always has its
 	// next kernel waiting, a cancel takes effect within two chunks, and nothing synchronises a whole stream.
 	size_t launched = 0, chunk_index = 0, prev_blocks = 0;
-	bool cancelled = false;
 	for (size_t first = 0; first < nblocks; first += chunk, chunk_index++)
 	{
-		if (job.cancel_flag && job.cancel_flag->load(std::memory_order_relaxed)) { cancelled = true; break; }
+		if (job.cancel_flag && job.cancel_flag->load(std::memory_order_relaxed)) break;
 		size_t n = nblocks - first < chunk ? nblocks - first : chunk;
 		if (banded)
 		{
@@ -458,12 +498,16 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		launched = first + n;
 		if (banded)
 		{
-			// this band's blocks go home on the copy stream once its kernel is done
+			// this band's blocks go home on the copy stream once its kernel is done; the band before it is collected
+			// meanwhile (its transfer was queued one iteration ago, behind its own kernel)
 			HIP_TRY(hipEventRecord(s->ev_band, stream), return 2);
 			HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_band, 0), return 2);
-			HIP_TRY(hipMemcpyAsync(job.host_out + first * 16, d_out + first * 16, n * 16, hipMemcpyDeviceToHost, s->copy_stream), return 2);
+			HIP_TRY(hipMemcpyAsync(s->h_out[chunk_index & 1], d_out + first * 16, n * 16, hipMemcpyDeviceToHost, s->copy_stream), return 2);
+			HIP_TRY(hipEventRecord(s->ev_out[chunk_index & 1], s->copy_stream), return 2);
+			if (chunk_index > 0 && collect_band(first - prev_blocks, prev_blocks) != 0) return 2;
+			prev_blocks = n;
 		}
-		if (chunked)
+		else if (chunked)
 		{
 			HIP_TRY(hipEventRecord(s->ev_done[chunk_index % 3], stream), return 2);
 			if (chunk_index > 0)
@@ -482,9 +526,13 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		HIP_TRY(hipMemcpyAsync(job.host_out, d_out, launched * 16, hipMemcpyDeviceToHost, stream), return 2);
 	}
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
-	if (banded) HIP_TRY(hipStreamSynchronize(s->copy_stream), return 2);
-	if (chunked && progress && prev_blocks && !cancelled) progress->add(prev_blocks);
-	else if (chunked && progress && prev_blocks && cancelled && launched) progress->add(prev_blocks);
+	if (banded)
+	{
+		// the last band that was launched (after a cancel: the last one before it) is still on its way
+		if (launched && collect_band(launched - prev_blocks, prev_blocks) != 0) return 2;
+		HIP_TRY(hipStreamSynchronize(s->copy_stream), return 2);
+	}
+	else if (chunked && progress && prev_blocks && launched) progress->add(prev_blocks);
 	if (job.kernel_ms) HIP_TRY(hipEventElapsedTime(job.kernel_ms, s->ev0, s->ev1), return 2);
 #if defined(ASTC_TRACE)
 	if (const char* path = getenv("ASTCENC_AMD_TRACE_FILE"))

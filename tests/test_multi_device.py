@@ -177,7 +177,8 @@ def test_eight_slots_on_the_baseline_image(product, ref, A):
         out = np.zeros(nb * nb * 16, dtype=np.uint8)
         assert product.compress_raw(ctx, img, out) == A.SUCCESS
         done = int(out.reshape(-1, 16).any(axis=1).sum())
-        assert 0 < done < nb * nb // 2, done          # eight shards x at most a few 2^18-block chunks each, of 1.87 M blocks
+        # each of the eight shards runs four bands and stays at most two bands ahead of what has been reported
+        assert 0 < done < nb * nb * 7 // 8, done
         assert calls == sorted(calls) and calls[-1] < 100.0
     finally:
         product.context_free(ctx)
