@@ -73,6 +73,9 @@ struct TrialInfo {
 	int   eci1_valid;
 	float eci1[4];            // rgb_scale, rgb_luma, luminance, alpha_drop of partition 0 of 1
 	int   ideal_1p1p_valid;   // ei_w / ei_wes / ep0 / ep1 / is_constant_wes hold the 1-partition 1-plane result
+	// the staged partitioning's per-partition start / size bytes (PartView::offsets / counts): every refinement step
+	// builds a view of it, and two dependent L2 round trips for the header each time would be most of such a step's latency
+	uint32_t part_offsets, part_counts;
 	// generic small uniform mailboxes
 	float fbox[128];
 	int   ibox[64];
@@ -135,6 +138,11 @@ struct LdsLayout {
 	uint32_t total;
 };
 
+/* Staged copy of a grid's tables in LDS (LdsLayout::dtab): its DecimationInfo record first (the refinement steps then
+ * find sizes and offsets with an LDS read instead of two dependent global loads), the tables DTAB_RECORD_BYTES in. */
+constexpr uint32_t DTAB_RECORD_BYTES = 64;
+static_assert(sizeof(DecimationInfo) <= DTAB_RECORD_BYTES, "DecimationInfo outgrew its staged slot");
+
 /* Sizes in bytes of the variable scratch regions. */
 
 /* (MODE_DESC_BYTES, the endpoint-format table sizes and uni_region_bytes() live in astc_tables.h: the table
@@ -194,7 +202,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	uint32_t end = o;
 	// refine phase
 	o = begin;
-	L.dtab = take(r.max_decimation_table_bytes);
+	L.dtab = take(DTAB_RECORD_BYTES + r.max_decimation_table_bytes);    // the candidate grid's DecimationInfo record, then its tables
 	L.ctab = take(512);
 	L.qtab = take(sizeof(QuantXfer));
 	L.rsc = take(19 * Tp * 4);
@@ -498,19 +506,24 @@ WV_FN PartView part_view_staged(const Ctx& c, int pcount, int packed)
 	uint8_t* dst = c.lds + c.L->ptab;
 	// of_texel[T] and sorted[T] are adjacent in the record; record stride is a multiple of 4
 	const uint8_t* src = reinterpret_cast<const uint8_t*>(v.h) + sizeof(PartitionHeader);
+	WV_ONE { c.tr().part_offsets = v.offsets; c.tr().part_counts = v.counts; }
 	stage_words(dst, src, (2 * c.T + 3) / 4);
 	v.of_texel = dst;
 	v.sorted = dst + c.T;
 	return v;
 }
 
-/* The same view without copying: for stage functions that run after part_view_staged() did. */
+/* The same view without copying: for stage functions that run after part_view_staged() did (no global memory access). */
 WV_FN PartView part_view_lds(const Ctx& c, int pcount, int packed)
 {
-	PartView v = part_view(c, pcount, packed);
+	PartView v;
 	const uint8_t* dst = c.lds + c.L->ptab;
+	v.h = reinterpret_cast<const PartitionHeader*>(c.part_rec(pcount, packed));     // (address only; not dereferenced on the hot paths)
 	v.of_texel = dst;
 	v.sorted = dst + c.T;
+	v.offsets = wv_uniform(c.tr().part_offsets);
+	v.counts = wv_uniform(c.tr().part_counts);
+	v.pcount = pcount;
 	return v;
 }
 
@@ -557,19 +570,12 @@ WV_FN DecView dec_view_global(const Ctx& c, int dm)
 	return dec_view_at(di, c.table(di.off_texel_weights));
 }
 
-WV_FN DecView dec_view_staged(const Ctx& c, int dm)
-{
-	const DecimationInfo& di = c.dec_info(dm);
-	uint8_t* dst = c.lds + c.L->dtab;
-	stage_words(dst, c.table(di.off_texel_weights), (int)((di.table_bytes + 3) / 4));
-	return dec_view_at(di, dst);
-}
-
-/* The staged view again, without copying (after dec_view_staged() of the same mode). */
+/* The staged view (after refine_candidate_setup staged the grid): sizes, offsets and tables all come from LDS. */
 WV_FN DecView dec_view_lds(const Ctx& c, int dm)
 {
-	const DecimationInfo& di = c.dec_info(dm);
-	DecView v = dec_view_at(di, c.lds + c.L->dtab);
+	(void)dm;
+	const DecimationInfo& di = *reinterpret_cast<const DecimationInfo*>(c.lds + c.L->dtab);
+	DecView v = dec_view_at(di, c.lds + c.L->dtab + DTAB_RECORD_BYTES);
 	if (di.realign_speculative) v.later = c.table(di.off_realign_later);
 	return v;
 }

@@ -532,10 +532,9 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	const int T = c.T;
 	if (wv_uniform((int)scb.block_type) == SYM_BTYPE_ERROR) return ERROR_CALC_DEFAULT;
 
-	const BlockMode& bm = c.block_mode(wv_uniform((int)scb.block_mode));
 	const uint8_t* tw = di.tw;
 	const uint8_t* tci = di.tci;
-	const bool dual = wv_uniform((int)bm.is_dual_plane) != 0;
+	const bool dual = wv_uniform((int)scb.plane2_component) >= 0;      // (refine_pack: -1 for a one-plane block)
 	const int pc = wv_uniform((int)scb.partition_count);
 	const int profile = c.cfg->profile;
 	const bool u8 = (c.cfg->flags & (1u << 1)) || profile == 0;
@@ -625,11 +624,10 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
-	const BlockMode& bm = c.block_mode(wv_uniform((int)scb.block_mode));
 	const int W = di.W;
 	const int pc = wv_uniform((int)scb.partition_count);
-	const int max_plane = wv_uniform((int)bm.is_dual_plane);
 	const int p2c = wv_uniform((int)scb.plane2_component);
+	const int max_plane = p2c >= 0 ? 1 : 0;                             // (refine_pack: -1 for a one-plane block)
 	const bool decimated = W != T;
 
 	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
