@@ -169,8 +169,11 @@ struct DecimationInfo {
 	uint32_t realign_speculative;        // 1: use the scheme above
 };
 constexpr int REALIGN_LATER_MAX = 16;
+// (measured on MI355X, same-call A/B: with the lane-per-weight evaluator of realign_weights the speculative scheme wins
+//  for every decimated grid -- 6x6 -medium 124.9 -> 127.8 Mtexels/s going from 7 to 2 -- so the level schedule is left
+//  for the grids whose later-neighbour lists do not fit, i.e. some 3D grids)
 #ifndef ASTC_REALIGN_SPEC_MIN
-#define ASTC_REALIGN_SPEC_MIN 7
+#define ASTC_REALIGN_SPEC_MIN 2
 #endif
 constexpr int REALIGN_SPECULATIVE_MIN_LEVELS = ASTC_REALIGN_SPEC_MIN;   // schedules at least this long are replaced by the speculative scheme
 

@@ -763,6 +763,96 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			int next = 0;                                 // SPEC_ALL: next weight to evaluate; SPEC_LATER: next entry of the mover's list
 			int start = 0, later_count = 0;               // SPEC_LATER: verdicts below `start` are final
 			uint8_t* later = reinterpret_cast<uint8_t*>(&tr.ibox[56]);    // [REALIGN_LATER_MAX] the mover's list, copied to LDS
+#if !defined(ASTC_REALIGN_GROUP_SPECULATION)
+			// Speculative grids (decimated in two dimensions: every weight reaches a dozen texels or more, and no two
+			// neighbours can be decided together): ONE LANE PER WEIGHT walks the weight's texels, keeps the twelve running
+			// sums in registers in the reference's order and decides on the spot -- all weights in a single pass, no term
+			// rows in LDS, no second and third phase per handful of weights.  (The (weight, texel)-lane evaluator below
+			// stays for the level schedule, whose groups are many weights with few texels each.)
+			if (speculative)
+			{
+				int items = W;                              // pass 1: every weight; then: the later neighbours of each mover
+				bool all = true;
+				for (;;)
+				{
+					WV_FOR(k, items)
+					{
+						const int we = all ? k : (int)later[k];
+						const int uqw = uq[we];
+						const uint32_t prev_and_next = pn[we];
+						const float uqw_base = (float)uqw;
+						const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+						const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+						f4 sb = splat4(0.0f), sd = splat4(0.0f), su = splat4(0.0f);
+						const int n = wtc[we];
+						for (int te = 0; te < n; te++)
+						{
+							const int texel = wt[te * W + we];
+							const float tw_base = tcw[te * W + we];
+							const float weight_base = wb[texel];
+							const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
+							const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
+							f4 color_offset = color_offset_1, color_base = color_base_1;
+							if (!one_partition)
+							{
+								const int p = pv.of_texel[texel];
+								color_offset = load4(&tr.fbox[p * 8 + 4]);
+								color_base = load4(&tr.fbox[p * 8]);
+							}
+							const f4 color = color_base + color_offset * weight_base;
+							const f4 orig_color = mk4(c.data(0)[texel], c.data(1)[texel], c.data(2)[texel], c.data(3)[texel]);
+							const f4 color_diff = color - orig_color;
+							const f4 color_down_diff = color_diff + color_offset * weight_down;
+							const f4 color_up_diff = color_diff + color_offset * weight_up;
+							sb = sb + color_diff * color_diff;
+							sd = sd + color_down_diff * color_down_diff;
+							su = su + color_up_diff * color_up_diff;
+						}
+						const float error_base = hadd_s(sb * error_weight);
+						const float error_down = hadd_s(sd * error_weight);
+						const float error_up = hadd_s(su * error_weight);
+						int new_value = 255;
+						if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+						else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+						verdict[we] = (uint8_t)new_value;
+					}
+					WV_SYNC();
+					// the first weight (in index order) whose verdict is "move" moves; what it invalidates is evaluated again
+					int mover;
+					for (;;)
+					{
+						mover = wv_find_first(W, [&](int w) { return w >= start && verdict[w] != 255; });
+						if (mover < 0) break;
+						adjustments = true;
+						const int new_value = wv_uniform((int)verdict[mover]);
+						WV_ONE
+						{
+							uq[mover] = (uint8_t)new_value;
+							uqf[mover] = (float)new_value;
+						}
+						WV_SYNC();
+						WV_FOR(te, (int)wtc[mover])
+						{
+							const int texel = wt[te * W + mover];
+							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
+						}
+						{
+							const uint32_t* list = reinterpret_cast<const uint32_t*>(di.later + mover * REALIGN_LATER_MAX);
+							WV_FOR(k, REALIGN_LATER_MAX / 4) { reinterpret_cast<uint32_t*>(later)[k] = list[k]; }
+						}
+						WV_SYNC();
+						later_count = 0;
+						while (later_count < REALIGN_LATER_MAX && later[later_count] != 255) later_count++;
+						start = mover + 1;
+						if (later_count != 0) break;
+					}
+					if (mover < 0) break;
+					items = later_count;
+					all = false;
+				}
+				continue;                                   // (next plane)
+			}
+#endif
 			for (;;)
 			{
 				// ---- which weights next: `gn` of them, weight of slot s = src[s] (kind 0, 2) or base + s (kind 1) ----
