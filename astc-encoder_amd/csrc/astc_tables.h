@@ -119,7 +119,7 @@ struct DwiSlot {
 // length instead of waiting for the longest one in packing order.  Copied ("direct") slots come last.
 constexpr int DWI_MAX_CHUNKS = 15;
 struct DwiOrderDir {
-	uint32_t list_off;                       // blob offset of the uint16_t slot indices of this (class, q)
+	uint32_t list_off;                       // blob offset of the DwiSlot records of this (class, q) in processing order; DwiSlot::refprec = the slot's packed index there
 	uint16_t chunk_start[DWI_MAX_CHUNKS + 1];  // list positions [chunk_start[c], chunk_start[c + 1]) belong to chunk c
 	uint16_t chunks;
 	uint16_t pad;

@@ -184,7 +184,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 	const uint32_t t_inv = c.L->t_inv24;                                       // k / T == (k * t_inv) >> 24
 	const DwiOrderDir& dir = reinterpret_cast<const DwiOrderDir*>(c.table(r.off_dwi_order[cls]))[quant_limit];
 	const bool sorted = all_grids && dir.chunks != 0;
-	const uint16_t* order = reinterpret_cast<const uint16_t*>(c.table(dir.list_off));
+	const DwiSlot* order = reinterpret_cast<const DwiSlot*>(c.table(dir.list_off));     // records in processing order, refprec = packed index
 
 	// chunks of (grid, plane) sets whose texel-resolution infill fits the scratch region
 	int p0 = 0, chunk = 0;
@@ -200,16 +200,40 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		const int o_begin = sorted ? (int)dir.chunk_start[chunk] : 0;
 		const int n_items = sorted ? (int)dir.chunk_start[chunk + 1] - o_begin : k_end - k_begin;
 
-		// sweep 1: initial guess for every (grid, plane, weight)
+		// sweep 1: initial guess for every (grid, plane, weight).  The next iteration's record is requested before this
+		// one's taps are (the sweeps are bound by the latency of their table loads, not by arithmetic).
 		{ PROF_SCOPE(c, PS_DEC1);
-		WV_FOR(j, n_items)
+		if (sorted)
 		{
-			const int k = sorted ? (int)table_at(order, (uint32_t)(o_begin + j)) : k_begin + j;
-			const DwiSlot sl = table_at(slots, (uint32_t)k);
-			if (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask))) continue;
-			const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
-			dwi_base[k] = w0;
-			if (sl.flags & 1) isamp[k] = angular_sample_row(w0);     // copied weights are final here
+#if WV_DEVICE
+			DwiSlot ahead = {};
+			if (WV_LANE < n_items) ahead = table_at(order, (uint32_t)(o_begin + WV_LANE));
+#endif
+			WV_FOR(jj, n_items)
+			{
+#if WV_DEVICE
+				const DwiSlot sl = ahead;
+				if (jj + 64 < n_items) ahead = table_at(order, (uint32_t)(o_begin + jj + 64));
+#else
+				const DwiSlot sl = table_at(order, (uint32_t)(o_begin + jj));
+#endif
+				const int k = sl.refprec;
+				const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
+				dwi_base[k] = w0;
+				if (sl.flags & 1) isamp[k] = angular_sample_row(w0);     // copied weights are final here
+			}
+		}
+		else
+		{
+			WV_FOR(j, n_items)
+			{
+				const int k = k_begin + j;
+				const DwiSlot sl = table_at(slots, (uint32_t)k);
+				if (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
+				const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
+				dwi_base[k] = w0;
+				if (sl.flags & 1) isamp[k] = angular_sample_row(w0);
+			}
 		}
 		WV_SYNC(); }
 
@@ -228,14 +252,38 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 
 		// sweep 3: one clamped gradient step
 		{ PROF_SCOPE(c, PS_DEC3);
-		WV_FOR(j, n_items)
+		if (sorted)
 		{
-			const int k = sorted ? (int)table_at(order, (uint32_t)(o_begin + j)) : k_begin + j;
-			const DwiSlot sl = table_at(slots, (uint32_t)k);
-			if ((sl.flags & 1) || (!sorted && (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)))) continue;
-			const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
-			dwi_base[k] = w1;
-			isamp[k] = angular_sample_row(w1);
+#if WV_DEVICE
+			DwiSlot ahead = {};
+			if (WV_LANE < n_items) ahead = table_at(order, (uint32_t)(o_begin + WV_LANE));
+#endif
+			WV_FOR(jj, n_items)
+			{
+#if WV_DEVICE
+				const DwiSlot sl = ahead;
+				if (jj + 64 < n_items) ahead = table_at(order, (uint32_t)(o_begin + jj + 64));
+#else
+				const DwiSlot sl = table_at(order, (uint32_t)(o_begin + jj));
+#endif
+				if (sl.flags & 1) continue;
+				const int k = sl.refprec;
+				const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+				dwi_base[k] = w1;
+				isamp[k] = angular_sample_row(w1);
+			}
+		}
+		else
+		{
+			WV_FOR(j, n_items)
+			{
+				const int k = k_begin + j;
+				const DwiSlot sl = table_at(slots, (uint32_t)k);
+				if ((sl.flags & 1) || sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
+				const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+				dwi_base[k] = w1;
+				isamp[k] = angular_sample_row(w1);
+			}
 		}
 		WV_SYNC(); }
 		p0 = p1;
