@@ -143,6 +143,8 @@ struct LdsLayout {
 constexpr uint32_t DTAB_RECORD_BYTES = 64;
 static_assert(sizeof(DecimationInfo) <= DTAB_RECORD_BYTES, "DecimationInfo outgrew its staged slot");
 
+constexpr uint32_t LDS_ALLOC_GRANULE = 1280;   // gfx950: 160 KiB of LDS per CU in 128 allocation units
+
 /* Sizes in bytes of the variable scratch regions. */
 
 /* (MODE_DESC_BYTES, the endpoint-format table sizes and uni_region_bytes() live in astc_tables.h: the table
@@ -215,6 +217,20 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
 	L.wsc = take(2 * 64 * 4);
 	if (o > end) end = o;
+	// The hardware hands out LDS in units of LDS_ALLOC_GRANULE bytes (measured on MI355X, DESIGN.md section 6: the
+	// workgroups per CU step at multiples of 1280 B): what the largest phase leaves of its last unit costs no occupancy.
+	// The mode scoring takes it -- more block modes per pass of its descriptor / quantize / score / sum sequence, whose
+	// table loads are latency-bound -- and so do the staged partition records below.
+	{
+		const uint32_t rounded = (end + LDS_ALLOC_GRANULE - 1u) / LDS_ALLOC_GRANULE * LDS_ALLOC_GRANULE;
+		if (rounded <= 64u * 1024u)
+		{
+			L.uni_bytes = (rounded - L.uni) & ~15u;
+			L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);
+			if (L.mode_chunk > 32u) L.mode_chunk = 32u;
+			end = rounded;
+		}
+	}
 	// partition search phase
 	o = begin;
 	uint32_t lim = cfg.tune_partition_index_limit[0];
