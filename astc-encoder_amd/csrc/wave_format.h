@@ -20,21 +20,27 @@ WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
 {
 #if WV_DEVICE
 	float best = ERROR_CALC_DEFAULT;
-	int idx = -1;
+	int idx = 0x7FFFFFFF;                    // (no candidate: compares above every index)
 	for (int i = start + WV_LANE; i < end; i += 64)
 	{
 		float e = v(i);
 		if (e < best) { best = e; idx = i; }
 	}
-	for (int off = 32; off > 0; off >>= 1)
-	{
-		float oe = __shfl_xor(best, off, 64);
-		int oi = __shfl_xor(idx, off, 64);
-		bool take = (oi >= 0) && (idx < 0 || oe < best || (oe == best && oi < idx));
-		if (take) { best = oe; idx = oi; }
-	}
+	// fold (value, index) pairs across the wave: smaller value wins, equal values go to the smaller index.  DPP steps
+	// (row_shr 1 / 2 / 4 / 8, then row_bcast 15 / 31; lanes without a source keep their own pair), no LDS traffic:
+	// the ds_bpermute butterfly this replaces was a dozen dependent LDS round trips per pick.
+	#define WV_ARGMIN_STEP(CTRL, ROW_MASK) do { \
+		const float ov = int_as_float(__builtin_amdgcn_update_dpp(float_as_int(best), float_as_int(best), CTRL, ROW_MASK, 0xF, false)); \
+		const int oi = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROW_MASK, 0xF, false); \
+		const bool take = ov < best || (ov == best && oi < idx); \
+		best = take ? ov : best; idx = take ? oi : idx; } while (0)
+	WV_ARGMIN_STEP(0x111, 0xF); WV_ARGMIN_STEP(0x112, 0xF); WV_ARGMIN_STEP(0x114, 0xF); WV_ARGMIN_STEP(0x118, 0xF);
+	WV_ARGMIN_STEP(0x142, 0xA); WV_ARGMIN_STEP(0x143, 0xC);
+	#undef WV_ARGMIN_STEP
 	(void)c;
-	return idx;
+	const int winner = __builtin_amdgcn_readlane(idx, 63);
+	const float winner_value = int_as_float(__builtin_amdgcn_readlane(float_as_int(best), 63));
+	return winner_value < ERROR_CALC_DEFAULT ? winner : -1;
 #else
 	(void)c;
 	float best = ERROR_CALC_DEFAULT;

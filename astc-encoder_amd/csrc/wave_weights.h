@@ -237,12 +237,22 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 		}
 		WV_SYNC(); }
 
-		// sweep 2: infill to texel resolution (ref: :910-926)
+		// sweep 2: infill to texel resolution (ref: :910-926); the set record of the next iteration is requested before this
+		// iteration's table loads are
 		{ PROF_SCOPE(c, PS_DEC2);
+#if WV_DEVICE
+		InfillSet ahead = {};
+		if (WV_LANE < nsets * T) ahead = table_at(isets, (uint32_t)(p0 + (int)(((uint32_t)WV_LANE * t_inv) >> 24)));
+#endif
 		WV_FOR(k, nsets * T)
 		{
 			int set = (int)(((uint32_t)k * t_inv) >> 24), t = k - set * T;
+#if WV_DEVICE
+			const InfillSet is = ahead;
+			if (k + 64 < nsets * T) ahead = table_at(isets, (uint32_t)(p0 + (int)(((uint32_t)(k + 64) * t_inv) >> 24)));
+#else
 			const InfillSet is = table_at(isets, (uint32_t)(p0 + set));
+#endif
 			if (is.direct || (int)is.dm >= max_dm || !(is.refprec & ref_mask)) continue;
 			const float* wts = dwi_base + is.dwi_offset;
 			infilled[set * Tp + t] = is.taps <= 2 ? infill2_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t)
