@@ -131,15 +131,36 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 	float* wes = c.ei_wes(plane);
 	float error_weight = blk.cw[component];
 
+	// (one partition -- the only case on the search path, the second plane of a two-plane trial -- : the channel's range
+	//  over the block by a wave reduction; minimum / maximum of finite values are exact whatever the order)
+	float lo_part = 1e10f, hi_part = -1e10f;
+	if (pc == 1)
+	{
+		WV_FOR(t, T)
+		{
+			const float value = d[t];
+			lo_part = f_min(value, lo_part);
+			hi_part = f_max(value, hi_part);
+		}
+		wv_all_minmax(lo_part, hi_part);
+	}
 	WV_FOR(p, pc)
 	{
 		float lowvalue = 1e10f, highvalue = -1e10f;
-		const uint8_t* tix = pv.sorted + pv.off(p);
-		for (int j = 0; j < pv.cnt(p); j++)
+		if (pc == 1)
 		{
-			float value = d[tix[j]];
-			lowvalue = f_min(value, lowvalue);
-			highvalue = f_max(value, highvalue);
+			lowvalue = lo_part;
+			highvalue = hi_part;
+		}
+		else
+		{
+			const uint8_t* tix = pv.sorted + pv.off(p);
+			for (int j = 0; j < pv.cnt(p); j++)
+			{
+				float value = d[tix[j]];
+				lowvalue = f_min(value, lowvalue);
+				highvalue = f_max(value, highvalue);
+			}
 		}
 		if (highvalue <= lowvalue)
 		{
@@ -207,7 +228,9 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	}
 	WV_SYNC();
 
-	// raw line parameter of every texel (ref: :282-291, :431-440, :553-562)
+	// raw line parameter of every texel (ref: :282-291, :431-440, :553-562); with one partition its range is folded
+	// across the wave on the way (minimum / maximum of finite values: exact whatever the order)
+	float lo_part = 1e10f, hi_part = -1e10f;
 	WV_FOR(t, T)
 	{
 		int p = pv.of_texel[t];
@@ -217,18 +240,29 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 		f4 b = load4(&tr.fbox[32 + p * 4]);
 		float param = n == 3 ? dot3_s(pt - a, b) : dot_s(pt - a, b);
 		w[t] = param;
+		lo_part = f_min(param, lo_part);
+		hi_part = f_max(param, hi_part);
 	}
+	if (pc == 1) wv_all_minmax(lo_part, hi_part);
 	WV_SYNC();
 
 	WV_FOR(p, pc)
 	{
 		float lowparam = 1e10f, highparam = -1e10f;
-		const uint8_t* tix = pv.sorted + pv.off(p);
-		for (int j = 0; j < pv.cnt(p); j++)
+		if (pc == 1)
 		{
-			float param = w[tix[j]];
-			lowparam = f_min(param, lowparam);
-			highparam = f_max(param, highparam);
+			lowparam = lo_part;
+			highparam = hi_part;
+		}
+		else
+		{
+			const uint8_t* tix = pv.sorted + pv.off(p);
+			for (int j = 0; j < pv.cnt(p); j++)
+			{
+				float param = w[tix[j]];
+				lowparam = f_min(param, lowparam);
+				highparam = f_max(param, highparam);
+			}
 		}
 		if (highparam <= lowparam)
 		{
