@@ -176,40 +176,69 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		}
 		WV_SYNC();
 
-		// empty-cluster repair, strictly sequential (ref: :184-198)
-		WV_ONE
+		// empty-cluster repair (ref: :184-198).  It only does anything when a cluster came out empty: the cluster sizes are
+		// counted across the wave first (integer counts: any order), and the strictly sequential repair runs in the rare
+		// case that one of them is zero.
 		{
-			// texels per cluster, in four scalars (a run-time indexed private array would live in scratch)
 			int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#if WV_DEVICE
+			for (int base = 0; base < T; base += 64)
+			{
+				const int i = base + WV_LANE;
+				const int a = i < T ? (int)assign[i] : -1;
+				c0 += __popcll(__ballot(a == 0)); c1 += __popcll(__ballot(a == 1));
+				c2 += __popcll(__ballot(a == 2)); c3 += __popcll(__ballot(a == 3));
+			}
+#else
 			for (int i = 0; i < T; i++)
 			{
 				int a = (int)assign[i];
 				c0 += a == 0; c1 += a == 1; c2 += a == 2; c3 += a == 3;
 			}
-			bool problem_case;
-			do
+#endif
+			bool any_empty = false;
+			for (int i = 0; i < pc; i++) any_empty = any_empty || (i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3) == 0;
+			if (any_empty)
 			{
-				problem_case = false;
-				for (int i = 0; i < pc; i++)
+				WV_ONE
 				{
-					int ci = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
-					if (ci == 0)
+					bool problem_case;
+					do
 					{
-						int a = (int)assign[i];
-						c0 -= a == 0; c1 -= a == 1; c2 -= a == 2; c3 -= a == 3;
-						c0 += i == 0; c1 += i == 1; c2 += i == 2; c3 += i == 3;
-						assign[i] = (float)i;
-						problem_case = true;
-					}
+						problem_case = false;
+						for (int i = 0; i < pc; i++)
+						{
+							int ci = i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3;
+							if (ci == 0)
+							{
+								int a = (int)assign[i];
+								c0 -= a == 0; c1 -= a == 1; c2 -= a == 2; c3 -= a == 3;
+								c0 += i == 0; c1 += i == 1; c2 += i == 2; c3 += i == 3;
+								assign[i] = (float)i;
+								problem_case = true;
+							}
+						}
+					} while (problem_case);
 				}
-			} while (problem_case);
+				WV_SYNC();
+			}
 		}
-		WV_SYNC();
 	}
 
 	// ---- bitmaps over the k-means texel subset (ref: :483-490) ----
 	const int texels_to_process = i_min(T, MAX_KMEANS_TEXELS);
 	const uint8_t* km = c.table(c.root->off_kmeans_texels);
+#if WV_DEVICE
+	{
+		// lane i looks at k-means texel i (at most 64 of them): a partition's bitmap is one ballot
+		const int a = WV_LANE < texels_to_process ? (int)assign[km[WV_LANE]] : -1;
+		for (int p = 0; p < pc; p++)
+		{
+			const uint64_t bm = __ballot(a == p);
+			WV_ONE { ps.bitmaps[p] = bm; }
+		}
+	}
+#else
 	WV_FOR(p, pc)
 	{
 		uint64_t bm = 0;
@@ -219,6 +248,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		}
 		ps.bitmaps[p] = bm;
 	}
+#endif
 	WV_SYNC();
 
 	// ---- mismatch counts against every selected partitioning (ref: :365-401) ----
