@@ -8,6 +8,7 @@
 #pragma once
 #include <stddef.h>
 #include "wave_ctx.h"
+#include "wave_quad.h"
 #include "wave_load.h"
 #include "wave_ideal.h"
 #include "wave_weights.h"
@@ -310,6 +311,8 @@ WV_OUT void refine_quantize_candidates(bool dual, int partition_count, int parti
 	else trial_scale_directions(c, part_view_lds(c, partition_count, partition_packed), false);
 	TrialInfo& tr = c.tr();
 	const int candidate_count = wv_uniform(tr.cand_count);
+	// (the search phase of this trial has used the bytes the staged colour rows live in)
+	WV_ONE { tr.staged_color_quant[0] = -1; }
 	PROF_SCOPE(c, PS_Y0);
 	// quantization parameters of each (candidate, plane) once, then one lane per (candidate, plane, weight)
 	const int plane_shift = dual ? 1 : 0;
@@ -760,48 +763,37 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 	const uint16_t ref_mask = (uint16_t)wv_uniform(ref_mask_i);
 	TrialInfo& tr = c.tr();
 
-	WV_ONE
+	// Weight cut-off of each plane (ref: compress_symbolic.cpp:409-418, :765-785): the smallest (1 - e0) / (e1 - e0) above
+	// 0.5 over the plane's channels, one channel per lane of a quad (wave_quad.h).  The values compared are finite
+	// (a NaN quotient fails both tests), so the minimum is the same in any order.
+	WV_QUADS(q, 1)
 	{
+		(void)q;
 		if (!dual)
 		{
-			f4 min_ep = splat4(10.0f);
+			qf min_ep = q_splat(10.0f);
 			for (int i = 0; i < partition_count; i++)
 			{
-				f4 e0 = load4(tr.ep0[0][i]), e1 = load4(tr.ep1[0][i]);
-				f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
-				for (int k = 0; k < 4; k++)
-				{
-					float v = lane(ep, k);
-					if (v > 0.5f && v < lane(min_ep, k)) set_lane(min_ep, k, v);
-				}
+				const qf ep = (q_splat(1.0f) - q_load(tr.ep0[0][i])) / (q_load(tr.ep1[0][i]) - q_load(tr.ep0[0][i]));
+				min_ep = q_zip(ep, min_ep, [](float v, float m) { return (v > 0.5f && v < m) ? v : m; });
 			}
-			tr.min_wt_cutoff[0] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+			const float cut = q_hmin(min_ep);
+			Q_ONCE { tr.min_wt_cutoff[0] = cut; }
 		}
 		else
 		{
-			float cut[2];
 			for (int plane = 0; plane < 2; plane++)
 			{
-				f4 e0 = load4(tr.ep0[plane][0]), e1 = load4(tr.ep1[plane][0]);
-				f4 ep = (splat4(1.0f) - e0) / (e1 - e0);
-				f4 min_ep = splat4(10.0f);
-				for (int k = 0; k < 4; k++)
-				{
-					float v = lane(ep, k);
-					if (v > 0.5f && v < 10.0f) set_lane(min_ep, k, v);
-				}
+				const qf ep = (q_splat(1.0f) - q_load(tr.ep0[plane][0])) / (q_load(tr.ep1[plane][0]) - q_load(tr.ep0[plane][0]));
+				qf min_ep = q_map(ep, [](float v) { return (v > 0.5f && v < 10.0f) ? v : 10.0f; });
 				// plane 0 ignores the separated component, plane 1 only looks at it
-				for (int k = 0; k < 4; k++)
-				{
-					bool is_p2 = k == plane2_component;
-					if (plane == 0 ? is_p2 : !is_p2) set_lane(min_ep, k, ERROR_CALC_DEFAULT);
-				}
-				cut[plane] = hmin4(min_ep.x, min_ep.y, min_ep.z, min_ep.w);
+				min_ep = q_map_ch(min_ep, [plane, plane2_component](int k, float v) {
+					const bool is_p2 = k == plane2_component;
+					return (plane == 0 ? is_p2 : !is_p2) ? ERROR_CALC_DEFAULT : v; });
+				const float cut = q_hmin(min_ep);
+				Q_ONCE { tr.min_wt_cutoff[plane] = cut; }
 			}
-			tr.min_wt_cutoff[0] = cut[0];
-			tr.min_wt_cutoff[1] = cut[1];
 		}
-
 	}
 	// list of the grids this trial uses, largest weight count first (the order the search batches them in)
 	const uint8_t* by_weights = c.table(c.root->off_dm_by_weights);

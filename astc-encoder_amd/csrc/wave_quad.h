@@ -92,6 +92,14 @@ WV_FN float q_hadd(qf a)
 	float v = a.v + q_perm_f<Q_SWAP2>(a.v);
 	return v + q_perm_f<Q_SWAP1>(v);
 }
+/* smallest component (finite values: exact whatever the order; ref: hmin, vecmathlib_none_4.h:888) */
+WV_FN float q_hmin(qf a)
+{
+	float v = a.v;
+	float o = q_perm_f<Q_SWAP1>(v); v = o < v ? o : v;
+	o = q_perm_f<Q_SWAP2>(v); v = o < v ? o : v;
+	return v;
+}
 /* stores: component ch of `a` to p[ch * stride] for ch < count */
 WV_FN void q_store_u8(uint8_t* p, int stride, qi a, int count) { if (Q_CH < count) p[Q_CH * stride] = (uint8_t)a.v; }
 WV_FN void q_store_i32(int* p, qi a) { p[Q_CH] = a.v; }
@@ -136,6 +144,7 @@ WV_FN bool q_any_rgb(qb a) { return a.v[0] || a.v[1] || a.v[2]; }
 WV_FN int q_sum_rgb(qi a) { return a.v[0] + a.v[1] + a.v[2]; }
 WV_FN float q_hadd_rgb(qf a) { return (a.v[0] + a.v[1]) + a.v[2]; }
 WV_FN float q_hadd(qf a) { return (a.v[0] + a.v[2]) + (a.v[1] + a.v[3]); }
+WV_FN float q_hmin(qf a) { float m = a.v[0]; for (int k = 1; k < 4; k++) m = a.v[k] < m ? a.v[k] : m; return m; }
 WV_FN void q_store_u8(uint8_t* p, int stride, qi a, int count) { for (int k = 0; k < count; k++) p[k * stride] = (uint8_t)a.v[k]; }
 WV_FN void q_store_i32(int* p, qi a) { for (int k = 0; k < 4; k++) p[k] = a.v[k]; }
 #define Q_ONCE if (true)
@@ -146,6 +155,7 @@ WV_FN void q_store_i32(int* p, qi a) { for (int k = 0; k < 4; k++) p[k] = a.v[k]
 WV_FN qf operator+(qf a, qf b) { return q_zip(a, b, [](float x, float y) { return x + y; }); }
 WV_FN qf operator-(qf a, qf b) { return q_zip(a, b, [](float x, float y) { return x - y; }); }
 WV_FN qf operator*(qf a, qf b) { return q_zip(a, b, [](float x, float y) { return x * y; }); }
+WV_FN qf operator/(qf a, qf b) { return q_zip(a, b, [](float x, float y) { return x / y; }); }
 WV_FN qf operator*(qf a, float s) { return q_map(a, [s](float x) { return x * s; }); }
 WV_FN qf operator+(qf a, float s) { return q_map(a, [s](float x) { return x + s; }); }
 WV_FN qf operator-(qf a, float s) { return q_map(a, [s](float x) { return x - s; }); }

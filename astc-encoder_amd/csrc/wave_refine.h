@@ -390,77 +390,68 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	WV_FOR(k, 4) { tr.fbox[22 + k] = k == plane2_component ? tr.fbox[27] : tr.fbox[26]; }
 	WV_SYNC();
 
-	WV_ONE
+	// the solve, one lane per channel (every quantity below is channel-wise in the reference's vector code, ref: :1514-1612;
+	// the per-plane scalars are simply recomputed by the four lanes): a channel belongs to plane 2 if it is the separated
+	// component, else to plane 1
+	WV_FOR(ch, 4)
 	{
 		const float* s = tr.fbox;
-		float wmin1 = s[0], wmax1 = s[1], wmin2 = s[2], wmax2 = s[3], scale_min = s[4], scale_max = s[5];
-		f4 color_weight = load4(blk.cw);
-		f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
+		const bool second = ch == plane2_component;
+		const float wmin1 = s[0], wmax1 = s[1], scale_min = s[4], scale_max = s[5];
+		const float wmin = second ? s[2] : wmin1, wmax = second ? s[3] : wmax1;
+		const float color_weight = blk.cw[ch];
+		const float cwn = color_weight * (float)T;
+		const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
+		const float left_sum = (second ? s[9] : s[6]) * color_weight;
+		const float middle_sum = (second ? s[10] : s[7]) * color_weight;
+		const float right_sum = (second ? s[11] : s[8]) * color_weight;
+		const float color_vec_x = s[12 + ch] * color_weight;
+		const float color_vec_y = s[16 + ch] * color_weight;
 
-		f4 left1_sum = splat4(s[6]) * color_weight, middle1_sum = splat4(s[7]) * color_weight, right1_sum = splat4(s[8]) * color_weight;
-		f4 lmrs_sum = mk4(s[6], s[7], s[8], 0.0f) * ls_weight;
-		f4 left2_sum = splat4(s[9]) * color_weight, middle2_sum = splat4(s[10]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
+		float ep0 = tr.wep0[0][ch], ep1 = tr.wep1[0][ch];
+		if (wmin >= wmax * 0.999f)
+		{
+			// all weights of the channel's plane (nearly) equal: both endpoints become the mean
+			const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+			if (avg == avg) { ep0 = avg; ep1 = avg; }
+		}
+		else
+		{
+			const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
+			const float color_rdet1 = 1.0f / color_det1;
+			const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
+			const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
+			const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
+			if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
+		}
 
-		f4 color_vec_x = load4(&s[12]) * color_weight;
-		f4 color_vec_y = load4(&s[16]) * color_weight;
-		float scale_vec0 = s[20], scale_vec1 = s[21];
-
+		// the RGB + scale vector follows plane 1 (lane ch: scale_dir * scale for RGB, the scale ratio for A)
+		const float scale_dir_ch = tr.pm_dir[0][ch];
 		float scalediv = scale_min / f_max(scale_max, 1e-10f);
 		scalediv = f_clamp1(scalediv);
-		f4 sds = scale_dir * scale_max;
-		f4 rgbs = mk4(sds.x, sds.y, sds.z, scalediv);
-
-		f4 ep0 = load4(tr.wep0[0]), ep1 = load4(tr.wep1[0]);
-
+		float rgbs = ch < 3 ? scale_dir_ch * scale_max : scalediv;
 		if (wmin1 >= wmax1 * 0.999f)
 		{
-			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
-			for (int k = 0; k < 4; k++)
-			{
-				float a = lane(avg, k);
-				if (k != plane2_component && a == a) { set_lane(ep0, k, a); set_lane(ep1, k, a); }
-			}
-			rgbs = mk4(sds.x, sds.y, sds.z, 1.0f);
+			if (ch == 3) rgbs = 1.0f;
 		}
 		else
 		{
-			PlaneSolve ps = solve_plane(left1_sum, middle1_sum, right1_sum, color_vec_x, color_vec_y);
-			float ls_det1 = (lmrs_sum.x * lmrs_sum.z) - (lmrs_sum.y * lmrs_sum.y);
-			float ls_rdet1 = 1.0f / ls_det1;
-			float ls_mss1 = (lmrs_sum.x * lmrs_sum.x) + (2.0f * lmrs_sum.y * lmrs_sum.y) + (lmrs_sum.z * lmrs_sum.z);
-			float scale_ep0 = (lmrs_sum.z * scale_vec0 - lmrs_sum.y * scale_vec1) * ls_rdet1;
-			float scale_ep1 = (lmrs_sum.x * scale_vec1 - lmrs_sum.y * scale_vec0) * ls_rdet1;
-			for (int k = 0; k < 4; k++)
-			{
-				if (k != plane2_component && ps.m(k)) { set_lane(ep0, k, lane(ps.ep0, k)); set_lane(ep1, k, lane(ps.ep1, k)); }
-			}
+			const float lm_x = s[6] * ls_weight, lm_y = s[7] * ls_weight, lm_z = s[8] * ls_weight;
+			const float scale_vec0 = s[20], scale_vec1 = s[21];
+			const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
+			const float ls_rdet1 = 1.0f / ls_det1;
+			const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
+			const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
+			const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
 			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
 			{
-				float scalediv2 = scale_ep0 / scale_ep1;
-				f4 sdsm = scale_dir * scale_ep1;
-				rgbs = mk4(sdsm.x, sdsm.y, sdsm.z, scalediv2);
+				rgbs = ch < 3 ? scale_dir_ch * scale_ep1 : scale_ep0 / scale_ep1;
 			}
 		}
 
-		if (wmin2 >= wmax2 * 0.999f)
-		{
-			f4 avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
-			float a = lane(avg, plane2_component);
-			if (a == a) { set_lane(ep0, plane2_component, a); set_lane(ep1, plane2_component, a); }
-		}
-		else
-		{
-			PlaneSolve ps = solve_plane(left2_sum, middle2_sum, right2_sum, color_vec_x, color_vec_y);
-			if (ps.m(plane2_component))
-			{
-				set_lane(ep0, plane2_component, lane(ps.ep0, plane2_component));
-				set_lane(ep1, plane2_component, lane(ps.ep1, plane2_component));
-			}
-		}
-
-		store4(tr.wep0[0], ep0);
-		store4(tr.wep1[0], ep1);
-		store4(tr.rgbs[0], rgbs);
+		tr.wep0[0][ch] = ep0;
+		tr.wep1[0][ch] = ep1;
+		tr.rgbs[0][ch] = rgbs;
 	}
 	WV_SYNC();
 
@@ -546,7 +537,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
 
 	float* term = c.rsc(0);        // (the endpoint re-fit rows are free between re-fits)
-	float* flag = c.rsc(1);
+	bool bad_here = false;         // RGBM: a texel of this lane decodes to M = 0
 	WV_FOR(i, T)
 	{
 		// 1-plane multi-partition sums in partition order, the other two in texel order
@@ -564,10 +555,9 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 			old[k] = c.data(k)[t];
 		}
 
-		float bad = 0.0f;
 		if (rgbm)
 		{
-			if (col[3] == 0.0f) bad = 1.0f;
+			if (col[3] == 0.0f) bad_here = true;
 			float ms = c.cfg->rgbm_m_scale;
 			for (int k = 0; k < 3; k++)
 			{
@@ -576,7 +566,6 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 			}
 			col[3] = 1.0f; old[3] = 1.0f;
 		}
-		flag[i] = bad;
 
 		float err[4];
 		for (int k = 0; k < 4; k++)
@@ -602,13 +591,19 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 	{
 		return wv_sum4(term, T);
 	}
+	// (the reference leaves its texel loop with the sentinel at the first texel whose M is zero, ref: :366-394, :470-480:
+	//  whichever texel that is, the result is the same)
+	if (rgbm && wv_any(bad_here)) return -ERROR_CALC_DEFAULT;
 
+	// strictly sequential sum (additions only; four terms fetched per step)
 	float summa = 0.0f;
-	for (int i = 0; i < T; i++)
+	int i = 0;
+	for (; i + 4 <= T; i += 4)
 	{
-		if (rgbm && flag[i] != 0.0f) return -ERROR_CALC_DEFAULT;
-		summa += term[i];
+		const float x0 = term[i], x1 = term[i + 1], x2 = term[i + 2], x3 = term[i + 3];
+		summa += x0; summa += x1; summa += x2; summa += x3;
 	}
+	for (; i < T; i++) summa += term[i];
 	return summa;
 }
 
