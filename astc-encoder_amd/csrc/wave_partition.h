@@ -103,15 +103,18 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 
 		while (true)
 		{
+			// (both scans add in texel order like the reference; no branch inside: the first index at which the running
+			//  sum reaches the cut-off is picked with selects)
 			float distance_sum = 0.0f;
 			for (int i = 0; i < T; i++) distance_sum += dist[i];
 
 			float summa = 0.0f;
 			float distance_cutoff = distance_sum * cluster_cutoffs[cutoff++];
-			for (sample = 0; sample < T; sample++)
+			sample = T;
+			for (int i = 0; i < T; i++)
 			{
-				summa += dist[sample];
-				if (summa >= distance_cutoff) break;
+				summa += dist[i];
+				sample = (sample == T && summa >= distance_cutoff) ? i : sample;
 			}
 			sample = i_min(sample, T - 1);
 
@@ -146,7 +149,10 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 				int cnt = 0;
 				for (int i = 0; i < T; i++)
 				{
-					if ((int)assign[i] == p) { sum += d[i]; cnt++; }
+					// (a texel of another cluster adds +0.0, which leaves the sum -- never -0.0 -- as it is)
+					const bool mine = (int)assign[i] == p;
+					sum += mine ? d[i] : 0.0f;
+					cnt += mine ? 1 : 0;
 				}
 				float scale = 1.0f / (float)cnt;
 				tr.fbox[16 + k] = sum * scale;

@@ -657,7 +657,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 		if (!decimated)
 		{
-			float* moved = c.rsc(0);
+			bool moved_here = false;         // (per lane on the device; wv_any folds the lanes)
 			WV_FOR(texel, T)
 			{
 				int uqw = uq[texel];
@@ -695,11 +695,10 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					uq[texel] = (uint8_t)uqw_down;
 					mv = 1.0f;
 				}
-				moved[texel] = mv;
+				moved_here = moved_here || mv != 0.0f;
 			}
 			WV_SYNC();
-			for (int t = 0; t < T; t++) adjustments = adjustments || (moved[t] != 0.0f);
-			WV_SYNC();
+			adjustments = adjustments || wv_any(moved_here);
 		}
 		else
 		{
