@@ -490,24 +490,18 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				for (int i = 0; i < steps; i++)
 				{
 					const float* r = base + i * 8;
-					int idx_span = float_as_int(r[2]);
-					float err = r[3], cl = r[4], ch = r[5];
-					if (idx_span == q)
-					{
-						if (best_err > err) { best_err = err; best_idx = (float)i; best_cut = 0.0f; }
-					}
-					else if (idx_span - 1 == q)
-					{
-						float e_low = err + cl;
-						float e_high = err + ch;
-						if (best_err > e_low) { best_err = e_low; best_idx = (float)i; best_cut = 1.0f; }
-						if (best_err > e_high) { best_err = e_high; best_idx = (float)i; best_cut = 0.0f; }
-					}
-					else if (idx_span - 2 == q)
-					{
-						float e_lh = err + cl + ch;
-						if (best_err > e_lh) { best_err = e_lh; best_idx = (float)i; best_cut = 1.0f; }
-					}
+					const int idx_span = float_as_int(r[2]);
+					const float err = r[3], cl = r[4], ch = r[5];
+					// Which of the reference's three cases this step is for span index q (ref: :300-340), without branching
+					// (every lane of the wave looks at a different (set, quant level)): the step offers up to two
+					// candidates in the reference's order -- a case that does not apply offers an error no best can exceed.
+					const int d = idx_span - q;                      // 0: exact span, 1: one end cut, 2: both ends cut
+					const float e_cut_low = err + cl;
+					const float first = d == 0 ? err : d == 1 ? e_cut_low : d == 2 ? e_cut_low + ch : 3.0e38f;
+					const float first_cut = d == 0 ? 0.0f : 1.0f;
+					const float second = d == 1 ? err + ch : 3.0e38f;
+					if (best_err > first) { best_err = first; best_idx = (float)i; best_cut = first_cut; }
+					if (best_err > second) { best_err = second; best_idx = (float)i; best_cut = 0.0f; }
 				}
 
 				int bsi = (int)best_idx;
