@@ -1229,9 +1229,13 @@ WV_FN void compress_block(const Ctx& c, uint8_t* out)
 				scb.constant_color[k] = (int)(v + 0.5f);
 			}
 		}
+	}
+	WV_SYNC();
+	{
+		const Ctx ce = ctx_make();
 		PROF_SCOPE(ce, PS_X1);
-		uint8_t* pcb = out + (size_t)blk.block_index * 16;
-		DUP_STAGE(ce, DUP_PHYSICAL, symbolic_to_physical(ce, scb, pcb));
+		uint8_t* pcb = out + (size_t)wv_uniform(ce.blk().block_index) * 16;
+		DUP_STAGE(ce, DUP_PHYSICAL, symbolic_to_physical(ce, ce.scb(), pcb));
 	}
 }
 
