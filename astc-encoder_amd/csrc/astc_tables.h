@@ -84,6 +84,22 @@ struct BlockMode {
 	uint8_t  pad[2];
 };
 
+// What scoring a block mode needs to know about it, gathered from its BlockMode, DecimationMode and DecimationInfo records
+// into one 24-byte record (TableRoot::off_mode_static): the mode lanes of score_block_modes then start with one load
+// instead of a chain of three dependent ones.
+struct ModeStatic {
+	uint32_t tw_off;          // DecimationInfo::off_texel_weights
+	uint32_t tcf_off;         // DecimationInfo::off_texel_contribs_f
+	uint16_t dwi_off[2];      // packed ideal-weight slot of plane 0 / 1 in the mode's trial class
+	uint16_t lh_off[2];       // float offset of the mode's (low, high) pair per plane in the angular bounds; 0xFFFF: quant level above QUANT_12
+	uint8_t  taps;            // 1, 2 or 4 grid weights per texel
+	uint8_t  weights;         // per plane
+	uint8_t  quant_mode;
+	uint8_t  weight_bits;
+	uint8_t  is_dual_plane;
+	uint8_t  pad[3];
+};
+
 // (ref: struct decimation_mode :449)
 struct DecimationMode {
 	int8_t   maxprec_1plane;
@@ -221,11 +237,13 @@ struct TableRoot {
 	uint32_t off_color_uquant_to_pquant;      // u8[17][256]
 	uint32_t off_quant_xfer;                  // QuantXfer[12]
 	uint32_t off_quant_mode_table;            // i8[10][128]
+	uint32_t off_quant_mode_by_bits;          // i8[128][16]: the same table transposed, one 16-byte row per bit budget
 	uint32_t off_integer_of_trits;            // u8[243]  index ((((t4*3+t3)*3+t2)*3+t1)*3+t0)
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
 	uint32_t off_dm_by_weights;               // u8[decimation_mode_count_selected]: the grids by descending weight count (angular batching order)
+	uint32_t off_mode_static;                 // ModeStatic[block_mode_count_1plane_2plane_selected]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)
 	uint32_t max_weight_texel_rows;           // largest DecimationInfo::max_weight_texel_count
 	uint32_t realign_rt_floats;               // LDS floats the realign term rows need: max over grids of slots * 12 * rows4

@@ -1116,6 +1116,11 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	build_weight_quant_tables(blob.at<QuantXfer>(off_qx));
 	uint32_t off_qm = blob.alloc(10 * 128);
 	build_quant_mode_table(blob.at<int8_t>(off_qm));
+	// ... and transposed: the levels of all integer counts for one bit budget in one 16-byte row (best_combination_for_bitcount)
+	uint32_t off_qm_bits = blob.alloc(128 * 16, 16);
+	for (int bits = 0; bits < 128; bits++)
+		for (int pairs = 0; pairs < 16; pairs++)
+			*blob.at<int8_t>((uint32_t)(off_qm_bits + bits * 16 + pairs)) = pairs < 10 ? *blob.at<int8_t>((uint32_t)(off_qm + pairs * 128 + bits)) : (int8_t)-1;
 	uint32_t off_tr = blob.alloc(243);
 	uint32_t off_qu = blob.alloc(125);
 	build_trit_quint_tables(blob.at<uint8_t>(off_tr), blob.at<uint8_t>(off_qu));
@@ -1161,6 +1166,7 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	r->off_color_uquant_to_pquant = off_cp;
 	r->off_quant_xfer = off_qx;
 	r->off_quant_mode_table = off_qm;
+	r->off_quant_mode_by_bits = off_qm_bits;
 	r->off_integer_of_trits = off_tr;
 	r->off_integer_of_quints = off_qu;
 	{
@@ -1176,6 +1182,36 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	}
 	r->off_sin_table = off_sin;
 	r->off_cos_table = off_cos;
+	{
+		// per block mode: everything its scoring reads from the mode / grid records (ModeStatic)
+		uint32_t off_ms = blob.alloc(std::max<size_t>(bms.size(), 1) * sizeof(ModeStatic), 8);
+		for (size_t i = 0; i < bms.size(); i++)
+		{
+			const BlockMode& bm = bms[i];
+			const DecimationMode& dm = dms[bm.decimation_mode];
+			const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + bm.decimation_mode * sizeof(DecimationInfo)));
+			ModeStatic ms;
+			memset(&ms, 0, sizeof(ms));
+			ms.tw_off = di.off_texel_weights;
+			ms.tcf_off = di.off_texel_contribs_f;
+			const int cls = bm.is_dual_plane ? 1 : 0;
+			const uint32_t used = (cls ? dm.refprec_2planes : dm.refprec_1plane) & 0xFFu;
+			for (int plane = 0; plane <= cls; plane++)
+			{
+				ms.dwi_off[plane] = dm.dwi_offset[cls + plane];
+				ms.lh_off[plane] = bm.quant_mode <= MAX_ANGULAR_QUANT
+				    ? (uint16_t)(dm.lowhigh_offset[cls + plane] + 2u * (uint32_t)__builtin_popcount(used & ((1u << bm.quant_mode) - 1u))) : (uint16_t)0xFFFF;
+			}
+			ms.taps = (uint8_t)(di.max_texel_weight_count > 2 ? 4 : di.max_texel_weight_count > 1 ? 2 : 1);
+			ms.weights = di.weight_count;
+			ms.quant_mode = bm.quant_mode;
+			ms.weight_bits = bm.weight_bits;
+			ms.is_dual_plane = bm.is_dual_plane;
+			*blob.at<ModeStatic>((uint32_t)(off_ms + i * sizeof(ModeStatic))) = ms;
+		}
+		r = blob.at<TableRoot>(0);
+		r->off_mode_static = off_ms;
+	}
 	{
 		auto used = [&](size_t i) { return dms[i].refprec_1plane != 0 || dms[i].refprec_2planes != 0; };
 		uint32_t mx = 0;

@@ -125,22 +125,24 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	for (int base = start; base < end; base += 64)
 	{
 	const int nwin = i_min(64, end - base);
+	const ModeStatic* mstat = reinterpret_cast<const ModeStatic*>(c.table(c.root->off_mode_static));
+	const int free_bits = dual ? 109 : partition_count == 1 ? 111 : partition_count == 2 ? 97 : partition_count == 3 ? 94 : 91;   // (ref: mode_bitcount)
 	unsigned long long vmask = 0;
 #if WV_DEVICE
 	{
 		bool ok = false;
 		if (WV_LANE < nwin)
 		{
-			const BlockMode& bm = c.block_mode(base + WV_LANE);
-			ok = bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0);
+			const ModeStatic ms = table_at(mstat, (uint32_t)(base + WV_LANE));
+			ok = ms.quant_mode <= max_weight_quant && (dual || free_bits - (int)ms.weight_bits > 0);
 		}
 		vmask = __ballot(ok);
 	}
 #else
 	for (int i = 0; i < nwin; i++)
 	{
-		const BlockMode& bm = c.block_mode(base + i);
-		if (bm.quant_mode <= max_weight_quant && (dual || mode_bitcount(partition_count, bm) > 0)) vmask |= 1ull << i;
+		const ModeStatic ms = table_at(mstat, (uint32_t)(base + i));
+		if (ms.quant_mode <= max_weight_quant && (dual || free_bits - (int)ms.weight_bits > 0)) vmask |= 1ull << i;
 	}
 #endif
 	const int nvalid = popcount64(vmask);
@@ -157,27 +159,32 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			if (!((vmask >> i) & 1ull) || plane >= planes) continue;
 			const int m = popcount64(vmask & ((1ull << i) - 1ull)) - first;       // descriptor slot of window mode i
 			if (m < 0 || m >= nm) continue;
-			const BlockMode& bm = c.block_mode(base + i);
+			const ModeStatic ms = table_at(mstat, (uint32_t)(base + i));
 			if (plane == 0)
 			{
-				const DecimationInfo& di = c.dec_info(bm.decimation_mode);
-				const int mtwc = di.max_texel_weight_count;
 				ModeHdr h;
-				h.tw_off = di.off_texel_weights;
-				h.tcf_off = di.off_texel_contribs_f;
-				h.taps = (int16_t)(mtwc > 2 ? 4 : mtwc > 1 ? 2 : 1);
-				h.weights = (int16_t)di.weight_count;
+				h.tw_off = ms.tw_off;
+				h.tcf_off = ms.tcf_off;
+				h.taps = (int16_t)ms.taps;
+				h.weights = (int16_t)ms.weights;
 				h.mode = base + i;
 				hdr[m] = h;
 			}
-			float low, high;
-			mode_weight_bounds(c, bm, plane, low, high);
-			QuantParams qp = quant_params(low, high, bm.quant_mode);
+			// the mode's weight range (ref: compress_symbolic.cpp:459-462, :819-827; the same as mode_weight_bounds())
+			float low = 0.0f, high = 1.0f;
+			if (ms.lh_off[plane] != 0xFFFF)
+			{
+				const float* lh = reinterpret_cast<const float*>(c.lds + c.L->lowhigh) + ms.lh_off[plane];
+				low = lh[0];
+				high = lh[1];
+			}
+			if (high > 1.02f * c.tr().min_wt_cutoff[plane]) high = 1.0f;
+			QuantParams qp = quant_params(low, high, ms.quant_mode);
 			ModeQ q;
 			q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
 			q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
-			q.q2u_off = c.root->off_quant_xfer + (uint32_t)bm.quant_mode * (uint32_t)sizeof(QuantXfer);
-			q.dwi_off = (uint32_t)(c.dwi(bm.decimation_mode, plane, dual) - ldsf);
+			q.q2u_off = c.root->off_quant_xfer + (uint32_t)ms.quant_mode * (uint32_t)sizeof(QuantXfer);
+			q.dwi_off = (c.L->dwi >> 2) + (uint32_t)ms.dwi_off[plane];
 			mq[m * 2 + plane] = q;
 		}
 		WV_SYNC(); }

@@ -474,6 +474,24 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 	}
 }
 
+/* The colour quant level of every integer-pair count for one bit budget: one 16-byte row of the transposed quant mode
+ * table (TableRoot::off_quant_mode_by_bits), fetched with a single load. */
+struct QuantLevels
+{
+	uint32_t w[4];
+	WV_FN int of(int pairs) const
+	{
+		const uint32_t word = pairs < 4 ? w[0] : pairs < 8 ? w[1] : w[2];
+		return (int)(int8_t)(uint8_t)(word >> (8 * (pairs & 3)));
+	}
+};
+static_assert(sizeof(QuantLevels) == 16, "one row of the transposed quant mode table");
+
+WV_FN QuantLevels quant_levels_for_bits(const Ctx& c, int bits_available)
+{
+	return table_at(reinterpret_cast<const QuantLevels*>(c.table(c.root->off_quant_mode_by_bits)), (uint32_t)bits_available);
+}
+
 /* Best (quant level, formats) for one block mode's colour bit budget. (ref: :678-718, :780-832,
  * :905-957, :1041-1093) */
 /* `quant` receives the colour quant level, `quant_mod` the level that matched formats would allow, `formats` [4] the
@@ -481,15 +499,15 @@ WV_FN void combine_partitions_for_quant(int pc, int quant, const FmtView& fs)
 WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available,
                                           uint8_t* quant, uint8_t* quant_mod, uint8_t* formats)
 {
-	const int8_t* qmt = reinterpret_cast<const int8_t*>(c.table(c.root->off_quant_mode_table));
 	float best_integer_count_error = ERROR_CALC_DEFAULT;
+	const QuantLevels levels = quant_levels_for_bits(c, bits_available);
 
 	if (pc == 1)
 	{
 		int best_integer_count = 0;
 		for (int integer_count = 1; integer_count <= 4; integer_count++)
 		{
-			int quant_level = qmt[integer_count * 128 + bits_available];
+			const int quant_level = levels.of(integer_count);
 			if (quant_level < QUANT_6) continue;
 			float e = fs.best_error(0, quant_level)[integer_count - 1];
 			if (e < best_integer_count_error)
@@ -500,7 +518,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 		}
 		if (quant)
 		{
-			int ql = qmt[(best_integer_count + 1) * 128 + bits_available];
+			int ql = levels.of(best_integer_count + 1);
 			*quant = (uint8_t)ql;
 			*quant_mod = (uint8_t)ql;
 			formats[0] = ql >= QUANT_6 ? fs.format_of_choice(0, ql)[best_integer_count] : (uint8_t)FMT_LUMINANCE;
@@ -514,7 +532,7 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 	int best_integer_count = 0;
 	for (int integer_count = lo; integer_count <= hi; integer_count++)
 	{
-		int quant_level = qmt[integer_count * 128 + bits_available];
+		const int quant_level = levels.of(integer_count);
 		if (quant_level < QUANT_6) break;
 		float e = fs.comb_error(quant_level)[integer_count - lo];
 		if (e < best_integer_count_error)
@@ -525,8 +543,8 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 	}
 	if (quant)
 	{
-		int ql = qmt[best_integer_count * 128 + bits_available];
-		int ql_mod = qmt[best_integer_count * 128 + bits_available + mod_bits];
+		int ql = levels.of(best_integer_count);
+		int ql_mod = quant_levels_for_bits(c, bits_available + mod_bits).of(best_integer_count);
 		*quant = (uint8_t)ql;
 		*quant_mod = (uint8_t)ql_mod;
 		for (int i = 0; i < pc; i++)

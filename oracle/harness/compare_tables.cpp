@@ -139,6 +139,8 @@ int main(int argc, char** argv)
 	}
 	const int8_t* qm = (const int8_t*)(B + r.off_quant_mode_table);
 	for (unsigned i = 0; i < 10; i++) for (unsigned j = 0; j < 128; j++) CHECK(qm[i * 128 + j] == quant_mode_table[i][j], "qmt %u %u: %d %d", i, j, qm[i * 128 + j], quant_mode_table[i][j]);
+	const int8_t* qmb = (const int8_t*)(B + r.off_quant_mode_by_bits);
+	for (unsigned i = 0; i < 10; i++) for (unsigned j = 0; j < 128; j++) CHECK(qmb[j * 16 + i] == quant_mode_table[i][j], "qmt by bits %u %u: %d %d", i, j, qmb[j * 16 + i], quant_mode_table[i][j]);
 
 	const uint8_t* tr = B + r.off_integer_of_trits; const uint8_t* qu = B + r.off_integer_of_quints;
 	for (unsigned a = 0; a < 3; a++) for (unsigned b = 0; b < 3; b++) for (unsigned cc = 0; cc < 3; cc++) for (unsigned d = 0; d < 3; d++) for (unsigned e = 0; e < 3; e++)
