@@ -38,7 +38,8 @@ for c in configs:
     if per("SQ_THREAD_CYCLES_VALU") and per("SQ_ACTIVE_INST_VALU"):
         e["active_lanes_avg"] = round(per("SQ_THREAD_CYCLES_VALU") / per("SQ_ACTIVE_INST_VALU"), 2)
     if per("SQ_ACTIVE_INST_VALU") and per("SQ_WAVE_CYCLES"):
-        # both tick in units of 4 clocks; 4 waves share a SIMD, so wave residency / 4 = SIMD time.  Every VALU instruction counts as
+        # both tick in units of 4 clocks; 4 waves share a SIMD (c2, c4; config 3 runs 10 blocks per CU = 2.5 per SIMD, see
+        # valu_busy_frac_of_kernel_time below), so wave residency / 4 = SIMD time.  Every VALU instruction counts as
         # one 4-clock slot whatever its real issue cost: an upper bound of the VALU pipe's busy fraction
         e["valu_issue_frac"] = round(per("SQ_ACTIVE_INST_VALU") / (per("SQ_WAVE_CYCLES") / 4.0), 4)
     if per("SQ_WAIT_ANY") and per("SQ_WAVE_CYCLES"):
@@ -51,6 +52,10 @@ for c in configs:
             if "astc_compress" in row.get("Name", ""):
                 e["rocprofv3_kernel_avg_ms"] = round(float(row["AverageNs"]) / 1e6, 3)
                 e["rocprofv3_kernel_calls"] = int(row["Calls"])
+    if per("SQ_ACTIVE_INST_VALU") and e.get("rocprofv3_kernel_avg_ms"):
+        # occupancy-independent form of the same bound: VALU slots (4 clocks each) against the launch's wall time on 1024 SIMDs at the
+        # nominal 2.4 GHz (the PMC pass and the traced pass run the same command line)
+        e["valu_busy_frac_of_kernel_time"] = round(per("SQ_ACTIVE_INST_VALU") * 4.0 / (e["rocprofv3_kernel_avg_ms"] * 1e6 * 2.4 * 1024.0), 4)
     out["configs"][c] = e
     print("== %s" % c)
     for k, v in e.items():
