@@ -550,7 +550,7 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		                                        "  dec sweep1", "  dec infill", "  dec sweep3", "  ang phase1", "  ang phase2",
 		                                        "  mode terms", "  mode acc", "  mode quant", "  fmt eci", "  fmt table", "  fmt combine", "  fmt select",
 		                                        "  cand staging", "  physical", "  refine (all)", "  trial (all)",
-		                                        "  y0 cand quantize", "  y1 cand setup", "  y2 after pack", "  y3 accept/copy", "  y4", "  y5", "  y6", "  y7" };
+		                                        "  y0 cand quantize", "  y1 cand setup", "  y2 after pack", "  y3 accept/copy", "  y4 realign infill", "  y5 realign undecimated", "  y6 realign lane-per-weight eval", "  y7 realign movers" };
 		unsigned long long h[2 * PS_COUNT];
 		HIP_TRY(hipMemcpy(h, s->d_prof, sizeof(h), hipMemcpyDeviceToHost), return 2);
 		HIP_TRY(hipMemset(s->d_prof, 0, sizeof(h)), return 2);

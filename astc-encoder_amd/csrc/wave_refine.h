@@ -657,6 +657,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 		if (!decimated)
 		{
+			PROF_SCOPE(c, PS_Y5);
 			bool moved_here = false;         // (per lane on the device; wv_any folds the lanes)
 			WV_FOR(texel, T)
 			{
@@ -725,13 +726,43 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			// when one of its grid weights moves, so it is kept here and refreshed on moves.
 			// (grids decimated in one dimension only: two taps; the other two would add 0.0 * weight, i.e. nothing)
 			const bool two_taps = di.max_texel_weight_count <= 2;
-			WV_FOR(t, T) { wb[t] = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t); }
-			WV_SYNC();
-
 			// with one partition the endpoint base / step are the same for every texel
 			const bool one_partition = pc == 1;
 			const f4 color_offset_1 = uniform4(load4(&tr.fbox[4]));
 			const f4 color_base_1 = uniform4(load4(&tr.fbox[0]));
+			const bool speculative = di.later != nullptr;
+#if !defined(ASTC_REALIGN_GROUP_SPECULATION)
+			// The one-lane-per-weight evaluator (below) keeps, per texel, what every weight reaching the texel would compute
+			// again: the decoded colour at the current weights minus the source colour, and the texel's endpoint step.  The
+			// term rows of the group evaluator are not used on that path; the three arrays take their place.
+			float* tdiff = rt + c.Tp;                          // [T][4]
+			float* toff = tdiff + 4 * c.Tp;                    // [T][4], more than one partition only
+			if (speculative) wb = rt;
+			auto refresh_texel = [&](int t)
+			{
+				const float w = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t);
+				wb[t] = w;
+				if (speculative)
+				{
+					f4 color_offset = color_offset_1, color_base = color_base_1;
+					if (!one_partition)
+					{
+						const int p = pv.of_texel[t];
+						color_offset = load4(&tr.fbox[p * 8 + 4]);
+						color_base = load4(&tr.fbox[p * 8]);
+						store4_aligned(&toff[t * 4], color_offset);
+					}
+					const f4 color = color_base + color_offset * w;
+					const f4 orig_color = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
+					store4_aligned(&tdiff[t * 4], color - orig_color);
+				}
+			};
+#else
+			auto refresh_texel = [&](int t) { wb[t] = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t); };
+#endif
+			{ PROF_SCOPE(c, PS_Y4);
+			WV_FOR(t, T) { refresh_texel(t); }
+			WV_SYNC(); }
 
 			// Two drivers feed ONE group evaluator (a single call site keeps a single copy of it in the kernel):
 			//
@@ -750,7 +781,6 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const uint8_t* order = di.ro;
 			const uint8_t* group_count = di.rc;
 			const int slots = di.slots;
-			const bool speculative = di.later != nullptr;
 			enum { LEVELS, SPEC_ALL, SPEC_LATER };
 			int phase = speculative ? SPEC_ALL : LEVELS;
 			int lv = 0, pos = 0;                          // LEVELS: next group of the schedule
@@ -769,48 +799,86 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				bool all = true;
 				for (;;)
 				{
-					WV_FOR(k, items)
+					{ PROF_SCOPE(c, PS_Y6);
+					if (items <= 16)
 					{
-						const int we = all ? k : (int)later[k];
-						const int uqw = uq[we];
-						const uint32_t prev_and_next = pn[we];
-						const float uqw_base = (float)uqw;
-						const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
-						const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
-						f4 sb = splat4(0.0f), sd = splat4(0.0f), su = splat4(0.0f);
-						const int n = wtc[we];
-						for (int te = 0; te < n; te++)
+						// Up to sixteen weights (every pass after a move, and the first pass of the small grids): one QUAD per
+						// weight, lane = colour channel.  The three running sums are one register each, the channel arithmetic one
+						// instruction instead of four, and the error is the quad's hadd in the reference's order.
+						const qf error_weight_q = q_load(blk.cw);
+						const qf color_offset_q = q_load(&tr.fbox[4]);
+						WV_QUADS(k, items)
 						{
-							const int texel = wt[te * W + we];
-							const float tw_base = tcw[te * W + we];
-							const float weight_base = wb[texel];
-							const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
-							const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
-							f4 color_offset = color_offset_1, color_base = color_base_1;
-							if (!one_partition)
+							const int we = all ? k : (int)later[k];
+							const int uqw = uq[we];
+							const uint32_t prev_and_next = pn[we];
+							const float uqw_base = (float)uqw;
+							const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+							const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+							qf sb = q_splat(0.0f), sd = q_splat(0.0f), su = q_splat(0.0f);
+							const int n = wtc[we];
+							for (int te = 0; te < n; te++)
 							{
-								const int p = pv.of_texel[texel];
-								color_offset = load4(&tr.fbox[p * 8 + 4]);
-								color_base = load4(&tr.fbox[p * 8]);
+								const int texel = wt[te * W + we];
+								const float tw_base = tcw[te * W + we];
+								const float weight_base = wb[texel];
+								const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
+								const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
+								const qf color_offset = one_partition ? color_offset_q : q_load(&toff[texel * 4]);
+								const qf color_diff = q_load(&tdiff[texel * 4]);
+								const qf color_down_diff = color_diff + color_offset * weight_down;
+								const qf color_up_diff = color_diff + color_offset * weight_up;
+								sb = sb + color_diff * color_diff;
+								sd = sd + color_down_diff * color_down_diff;
+								su = su + color_up_diff * color_up_diff;
 							}
-							const f4 color = color_base + color_offset * weight_base;
-							const f4 orig_color = mk4(c.data(0)[texel], c.data(1)[texel], c.data(2)[texel], c.data(3)[texel]);
-							const f4 color_diff = color - orig_color;
-							const f4 color_down_diff = color_diff + color_offset * weight_down;
-							const f4 color_up_diff = color_diff + color_offset * weight_up;
-							sb = sb + color_diff * color_diff;
-							sd = sd + color_down_diff * color_down_diff;
-							su = su + color_up_diff * color_up_diff;
+							const float error_base = q_hadd(sb * error_weight_q);
+							const float error_down = q_hadd(sd * error_weight_q);
+							const float error_up = q_hadd(su * error_weight_q);
+							int new_value = 255;
+							if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+							else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+							Q_ONCE { verdict[we] = (uint8_t)new_value; }
 						}
-						const float error_base = hadd_s(sb * error_weight);
-						const float error_down = hadd_s(sd * error_weight);
-						const float error_up = hadd_s(su * error_weight);
-						int new_value = 255;
-						if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
-						else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
-						verdict[we] = (uint8_t)new_value;
 					}
-					WV_SYNC();
+					else
+					{
+						WV_FOR(k, items)
+						{
+							const int we = all ? k : (int)later[k];
+							const int uqw = uq[we];
+							const uint32_t prev_and_next = pn[we];
+							const float uqw_base = (float)uqw;
+							const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+							const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+							f4 sb = splat4(0.0f), sd = splat4(0.0f), su = splat4(0.0f);
+							const int n = wtc[we];
+							for (int te = 0; te < n; te++)
+							{
+								const int texel = wt[te * W + we];
+								const float tw_base = tcw[te * W + we];
+								const float weight_base = wb[texel];
+								const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
+								const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
+								const f4 color_offset = one_partition ? color_offset_1 : load4_aligned(&toff[texel * 4]);
+								const f4 color_diff = load4_aligned(&tdiff[texel * 4]);        // (base + step * weight_base) - source colour
+								const f4 color_down_diff = color_diff + color_offset * weight_down;
+								const f4 color_up_diff = color_diff + color_offset * weight_up;
+								sb = sb + color_diff * color_diff;
+								sd = sd + color_down_diff * color_down_diff;
+								su = su + color_up_diff * color_up_diff;
+							}
+							const float error_base = hadd_s(sb * error_weight);
+							const float error_down = hadd_s(sd * error_weight);
+							const float error_up = hadd_s(su * error_weight);
+							int new_value = 255;
+							if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+							else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+							verdict[we] = (uint8_t)new_value;
+						}
+					}
+					WV_SYNC(); }
+					PROF_SCOPE(c, PS_Y7);
 					// the first weight (in index order) whose verdict is "move" moves; what it invalidates is evaluated again
 					int mover;
 					for (;;)
@@ -825,11 +893,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 							uqf[mover] = (float)new_value;
 						}
 						WV_SYNC();
-						WV_FOR(te, (int)wtc[mover])
-						{
-							const int texel = wt[te * W + mover];
-							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
-						}
+						WV_FOR(te, (int)wtc[mover]) { refresh_texel((int)wt[te * W + mover]); }
 						{
 							const uint32_t* list = reinterpret_cast<const uint32_t*>(di.later + mover * REALIGN_LATER_MAX);
 							WV_FOR(k, REALIGN_LATER_MAX / 4) { reinterpret_cast<uint32_t*>(later)[k] = list[k]; }

@@ -387,7 +387,7 @@ def roofline_of(cfg, kernel_s, hdr_kernel, name):
                             "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_S,
                             "what": "wave-level VALU instructions per block x blocks / kernel time of this run, against 1024 SIMDs x 2.4 GHz / 2 "
                                     "clocks; active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
-        for key in ("salu_insts_per_block", "lds_insts_per_block", "valu_issue_frac"):
+        for key in ("salu_insts_per_block", "lds_insts_per_block", "valu_issue_frac", "valu_busy_frac_of_kernel_time"):
             if key in counters:
                 roof[key] = counters[key]
     return roof
