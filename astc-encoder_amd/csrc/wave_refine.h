@@ -797,8 +797,20 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			{
 				int items = W;                              // pass 1: every weight; then: the later neighbours of each mover
 				bool all = true;
+				const int last_row = di.rows - 1;
+				// the mover's later neighbours: on the device entry k sits in a register of the lanes of quad k
+				const uint8_t* later_row = di.later;
+#if WV_DEVICE
+				int later_mine = 255;
+#define REALIGN_LATER_ENTRY(k) later_mine
+#else
+#define REALIGN_LATER_ENTRY(k) ((int)later_row[k])
+#endif
 				for (;;)
 				{
+					// Both evaluators walk a weight's texel list with the table reads two rows ahead and the per-texel reads one
+					// row ahead of the arithmetic (rows past the list are clamped to the grid's last row and never used): the
+					// loop is a chain of dependent LDS reads otherwise, two round trips per texel.
 					{ PROF_SCOPE(c, PS_Y6);
 					if (items <= 16)
 					{
@@ -809,28 +821,44 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						const qf color_offset_q = q_load(&tr.fbox[4]);
 						WV_QUADS(k, items)
 						{
-							const int we = all ? k : (int)later[k];
+							const int we = all ? k : REALIGN_LATER_ENTRY(k);
 							const int uqw = uq[we];
 							const uint32_t prev_and_next = pn[we];
+							const int n = wtc[we];
+							int texel_next = wt[we];
+							float tw_cur = tcw[we];
+							const int row1 = i_min(1, last_row);
+							int texel_ahead = wt[row1 * W + we];
+							float tw_next = tcw[row1 * W + we];
 							const float uqw_base = (float)uqw;
 							const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
 							const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
 							qf sb = q_splat(0.0f), sd = q_splat(0.0f), su = q_splat(0.0f);
-							const int n = wtc[we];
+							float weight_cur = wb[texel_next];
+							qf diff_cur = q_load(&tdiff[texel_next * 4]);
+							qf offset_cur = one_partition ? color_offset_q : q_load(&toff[texel_next * 4]);
+							texel_next = texel_ahead;
 							for (int te = 0; te < n; te++)
 							{
-								const int texel = wt[te * W + we];
-								const float tw_base = tcw[te * W + we];
-								const float weight_base = wb[texel];
-								const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
-								const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
-								const qf color_offset = one_partition ? color_offset_q : q_load(&toff[texel * 4]);
-								const qf color_diff = q_load(&tdiff[texel * 4]);
-								const qf color_down_diff = color_diff + color_offset * weight_down;
-								const qf color_up_diff = color_diff + color_offset * weight_up;
+								const int row2 = i_min(te + 2, last_row);
+								texel_ahead = wt[row2 * W + we];
+								const float tw_ahead = tcw[row2 * W + we];
+								const float weight_next = wb[texel_next];
+								const qf diff_next = q_load(&tdiff[texel_next * 4]);
+								const qf offset_next = one_partition ? color_offset_q : q_load(&toff[texel_next * 4]);
+
+								const float weight_base = weight_cur;
+								const float weight_down = weight_base + uqw_diff_down * tw_cur - weight_base;
+								const float weight_up = weight_base + uqw_diff_up * tw_cur - weight_base;
+								const qf color_diff = diff_cur;                         // (base + step * weight_base) - source colour
+								const qf color_down_diff = color_diff + offset_cur * weight_down;
+								const qf color_up_diff = color_diff + offset_cur * weight_up;
 								sb = sb + color_diff * color_diff;
 								sd = sd + color_down_diff * color_down_diff;
 								su = su + color_up_diff * color_up_diff;
+
+								texel_next = texel_ahead; tw_cur = tw_next; tw_next = tw_ahead;
+								weight_cur = weight_next; diff_cur = diff_next; offset_cur = offset_next;
 							}
 							const float error_base = q_hadd(sb * error_weight_q);
 							const float error_down = q_hadd(sd * error_weight_q);
@@ -843,20 +871,23 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					}
 					else
 					{
-						WV_FOR(k, items)
+						// (more than sixteen weights: only ever the first pass, one lane per weight; the table reads run one row ahead)
+						WV_FOR(we, items)
 						{
-							const int we = all ? k : (int)later[k];
 							const int uqw = uq[we];
 							const uint32_t prev_and_next = pn[we];
+							const int n = wtc[we];
+							int texel = wt[we];
+							float tw_base = tcw[we];
 							const float uqw_base = (float)uqw;
 							const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
 							const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
 							f4 sb = splat4(0.0f), sd = splat4(0.0f), su = splat4(0.0f);
-							const int n = wtc[we];
 							for (int te = 0; te < n; te++)
 							{
-								const int texel = wt[te * W + we];
-								const float tw_base = tcw[te * W + we];
+								const int row1 = i_min(te + 1, last_row);
+								const int texel_next = wt[row1 * W + we];
+								const float tw_next = tcw[row1 * W + we];
 								const float weight_base = wb[texel];
 								const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
 								const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
@@ -867,6 +898,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 								sb = sb + color_diff * color_diff;
 								sd = sd + color_down_diff * color_down_diff;
 								su = su + color_up_diff * color_up_diff;
+								texel = texel_next; tw_base = tw_next;
 							}
 							const float error_base = hadd_s(sb * error_weight);
 							const float error_down = hadd_s(sd * error_weight);
@@ -880,27 +912,44 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					WV_SYNC(); }
 					PROF_SCOPE(c, PS_Y7);
 					// the first weight (in index order) whose verdict is "move" moves; what it invalidates is evaluated again
-					int mover;
+					int mover, later_count = 0;
 					for (;;)
 					{
+						int new_value;
+#if WV_DEVICE
+						{
+							// one LDS read per lane answers both "who moves" and "to which value"
+							const int mine = WV_LANE < W ? (int)verdict[WV_LANE] : 255;
+							const unsigned long long movers = __ballot(WV_LANE >= start && mine != 255);
+							mover = movers ? (int)__builtin_ctzll(movers) : -1;
+							if (mover < 0) break;
+							new_value = __builtin_amdgcn_readlane(mine, mover);
+							// the list of the weights to look at again (global memory): requested now, needed after the move
+							later_row = di.later + mover * REALIGN_LATER_MAX;
+							later_mine = later_row[WV_LANE >> 2];
+						}
+#else
 						mover = wv_find_first(W, [&](int w) { return w >= start && verdict[w] != 255; });
 						if (mover < 0) break;
+						new_value = verdict[mover];
+						later_row = di.later + mover * REALIGN_LATER_MAX;
+#endif
 						adjustments = true;
-						const int new_value = wv_uniform((int)verdict[mover]);
 						WV_ONE
 						{
 							uq[mover] = (uint8_t)new_value;
 							uqf[mover] = (float)new_value;
 						}
 						WV_SYNC();
-						WV_FOR(te, (int)wtc[mover]) { refresh_texel((int)wt[te * W + mover]); }
-						{
-							const uint32_t* list = reinterpret_cast<const uint32_t*>(di.later + mover * REALIGN_LATER_MAX);
-							WV_FOR(k, REALIGN_LATER_MAX / 4) { reinterpret_cast<uint32_t*>(later)[k] = list[k]; }
-						}
+						// (the list length and the list entries are read side by side, not one after the other)
+						WV_FOR(te, di.rows) { if (te < (int)wtc[mover]) refresh_texel((int)wt[te * W + mover]); }
 						WV_SYNC();
+#if WV_DEVICE
+						later_count = popcount64(__ballot((WV_LANE & 3) == 0 && later_mine != 255));
+#else
 						later_count = 0;
-						while (later_count < REALIGN_LATER_MAX && later[later_count] != 255) later_count++;
+						while (later_count < REALIGN_LATER_MAX && later_row[later_count] != 255) later_count++;
+#endif
 						start = mover + 1;
 						if (later_count != 0) break;
 					}
@@ -908,6 +957,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					items = later_count;
 					all = false;
 				}
+#undef REALIGN_LATER_ENTRY
 				continue;                                   // (next plane)
 			}
 #endif
