@@ -754,7 +754,7 @@ WV_OUT void stage_ideal(bool dual, int partition_count, int partition_packed, in
 
 WV_OUT void stage_decimate(int nplanes, int ref_mask, int max_decimation_modes)
 {
-	const Ctx c = ctx_make();
+	const Ctx c = ctx_make_vector_tables();
 	nplanes = wv_uniform(nplanes); ref_mask = wv_uniform(ref_mask); max_decimation_modes = wv_uniform(max_decimation_modes);
 	PROF_SCOPE(c, PS_DECIMATE);
 	ideal_weights_all_grids(c, nplanes, (uint16_t)ref_mask, max_decimation_modes);
@@ -861,7 +861,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 
 WV_OUT void stage_modes(int partition_count, int start, int end, int max_weight_quant, bool dual)
 {
-	const Ctx c = ctx_make();
+	const Ctx c = ctx_make_vector_tables();
 	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
 	max_weight_quant = wv_uniform(max_weight_quant); dual = wv_uniform(dual);
 	PROF_SCOPE(c, PS_MODES);

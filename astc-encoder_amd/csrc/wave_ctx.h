@@ -341,15 +341,22 @@ struct Ctx {
 extern __shared__ __attribute__((aligned(16))) uint8_t astc_lds[];
 #endif
 #if WV_DEVICE
-WV_FN Ctx ctx_make()
+/* SCALAR_TABLES: the table blob, the config and the LDS layout never change while a kernel runs, so they may be read
+ * through the constant address space: every read at a wave-uniform address then goes through the scalar cache instead
+ * of the vector memory pipeline (shorter latency, no vector register).  The values live in scalar registers, though:
+ * the two stages that run out of those (mode scoring, decimation) keep the global address space. */
+template <bool SCALAR_TABLES>
+WV_FN Ctx ctx_make_as()
 {
 	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(astc_lds);
 	Ctx c;
 	// A pointer rebuilt from integers would be a generic (flat) pointer to the compiler: go through
-	// explicit global-address-space pointers so that table reads stay s_load / global_load.
+	// explicit address-space pointers so that table reads stay s_load / global_load.
 	typedef const __attribute__((address_space(1))) uint8_t* global_bytes;
+	typedef const __attribute__((address_space(4))) uint8_t* constant_bytes;
 	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
-	c.tab = (const uint8_t*)(global_bytes)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->tab));
+	const uintptr_t tab = (uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->tab));
+	c.tab = SCALAR_TABLES ? (const uint8_t*)(constant_bytes)tab : (const uint8_t*)(global_bytes)tab;
 	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
 	c.root = reinterpret_cast<const TableRoot*>(c.tab);
 	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
@@ -359,9 +366,12 @@ WV_FN Ctx ctx_make()
 	c.Tp = (c.T + 3) & ~3;
 	return c;
 }
+WV_FN Ctx ctx_make() { return ctx_make_as<true>(); }
+WV_FN Ctx ctx_make_vector_tables() { return ctx_make_as<false>(); }
 #else
 extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block
 WV_FN Ctx ctx_make() { return *g_wave_ctx; }
+WV_FN Ctx ctx_make_vector_tables() { return *g_wave_ctx; }
 #endif
 
 /* Lowest index i in [0, n), n <= 64, for which pred(i) holds, or -1; the same value on every lane. */
