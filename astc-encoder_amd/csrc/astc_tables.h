@@ -238,6 +238,7 @@ struct TableRoot {
 	uint32_t off_quant_xfer;                  // QuantXfer[12]
 	uint32_t off_quant_mode_table;            // i8[10][128]
 	uint32_t off_quant_mode_by_bits;          // i8[128][16]: the same table transposed, one 16-byte row per bit budget
+	uint32_t off_mode_levels;                 // i8[4][block_mode_count_1plane_2plane_selected][16]: that row for every (partition count, block mode)
 	uint32_t off_integer_of_trits;            // u8[243]  index ((((t4*3+t3)*3+t2)*3+t1)*3+t0)
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]

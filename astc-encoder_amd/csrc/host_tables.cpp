@@ -1209,8 +1209,22 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			ms.is_dual_plane = bm.is_dual_plane;
 			*blob.at<ModeStatic>((uint32_t)(off_ms + i * sizeof(ModeStatic))) = ms;
 		}
+		// ... and the colour quant levels its bit budget allows, per partition count (format selection: one load per mode
+		// instead of block mode -> bit count -> table row)
+		const size_t nm = std::max<size_t>(bms.size(), 1);
+		uint32_t off_ml = blob.alloc(4 * nm * 16, 16);
+		for (int pc = 1; pc <= 4; pc++)
+			for (size_t i = 0; i < bms.size(); i++)
+			{
+				const int free_bits[4] = { 111, 97, 94, 91 };
+				const int bits = (bms[i].is_dual_plane ? 109 : free_bits[pc - 1]) - (int)bms[i].weight_bits;      // (ref: compress_symbolic.cpp:434-453, :817)
+				int8_t* row = blob.at<int8_t>((uint32_t)(off_ml + ((size_t)(pc - 1) * nm + i) * 16));
+				for (int pairs = 0; pairs < 16; pairs++)
+					row[pairs] = (bits > 0 && bits < 128) ? *blob.at<int8_t>((uint32_t)(off_qm_bits + bits * 16 + pairs)) : (int8_t)-1;
+			}
 		r = blob.at<TableRoot>(0);
 		r->off_mode_static = off_ms;
+		r->off_mode_levels = off_ml;
 	}
 	{
 		auto used = [&](size_t i) { return dms[i].refprec_1plane != 0 || dms[i].refprec_2planes != 0; };

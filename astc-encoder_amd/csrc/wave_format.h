@@ -15,20 +15,13 @@ namespace astcd { inline namespace ASTC_VARIANT {
 
 /* Wave-wide argmin with lowest-index tie break over v(i), i in [start, end); entries >= 1e30 are
  * never selected (returns -1 if none).  Uniform result. */
-template <typename ValFn>
-WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
-{
 #if WV_DEVICE
-	float best = ERROR_CALC_DEFAULT;
-	int idx = 0x7FFFFFFF;                    // (no candidate: compares above every index)
-	for (int i = start + WV_LANE; i < end; i += 64)
-	{
-		float e = v(i);
-		if (e < best) { best = e; idx = i; }
-	}
-	// fold (value, index) pairs across the wave: smaller value wins, equal values go to the smaller index.  DPP steps
-	// (row_shr 1 / 2 / 4 / 8, then row_bcast 15 / 31; lanes without a source keep their own pair), no LDS traffic:
-	// the ds_bpermute butterfly this replaces was a dozen dependent LDS round trips per pick.
+/* Fold per-lane (value, index) pairs across the wave: smaller value wins, equal values go to the smaller index; the
+ * winning pair is returned on every lane.  DPP steps (row_shr 1 / 2 / 4 / 8, then row_bcast 15 / 31; lanes without a
+ * source keep their own pair), no LDS traffic: the ds_bpermute butterfly this replaces was a dozen dependent LDS round
+ * trips per pick. */
+WV_FN void wave_argmin_fold(float& best, int& idx)
+{
 	#define WV_ARGMIN_STEP(CTRL, ROW_MASK) do { \
 		const float ov = int_as_float(__builtin_amdgcn_update_dpp(float_as_int(best), float_as_int(best), CTRL, ROW_MASK, 0xF, false)); \
 		const int oi = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROW_MASK, 0xF, false); \
@@ -37,12 +30,26 @@ WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
 	WV_ARGMIN_STEP(0x111, 0xF); WV_ARGMIN_STEP(0x112, 0xF); WV_ARGMIN_STEP(0x114, 0xF); WV_ARGMIN_STEP(0x118, 0xF);
 	WV_ARGMIN_STEP(0x142, 0xA); WV_ARGMIN_STEP(0x143, 0xC);
 	#undef WV_ARGMIN_STEP
+	idx = __builtin_amdgcn_readlane(idx, 63);
+	best = int_as_float(__builtin_amdgcn_readlane(float_as_int(best), 63));
+}
+#endif
+
+template <typename ValFn>
+WV_FN int wave_argmin(const Ctx& c, int start, int end, ValFn v)
+{
 	(void)c;
-	const int winner = __builtin_amdgcn_readlane(idx, 63);
-	const float winner_value = int_as_float(__builtin_amdgcn_readlane(float_as_int(best), 63));
-	return winner_value < ERROR_CALC_DEFAULT ? winner : -1;
+#if WV_DEVICE
+	float best = ERROR_CALC_DEFAULT;
+	int idx = 0x7FFFFFFF;                    // (no candidate: compares above every index)
+	for (int i = start + WV_LANE; i < end; i += 64)
+	{
+		float e = v(i);
+		if (e < best) { best = e; idx = i; }
+	}
+	wave_argmin_fold(best, idx);
+	return best < ERROR_CALC_DEFAULT ? idx : -1;
 #else
-	(void)c;
 	float best = ERROR_CALC_DEFAULT;
 	int idx = -1;
 	for (int i = start; i < end; i++)
@@ -496,11 +503,10 @@ WV_FN QuantLevels quant_levels_for_bits(const Ctx& c, int bits_available)
  * :905-957, :1041-1093) */
 /* `quant` receives the colour quant level, `quant_mod` the level that matched formats would allow, `formats` [4] the
  * endpoint formats; all three null in the scoring pass, which only wants the error. */
-WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available,
-                                          uint8_t* quant, uint8_t* quant_mod, uint8_t* formats)
+WV_FN float best_combination_for_levels(const Ctx& c, int pc, const FmtView& fs, const QuantLevels levels, int bits_available,
+                                        uint8_t* quant, uint8_t* quant_mod, uint8_t* formats)
 {
 	float best_integer_count_error = ERROR_CALC_DEFAULT;
-	const QuantLevels levels = quant_levels_for_bits(c, bits_available);
 
 	if (pc == 1)
 	{
@@ -555,6 +561,12 @@ WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& f
 	return best_integer_count_error;
 }
 
+WV_FN float best_combination_for_bitcount(const Ctx& c, int pc, const FmtView& fs, int bits_available,
+                                          uint8_t* quant, uint8_t* quant_mod, uint8_t* formats)
+{
+	return best_combination_for_levels(c, pc, fs, quant_levels_for_bits(c, bits_available), bits_available, quant, quant_mod, formats);
+}
+
 /* Colour bits left after the weights. (ref: compress_symbolic.cpp:434-453, :817) */
 WV_FN int mode_bitcount(int partition_count, const BlockMode& bm)
 {
@@ -591,6 +603,8 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	}
 
 	PROF_SCOPE(c, PS_FMT4);
+	const QuantLevels* mode_levels = reinterpret_cast<const QuantLevels*>(c.table(c.root->off_mode_levels))
+	                                 + (uint32_t)(pc - 1) * (uint32_t)i_max(1, (int)c.root->block_mode_count_1plane_2plane_selected);
 	WV_FOR(i, end_block_mode - start_block_mode)
 	{
 		ModeRec& m = modes[start_block_mode + i];
@@ -600,8 +614,9 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 		}
 		else
 		{
-			int bitcount = mode_bitcount(pc, c.block_mode(start_block_mode + i));
-			float error_of_best = best_combination_for_bitcount(c, pc, fs, bitcount, nullptr, nullptr, nullptr);
+			// (the levels the mode's colour bit budget allows: TableRoot::off_mode_levels)
+			const QuantLevels levels = table_at(mode_levels, (uint32_t)(start_block_mode + i));
+			float error_of_best = best_combination_for_levels(c, pc, fs, levels, 0, nullptr, nullptr, nullptr);
 			m.error = error_of_best + m.error;
 		}
 	}
@@ -610,6 +625,31 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	// top-N by repeated argmin, lowest index on ties (ref: :1156-1333)
 	int limit = (int)c.cfg->tune_candidate_limit;
 	int count = 0;
+#if WV_DEVICE
+	if (end_block_mode - start_block_mode <= 128)
+	{
+		// up to two modes per lane: their errors stay in registers while the winners are picked (no LDS reads, no
+		// hand-offs between the picks); a winner is struck out in the register of the lane that holds it
+		const int i0 = start_block_mode + WV_LANE, i1 = i0 + 64;
+		float e0 = i0 < end_block_mode ? modes[i0].error : ERROR_CALC_DEFAULT;
+		float e1 = i1 < end_block_mode ? modes[i1].error : ERROR_CALC_DEFAULT;
+		for (int n = 0; n < limit; n++)
+		{
+			float best = ERROR_CALC_DEFAULT;
+			int idx = 0x7FFFFFFF;
+			if (e0 < best) { best = e0; idx = i0; }
+			if (e1 < best) { best = e1; idx = i1; }
+			wave_argmin_fold(best, idx);
+			if (!(best < ERROR_CALC_DEFAULT)) break;
+			WV_ONE { tr.cand_block_mode[n] = idx; }
+			e0 = idx == i0 ? ERROR_CALC_DEFAULT : e0;
+			e1 = idx == i1 ? ERROR_CALC_DEFAULT : e1;
+			count++;
+		}
+		WV_SYNC();
+	}
+	else
+#endif
 	for (int n = 0; n < limit; n++)
 	{
 		int best = wave_argmin(c, start_block_mode, end_block_mode, [&](int i) { return modes[i].error; });

@@ -638,6 +638,54 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 WV_FN int partition_search_select(const Ctx& c, int partition_search_limit, int requested_candidates)
 {
 	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
+#if WV_DEVICE
+	// The reference inserts the candidates one by one into two sorted top-N lists (ref: :589-600, :672-673), then
+	// interleaves the lists and drops repeats (ref: :745-776).  Without equal errors the lists are simply the N smallest
+	// in ascending order, and a candidate's place is the number of candidates with a smaller error: one lane per
+	// candidate counts that over registers (no LDS inside the loops).  With equal errors, or an error at or above the
+	// lists' initial value, the insertion order decides and the sequential replay below runs instead.
+	if (partition_search_limit <= 64)
+	{
+		const int lane = WV_LANE;
+		const bool live = lane < partition_search_limit;
+		const float ue = live ? ps.uncor_err()[lane] : 0.0f;
+		const float se = live ? ps.samec_err()[lane] : 0.0f;
+		const int part = live ? (int)ps.ordering()[lane] : -1;
+		int urank = 0, srank = 0;
+		bool plain = !live || (ue < ERROR_CALC_DEFAULT && se < ERROR_CALC_DEFAULT);       // (false for NaN as well)
+		for (int j = 0; j < partition_search_limit; j++)
+		{
+			const float uj = int_as_float(__builtin_amdgcn_readlane(float_as_int(ue), j));
+			const float sj = int_as_float(__builtin_amdgcn_readlane(float_as_int(se), j));
+			urank += uj < ue ? 1 : 0;
+			srank += sj < se ? 1 : 0;
+			plain = plain && (j == lane || (uj != ue && sj != se));
+		}
+		if (__ballot(live && !plain) == 0ull)
+		{
+			// interleaved order: uncorrelated rank r at slot 2r, same-chroma rank r at slot 2r + 1; lane k picks up slot k
+			int* slot_part = reinterpret_cast<int*>(ps.mscount);
+			if (live && urank < requested_candidates) slot_part[2 * urank] = part;
+			if (live && srank < requested_candidates) slot_part[2 * srank + 1] = part;
+			WV_SYNC();
+			const int nslots = 2 * requested_candidates;                              // <= 16
+			const int mine = lane < nslots ? slot_part[lane] : -1;
+			bool repeat = false;
+			for (int j = 0; j < nslots; j++)
+			{
+				const int pj = __builtin_amdgcn_readlane(mine, j);
+				repeat = repeat || (j < lane && pj == mine);
+			}
+			const unsigned long long fresh = __ballot(lane < nslots && !repeat);
+			const int at = __popcll(fresh & ((1ull << lane) - 1ull));
+			if (lane < nslots && !repeat && at < requested_candidates) ps.best[at] = mine;
+			const int emitted = i_min(__popcll(fresh), requested_candidates);
+			WV_ONE { ps.best_count = emitted; }
+			WV_SYNC();
+			return emitted;
+		}
+	}
+#endif
 	// sorted insertion is order dependent on ties: replay it sequentially (ref: :589-600, :672-673)
 	WV_ONE
 	{
