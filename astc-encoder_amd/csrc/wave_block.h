@@ -893,6 +893,14 @@ WV_OUT void stage_formats(bool dual, int partition_count, int partition_packed, 
 		compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], start, end);
 }
 
+WV_OUT void stage_format_select(int partition_count, int start, int end)
+{
+	const Ctx c = ctx_make();
+	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
+	PROF_SCOPE(c, PS_FORMATS);
+	select_candidate_modes(c, partition_count, start, end);
+}
+
 WV_FN float stage_refine(int partition_count, int partition_packed, int plane2_component, float tune_errorval_threshold)
 {
 	const Ctx c = ctx_make();
@@ -933,7 +941,8 @@ __attribute__((always_inline)) WV_FN float compress_trial(const Ctx& c, bool dua
 	// (the format search adds to the mode records in place, so it is doubled together with the scoring that resets them)
 	DUP_STAGE(c, DUP_MODES_FORMATS, {
 	DUP_STAGE(c, DUP_MODES, stage_modes(partition_count, mode_start, mode_end, max_weight_quant, dual));
-	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end); });
+	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end);
+	stage_format_select(partition_count, mode_start, mode_end); });
 	return wv_uniform(stage_refine(partition_count, partition_packed, dual ? plane2_component : -1, tune_errorval_threshold));
 }
 

@@ -491,8 +491,38 @@ struct QuantLevels
 		const uint32_t word = pairs < 4 ? w[0] : pairs < 8 ? w[1] : w[2];
 		return (int)(int8_t)(uint8_t)(word >> (8 * (pairs & 3)));
 	}
+	/* The row moved down by `first` entries (0 .. 7): result.of(k) == of(first + k), -1 past the end.  Loops over
+	 * "first + k" with a wave-uniform `first` then index with constants (a run-time entry index costs a scalar lane mask
+	 * per word choice). */
+	WV_FN QuantLevels from(int first) const
+	{
+		QuantLevels r;
+		const bool word_up = first >= 4;
+		const uint32_t a0 = word_up ? w[1] : w[0], a1 = word_up ? w[2] : w[1], a2 = word_up ? w[3] : w[2], a3 = word_up ? 0xFFFFFFFFu : w[3];
+		const uint32_t s = 8u * ((uint32_t)first & 3u);
+#if WV_DEVICE
+		r.w[0] = __builtin_amdgcn_alignbit(a1, a0, s);
+		r.w[1] = __builtin_amdgcn_alignbit(a2, a1, s);
+		r.w[2] = __builtin_amdgcn_alignbit(a3, a2, s);
+		r.w[3] = __builtin_amdgcn_alignbit(0xFFFFFFFFu, a3, s);
+#else
+		r.w[0] = (uint32_t)((((uint64_t)a1 << 32) | a0) >> s);
+		r.w[1] = (uint32_t)((((uint64_t)a2 << 32) | a1) >> s);
+		r.w[2] = (uint32_t)((((uint64_t)a3 << 32) | a2) >> s);
+		r.w[3] = (uint32_t)(((0xFFFFFFFFull << 32) | a3) >> s);
+#endif
+		return r;
+	}
 };
 static_assert(sizeof(QuantLevels) == 16, "one row of the transposed quant mode table");
+
+/* `e` if `level` is a legal colour quant level (>= QUANT_6), else ERROR_CALC_DEFAULT -- as bit arithmetic on the vector
+ * unit: a handful of these in flight as compare + select would each hold a lane mask in a scalar register pair. */
+WV_FN float error_unless_legal(float e, int level)
+{
+	const int illegal = (level - (int)QUANT_6) >> 31;            // all ones below QUANT_6
+	return int_as_float((float_as_int(e) & ~illegal) | (float_as_int(ERROR_CALC_DEFAULT) & illegal));
+}
 
 WV_FN QuantLevels quant_levels_for_bits(const Ctx& c, int bits_available)
 {
@@ -511,15 +541,19 @@ WV_FN float best_combination_for_levels(const Ctx& c, int pc, const FmtView& fs,
 	if (pc == 1)
 	{
 		int best_integer_count = 0;
-		for (int integer_count = 1; integer_count <= 4; integer_count++)
+		// (all four table reads are issued together -- a level below QUANT_6 reads the QUANT_6 row and is ignored --, then
+		// the reference's loop runs over the values: one LDS round trip instead of four dependent ones)
+		float e[4];
+		#pragma unroll
+		for (int k = 0; k < 4; k++) e[k] = fs.best_error(0, i_max(levels.of(k + 1), (int)QUANT_6))[k];
+		#pragma unroll
+		for (int k = 0; k < 4; k++)
 		{
-			const int quant_level = levels.of(integer_count);
-			if (quant_level < QUANT_6) continue;
-			float e = fs.best_error(0, quant_level)[integer_count - 1];
-			if (e < best_integer_count_error)
+			const float ek = error_unless_legal(e[k], levels.of(k + 1));                   // (1e30: never below the running best)
+			if (ek < best_integer_count_error)
 			{
-				best_integer_count_error = e;
-				best_integer_count = integer_count - 1;
+				best_integer_count_error = ek;
+				best_integer_count = k;
 			}
 		}
 		if (quant)
@@ -536,15 +570,21 @@ WV_FN float best_combination_for_levels(const Ctx& c, int pc, const FmtView& fs,
 	const int hi = pc == 2 ? 8 : 9;
 	const int mod_bits = pc == 2 ? 2 : pc == 3 ? 5 : 8;
 	int best_integer_count = 0;
-	for (int integer_count = lo; integer_count <= hi; integer_count++)
+	// (the same with up to seven reads in flight; the reference stops at the first integer count whose level is too low)
+	const QuantLevels from_lo = levels.from(lo);
+	float e[7];
+	#pragma unroll
+	for (int k = 0; k < 7; k++) e[k] = fs.comb_error(i_max(from_lo.of(k), (int)QUANT_6))[k];
+	// (the levels never rise with the integer count -- more values in the same bits --, so "stop at the first level that
+	// is too low" and "skip every level that is too low" are the same thing; tests/test_tables.py checks the table)
+	#pragma unroll
+	for (int k = 0; k < 7; k++)
 	{
-		const int quant_level = levels.of(integer_count);
-		if (quant_level < QUANT_6) break;
-		float e = fs.comb_error(quant_level)[integer_count - lo];
-		if (e < best_integer_count_error)
+		const float ek = error_unless_legal(e[k], from_lo.of(k));          // (integer counts past `hi`: the rows hold -1 there)
+		if (ek < best_integer_count_error)
 		{
-			best_integer_count_error = e;
-			best_integer_count = integer_count;
+			best_integer_count_error = ek;
+			best_integer_count = lo + k;
 		}
 	}
 	if (quant)
@@ -575,8 +615,8 @@ WV_FN int mode_bitcount(int partition_count, const BlockMode& bm)
 	return free_bits[partition_count - 1] - bm.weight_bits;
 }
 
-/* (ref: compute_ideal_endpoint_formats :1096).  modes()[i].qwt_error must be filled for
- * [start, end).  Results in tr.cand_*. */
+/* (ref: compute_ideal_endpoint_formats :1096), first half: the error tables of every (partition, quant level, format
+ * class) and their best combinations over the partitions, in the `uni` LDS region (FmtView). */
 WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, const float (*ep0)[4], const float (*ep1)[4],
                                           int start_block_mode, int end_block_mode)
 {
@@ -602,6 +642,17 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 		WV_SYNC();
 	}
 
+	(void)tr; (void)modes; (void)start_block_mode; (void)end_block_mode;
+}
+
+/* Second half (ref: :1133-1333): the best colour encoding of every scored block mode, then the tune_candidate_limit best
+ * modes with their quant levels and formats -> tr.cand_*.  Its own out-of-line stage on the device: together with the
+ * table building above it runs out of scalar registers. */
+WV_FN void select_candidate_modes(const Ctx& c, int pc, int start_block_mode, int end_block_mode)
+{
+	TrialInfo& tr = c.tr();
+	const FmtView fs = fmt_view(c);
+	ModeRec* modes = c.modes(start_block_mode);
 	PROF_SCOPE(c, PS_FMT4);
 	const QuantLevels* mode_levels = reinterpret_cast<const QuantLevels*>(c.table(c.root->off_mode_levels))
 	                                 + (uint32_t)(pc - 1) * (uint32_t)i_max(1, (int)c.root->block_mode_count_1plane_2plane_selected);
@@ -669,7 +720,10 @@ WV_FN void compute_ideal_endpoint_formats(const Ctx& c, const PartView& pv, cons
 	{
 		const int mode = tr.cand_block_mode[n];
 		for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = 0;
-		(void)best_combination_for_bitcount(c, pc, fs, mode_bitcount(pc, c.block_mode(mode)), &tr.cand_quant[n], &tr.cand_quant_mod[n], tr.cand_formats[n]);
+		// (the mode's levels row and its record are requested side by side; the bit count only selects the "matched formats" row)
+		const QuantLevels levels = table_at(mode_levels, (uint32_t)mode);
+		const int bitcount = mode_bitcount(pc, c.block_mode(mode));
+		(void)best_combination_for_levels(c, pc, fs, levels, bitcount, &tr.cand_quant[n], &tr.cand_quant_mod[n], tr.cand_formats[n]);
 	}
 	WV_ONE { tr.cand_count = count; }
 	WV_SYNC();

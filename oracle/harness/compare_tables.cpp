@@ -139,6 +139,26 @@ int main(int argc, char** argv)
 	}
 	const int8_t* qm = (const int8_t*)(B + r.off_quant_mode_table);
 	for (unsigned i = 0; i < 10; i++) for (unsigned j = 0; j < 128; j++) CHECK(qm[i * 128 + j] == quant_mode_table[i][j], "qmt %u %u: %d %d", i, j, qm[i * 128 + j], quant_mode_table[i][j]);
+	// the levels never rise with the integer-pair count (format selection relies on it: wave_format.h, "stop at the first
+	// level that is too low" == "skip every level that is too low")
+	for (unsigned j = 0; j < 128; j++) for (unsigned i = 1; i < 10; i++) CHECK(quant_mode_table[i][j] <= quant_mode_table[i - 1][j] || i == 1, "qmt not monotone at %u %u", i, j);
+	// per (partition count, block mode): the row of the mode's colour bit budget
+	{
+		const int8_t* ml = (const int8_t*)(B + r.off_mode_levels);
+		const astcd::BlockMode* bmods = (const astcd::BlockMode*)(B + r.off_block_modes);
+		const unsigned nm = r.block_mode_count_1plane_2plane_selected ? r.block_mode_count_1plane_2plane_selected : 1u;
+		for (int pc = 1; pc <= 4; pc++)
+			for (unsigned m = 0; m < r.block_mode_count_1plane_2plane_selected; m++)
+			{
+				const int free_bits[4] = { 111, 97, 94, 91 };
+				const int bits = (bmods[m].is_dual_plane ? 109 : free_bits[pc - 1]) - (int)bmods[m].weight_bits;
+				for (unsigned i = 0; i < 16; i++)
+				{
+					const int want = (bits > 0 && bits < 128 && i < 10) ? quant_mode_table[i][bits] : -1;
+					CHECK(ml[((pc - 1) * nm + m) * 16 + i] == want, "mode levels pc %d mode %u pairs %u: %d %d", pc, m, i, ml[((pc - 1) * nm + m) * 16 + i], want);
+				}
+			}
+	}
 	const int8_t* qmb = (const int8_t*)(B + r.off_quant_mode_by_bits);
 	for (unsigned i = 0; i < 10; i++) for (unsigned j = 0; j < 128; j++) CHECK(qmb[j * 16 + i] == quant_mode_table[i][j], "qmt by bits %u %u: %d %d", i, j, qmb[j * 16 + i], quant_mode_table[i][j]);
 
