@@ -88,8 +88,8 @@ struct BlockMode {
 // into one 24-byte record (TableRoot::off_mode_static): the mode lanes of score_block_modes then start with one load
 // instead of a chain of three dependent ones.
 struct ModeStatic {
-	uint32_t tw_off;          // DecimationInfo::off_texel_weights
-	uint32_t tcf_off;         // DecimationInfo::off_texel_contribs_f
+	uint32_t tw_off;          // DecimationInfo::off_texel_taps_idx
+	uint32_t tcf_off;         // DecimationInfo::off_texel_taps_f4
 	uint16_t dwi_off[2];      // packed ideal-weight slot of plane 0 / 1 in the mode's trial class
 	uint16_t lh_off[2];       // float offset of the mode's (low, high) pair per plane in the angular bounds; 0xFFFF: quant level above QUANT_12
 	uint8_t  taps;            // 1, 2 or 4 grid weights per texel
@@ -143,8 +143,8 @@ struct DwiOrderDir {
 
 // The same for the texel-resolution infill of one (grid, plane) of a trial class (TableRoot::off_infill_sets).
 struct InfillSet {
-	uint32_t tw_off;        // blob offset of texel_weights
-	uint32_t tcf_off;       // blob offset of texel_contribs_f
+	uint32_t tw_off;        // blob offset of the grid's per-texel index words (DecimationInfo::off_texel_taps_idx)
+	uint32_t tcf_off;       // blob offset of the grid's per-texel contributions (DecimationInfo::off_texel_taps_f4)
 	uint16_t dwi_offset;    // float offset of the grid's ideal weights in the packed region
 	uint16_t refprec;
 	uint8_t  taps;          // 1, 2 or 4 weights per texel
@@ -183,7 +183,13 @@ struct DecimationInfo {
 	// (few do) only the later weights that share a texel with it, listed here, are evaluated again.
 	uint32_t off_realign_later;          // u8 [W][REALIGN_LATER_MAX] later neighbours of each weight, 255-terminated (not staged in LDS)
 	uint32_t realign_speculative;        // 1: use the scheme above
+	// The texel tables once more, one record per texel, for the sweeps that read them from HBM / L2 (mode scoring, the
+	// infill of the decimation sweeps): a lane fetches its texel's four weight indices with ONE 32-bit load and the four
+	// contributions with ONE 128-bit load instead of four byte loads and four float loads.  (Not staged in LDS.)
+	uint32_t off_texel_taps_idx;         // u32 [T]      texel_weights[0..3][t] as bytes 0..3
+	uint32_t off_texel_taps_f4;          // f32 [T][4]   texel_contribs_f[0..3][t], 16-byte aligned
 };
+static_assert(sizeof(DecimationInfo) == 64, "DecimationInfo is staged as one 64-byte record");
 constexpr int REALIGN_LATER_MAX = 16;
 // (measured on MI355X, same-call A/B: with the lane-per-weight evaluator of realign_weights the speculative scheme wins
 //  for every decimated grid -- 6x6 -medium 124.9 -> 127.8 Mtexels/s going from 7 to 2 -- so the level schedule is left

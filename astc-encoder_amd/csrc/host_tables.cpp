@@ -259,6 +259,8 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	//  refined candidate stages into LDS, DecimationInfo::table_bytes)
 	uint32_t o_wc  = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_later = blob.alloc((size_t)W * REALIGN_LATER_MAX, 4);   // later neighbours (not part of the staged range), see build_realign_schedule()
+	uint32_t o_taps_idx = blob.alloc((size_t)T * 4, 4);                // per-texel records of the texel tables (DecimationInfo::off_texel_taps_*)
+	uint32_t o_taps_f4 = blob.alloc((size_t)T * 16, 16);
 
 	uint8_t* p_tw = blob.at<uint8_t>(o_tw);
 	uint8_t* p_tci = blob.at<uint8_t>(o_tci);
@@ -327,6 +329,18 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	di->off_realign_counts = o_rc;
 	di->off_realign_later = o_later;
 	di->realign_speculative = 0;
+	di->off_texel_taps_idx = o_taps_idx;
+	di->off_texel_taps_f4 = o_taps_f4;
+	for (unsigned int t = 0; t < T; t++)
+	{
+		uint32_t word = 0;
+		for (unsigned int k = 0; k < 4; k++)
+		{
+			word |= (uint32_t)p_tw[k * T + t] << (8 * k);
+			*blob.at<float>((uint32_t)(o_taps_f4 + (t * 4 + k) * sizeof(float))) = p_tcf[k * T + t];
+		}
+		*blob.at<uint32_t>((uint32_t)(o_taps_idx + t * 4)) = word;
+	}
 	di->realign_levels = 0;
 	di->table_bytes = (uint32_t)(o_rc + ((W + 3u) & ~3u) - o_tw);
 }
@@ -1031,8 +1045,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			for (int plane = 0; plane < planes; plane++, set++)
 			{
 				InfillSet* is = blob.at<InfillSet>((uint32_t)(off_isets[cls] + set * sizeof(InfillSet)));
-				is->tw_off = di.off_texel_weights;
-				is->tcf_off = di.off_texel_contribs_f;
+				is->tw_off = di.off_texel_taps_idx;
+				is->tcf_off = di.off_texel_taps_f4;
 				is->dwi_offset = dms[i].dwi_offset[cls + plane];
 				is->refprec = refprec;
 				is->taps = (uint8_t)(di.max_texel_weight_count > 2 ? 4 : di.max_texel_weight_count > 1 ? 2 : 1);
@@ -1192,8 +1206,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + bm.decimation_mode * sizeof(DecimationInfo)));
 			ModeStatic ms;
 			memset(&ms, 0, sizeof(ms));
-			ms.tw_off = di.off_texel_weights;
-			ms.tcf_off = di.off_texel_contribs_f;
+			ms.tw_off = di.off_texel_taps_idx;
+			ms.tcf_off = di.off_texel_taps_f4;
 			const int cls = bm.is_dual_plane ? 1 : 0;
 			const uint32_t used = (cls ? dm.refprec_2planes : dm.refprec_1plane) & 0xFFu;
 			for (int plane = 0; plane <= cls; plane++)

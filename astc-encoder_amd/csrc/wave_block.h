@@ -225,15 +225,13 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 			const ModeHdr h = hdr[m];
 			float term = 0.0f;
 			{
-				const uint8_t* tab = c.tab;
-				const float* tabf = reinterpret_cast<const float*>(c.tab);
-				const uint32_t tw = h.tw_off + (uint32_t)t, tcf = (h.tcf_off >> 2) + (uint32_t)t;
-				const uint32_t uT = (uint32_t)T;
+				// (the texel's record of the mode's grid: one 32-bit and one 128-bit load, whatever the tap count)
+				const TexelTaps taps = texel_taps_at(c.tab, h.tw_off, h.tcf_off, (uint32_t)t);
 				const uint8_t* uq = uqw + m * (int)MODE_WEIGHT_BYTES;
 				if (h.taps == 4)
 				{
-					const int i0 = tab[tw], i1 = tab[tw + uT], i2 = tab[tw + 2 * uT], i3 = tab[tw + 3 * uT];
-					const float c0 = table_at(tabf, tcf), c1 = table_at(tabf, tcf + uT), c2 = table_at(tabf, tcf + 2 * uT), c3 = table_at(tabf, tcf + 3 * uT);
+					const int i0 = (int)(taps.idx & 0xFFu), i1 = (int)((taps.idx >> 8) & 0xFFu), i2 = (int)((taps.idx >> 16) & 0xFFu), i3 = (int)(taps.idx >> 24);
+					const float c0 = taps.c0, c1 = taps.c1, c2 = taps.c2, c3 = taps.c3;
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];
@@ -250,8 +248,8 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				}
 				else if (h.taps == 2)
 				{
-					const int i0 = tab[tw], i1 = tab[tw + uT];
-					const float c0 = table_at(tabf, tcf), c1 = table_at(tabf, tcf + uT);
+					const int i0 = (int)(taps.idx & 0xFFu), i1 = (int)((taps.idx >> 8) & 0xFFu);
+					const float c0 = taps.c0, c1 = taps.c1;
 					for (int plane = 0; plane < planes; plane++)
 					{
 						const ModeQ q = mq[m * 2 + plane];

@@ -25,20 +25,25 @@ WV_FN float infill2(const float* wts, const uint8_t* tw, const float* tcf, int T
 	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]);
 }
 
-/* The same with the tables addressed as uniform base + 32-bit offset (tw_off in bytes, tcf_off in floats):
- * the address of every load is one VGPR next to a scalar base instead of a 64-bit per-lane pointer. */
-WV_FN float infill4_at(const float* wts, const uint8_t* tab, uint32_t tw_off, uint32_t tcf_off, uint32_t T, uint32_t t)
+/* The same from the per-texel records of the table blob (DecimationInfo::off_texel_taps_idx / _f4, byte offsets): the
+ * texel's four weight indices arrive in one 32-bit load and its four contributions in one 128-bit load, addressed as
+ * uniform base + 32-bit offset.  `four_taps`: the grid has texels with more than two weights (else the 2-tap form). */
+struct TexelTaps { uint32_t idx; float c0, c1, c2, c3; };
+struct TapContribs { float c0, c1, c2, c3; };
+WV_FN TexelTaps texel_taps_at(const uint8_t* tab, uint32_t idx_off, uint32_t f4_off, uint32_t t)
 {
-	const float* tabf = reinterpret_cast<const float*>(tab);
-	const uint32_t a = tw_off + t, b = tcf_off + t;
-	return (wts[tab[a]] * table_at(tabf, b) + wts[tab[a + T]] * table_at(tabf, b + T)) +
-	       (wts[tab[a + 2 * T]] * table_at(tabf, b + 2 * T) + wts[tab[a + 3 * T]] * table_at(tabf, b + 3 * T));
+	TexelTaps r;
+	r.idx = table_at_byte<uint32_t>(tab, idx_off + 4u * t);
+	const TapContribs cf = table_at_byte<TapContribs>(tab, f4_off + 16u * t);
+	r.c0 = cf.c0; r.c1 = cf.c1; r.c2 = cf.c2; r.c3 = cf.c3;
+	return r;
 }
-WV_FN float infill2_at(const float* wts, const uint8_t* tab, uint32_t tw_off, uint32_t tcf_off, uint32_t T, uint32_t t)
+WV_FN float infill_taps_at(const float* wts, const uint8_t* tab, uint32_t idx_off, uint32_t f4_off, uint32_t t, bool four_taps)
 {
-	const float* tabf = reinterpret_cast<const float*>(tab);
-	const uint32_t a = tw_off + t, b = tcf_off + t;
-	return (wts[tab[a]] * table_at(tabf, b) + wts[tab[a + T]] * table_at(tabf, b + T));
+	const TexelTaps k = texel_taps_at(tab, idx_off, f4_off, t);
+	const float lo = wts[k.idx & 0xFFu] * k.c0 + wts[(k.idx >> 8) & 0xFFu] * k.c1;
+	const float hi = wts[(k.idx >> 16) & 0xFFu] * k.c2 + wts[k.idx >> 24] * k.c3;
+	return four_taps ? lo + hi : lo;
 }
 
 // weights per round trip in the angular search's two per-(grid, step) loops.  Measured on config 2: 8 -> 4 +1.2 %
@@ -255,8 +260,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 #endif
 			if (is.direct || (int)is.dm >= max_dm || !(is.refprec & ref_mask)) continue;
 			const float* wts = dwi_base + is.dwi_offset;
-			infilled[set * Tp + t] = is.taps <= 2 ? infill2_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t)
-			                                      : infill4_at(wts, c.tab, is.tw_off, is.tcf_off >> 2, (uint32_t)T, (uint32_t)t);
+			infilled[set * Tp + t] = infill_taps_at(wts, c.tab, is.tw_off, is.tcf_off, (uint32_t)t, is.taps > 2);
 		}
 		WV_SYNC(); }
 
