@@ -116,9 +116,11 @@ struct DecimationMode {
 
 // Everything the decimation sweeps need about one packed ideal-weight slot (TableRoot::off_dwi_slots):
 // one 16-byte load per lane instead of walking owner -> decimation mode -> decimation info.
+struct DwiTap { uint32_t texel; float contrib; };     // one tap of a weight: weight_texels[j][i], weight_contribs[j][i]
 struct DwiSlot {
-	uint32_t wt_off;        // blob offset of weight_texels[0][i]   (tap j at + j * weight_count)
-	uint32_t wc_off;        // blob offset of weight_contribs[0][i] (tap j at + j * weight_count floats)
+	uint32_t wt_off;        // blob offset of the weight's DwiTap records, taps in order, 16-byte aligned and padded to an even count
+	                        // with zero contributions: a sweep fetches two taps with one 128-bit load
+	uint32_t wc_off;        // (unused)
 	uint16_t refprec;       // quant levels (bit mask) of the block modes using this grid in this trial class
 	uint8_t  weight_count;
 	uint8_t  taps;          // texels this weight touches; 0 for the padding slots past weight_count
@@ -249,6 +251,7 @@ struct TableRoot {
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
+	uint32_t off_cos_sin_table;               // f32[64][32][2]: (cos, sin) side by side, one 64-bit load per (row, step) in the angular search
 	uint32_t off_dm_by_weights;               // u8[decimation_mode_count_selected]: the grids by descending weight count (angular batching order)
 	uint32_t off_mode_static;                 // ModeStatic[block_mode_count_1plane_2plane_selected]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)

@@ -1025,6 +1025,25 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 		}
 	}
 
+	// the taps of every weight as consecutive DwiTap records (see DwiSlot::wt_off)
+	std::vector<uint32_t> weight_taps_off(dms.size(), 0), weight_taps_stride(dms.size(), 0);
+	for (size_t i = 0; i < dms.size(); i++)
+	{
+		const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)));
+		const uint32_t W = di.weight_count, rows = di.max_weight_texel_count, rows2 = (rows + 1u) & ~1u;
+		const uint32_t off = blob.alloc((size_t)std::max<uint32_t>(W * rows2, 2u) * sizeof(DwiTap), 16);
+		for (uint32_t w = 0; w < W; w++)
+			for (uint32_t j = 0; j < rows2; j++)
+			{
+				DwiTap tap;
+				tap.texel = j < rows ? *blob.at<uint8_t>((uint32_t)(di.off_weight_texels + j * W + w)) : 0u;
+				tap.contrib = j < rows ? *blob.at<float>((uint32_t)(di.off_weight_contribs + (j * W + w) * sizeof(float))) : 0.0f;
+				*blob.at<DwiTap>((uint32_t)(off + (w * rows2 + j) * sizeof(DwiTap))) = tap;
+			}
+		weight_taps_off[i] = off;
+		weight_taps_stride[i] = rows2 * (uint32_t)sizeof(DwiTap);
+	}
+
 	// per-slot / per-set records of the decimation sweeps (see DwiSlot, InfillSet), in packing order
 	uint32_t off_slots[2], off_isets[2], n_sets[2], used_sets[2][12];
 	for (int cls = 0; cls < 2; cls++)
@@ -1056,8 +1075,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 				for (uint32_t k = 0; k < wc4; k++)
 				{
 					DwiSlot* sl = blob.at<DwiSlot>((uint32_t)(off_slots[cls] + (dms[i].dwi_offset[cls + plane] + k) * sizeof(DwiSlot)));
-					sl->wt_off = di.off_weight_texels + k;
-					sl->wc_off = di.off_weight_contribs + k * (uint32_t)sizeof(float);
+					sl->wt_off = weight_taps_off[i] + (k < di.weight_count ? k : 0u) * weight_taps_stride[i];
+					sl->wc_off = 0;
 					sl->refprec = refprec;
 					sl->weight_count = di.weight_count;
 					sl->taps = k < di.weight_count ? wtc[k] : 0;
@@ -1196,6 +1215,17 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	}
 	r->off_sin_table = off_sin;
 	r->off_cos_table = off_cos;
+	{
+		const uint32_t n = (uint32_t)SINCOS_STEPS * (uint32_t)ANGULAR_STEPS;
+		uint32_t off_cs = blob.alloc((size_t)n * 2 * sizeof(float), 8);
+		for (uint32_t i = 0; i < n; i++)
+		{
+			*blob.at<float>((uint32_t)(off_cs + (2 * i) * sizeof(float))) = *blob.at<float>((uint32_t)(off_cos + i * sizeof(float)));
+			*blob.at<float>((uint32_t)(off_cs + (2 * i + 1) * sizeof(float))) = *blob.at<float>((uint32_t)(off_sin + i * sizeof(float)));
+		}
+		r = blob.at<TableRoot>(0);
+		r->off_cos_sin_table = off_cs;
+	}
 	{
 		// per block mode: everything its scoring reads from the mode / grid records (ModeStatic)
 		uint32_t off_ms = blob.alloc(std::max<size_t>(bms.size(), 1) * sizeof(ModeStatic), 8);

@@ -51,11 +51,6 @@ WV_FN float infill_taps_at(const float* wts, const uint8_t* tab, uint32_t idx_of
 #ifndef ASTC_ANG_GROUP
 #define ASTC_ANG_GROUP 4
 #endif
-// taps of a weight fetched per round trip in the decimation sweeps (table loads in flight per lane = 2x this)
-// (measured on config 2: 8 -1.5 %, 4 = baseline, 3 +-0, 2 +0.5 %)
-#ifndef ASTC_DWI_GROUP
-#define ASTC_DWI_GROUP 2
-#endif
 
 /* Row of the sin/cos tables an ideal weight selects in the angular search (ref: compute_angular_offsets,
  * weight_align.cpp:110-118).  It depends on the weight only, not on the angular step, so it is computed once when
@@ -67,94 +62,67 @@ WV_FN uint8_t angular_sample_row(float weight)
 }
 
 /* One slot of sweep 1: initial guess for weight `sl.index` of its grid (ref: :877-905; direct grids copy, :858-866).
- * Taps in groups of GROUP: all table loads of a group are issued together, then all gathers, then the (strictly
- * ordered) accumulation -- one memory round trip per group instead of one per tap. */
-template <int GROUP>
+ * Two taps per round trip: the pair's (texel, contribution) records arrive with one 128-bit load, then both gathers
+ * are issued, then the (strictly ordered) accumulation runs. */
+struct DwiTapPair { uint32_t texel0; float contrib0; uint32_t texel1; float contrib1; };
 WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 {
 	const int plane = (sl.flags >> 1) & 1;
 	const float* eiw = c.ei_w(plane);
 	const float* eiwes = c.ei_wes(plane);
 	if (sl.flags & 1) return eiw[sl.index];
-	const uint8_t* tab = c.tab;
-	const float* tabf = reinterpret_cast<const float*>(c.tab);
-	const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)sl.weight_count;
 	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 	const float wes0 = eiwes[0];
 	float weight_weight = 1e-10f;
 	float initial_weight = 0.0f;
 	const int cnt = sl.taps;
-	for (int j0 = 0; j0 < cnt; j0 += GROUP)
+	for (int j0 = 0; j0 < cnt; j0 += 2)
 	{
-		int tx[GROUP]; float wv[GROUP], iw[GROUP], es[GROUP];
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
+		const DwiTapPair tp = table_at_byte<DwiTapPair>(c.tab, sl.wt_off + (uint32_t)j0 * (uint32_t)sizeof(DwiTap));
+		const float iw0 = eiw[tp.texel0], iw1 = eiw[tp.texel1];
+		const float es0 = constant_wes ? wes0 : eiwes[tp.texel0], es1 = constant_wes ? wes0 : eiwes[tp.texel1];
 		{
-			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
-			tx[u] = tab[wt + j * uW];
-			wv[u] = table_at(tabf, wc + j * uW);
+			float contrib_weight = tp.contrib0 * es0;
+			weight_weight += contrib_weight;
+			initial_weight += iw0 * contrib_weight;
 		}
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
+		if (j0 + 1 < cnt)
 		{
-			iw[u] = eiw[tx[u]];
-			es[u] = constant_wes ? wes0 : eiwes[tx[u]];
-		}
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
-		{
-			if (j0 + u < cnt)
-			{
-				float contrib_weight = wv[u] * es[u];
-				weight_weight += contrib_weight;
-				initial_weight += iw[u] * contrib_weight;
-			}
+			float contrib_weight = tp.contrib1 * es1;
+			weight_weight += contrib_weight;
+			initial_weight += iw1 * contrib_weight;
 		}
 	}
 	return initial_weight / weight_weight;
 }
 
 /* One slot of sweep 3: the clamped gradient step (ref: :930-970); `inf` = the grid's infill at texel resolution. */
-template <int GROUP>
 WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf, float weight_val)
 {
 	const int plane = (sl.flags >> 1) & 1;
 	const float* eiw = c.ei_w(plane);
 	const float* eiwes = c.ei_wes(plane);
-	const uint8_t* tab = c.tab;
-	const float* tabf = reinterpret_cast<const float*>(c.tab);
-	const uint32_t wt = sl.wt_off, wc = sl.wc_off >> 2, uW = (uint32_t)sl.weight_count;
 	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
 	const float wes0 = eiwes[0];
 	float error_change0 = 1e-10f;
 	float error_change1 = 0.0f;
 	const int cnt = sl.taps;
-	for (int j0 = 0; j0 < cnt; j0 += GROUP)
+	for (int j0 = 0; j0 < cnt; j0 += 2)
 	{
-		int tx[GROUP]; float wv[GROUP], iw[GROUP], es[GROUP], ow[GROUP];
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
+		const DwiTapPair tp = table_at_byte<DwiTapPair>(c.tab, sl.wt_off + (uint32_t)j0 * (uint32_t)sizeof(DwiTap));
+		const float iw0 = eiw[tp.texel0], iw1 = eiw[tp.texel1];
+		const float ow0 = inf[tp.texel0], ow1 = inf[tp.texel1];
+		const float es0 = constant_wes ? wes0 : eiwes[tp.texel0], es1 = constant_wes ? wes0 : eiwes[tp.texel1];
 		{
-			uint32_t j = j0 + u < cnt ? (uint32_t)(j0 + u) : 0u;
-			tx[u] = tab[wt + j * uW];
-			wv[u] = table_at(tabf, wc + j * uW);
+			float scale = es0 * tp.contrib0;
+			error_change0 += tp.contrib0 * scale;
+			error_change1 += (ow0 - iw0) * scale;
 		}
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
+		if (j0 + 1 < cnt)
 		{
-			iw[u] = eiw[tx[u]];
-			ow[u] = inf[tx[u]];
-			es[u] = constant_wes ? wes0 : eiwes[tx[u]];
-		}
-		#pragma unroll
-		for (int u = 0; u < GROUP; u++)
-		{
-			if (j0 + u < cnt)
-			{
-				float scale = es[u] * wv[u];
-				error_change0 += wv[u] * scale;
-				error_change1 += (ow[u] - iw[u]) * scale;
-			}
+			float scale = es1 * tp.contrib1;
+			error_change0 += tp.contrib1 * scale;
+			error_change1 += (ow1 - iw1) * scale;
 		}
 	}
 	float step = (error_change1 * -16.0f) / error_change0;
@@ -223,7 +191,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 				const DwiSlot sl = table_at(order, (uint32_t)(o_begin + jj));
 #endif
 				const int k = sl.refprec;
-				const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
+				const float w0 = dwi_initial_weight(c, sl);
 				dwi_base[k] = w0;
 				if (sl.flags & 1) isamp[k] = angular_sample_row(w0);     // copied weights are final here
 			}
@@ -235,7 +203,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 				const int k = k_begin + j;
 				const DwiSlot sl = table_at(slots, (uint32_t)k);
 				if (sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
-				const float w0 = dwi_initial_weight<ASTC_DWI_GROUP>(c, sl);
+				const float w0 = dwi_initial_weight(c, sl);
 				dwi_base[k] = w0;
 				if (sl.flags & 1) isamp[k] = angular_sample_row(w0);
 			}
@@ -282,7 +250,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 #endif
 				if (sl.flags & 1) continue;
 				const int k = sl.refprec;
-				const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+				const float w1 = dwi_refined_weight(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
 				dwi_base[k] = w1;
 				isamp[k] = angular_sample_row(w1);
 			}
@@ -294,7 +262,7 @@ WV_FN void ideal_weights_all_grids(const Ctx& c, int nplanes, uint16_t ref_mask,
 				const int k = k_begin + j;
 				const DwiSlot sl = table_at(slots, (uint32_t)k);
 				if ((sl.flags & 1) || sl.taps == 0 || (int)sl.dm >= max_dm || !(sl.refprec & ref_mask)) continue;
-				const float w1 = dwi_refined_weight<ASTC_DWI_GROUP>(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
+				const float w1 = dwi_refined_weight(c, sl, infilled + ((int)sl.set - p0) * Tp, dwi_base[k]);
 				dwi_base[k] = w1;
 				isamp[k] = angular_sample_row(w1);
 			}
@@ -336,8 +304,8 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 {
 	float* ang = c.ang();               // [64][8]: offset, lowest, span, err, cut_low, cut_high
 	TrialInfo& tr = c.tr();
-	const float* sin_table = reinterpret_cast<const float*>(c.table(c.root->off_sin_table));
-	const float* cos_table = reinterpret_cast<const float*>(c.table(c.root->off_cos_table));
+	struct CosSin { float cs, sn; };
+	const CosSin* cos_sin_table = reinterpret_cast<const CosSin*>(c.table(c.root->off_cos_sin_table));
 
 	// steps of every set, one per lane: the batching below then needs no memory access per set
 	LaneArray128 steps_of;
@@ -413,8 +381,9 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
 					const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
-					cs[u] = table_at(cos_table, at);
-					sn[u] = table_at(sin_table, at);
+					const CosSin both = table_at(cos_sin_table, at);      // one 64-bit load
+					cs[u] = both.cs;
+					sn[u] = both.sn;
 				}
 				#pragma unroll
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)

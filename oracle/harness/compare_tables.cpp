@@ -177,6 +177,7 @@ int main(int argc, char** argv)
 	{
 		CHECK(st[j * 32 + i] == sin_table[j][i], "sin");
 		CHECK(ct[j * 32 + i] == cos_table[j][i], "cos");
+		CHECK(((const float*)(B + r.off_cos_sin_table))[(j * 32 + i) * 2] == cos_table[j][i] && ((const float*)(B + r.off_cos_sin_table))[(j * 32 + i) * 2 + 1] == sin_table[j][i], "cos/sin pair");
 	}
 
 	printf("%ux%u q=%.0f: %u block modes, %u decimation modes, partitions %u/%u/%u, blob %zu bytes: %s (%d mismatches)\n",
