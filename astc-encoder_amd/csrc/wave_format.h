@@ -567,7 +567,7 @@ WV_FN float best_combination_for_levels(const Ctx& c, int pc, const FmtView& fs,
 	}
 
 	const int lo = pc;                       // minimum integer-pair count
-	const int hi = pc == 2 ? 8 : 9;
+	// (integer-pair counts lo .. 8 for two partitions, lo .. 9 for three and four: at most seven)
 	const int mod_bits = pc == 2 ? 2 : pc == 3 ? 5 : 8;
 	int best_integer_count = 0;
 	// (the same with up to seven reads in flight; the reference stops at the first integer count whose level is too low)
