@@ -88,8 +88,8 @@ struct BlockMode {
 // into one 24-byte record (TableRoot::off_mode_static): the mode lanes of score_block_modes then start with one load
 // instead of a chain of three dependent ones.
 struct ModeStatic {
-	uint32_t tw_off;          // DecimationInfo::off_texel_taps_idx
-	uint32_t tcf_off;         // DecimationInfo::off_texel_taps_f4
+	uint32_t tw_off;          // DecimationInfo::off_texel_weights
+	uint32_t tcf_off;         // DecimationInfo::off_texel_contribs_f
 	uint16_t dwi_off[2];      // packed ideal-weight slot of plane 0 / 1 in the mode's trial class
 	uint16_t lh_off[2];       // float offset of the mode's (low, high) pair per plane in the angular bounds; 0xFFFF: quant level above QUANT_12
 	uint8_t  taps;            // 1, 2 or 4 grid weights per texel
@@ -145,8 +145,8 @@ struct DwiOrderDir {
 
 // The same for the texel-resolution infill of one (grid, plane) of a trial class (TableRoot::off_infill_sets).
 struct InfillSet {
-	uint32_t tw_off;        // blob offset of the grid's per-texel index words (DecimationInfo::off_texel_taps_idx)
-	uint32_t tcf_off;       // blob offset of the grid's per-texel contributions (DecimationInfo::off_texel_taps_f4)
+	uint32_t tw_off;        // blob offset of the grid's per-texel index words (DecimationInfo::off_texel_weights)
+	uint32_t tcf_off;       // blob offset of the grid's per-texel contributions (DecimationInfo::off_texel_contribs_f)
 	uint16_t dwi_offset;    // float offset of the grid's ideal weights in the packed region
 	uint16_t refprec;
 	uint8_t  taps;          // 1, 2 or 4 weights per texel
@@ -166,9 +166,11 @@ struct DecimationInfo {
 	uint8_t  max_weight_texel_count;     // rows in the per-weight arrays
 	uint8_t  realign_levels;             // number of groups in the realign schedule below
 	uint8_t  realign_slots;              // most weights per group for this grid (lanes: slots * rows rounded to 4 <= 64)
-	uint32_t off_texel_weights;          // u8  [4][T]   ref: texel_weights_tr
-	uint32_t off_texel_contribs_int;     // u8  [4][T]   ref: texel_weight_contribs_int_tr
-	uint32_t off_texel_contribs_f;       // f32 [4][T]   ref: texel_weight_contribs_float_tr
+	// one record per texel: its (up to) four grid weights and their contributions side by side, so that a lane fetches them
+	// with one 32-bit / 128-bit access (the reference keeps them transposed, [4][T], for its SIMD gathers)
+	uint32_t off_texel_weights;          // u8  [T][4]   ref: texel_weights_tr[j][t] at [t][j]; 16-byte aligned
+	uint32_t off_texel_contribs_int;     // u8  [T][4]   ref: texel_weight_contribs_int_tr
+	uint32_t off_texel_contribs_f;       // f32 [T][4]   ref: texel_weight_contribs_float_tr; 16-byte aligned
 	uint32_t off_weight_texel_count;     // u8  [W]      ref: weight_texel_count
 	uint32_t off_weight_texels;          // u8  [rows][W] ref: weight_texels_tr
 	uint32_t off_weight_contribs;        // f32 [rows][W] ref: weights_texel_contribs_tr
@@ -185,11 +187,7 @@ struct DecimationInfo {
 	// (few do) only the later weights that share a texel with it, listed here, are evaluated again.
 	uint32_t off_realign_later;          // u8 [W][REALIGN_LATER_MAX] later neighbours of each weight, 255-terminated (not staged in LDS)
 	uint32_t realign_speculative;        // 1: use the scheme above
-	// The texel tables once more, one record per texel, for the sweeps that read them from HBM / L2 (mode scoring, the
-	// infill of the decimation sweeps): a lane fetches its texel's four weight indices with ONE 32-bit load and the four
-	// contributions with ONE 128-bit load instead of four byte loads and four float loads.  (Not staged in LDS.)
-	uint32_t off_texel_taps_idx;         // u32 [T]      texel_weights[0..3][t] as bytes 0..3
-	uint32_t off_texel_taps_f4;          // f32 [T][4]   texel_contribs_f[0..3][t], 16-byte aligned
+	uint32_t pad[2];
 };
 static_assert(sizeof(DecimationInfo) == 64, "DecimationInfo is staged as one 64-byte record");
 constexpr int REALIGN_LATER_MAX = 16;

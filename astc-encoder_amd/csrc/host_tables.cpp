@@ -247,9 +247,11 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	for (unsigned int i = 0; i < W; i++) rows = std::max<unsigned>(rows, cnt_w[i]);
 	for (unsigned int i = 0; i < T; i++) max_tw = std::max<unsigned>(max_tw, cnt_t[i]);
 
-	uint32_t o_tw  = blob.alloc(4 * T, 4);
+	// the three texel tables as one record per texel ([T][4]; the staged copy in LDS and the sweeps that read the blob both
+	// fetch a texel's four indices / contributions with one 32-bit / 128-bit access)
+	uint32_t o_tw  = blob.alloc(4 * T, 16);
 	uint32_t o_tci = blob.alloc(4 * T, 4);
-	uint32_t o_tcf = blob.alloc(4 * T * sizeof(float), 4);
+	uint32_t o_tcf = blob.alloc(4 * T * sizeof(float), 16);
 	uint32_t o_wtc = blob.alloc(W, 4);
 	uint32_t o_wt  = blob.alloc(rows * W, 4);
 	uint32_t o_tcw = blob.alloc(rows * W * sizeof(float), 4);
@@ -259,8 +261,6 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	//  refined candidate stages into LDS, DecimationInfo::table_bytes)
 	uint32_t o_wc  = blob.alloc(rows * W * sizeof(float), 4);
 	uint32_t o_later = blob.alloc((size_t)W * REALIGN_LATER_MAX, 4);   // later neighbours (not part of the staged range), see build_realign_schedule()
-	uint32_t o_taps_idx = blob.alloc((size_t)T * 4, 4);                // per-texel records of the texel tables (DecimationInfo::off_texel_taps_*)
-	uint32_t o_taps_f4 = blob.alloc((size_t)T * 16, 16);
 
 	uint8_t* p_tw = blob.at<uint8_t>(o_tw);
 	uint8_t* p_tci = blob.at<uint8_t>(o_tci);
@@ -270,9 +270,9 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 		for (unsigned int j = 0; j < 4; j++)
 		{
 			bool used = j < cnt_t[t];
-			p_tw[j * T + t]  = used ? gw[t * 4 + j] : 0;
-			p_tci[j * T + t] = used ? gc[t * 4 + j] : 0;
-			p_tcf[j * T + t] = used ? (float)gc[t * 4 + j] * (1.0f / 16.0f) : 0.0f;
+			p_tw[t * 4 + j]  = used ? gw[t * 4 + j] : 0;
+			p_tci[t * 4 + j] = used ? gc[t * 4 + j] : 0;
+			p_tcf[t * 4 + j] = used ? (float)gc[t * 4 + j] * (1.0f / 16.0f) : 0.0f;
 		}
 	}
 
@@ -293,9 +293,9 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 				float c = 0.0f;
 				for (unsigned int k = 0; k < 4; k++)
 				{
-					if (p_tw[k * T + texel] == w && p_tcf[k * T + texel] != 0.0f)
+					if (p_tw[texel * 4 + k] == w && p_tcf[texel * 4 + k] != 0.0f)
 					{
-						c = p_tcf[k * T + texel];
+						c = p_tcf[texel * 4 + k];
 						break;
 					}
 				}
@@ -329,19 +329,6 @@ static void build_decimation_info(Blob& blob, uint32_t di_off, unsigned int tx, 
 	di->off_realign_counts = o_rc;
 	di->off_realign_later = o_later;
 	di->realign_speculative = 0;
-	di->off_texel_taps_idx = o_taps_idx;
-	di->off_texel_taps_f4 = o_taps_f4;
-	for (unsigned int t = 0; t < T; t++)
-	{
-		uint32_t word = 0;
-		for (unsigned int k = 0; k < 4; k++)
-		{
-			word |= (uint32_t)p_tw[k * T + t] << (8 * k);
-			*blob.at<float>((uint32_t)(o_taps_f4 + (t * 4 + k) * sizeof(float))) = p_tcf[k * T + t];
-		}
-		*blob.at<uint32_t>((uint32_t)(o_taps_idx + t * 4)) = word;
-	}
-	di->realign_levels = 0;
 	di->table_bytes = (uint32_t)(o_rc + ((W + 3u) & ~3u) - o_tw);
 }
 
@@ -1064,8 +1051,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			for (int plane = 0; plane < planes; plane++, set++)
 			{
 				InfillSet* is = blob.at<InfillSet>((uint32_t)(off_isets[cls] + set * sizeof(InfillSet)));
-				is->tw_off = di.off_texel_taps_idx;
-				is->tcf_off = di.off_texel_taps_f4;
+				is->tw_off = di.off_texel_weights;
+				is->tcf_off = di.off_texel_contribs_f;
 				is->dwi_offset = dms[i].dwi_offset[cls + plane];
 				is->refprec = refprec;
 				is->taps = (uint8_t)(di.max_texel_weight_count > 2 ? 4 : di.max_texel_weight_count > 1 ? 2 : 1);
@@ -1236,8 +1223,8 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 			const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + bm.decimation_mode * sizeof(DecimationInfo)));
 			ModeStatic ms;
 			memset(&ms, 0, sizeof(ms));
-			ms.tw_off = di.off_texel_taps_idx;
-			ms.tcf_off = di.off_texel_taps_f4;
+			ms.tw_off = di.off_texel_weights;
+			ms.tcf_off = di.off_texel_contribs_f;
 			const int cls = bm.is_dual_plane ? 1 : 0;
 			const uint32_t used = (cls ? dm.refprec_2planes : dm.refprec_1plane) & 0xFFu;
 			for (int plane = 0; plane <= cls; plane++)

@@ -499,9 +499,12 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 WV_FN int unpack_texel_weight(const uint8_t* uq, const uint8_t* tw, const uint8_t* tci, int T, int t, int taps)
 {
 	if (taps == 1) return uq[t];                  // an undecimated grid: one tap of weight 16, (8 + 16 w) >> 4 = w
+	(void)T;
+	// (the texel's four indices and four contributions: one 32-bit read each)
+	const uint32_t idx = reinterpret_cast<const uint32_t*>(tw)[t], contrib = reinterpret_cast<const uint32_t*>(tci)[t];
 	int sum = 8;
-	sum += uq[tw[t]] * tci[t] + uq[tw[T + t]] * tci[T + t];
-	if (taps > 2) sum += uq[tw[2 * T + t]] * tci[2 * T + t] + uq[tw[3 * T + t]] * tci[3 * T + t];
+	sum += (int)uq[idx & 0xFFu] * (int)(contrib & 0xFFu) + (int)uq[(idx >> 8) & 0xFFu] * (int)((contrib >> 8) & 0xFFu);
+	if (taps > 2) sum += (int)uq[(idx >> 16) & 0xFFu] * (int)((contrib >> 16) & 0xFFu) + (int)uq[idx >> 24] * (int)(contrib >> 24);
 	return sum >> 4;
 }
 

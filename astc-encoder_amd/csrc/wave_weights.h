@@ -12,20 +12,26 @@
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
-/* Bilinear infill of one texel from a weight array (ref: bilinear_infill_vla[_2] :38-97).  Unused
- * taps have zero contribution, so the 4-tap form equals the reference's count-specialised forms
- * whenever max_texel_weight_count > 2; the 2-tap form must be used otherwise. */
+/* Bilinear infill of one texel from a weight array (ref: bilinear_infill_vla[_2] :38-97).  `tw` / `tcf` are the
+ * per-texel records of a grid (DecimationInfo: [T][4] indices / contributions, usually the copy staged in LDS): one
+ * 32-bit and one 128-bit read.  Unused taps have zero contribution, so the 4-tap form equals the reference's
+ * count-specialised forms whenever max_texel_weight_count > 2; the 2-tap form must be used otherwise. */
 WV_FN float infill4(const float* wts, const uint8_t* tw, const float* tcf, int T, int t)
 {
-	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]) +
-	       (wts[tw[2 * T + t]] * tcf[2 * T + t] + wts[tw[3 * T + t]] * tcf[3 * T + t]);
+	(void)T;
+	const uint32_t idx = reinterpret_cast<const uint32_t*>(tw)[t];
+	const f4 cf = load4_aligned(tcf + 4 * t);
+	return (wts[idx & 0xFFu] * cf.x + wts[(idx >> 8) & 0xFFu] * cf.y) + (wts[(idx >> 16) & 0xFFu] * cf.z + wts[idx >> 24] * cf.w);
 }
 WV_FN float infill2(const float* wts, const uint8_t* tw, const float* tcf, int T, int t)
 {
-	return (wts[tw[t]] * tcf[t] + wts[tw[T + t]] * tcf[T + t]);
+	(void)T;
+	const uint32_t idx = reinterpret_cast<const uint32_t*>(tw)[t];
+	const float c0 = tcf[4 * t], c1 = tcf[4 * t + 1];
+	return (wts[idx & 0xFFu] * c0 + wts[(idx >> 8) & 0xFFu] * c1);
 }
 
-/* The same from the per-texel records of the table blob (DecimationInfo::off_texel_taps_idx / _f4, byte offsets): the
+/* The same from the table blob itself (DecimationInfo::off_texel_weights / off_texel_contribs_f as byte offsets): the
  * texel's four weight indices arrive in one 32-bit load and its four contributions in one 128-bit load, addressed as
  * uniform base + 32-bit offset.  `four_taps`: the grid has texels with more than two weights (else the 2-tap form). */
 struct TexelTaps { uint32_t idx; float c0, c1, c2, c3; };

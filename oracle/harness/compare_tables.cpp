@@ -70,14 +70,12 @@ int main(int argc, char** argv)
 		const float* tcf = (const float*)(B + e.off_texel_contribs_f);
 		for (unsigned t = 0; t < T; t++) for (unsigned j = 0; j < 4; j++)
 		{
-			CHECK(tw[j * T + t] == d.texel_weights_tr[j][t], "di %u tw", i);
-			CHECK(tci[j * T + t] == d.texel_weight_contribs_int_tr[j][t], "di %u tci", i);
-			CHECK(tcf[j * T + t] == d.texel_weight_contribs_float_tr[j][t], "di %u tcf", i);
-			// the per-texel records of the same tables
-			CHECK(B[e.off_texel_taps_idx + 4 * t + j] == d.texel_weights_tr[j][t], "di %u taps idx", i);
-			CHECK(((const float*)(B + e.off_texel_taps_f4))[4 * t + j] == d.texel_weight_contribs_float_tr[j][t], "di %u taps f4", i);
+			// (one record per texel here, transposed in the reference)
+			CHECK(tw[t * 4 + j] == d.texel_weights_tr[j][t], "di %u tw", i);
+			CHECK(tci[t * 4 + j] == d.texel_weight_contribs_int_tr[j][t], "di %u tci", i);
+			CHECK(tcf[t * 4 + j] == d.texel_weight_contribs_float_tr[j][t], "di %u tcf", i);
 		}
-		CHECK((e.off_texel_taps_f4 & 15u) == 0, "di %u taps f4 alignment", i);
+		CHECK((e.off_texel_weights & 15u) == 0 && (e.off_texel_contribs_f & 15u) == 0, "di %u texel table alignment", i);
 		const uint8_t* wtc = B + e.off_weight_texel_count; const uint8_t* wt = B + e.off_weight_texels;
 		const float* wc = (const float*)(B + e.off_weight_contribs); const float* tcw = (const float*)(B + e.off_texel_contrib_for_weight);
 		for (unsigned w = 0; w < W; w++)
