@@ -376,8 +376,9 @@ WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_co
 		if (stage_dm >= 0)
 		{
 			const DecimationInfo& dinfo = c.dec_info(stage_dm);
-			stage_words_nosync(c.lds + c.L->dtab, reinterpret_cast<const uint8_t*>(&dinfo), (int)(sizeof(DecimationInfo) / 4));
-			stage_words_nosync(c.lds + c.L->dtab + DTAB_RECORD_BYTES, c.table(dinfo.off_texel_weights), (int)((dinfo.table_bytes + 3) / 4));
+			// (the record and the tables are 16-byte aligned in the blob: 128-bit copies)
+			stage_quads_nosync(c.lds + c.L->dtab, reinterpret_cast<const uint8_t*>(&dinfo), (int)sizeof(DecimationInfo));
+			stage_quads_nosync(c.lds + c.L->dtab + DTAB_RECORD_BYTES, c.table(dinfo.off_texel_weights), (int)dinfo.table_bytes);
 		}
 		if (stage_wq >= 0)
 		{

@@ -35,7 +35,7 @@ WV_FN void stage_color_rows(const Ctx& c, int q0)
 	// (the rows of this level are there already: the previous candidate of the trial used the same one)
 	if (wv_uniform(tr.staged_color_quant[0]) == q0) { WV_SYNC(); return; }
 	const uint32_t* s0 = reinterpret_cast<const uint32_t*>(c.table(c.root->off_color_unquant_to_uquant) + (q0 - QUANT_6) * 512);
-	stage_words_nosync(c.lds + c.L->ctab, reinterpret_cast<const uint8_t*>(s0), 128);
+	stage_quads_nosync(c.lds + c.L->ctab, reinterpret_cast<const uint8_t*>(s0), 512);
 	WV_ONE { tr.staged_color_quant[0] = q0; tr.staged_color_quant[1] = -1; }
 	WV_SYNC();
 }

@@ -497,27 +497,61 @@ WV_FN void stage_words_nosync(uint8_t* lds_dst, const uint8_t* src, int words)
 	const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
 	uint32_t* d = reinterpret_cast<uint32_t*>(lds_dst);
 #if WV_DEVICE
-	// 8 loads in flight per lane before the first store: one memory round trip per 512 words
+	// up to 8 loads in flight per lane before the first store: one memory round trip per 512 words (and no more load
+	// instructions than the copy has 64-word pieces: most copies are one or two)
 	for (int base = 0; base < words; base += 512)
 	{
+		const int pieces = i_min(8, (words - base + 63) >> 6);        // wave-uniform
 		uint32_t v[8];
 		#pragma unroll
 		for (int u = 0; u < 8; u++)
 		{
-			int i = base + u * 64 + WV_LANE;
-			v[u] = s[i < words ? i : 0];
+			if (u < pieces)
+			{
+				int i = base + u * 64 + WV_LANE;
+				v[u] = s[i < words ? i : 0];
+			}
 		}
 		#pragma unroll
 		for (int u = 0; u < 8; u++)
 		{
 			int i = base + u * 64 + WV_LANE;
-			if (i < words) d[i] = v[u];
+			if (u < pieces && i < words) d[i] = v[u];
 		}
 	}
 #else
 	for (int i = 0; i < words; i++) d[i] = s[i];
 #endif
 }
+/* The same in 16-byte pieces (both addresses 16-byte aligned; the source may be read up to 12 bytes past `bytes`, the
+ * destination must hold the rounded size): a quarter of the load / store instructions of the word copy. */
+WV_FN void stage_quads_nosync(uint8_t* lds_dst, const uint8_t* src, int bytes)
+{
+	typedef uint32_t Quad __attribute__((vector_size(16)));       // (a native 128-bit value: stays in registers)
+	const int quads = (bytes + 15) >> 4;
+#if WV_DEVICE
+	const Quad* s = static_cast<const Quad*>(__builtin_assume_aligned(src, 16));
+	Quad* d = static_cast<Quad*>(__builtin_assume_aligned(lds_dst, 16));
+	// up to four loads in flight per lane, and no more load instructions than the copy has 64-quad pieces (named
+	// registers, not an indexed array: a conditionally filled array would live in scratch memory)
+	for (int base = 0; base < quads; base += 256)
+	{
+		const int n = quads - base;                                   // wave-uniform
+		const int i0 = base + WV_LANE, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+		Quad q0 = table_at(s, (uint32_t)(i0 < quads ? i0 : 0)), q1 = q0, q2 = q0, q3 = q0;
+		if (n > 64) q1 = table_at(s, (uint32_t)(i1 < quads ? i1 : 0));
+		if (n > 128) q2 = table_at(s, (uint32_t)(i2 < quads ? i2 : 0));
+		if (n > 192) q3 = table_at(s, (uint32_t)(i3 < quads ? i3 : 0));
+		if (i0 < quads) d[i0] = q0;
+		if (n > 64 && i1 < quads) d[i1] = q1;
+		if (n > 128 && i2 < quads) d[i2] = q2;
+		if (n > 192 && i3 < quads) d[i3] = q3;
+	}
+#else
+	__builtin_memcpy(lds_dst, src, (size_t)quads * 16);
+#endif
+}
+
 WV_FN void stage_words(uint8_t* lds_dst, const uint8_t* src, int words)
 {
 	stage_words_nosync(lds_dst, src, words);
