@@ -49,6 +49,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	c.L = reinterpret_cast<const LdsLayout*>(tab - CTX_LAYOUT_BACK);
 	c.T = wv_uniform((int)c.root->texel_count);
 	c.Tp = (c.T + 3) & ~3;
+	c.Ts = lds_row_stride(c.Tp);
 #if defined(ASTC_TRACE)
 	// trace builds: `prof` is the search trace buffer, one slice per block of the image (wave_ctx.h: TRACE_PUT)
 	if (prof) prof = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint32_t*>(prof) + (size_t)b * TRACE_WORDS_PER_BLOCK);

@@ -105,7 +105,7 @@ WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* tab, float ideal)
 WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
 {
 	ModeRec* modes = c.modes(start);
-	const int T = c.T, Tp = c.Tp;
+	const int T = c.T, Tp = c.Ts;                       // (Tp: the stride of the term rows below)
 	const int planes = dual ? 2 : 1;
 	const int chunk_modes = (int)c.L->mode_chunk;
 	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);

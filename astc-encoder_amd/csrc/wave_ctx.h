@@ -141,6 +141,12 @@ struct LdsLayout {
 /* Staged copy of a grid's tables in LDS (LdsLayout::dtab): its DecimationInfo record first (the refinement steps then
  * find sizes and offsets with an LDS read instead of two dependent global loads), the tables DTAB_RECORD_BYTES in. */
 constexpr uint32_t DTAB_RECORD_BYTES = 64;
+
+/* Stride (floats) of the texel-length scratch rows that several lanes walk side by side, one row each (the running sums
+ * of the endpoint re-fit, the term rows of the mode scoring): a texel count that is a multiple of 16 would put the same
+ * column of every row into the same LDS bank -- 8x8 blocks: 64 floats = twice the 32 banks, a 14-way conflict on every
+ * read of the re-fit's chains -- so those footprints get four floats of padding per row (rows stay 16-byte aligned). */
+WV_FN int lds_row_stride(int Tp) { return Tp + ((Tp & 15) == 0 ? 4 : 0); }
 static_assert(sizeof(DecimationInfo) <= DTAB_RECORD_BYTES, "DecimationInfo outgrew its staged slot");
 
 constexpr uint32_t LDS_ALLOC_GRANULE = 1280;   // gfx950: 160 KiB of LDS per CU in 128 allocation units
@@ -193,7 +199,8 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	}
 	L.uni_bytes = uni_region_bytes(r.texel_count, cfg.tune_partition_count_limit);
 	L.t_inv24 = ((1u << 24) + (uint32_t)r.texel_count - 1u) / (uint32_t)r.texel_count;
-	L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);
+	const uint32_t Ts = (uint32_t)lds_row_stride((int)Tp);
+	L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Ts * 4);
 	for (int cls = 0; cls < 2; cls++)
 	{
 		const uint32_t cap = (r.max_weights[cls] + 3u) & ~3u;
@@ -207,12 +214,12 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.dtab = take(DTAB_RECORD_BYTES + r.max_decimation_table_bytes);    // the candidate grid's DecimationInfo record, then its tables
 	L.ctab = take(512);
 	L.qtab = take(sizeof(QuantXfer));
-	L.rsc = take(19 * Tp * 4);
+	L.rsc = take(19 * Ts * 4);
 	{
 		// the re-fit rows double as scratch of the difference / realign steps; realign needs 3 texel rows + 12 rows of
 		// one weight's texel list
-		uint32_t need = 3 * Tp + r.realign_rt_floats;
-		if (need > 19 * Tp) { o = L.rsc; take(need * 4); }
+		uint32_t need = 3 * Ts + r.realign_rt_floats;
+		if (need > 19 * Ts) { o = L.rsc; take(need * 4); }
 	}
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
 	L.wsc = take(2 * 64 * 4);
@@ -226,7 +233,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		if (rounded <= 64u * 1024u)
 		{
 			L.uni_bytes = (rounded - L.uni) & ~15u;
-			L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);
+			L.mode_chunk = L.uni_bytes / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Ts * 4);
 			if (L.mode_chunk > 32u) L.mode_chunk = 32u;
 			end = rounded;
 		}
@@ -294,6 +301,7 @@ struct Ctx {
 	const LdsLayout* L;          // in the table blob (constant memory): fields are scalar loads
 	int T;                       // texels per block
 	int Tp;                      // T rounded up to 4
+	int Ts;                      // lds_row_stride(Tp): stride of the scratch rows that lanes walk side by side
 	unsigned long long* prof;    // stage cycle counters (profiling builds only), else null
 
 	// a table of the blob at byte offset `off` (an offset read from the blob): scalar base pointer, so that lane-variant
@@ -323,7 +331,7 @@ struct Ctx {
 	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L->wsc) + row * 64; }
 	WV_FN uint8_t* fmt() const { return lds + L->uni; }
 	WV_FN uint8_t* part() const { return lds + L->part; }
-	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L->rsc) + row * Tp; }
+	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L->rsc) + row * Ts; }
 	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
@@ -364,6 +372,7 @@ WV_FN Ctx ctx_make_as()
 	c.lds = astc_lds;
 	c.T = wv_uniform((int)c.root->texel_count);
 	c.Tp = (c.T + 3) & ~3;
+	c.Ts = lds_row_stride(c.Tp);
 	return c;
 }
 WV_FN Ctx ctx_make() { return ctx_make_as<true>(); }

@@ -70,6 +70,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.lds = lds.data();
 	c.T = root->texel_count;
 	c.Tp = (c.T + 3) & ~3;
+	c.Ts = lds_row_stride(c.Tp);
 	c.prof = nullptr;
 	g_wave_ctx = &c;
 

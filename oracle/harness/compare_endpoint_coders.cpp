@@ -50,7 +50,7 @@ int main(int argc, char** argv)
 	astcd::DeviceConfig cfg; memset(&cfg, 0, sizeof(cfg));
 	astcd::TableRoot root; memset(&root, 0, sizeof(root));
 	astcd::Ctx c; memset(&c, 0, sizeof(c));
-	c.lds = lds.data(); c.L = &L; c.cfg = &cfg; c.root = &root; c.T = 16; c.Tp = 16;
+	c.lds = lds.data(); c.L = &L; c.cfg = &cfg; c.root = &root; c.T = 16; c.Tp = 16; c.Ts = astcd::lds_row_stride(16);
 	astcd::g_wave_ctx = &c;
 	astcd::TrialInfo& tr = c.tr();
 
