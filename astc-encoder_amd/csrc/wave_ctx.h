@@ -147,6 +147,10 @@ constexpr uint32_t DTAB_RECORD_BYTES = 64;
  * column of every row into the same LDS bank -- 8x8 blocks: 64 floats = twice the 32 banks, a 14-way conflict on every
  * read of the re-fit's chains -- so those footprints get four floats of padding per row (rows stay 16-byte aligned). */
 WV_FN int lds_row_stride(int Tp) { return Tp + ((Tp & 15) == 0 ? 4 : 0); }
+/* ... and the re-fit rows (Ctx::rsc): up to 18 lanes each walk their own row; Tp is a multiple of 4, so Tp + 2 shares
+ * only a factor 2 with the 32 banks: sixteen consecutive rows start in sixteen different banks (even rows stay 16-byte
+ * aligned, which is what the arrays carved out of row 2 onwards rely on). */
+WV_FN int lds_refit_stride(int Tp) { return Tp + 2; }
 static_assert(sizeof(DecimationInfo) <= DTAB_RECORD_BYTES, "DecimationInfo outgrew its staged slot");
 
 constexpr uint32_t LDS_ALLOC_GRANULE = 1280;   // gfx950: 160 KiB of LDS per CU in 128 allocation units
@@ -214,12 +218,13 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.dtab = take(DTAB_RECORD_BYTES + r.max_decimation_table_bytes);    // the candidate grid's DecimationInfo record, then its tables
 	L.ctab = take(512);
 	L.qtab = take(sizeof(QuantXfer));
-	L.rsc = take(19 * Ts * 4);
+	const uint32_t Tr = (uint32_t)lds_refit_stride((int)Tp);
+	L.rsc = take(19 * Tr * 4);
 	{
 		// the re-fit rows double as scratch of the difference / realign steps; realign needs 3 texel rows + 12 rows of
 		// one weight's texel list
-		uint32_t need = 3 * Ts + r.realign_rt_floats;
-		if (need > 19 * Ts) { o = L.rsc; take(need * 4); }
+		uint32_t need = 3 * Tr + r.realign_rt_floats;
+		if (need > 19 * Tr) { o = L.rsc; take(need * 4); }
 	}
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
 	L.wsc = take(2 * 64 * 4);
@@ -331,7 +336,7 @@ struct Ctx {
 	WV_FN float* wsc(int row) const { return reinterpret_cast<float*>(lds + L->wsc) + row * 64; }
 	WV_FN uint8_t* fmt() const { return lds + L->uni; }
 	WV_FN uint8_t* part() const { return lds + L->part; }
-	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L->rsc) + row * Ts; }
+	WV_FN float* rsc(int row) const { return reinterpret_cast<float*>(lds + L->rsc) + row * lds_refit_stride(Tp); }
 	WV_FN uint8_t* candw(int n) const { return lds + L->candw + n * 64; }
 
 	// table accessors
