@@ -61,10 +61,13 @@ ASTC_HD inline uint32_t fmt_scratch_bytes(uint32_t partition_limit)
 	// best_error f32 [P][17][4], format_of_choice u8 [P][17][4]; comb_error f32 [17][cols], comb_format u16 [17][cols] (four 4-bit formats)
 	return P * FMT_QUANT_ROWS * 4 * 4 + P * FMT_QUANT_ROWS * 4 + FMT_QUANT_ROWS * fmt_comb_cols(P) * (4 + 2);
 }
+// floats per (grid, step) record of the angular search's batch (six used; nine: an odd stride, so that the lanes of a
+// batch -- one record each -- do not all land in the same four LDS banks)
+constexpr uint32_t ANG_PAIR_STRIDE = 9;
 ASTC_HD inline uint32_t uni_region_bytes(uint32_t texel_count, uint32_t partition_limit)
 {
 	const uint32_t Tp = (texel_count + 3u) & ~3u;
-	uint32_t bytes = 64 * 8 * 4;                                   // angular batch
+	uint32_t bytes = 64 * ANG_PAIR_STRIDE * 4;                     // angular batch
 	if (8u * (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4) > bytes) bytes = 8u * (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);   // mode scoring: descriptors, quantized weights, texel terms of 8 modes
 	if (fmt_scratch_bytes(partition_limit) > bytes) bytes = fmt_scratch_bytes(partition_limit);
 	if (5 * Tp * 4 > bytes) bytes = 5 * Tp * 4;                    // encoding-choice rows

@@ -253,6 +253,9 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	{
 		// as many candidate records as fit without growing the block's LDS (at least 8, at most one per lane)
 		uint32_t rec = (uint32_t)(sizeof(PartitionHeader) + 2 * r.texel_count + 3u) & ~3u;
+		// (an odd number of words: the candidates' lanes read the same position of consecutive records, which then fall
+		// into different banks; the extra word is the first one of the next record in the blob)
+		if (((rec >> 2) & 1u) == 0) rec += 4;
 		uint32_t room = end > o ? (end - o) / rec : 0;
 		uint32_t chunk = room < 8 ? 8 : room;
 		if (chunk > 64) chunk = 64;

@@ -308,7 +308,7 @@ struct AngSet {
 template <typename SetFn>
 WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 {
-	float* ang = c.ang();               // [64][8]: offset, lowest, span, err, cut_low, cut_high
+	float* ang = c.ang();               // [64][ANG_PAIR_STRIDE]: offset, lowest, span, err, cut_low, cut_high
 	TrialInfo& tr = c.tr();
 	struct CosSin { float cs, sn; };
 	const CosSin* cos_sin_table = reinterpret_cast<const CosSin*>(c.table(c.root->off_cos_sin_table));
@@ -441,7 +441,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			float ssize = 1.0f / rcp_stepsize;
 			float errscale = ssize * ssize;
 
-			float* o = ang + k * 8;
+			float* o = ang + k * (int)ANG_PAIR_STRIDE;
 			o[0] = offset;
 			o[1] = minidx;
 			o[2] = int_as_float(span);
@@ -458,7 +458,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			if (qi <= a.maxq && ((a.used >> qi) & 1u))
 			{
 				int steps = steps_for_quant_level(a.maxq);
-				const float* base = ang + tr.ibox[s - s0] * 8;
+				const float* base = ang + tr.ibox[s - s0] * (int)ANG_PAIR_STRIDE;
 				int q = steps_for_quant_level(qi);
 
 				// sequential scan with the reference's update order and strict '>' tests,
@@ -468,7 +468,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				float best_cut = 0.0f;
 				for (int i = 0; i < steps; i++)
 				{
-					const float* r = base + i * 8;
+					const float* r = base + i * (int)ANG_PAIR_STRIDE;
 					const int idx_span = float_as_int(r[2]);
 					const float err = r[3], cl = r[4], ch = r[5];
 					// Which of the reference's three cases this step is for span index q (ref: :300-340), without branching
@@ -485,7 +485,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 
 				int bsi = (int)best_idx;
 				bsi = i_max(0, bsi);
-				const float* r = base + bsi * 8;
+				const float* r = base + bsi * (int)ANG_PAIR_STRIDE;
 				float lwi = r[1] + best_cut;
 				float hwi = lwi + (float)q - 1.0f;
 				float stepsize = 1.0f / (1.0f + (float)bsi);
