@@ -53,6 +53,10 @@
 	#endif
 	#define WV_FOR(i, n) for (int i = WV_LANE; i < (int)(n); i += 64)
 	#define WV_ONE if (WV_LANE == 0)
+	// WV_FOR for a count that is known to be at most 64 (the weights of a grid, partitions x channels, candidates ...): one
+	// trip by construction -- the compiler cannot see the bound of a run-time count and would otherwise wrap the body in a
+	// divergent loop (an exec-mask exit test of half a dozen instructions) that never takes its back edge
+	#define WV_FOR64(i, n) for (int i = WV_LANE, wv_once_##i = 1; wv_once_##i && i < (int)(n); wv_once_##i = 0)
 #else
 	#define WV_DEVICE 0
 	#if defined(__HIPCC__)
@@ -70,6 +74,7 @@
 	#else
 	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)
 	#endif
+	#define WV_FOR64(i, n) WV_FOR(i, n)
 	#define WV_ONE if (true)
 #endif
 

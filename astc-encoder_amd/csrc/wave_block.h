@@ -61,7 +61,7 @@ WV_FN void quantize_mode_weights(const Ctx& c, const BlockMode& bm, int plane, f
 	QuantParams qp = quant_params(low, high, bm.quant_mode);
 	const uint8_t* q2u = c.qxfer(bm.quant_mode).quant_to_unquant;
 	const float* ideal = c.dwi(bm.decimation_mode, plane, bm.is_dual_plane != 0);
-	WV_FOR(i, di.weight_count)
+	WV_FOR64(i, di.weight_count)
 	{
 		float f;
 		int w = quantize_weight(qp, q2u, ideal[i], &f);
@@ -323,7 +323,7 @@ WV_OUT void refine_quantize_candidates(bool dual, int partition_count, int parti
 	const int plane_shift = dual ? 1 : 0;
 	ModeQ* cq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni);          // [candidate][plane]; the scoring scratch is idle now
 	const float* ldsf = reinterpret_cast<const float*>(c.lds);
-	WV_FOR(k, candidate_count << plane_shift)
+	WV_FOR64(k, candidate_count << plane_shift)
 	{
 		const int ci = k >> plane_shift, plane = k & plane_shift;
 		const BlockMode& bm = c.block_mode(tr.cand_block_mode[ci]);
@@ -390,7 +390,7 @@ WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_co
 	// workep = ideal endpoints (merged across planes for dual plane); quantized weights come from
 	// refine_quantize_candidates()
 	PROF_SCOPE(c, PS_Y1);
-	WV_FOR(k, partition_count * 4)
+	WV_FOR64(k, partition_count * 4)
 	{
 		int p = k >> 2, ch = k & 3;
 		int plane = (dual && ch == plane2_component) ? 1 : 0;
@@ -445,7 +445,7 @@ WV_OUT void refine_pack_hdr(int partition_count, int candidate, int to_scratch, 
 	uint8_t* have_decoded = fmts + 4;
 	uint8_t* tries = reinterpret_cast<uint8_t*>(tr.fbox);             // (the re-fit's sums are consumed by now)
 	static_assert(sizeof(tr.fbox) >= 4 * HDR_TRY_LANES * HDR_TRY_BYTES, "sub-mode records do not fit the mailbox");
-	WV_FOR(j, partition_count) { if (!to_scratch && endpoint_format_is_hdr(tr.cand_formats[candidate][j])) have_decoded[j] = 0; }
+	WV_FOR64(j, partition_count) { if (!to_scratch && endpoint_format_is_hdr(tr.cand_formats[candidate][j])) have_decoded[j] = 0; }
 	pack_endpoints_hdr(c, partition_count, tr.cand_formats[candidate], to_scratch ? colorvals : &workscb.color_values[0][0],
 	                   to_scratch ? fmts : workscb.color_formats, quant_level, tries);
 }
@@ -478,7 +478,7 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 		const int q = to_scratch ? quant_level_mod : quant_level;
 		if (to_scratch) stage_color_rows(c, q);        // (rare: the retry level's rows replace the candidate's, put back below)
 		// four lanes per partition, one colour channel each (wave_quad.h)
-		WV_QUADS(j, partition_count)
+		WV_QUADS16(j, partition_count)
 		{
 			const int requested = tr.cand_formats[candidate][j];
 			if (kHdr && endpoint_format_is_hdr(requested)) continue;
@@ -522,8 +522,8 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 			if (wv_uniform(all_same_mod))
 			{
 				formats_matched = 1;
-				WV_FOR(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
-				WV_FOR(j, partition_count) { workscb.color_formats[j] = fmts[j]; have_decoded[j] = 0; }
+				WV_FOR64(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = colorvals[k]; }
+				WV_FOR64(j, partition_count) { workscb.color_formats[j] = fmts[j]; have_decoded[j] = 0; }
 			}
 			WV_SYNC();
 		}
@@ -531,7 +531,7 @@ __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_c
 	// The decoded endpoints of what was just packed: the scoring and weight realignment steps that follow (up to three
 	// of them before the next packing) all start from these (tr.ibox[p * 8 ..]).  The direct and base + offset formats
 	// left them there while packing; the others (and a retry that replaced the values) are decoded here.
-	WV_FOR(p, partition_count)
+	WV_FOR64(p, partition_count)
 	{
 		if (have_decoded[p]) continue;
 		i4 e0, e1;

@@ -568,7 +568,7 @@ WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* 
 	const TrialInfo& tr = c.tr();
 	const ColorTabs t = color_tabs(c, quant_level);
 	// the sub-modes, side by side
-	WV_FOR(k, partition_count * HDR_TRY_LANES)
+	WV_FOR64(k, partition_count * HDR_TRY_LANES)
 	{
 		const int p = k / HDR_TRY_LANES, lane = k % HDR_TRY_LANES;
 		const int format = requested[p];
@@ -586,7 +586,7 @@ WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* 
 	}
 	WV_SYNC();
 	// first sub-mode that fits, else the escape layout
-	WV_FOR(p, partition_count)
+	WV_FOR64(p, partition_count)
 	{
 		const int format = requested[p];
 		if (!endpoint_format_is_hdr(format)) continue;

@@ -123,7 +123,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 		compute_avgs_and_dirs(c, pv, rgb);
 
 		// processed lines per partition -> fbox[p*16 + ..]: uncor amod(3) bs(3), samec bs(3), rgbl amod(3)
-		WV_FOR(p, pc)
+		WV_FOR64(p, pc)
 		{
 			f4 avg = load4(tr.pm_avg[p]);
 			f4 dir = load4(tr.pm_dir[p]);
@@ -181,7 +181,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 		}
 		WV_SYNC();
 
-		WV_FOR(k, pc * 5)
+		WV_FOR64(k, pc * 5)
 		{
 			int p = k / 5, which = k % 5;
 			tr.fbox[64 - 20 + k] = sum4(c.tsc_f(which) + pv.off(p), pv.cnt(p));
@@ -190,7 +190,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 
 	}
 
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		const float* s = &tr.fbox[64 - 20 + p * 5];
 		float e_scale, e_luma, e_lum, e_drop;
@@ -716,7 +716,7 @@ WV_FN void select_candidate_modes(const Ctx& c, int pc, int start_block_mode, in
 	}
 	// the quant levels and formats of the winners: the same pick as in the scoring pass, now with its outputs, one lane
 	// per winner (the table lookups of all of them in flight together)
-	WV_FOR(n, count)
+	WV_FOR64(n, count)
 	{
 		const int mode = tr.cand_block_mode[n];
 		for (int j = 0; j < 4; j++) tr.cand_formats[n][j] = 0;

@@ -39,7 +39,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	else
 	{
 		// 4-accumulator masked sums for all but the last partition (ref: :67-84, :238-258)
-		WV_FOR(k, (pc - 1) * n * 4)
+		WV_FOR64(k, (pc - 1) * n * 4)
 		{
 			const uint32_t n_inv = n == 4 ? 64u : n == 3 ? 86u : n == 2 ? 128u : 256u;      // (k >> 2) / n by multiply-shift
 			int l = k & 3, p = (int)((((uint32_t)k >> 2) * n_inv) >> 8), j = (k >> 2) - p * n;
@@ -77,7 +77,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	WV_SYNC();
 
 	// sum of offsets over the texels whose component `which` is above the mean (ref: :409-433)
-	WV_FOR(k, pc * n * n)
+	WV_FOR64(k, pc * n * n)
 	{
 		// (n is 2, 3 or 4: divisions by multiply-shift, exact for k < 128 -- the device has no integer divide)
 		const uint32_t n_inv = n == 4 ? 64u : n == 3 ? 86u : n == 2 ? 128u : 256u;
@@ -100,7 +100,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	}
 	WV_SYNC();
 
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		float best[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 		float best_sum = 0.0f;
@@ -144,7 +144,7 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 		}
 		wv_all_minmax(lo_part, hi_part);
 	}
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		float lowvalue = 1e10f, highvalue = -1e10f;
 		if (pc == 1)
@@ -214,7 +214,7 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	compute_avgs_and_dirs(c, pv, cs);
 
 	// normalised line direction per partition -> fbox[32 + p*4 + j]
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		f4 dir = load4(tr.pm_dir[p]);
 		float s = n == 2 ? hadd_s(dir) : hadd_rgb_s(dir);
@@ -246,7 +246,7 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	if (pc == 1) wv_all_minmax(lo_part, hi_part);
 	WV_SYNC();
 
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		float lowparam = 1e10f, highparam = -1e10f;
 		if (pc == 1)

@@ -63,7 +63,7 @@ WV_FN void encode_ise_lanes(const Ctx& c, int quant, int count, const uint8_t* s
 	const uint32_t bits = b.bits, low_mask = (1u << bits) - 1u;
 	const uint8_t* trit_tab = c.table(c.root->off_integer_of_trits);
 	const uint8_t* quint_tab = c.table(c.root->off_integer_of_quints);
-	WV_FOR(s, count)
+	WV_FOR64(s, count)
 	{
 		const uint32_t v = sym[s];
 		if (b.trits)
@@ -148,7 +148,7 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 	{
 		const QuantXfer& qat = c.qxfer(wq);
 		const float top = (float)quant_level_count(wq) - 1.0f;
-		WV_FOR(s, real_weight_count)
+		WV_FOR64(s, real_weight_count)
 		{
 			const int i = dual ? s >> 1 : s, plane = dual ? s & 1 : 0;
 			const float uqw = (float)scb.weights[i + plane * PLANE2_OFFSET];
@@ -161,7 +161,7 @@ WV_FN void symbolic_to_physical(const Ctx& c, const Scb& scb, uint8_t* pcb_out)
 	value_count = wv_uniform(value_count);
 	{
 		const uint8_t* pack_table = c.table(c.root->off_color_uquant_to_pquant) + (colour_quant - QUANT_6) * 256;
-		WV_FOR(v, value_count)
+		WV_FOR64(v, value_count)
 		{
 			// value v of the block = value j of partition p
 			int p = 0, j = v;

@@ -141,7 +141,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		if (iter > 0)
 		{
 			// kmeans_update: per (partition, channel) sequential sums in texel order (ref: :210-243)
-			WV_FOR(k, pc * 4)
+			WV_FOR64(k, pc * 4)
 			{
 				int p = k >> 2, ch = k & 3;
 				const float* d = c.data(ch);
@@ -158,7 +158,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 				tr.fbox[16 + k] = sum * scale;
 			}
 			WV_SYNC();
-			WV_FOR(k, pc * 4) { centers[k] = tr.fbox[16 + k]; }
+			WV_FOR64(k, pc * 4) { centers[k] = tr.fbox[16 + k]; }
 			WV_SYNC();
 		}
 
@@ -245,7 +245,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		}
 	}
 #else
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		uint64_t bm = 0;
 		for (int i = 0; i < texels_to_process; i++)
@@ -604,7 +604,7 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 			staged[wv_opaque(k)] = table_at_byte<uint32_t>(part_base, (uint32_t)ps.ordering()[first + sl] * part_stride + (uint32_t)w * 4u);
 		}
 		WV_SYNC();
-		WV_FOR(i, nn)
+		WV_FOR64(i, nn)
 		{
 			const uint8_t* rec = reinterpret_cast<const uint8_t*>(staged + i * rec_words);
 			PartView pv;

@@ -24,6 +24,8 @@ namespace astcd { inline namespace ASTC_VARIANT {
 #define Q_CH (WV_LANE & 3)
 /* Quad p runs on lanes 4p .. 4p+3; at most 16 quads per pass. */
 #define WV_QUADS(p, n) for (int p = WV_LANE >> 2; p < (int)(n); p += 16)
+/* ... at most 16 of them: one trip by construction (see WV_FOR64) */
+#define WV_QUADS16(p, n) for (int p = WV_LANE >> 2, wv_once_##p = 1; wv_once_##p && p < (int)(n); wv_once_##p = 0)
 
 struct qf { float v; };
 struct qi { int v; };
@@ -109,6 +111,7 @@ WV_FN void q_store_i32(int* p, qi a) { p[Q_CH] = a.v; }
 #else // ------------------------------------------------------------------------------------------------------
 
 #define WV_QUADS(p, n) for (int p = 0; p < (int)(n); p++)
+#define WV_QUADS16(p, n) WV_QUADS(p, n)
 
 struct qf { float v[4]; };
 struct qi { int v[4]; };

@@ -43,7 +43,7 @@ WV_FN void expand_weights(const Ctx& c, const DecView& di, const uint8_t* uq, fl
 {
 	(void)c;
 	const int T = di.T, W = di.W;
-	WV_FOR(i, W) { grid[i] = (float)uq[i] * (1.0f / 64.0f); }
+	WV_FOR64(i, W) { grid[i] = (float)uq[i] * (1.0f / 64.0f); }
 	WV_SYNC();
 	const uint8_t* tw = di.tw;
 	const float* tcf = di.tcf;
@@ -106,7 +106,7 @@ WV_FN void trial_scale_directions(const Ctx& c, const PartView& pv, bool dual)
 	}
 	if (pc > 1)
 	{
-		WV_FOR(k, pc * 4)
+		WV_FOR64(k, pc * 4)
 		{
 			int p = k >> 2, ch = k & 3;
 			const float* d = c.data(ch);
@@ -121,7 +121,7 @@ WV_FN void trial_scale_directions(const Ctx& c, const PartView& pv, bool dual)
 		WV_FOR(k, 4) { tr.fbox[96 + k] = blk.data_mean[k] * (float)c.T; }
 	}
 	WV_SYNC();
-	WV_FOR(p, pc)
+	WV_FOR64(p, pc)
 	{
 		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * load4(blk.cw);
 		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.cnt(p), splat4(1e-17f));
@@ -200,7 +200,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	}
 	else
 	{
-		WV_FOR(k, pc * 15)
+		WV_FOR64(k, pc * 15)
 		{
 			int p = k / 15, r = k % 15;
 			const float* v = c.rsc(r) + pv.off(p);
@@ -228,7 +228,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 
 	// the solve, one lane per (partition, channel): every quantity below is channel-wise in the reference's vector
 	// code (ref: :1271-1340), the per-partition scalars are simply recomputed by the four lanes of a partition
-	WV_FOR(k, pc * 4)
+	WV_FOR64(k, pc * 4)
 	{
 		const int p = k >> 2, ch = k & 3;
 		const float* s = &tr.fbox[p * 24];
@@ -291,7 +291,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	WV_SYNC();
 	if (kHdr && (blk.rgb_lns || blk.alpha_lns))
 	{
-		WV_FOR(p, pc)
+		WV_FOR64(p, pc)
 		{
 			const float* s = &tr.fbox[p * 24];
 			const float right_sum_s = s[6], weight_weight_sum_s = s[7];
@@ -647,7 +647,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 		// endpoint base and per-weight-step offset, with the other plane's channels frozen
 		// -> fbox[p*8 + 0..3] = endpnt0f, fbox[p*8 + 4..7] = offset
-		WV_FOR(k, pc * 4)
+		WV_FOR64(k, pc * 4)
 		{
 			int p = k >> 2, ch = k & 3;
 			const int* e = &tr.ibox[p * 8];
@@ -718,7 +718,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			float* rt = c.rsc(2);                                    // [slots of this grid][12] rows of `rs` floats
 			float* wb = rt + (int)c.root->realign_rt_floats;         // [T] current weights infilled to texel resolution
 
-			WV_FOR(i, W)
+			WV_FOR64(i, W)
 			{
 				int u = uq[i];
 				uqf[i] = (float)u;
@@ -822,7 +822,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						// instruction instead of four, and the error is the quad's hadd in the reference's order.
 						const qf error_weight_q = q_load(blk.cw);
 						const qf color_offset_q = q_load(&tr.fbox[4]);
-						WV_QUADS(k, items)
+						WV_QUADS16(k, items)
 						{
 							const int we = all ? k : REALIGN_LATER_ENTRY(k);
 							const int uqw = uq[we];

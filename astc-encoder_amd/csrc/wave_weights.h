@@ -352,7 +352,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			s1++;
 		}
 		WV_SYNC();
-		WV_FOR(sl, s1 - s0)
+		WV_FOR64(sl, s1 - s0)
 		{
 			const int base = tr.ibox[sl], steps = set_steps[sl];
 			for (int j = 0; j < steps; j++) pair_set[base + j] = (uint8_t)sl;
@@ -360,7 +360,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		WV_SYNC();
 
 		{ PROF_SCOPE(c, PS_ANG1);
-		WV_FOR(k, pairs)
+		WV_FOR64(k, pairs)
 		{
 			// (set, step) of pair k
 			const int sl = pair_set[k];
