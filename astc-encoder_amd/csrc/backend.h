@@ -95,6 +95,11 @@ int astc_kernel_prepare_ldr(const TableRoot& root, const DeviceConfig& cfg, uint
 int astc_kernel_prepare_hdr(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
 int astc_kernel_launch_ldr(const KernelLaunch& k);
 int astc_kernel_launch_hdr(const KernelLaunch& k);
+// ... and the builds for footprints of at most 64 texels (kernel_ldr64.hip / kernel_hdr64.hip)
+int astc_kernel_prepare_ldr64(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
+int astc_kernel_prepare_hdr64(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
+int astc_kernel_launch_ldr64(const KernelLaunch& k);
+int astc_kernel_launch_hdr64(const KernelLaunch& k);
 
 /* Alpha-average pre-pass launch (kernel_alpha.hip).  The padded tile of a region lives in LDS while it fits
  * (ALPHA_LDS_LIMIT) and otherwise in d_scratch: astc_alpha_scratch_bytes() says how much of it and for how many

@@ -75,6 +75,23 @@ struct DeviceGuard {
 	~DeviceGuard() { if (ok) (void)hipSetDevice(saved); }
 };
 
+/* Four builds of the compression kernel: LDR / HDR coders x footprints of at most 64 texels (whose texel loops make one
+ * trip, kernel_ldr64.hip) / the larger ones. */
+int kernel_prepare(const Backend* b, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes)
+{
+	const bool small = b->root.texel_count <= 64;
+	if (b->hdr) return small ? astc_kernel_prepare_hdr64(b->root, b->cfg, lds_bytes, layout_out, layout_bytes)
+	                         : astc_kernel_prepare_hdr(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
+	return small ? astc_kernel_prepare_ldr64(b->root, b->cfg, lds_bytes, layout_out, layout_bytes)
+	             : astc_kernel_prepare_ldr(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
+}
+int kernel_launch(const Backend* b, const KernelLaunch& k)
+{
+	const bool small = b->root.texel_count <= 64;
+	if (b->hdr) return small ? astc_kernel_launch_hdr64(k) : astc_kernel_launch_hdr(k);
+	return small ? astc_kernel_launch_ldr64(k) : astc_kernel_launch_ldr(k);
+}
+
 void slot_destroy(DeviceSlot* s)
 {
 	if (!s) return;
@@ -113,8 +130,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	SLOT_TRY(hipSetDevice(device), 2);
 	{
 		uint8_t layout[256]; uint32_t layout_bytes = 0, lds_bytes = 0;
-		int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &lds_bytes, layout, &layout_bytes)
-		                 : astc_kernel_prepare_ldr(b->root, b->cfg, &lds_bytes, layout, &layout_bytes);
+		int prc = kernel_prepare(b, &lds_bytes, layout, &layout_bytes);
 		if (prc != 0)
 		{
 			fprintf(stderr, "astcenc_amd: kernel setup failed on device %d (hip error %d)\n", device, prc);
@@ -252,8 +268,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	uint32_t layout_bytes = 0;
 	{
 		// layout record of the block's LDS working set (the kernels' dynamic-LDS attribute is per device: slot_create)
-		int prc = b->hdr ? astc_kernel_prepare_hdr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes)
-		                 : astc_kernel_prepare_ldr(b->root, b->cfg, &b->lds_bytes, layout, &layout_bytes);
+		int prc = kernel_prepare(b, &b->lds_bytes, layout, &layout_bytes);
 		if (prc != 0)
 		{
 			fprintf(stderr, "astcenc_amd: kernel setup failed (hip error %d)\n", prc);
@@ -493,7 +508,7 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		KernelLaunch k;
 		k.d_tab = s->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
 		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = s->d_prof;
-		int lrc = b->hdr ? astc_kernel_launch_hdr(k) : astc_kernel_launch_ldr(k);
+		int lrc = kernel_launch(b, k);
 		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }
 		launched = first + n;
 		if (banded)

@@ -57,6 +57,13 @@
 	// trip by construction -- the compiler cannot see the bound of a run-time count and would otherwise wrap the body in a
 	// divergent loop (an exec-mask exit test of half a dozen instructions) that never takes its back edge
 	#define WV_FOR64(i, n) for (int i = WV_LANE, wv_once_##i = 1; wv_once_##i && i < (int)(n); wv_once_##i = 0)
+	// loops over the texels of a block: one trip in the kernel build for footprints of at most 64 texels (every 2D
+	// footprint up to 8x8, 3D up to 4x4x4), the general loop in the build for the larger ones
+	#if defined(ASTC_TEXELS_LE_64)
+	#define WV_FOR_T(i, n) WV_FOR64(i, n)
+	#else
+	#define WV_FOR_T(i, n) WV_FOR(i, n)
+	#endif
 #else
 	#define WV_DEVICE 0
 	#if defined(__HIPCC__)
@@ -75,6 +82,7 @@
 	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)
 	#endif
 	#define WV_FOR64(i, n) WV_FOR(i, n)
+	#define WV_FOR_T(i, n) WV_FOR(i, n)
 	#define WV_ONE if (true)
 #endif
 

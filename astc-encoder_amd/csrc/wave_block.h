@@ -1032,7 +1032,7 @@ WV_FN float prepare_block_statistics(const Ctx& c)
 
 WV_OUT int stage_partition_order(int partition_count)
 {
-	const Ctx c = ctx_make();
+	const Ctx c = ctx_make_vector_tables();
 	partition_count = wv_uniform(partition_count);
 	PROF_SCOPE(c, PS_KMEANS);
 	return partition_search_order(c, partition_count);

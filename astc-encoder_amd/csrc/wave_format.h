@@ -145,7 +145,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 		// per-texel error terms in partition order (ref: :124-201)
 		const float default_a = blk_default_alpha(blk);
 		const float ew0 = blk.cw[0], ew1 = blk.cw[1], ew2 = blk.cw[2];
-		WV_FOR(i, T)
+		WV_FOR_T(i, T)
 		{
 			int t = pv.sorted[i];
 			int p = pv.of_texel[t];

@@ -136,7 +136,7 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 	float lo_part = 1e10f, hi_part = -1e10f;
 	if (pc == 1)
 	{
-		WV_FOR(t, T)
+		WV_FOR_T(t, T)
 		{
 			const float value = d[t];
 			lo_part = f_min(value, lo_part);
@@ -178,7 +178,7 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 		}
 	}
 	WV_SYNC();
-	WV_FOR(t, c.Tp)
+	WV_FOR_T(t, c.Tp)
 	{
 		if (t < T)
 		{
@@ -231,7 +231,7 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	// raw line parameter of every texel (ref: :282-291, :431-440, :553-562); with one partition its range is folded
 	// across the wave on the way (minimum / maximum of finite values: exact whatever the order)
 	float lo_part = 1e10f, hi_part = -1e10f;
-	WV_FOR(t, T)
+	WV_FOR_T(t, T)
 	{
 		int p = pv.of_texel[t];
 		f4 pt = mk4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -291,7 +291,7 @@ WV_FN void ideal_colors_and_weights_ncomp(const Ctx& c, const PartView& pv, int 
 	}
 	WV_SYNC();
 
-	WV_FOR(t, c.Tp)
+	WV_FOR_T(t, c.Tp)
 	{
 		if (t < T)
 		{

@@ -74,7 +74,7 @@ WV_FN void load_block(const Ctx& c, const ImageDesc& img, unsigned int bx, unsig
 	const int rgb_lns = (kHdr && (profile == 3 /*HDR*/ || profile == 2 /*HDR_RGB_LDR_A*/)) ? 1 : 0;
 	const int a_lns = (kHdr && profile == 3) ? 1 : 0;
 
-	WV_FOR(t, T)
+	WV_FOR_T(t, T)
 	{
 		// texel order inside a block is x fastest, then y, then z (ref: image.cpp:221-233)
 		unsigned int tz = volume ? (unsigned)t / plane_texels : 0u;
@@ -202,7 +202,7 @@ WV_FN bool block_has_visible_alpha(const Ctx& c, const ImageDesc& img, unsigned 
 	const float footprint = (float)((size_t)(dim_x + 2 * (r - 1)) * (size_t)(dim_y + 2 * (r - 1)));
 	const float threshold = 0.9f / (255.0f * footprint);
 	bool seen = false;
-	WV_FOR(t, c.T)
+	WV_FOR_T(t, c.T)
 	{
 		unsigned int ty = (unsigned)t / (unsigned)dim_x;
 		unsigned int tx = (unsigned)t - ty * (unsigned)dim_x;

@@ -86,7 +86,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		WV_SYNC();
 		int clusters_selected = 1;
 
-		WV_FOR(i, T)
+		WV_FOR_T(i, T)
 		{
 			f4 color = mk4(c.data(0)[i], c.data(1)[i], c.data(2)[i], c.data(3)[i]);
 			f4 diff = color - load4(centers);
@@ -124,7 +124,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 			clusters_selected++;
 			if (clusters_selected >= pc) break;
 
-			WV_FOR(i, T)
+			WV_FOR_T(i, T)
 			{
 				f4 color = mk4(c.data(0)[i], c.data(1)[i], c.data(2)[i], c.data(3)[i]);
 				f4 diff = color - load4(&centers[(clusters_selected - 1) * 4]);
@@ -163,7 +163,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 		}
 
 		// kmeans_assign (ref: :146-199)
-		WV_FOR(i, T)
+		WV_FOR_T(i, T)
 		{
 			float best_distance = 3.402823466e+38f;
 			int best_partition = 0;

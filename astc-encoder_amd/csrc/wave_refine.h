@@ -49,15 +49,15 @@ WV_FN void expand_weights(const Ctx& c, const DecView& di, const uint8_t* uq, fl
 	const float* tcf = di.tcf;
 	if (di.max_texel_weight_count == 1)
 	{
-		WV_FOR(t, T) { dst[t] = grid[t]; }
+		WV_FOR_T(t, T) { dst[t] = grid[t]; }
 	}
 	else if (di.max_texel_weight_count <= 2)
 	{
-		WV_FOR(t, T) { dst[t] = infill2(grid, tw, tcf, T, t); }
+		WV_FOR_T(t, T) { dst[t] = infill2(grid, tw, tcf, T, t); }
 	}
 	else
 	{
-		WV_FOR(t, T) { dst[t] = infill4(grid, tw, tcf, T, t); }
+		WV_FOR_T(t, T) { dst[t] = infill4(grid, tw, tcf, T, t); }
 	}
 	WV_SYNC();
 }
@@ -150,7 +150,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	// partition they are wave-wide reductions of per-lane partials (exact: the values are finite); with several
 	// partitions the chain lanes of rows 0 and 1 pick them up below.
 	float wmin_part = 1.0f, wmax_part = 0.0f, smin_part = 1e10f, smax_part = 0.0f;
-	WV_FOR(i, T)
+	WV_FOR_T(i, T)
 	{
 		int t = pv.sorted[i];
 		int p = pv.of_texel[t];
@@ -337,7 +337,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 
 	// Per-texel terms lane-parallel, then one sequential lane per running sum (ref: :1474-1512).
 	// rows: 0 idx0, 1 idx1, 3-5 l/m/r plane1, 6-8 l/m/r plane2, 9-12 x, 13-16 y, 17-18 scale_vec
-	WV_FOR(j, T)
+	WV_FOR_T(j, T)
 	{
 		f4 rgba = mk4(c.data(0)[j], c.data(1)[j], c.data(2)[j], c.data(3)[j]);
 		float idx0 = undec1[j], idx1 = undec2[j];
@@ -541,7 +541,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 
 	float* term = c.rsc(0);        // (the endpoint re-fit rows are free between re-fits)
 	bool bad_here = false;         // RGBM: a texel of this lane decodes to M = 0
-	WV_FOR(i, T)
+	WV_FOR_T(i, T)
 	{
 		// 1-plane multi-partition sums in partition order, the other two in texel order
 		int t = (!dual && !fast_1p) ? pv.sorted[i] : i;
@@ -662,7 +662,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 		{
 			PROF_SCOPE(c, PS_Y5);
 			bool moved_here = false;         // (per lane on the device; wv_any folds the lanes)
-			WV_FOR(texel, T)
+			WV_FOR_T(texel, T)
 			{
 				int uqw = uq[texel];
 				uint32_t prev_and_next = qat.prev_next_values[uqw];
@@ -764,7 +764,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			auto refresh_texel = [&](int t) { wb[t] = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t); };
 #endif
 			{ PROF_SCOPE(c, PS_Y4);
-			WV_FOR(t, T) { refresh_texel(t); }
+			WV_FOR_T(t, T) { refresh_texel(t); }
 			WV_SYNC(); }
 
 			// Two drivers feed ONE group evaluator (a single call site keeps a single copy of it in the kernel):

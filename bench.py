@@ -371,7 +371,7 @@ def roofline_of(cfg, kernel_s, hdr_kernel, name):
     achieved = algo / kernel_s / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
-            "kernel": "astcd::astc_compress_blocks_%s" % ("hdr" if hdr_kernel else "ldr"), "kernel_ms": round(kernel_s * 1e3, 3),
+            "kernel": "astcd::astc_compress_blocks_%s%s" % ("hdr" if hdr_kernel else "ldr", "64" if cfg["block"][0] * cfg["block"][1] <= 64 else ""), "kernel_ms": round(kernel_s * 1e3, 3),
             "algorithmic_bytes_per_launch": algo}
     counters, src = measured_counters(name)
     if counters:

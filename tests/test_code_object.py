@@ -40,8 +40,12 @@ def kernel_descriptors(lib, tmp):
 def test_kernel_descriptors(tmp_path):
     k = kernel_descriptors(A.LIB_PRODUCT, str(tmp_path))
     by_short = {re.sub(r"^_ZN5astcd\d+", "", n): d for n, d in k.items()}
-    ldr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_ldr"))
-    hdr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_hdr"))
+    # four builds of the compression kernel: LDR / HDR coders x footprints of at most 64 texels ("64") / larger ones
+    ldr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_ldr64"))
+    hdr = next(d for n, d in by_short.items() if n.startswith("astc_compress_blocks_hdr64"))
+    for name in ("astc_compress_blocks_ldrEP", "astc_compress_blocks_hdrEP"):
+        big = next(d for n, d in by_short.items() if n.startswith(name))
+        assert big["private_segment_fixed_size"] == 0 and big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 128, (name, big)
     assert any(n.startswith("astc_decompress_blocks") for n in by_short)
     assert any(n.startswith("astc_alpha_averages") for n in by_short)
     assert sum(n.startswith("astc_compare_") for n in by_short) == 3
