@@ -146,7 +146,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	}
 #endif
 	const int nvalid = popcount64(vmask);
-	WV_FOR(i, nwin) { if (!((vmask >> i) & 1ull)) modes[base + i].error = 1e38f; }
+	WV_FOR64(i, nwin) { if (!((vmask >> i) & 1ull)) modes[base + i].error = 1e38f; }
 
 	for (int first = 0; first < nvalid; first += chunk_modes)
 	{
@@ -291,7 +291,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 		}
 		WV_SYNC(); }
 
-		WV_FOR(m, nm)
+		WV_FOR64(m, nm)
 		{
 			modes[hdr[m].mode].error = (buf[m * Tp] + buf[m * Tp + 2]) + (buf[m * Tp + 1] + buf[m * Tp + 3]);
 		}

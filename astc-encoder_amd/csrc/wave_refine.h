@@ -945,7 +945,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						}
 						WV_SYNC();
 						// (the list length and the list entries are read side by side, not one after the other)
-						WV_FOR(te, di.rows) { if (te < (int)wtc[mover]) refresh_texel((int)wt[te * W + mover]); }
+						WV_FOR_T(te, di.rows) { if (te < (int)wtc[mover]) refresh_texel((int)wt[te * W + mover]); }
 						WV_SYNC();
 #if WV_DEVICE
 						later_count = popcount64(__ballot((WV_LANE & 3) == 0 && later_mine != 255));
@@ -995,7 +995,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 							uqf[mover] = (float)new_value;
 						}
 						WV_SYNC();
-						WV_FOR(te, (int)wtc[mover])
+						WV_FOR_T(te, (int)wtc[mover])
 						{
 							const int texel = wt[te * W + mover];
 							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
@@ -1019,7 +1019,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 
 				// ---- evaluate the group: one lane per (weight of the group, texel row of that weight) writes the squared
 				//      differences for the current / next lower / next higher quantized value, 4 channels each ----
-				WV_FOR(k, gn * rs)
+				WV_FOR_T(k, gn * rs)
 				{
 					const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
 					const int we = src ? (int)src[slot] : base + slot;
@@ -1069,7 +1069,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				WV_SYNC();
 				// one lane per weight decides (ref: :250-316); under the level schedule the move happens right away
 				bool moved_here = false;                  // per lane on the device; wv_any() folds the lanes
-				WV_FOR(slot, gn)
+				WV_FOR64(slot, gn)
 				{
 					const int we = src ? (int)src[slot] : base + slot;
 					const int uqw = uq[we];
@@ -1097,7 +1097,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					if (wv_any(moved_here))
 					{
 						adjustments = true;
-						WV_FOR(k, gn * rs)
+						WV_FOR_T(k, gn * rs)
 						{
 							const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
 							const int we = order[pos + slot];
