@@ -281,7 +281,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 
 		// 4 interleaved accumulators per mode, in place (lane l only touches indices = l mod 4)
 		{ PROF_SCOPE(c, PS_MODE2);
-		WV_FOR(k, nm * 4)
+		WV_FOR64(k, nm * 4)                              // (nm <= mode_chunk <= 16)
 		{
 			int m = k >> 2, l = k & 3;
 			float* v = buf + m * Tp;
@@ -1166,7 +1166,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 			partition_indices.clear();
 			{
 				const PartScratch& ps = *reinterpret_cast<const PartScratch*>(c.part());
-				WV_FOR(i, actual_trials) { partition_indices.set(i, ps.best[i]); }
+				WV_FOR64(i, actual_trials) { partition_indices.set(i, ps.best[i]); }
 			}
 			WV_SYNC();
 
