@@ -2,8 +2,9 @@
 """Static facts about the compression kernel's code object: per-function instruction counts, VGPRs, scratch frames,
 SGPR spills (v_writelane / v_readlane), and the kernel descriptor's private segment size and spill counts.
 
-Compiles csrc/kernel_ldr.hip (or kernel_hdr.hip) to gfx950 assembly with the product's flags and reads the
-assembler's own function / kernel info comments and metadata.  usage: kernel_stats.py [ldr|hdr] [--json out.json]"""
+Compiles csrc/kernel_<which>.hip to gfx950 assembly with the product's flags and reads the assembler's own function /
+kernel info comments and metadata.  usage: kernel_stats.py [ldr|hdr|ldr64|hdr64] [--json out.json]
+(ldr64 / hdr64: the builds for footprints of at most 64 texels, i.e. what BASELINE configs 2-4 run)"""
 import json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "astc-encoder_amd")
