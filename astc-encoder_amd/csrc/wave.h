@@ -81,7 +81,9 @@
 	#else
 	#define WV_FOR(i, n) for (int i = 0; i < (int)(n); i++)
 	#endif
-	#define WV_FOR64(i, n) WV_FOR(i, n)
+	// (the sequential build checks what the device build relies on: a count above the promised bound stops the run)
+	WV_FN int wv_checked_count(int n, int bound) { if (n > bound) __builtin_trap(); return n; }
+	#define WV_FOR64(i, n) WV_FOR(i, wv_checked_count((int)(n), 64))
 	#define WV_FOR_T(i, n) WV_FOR(i, n)
 	#define WV_ONE if (true)
 #endif

@@ -111,7 +111,7 @@ WV_FN void q_store_i32(int* p, qi a) { p[Q_CH] = a.v; }
 #else // ------------------------------------------------------------------------------------------------------
 
 #define WV_QUADS(p, n) for (int p = 0; p < (int)(n); p++)
-#define WV_QUADS16(p, n) WV_QUADS(p, n)
+#define WV_QUADS16(p, n) WV_QUADS(p, wv_checked_count((int)(n), 16))
 
 struct qf { float v[4]; };
 struct qi { int v[4]; };
