@@ -545,9 +545,9 @@ WV_FN void stage_words_nosync(uint8_t* lds_dst, const uint8_t* src, int words)
  * destination must hold the rounded size): a quarter of the load / store instructions of the word copy. */
 WV_FN void stage_quads_nosync(uint8_t* lds_dst, const uint8_t* src, int bytes)
 {
-	typedef uint32_t Quad __attribute__((vector_size(16)));       // (a native 128-bit value: stays in registers)
 	const int quads = (bytes + 15) >> 4;
 #if WV_DEVICE
+	typedef uint32_t Quad __attribute__((vector_size(16)));       // (a native 128-bit value: stays in registers)
 	const Quad* s = static_cast<const Quad*>(__builtin_assume_aligned(src, 16));
 	Quad* d = static_cast<Quad*>(__builtin_assume_aligned(lds_dst, 16));
 	// up to four loads in flight per lane, and no more load instructions than the copy has 64-quad pieces (named
