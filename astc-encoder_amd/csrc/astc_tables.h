@@ -252,7 +252,7 @@ struct TableRoot {
 	uint32_t off_integer_of_quints;           // u8[125]  index ((q2*5+q1)*5+q0)
 	uint32_t off_sin_table;                   // f32[64][32]
 	uint32_t off_cos_table;                   // f32[64][32]
-	uint32_t off_cos_sin_table;               // f32[64][32][2]: (cos, sin) side by side, one 64-bit load per (row, step) in the angular search
+	uint32_t off_cos_sin_table;               // f32[65][32][2]: (cos, sin) side by side, one 64-bit load per (row, step) in the angular search; row 64 is all +0.0
 	uint32_t off_dm_by_weights;               // u8[decimation_mode_count_selected]: the grids by descending weight count (angular batching order)
 	uint32_t off_mode_static;                 // ModeStatic[block_mode_count_1plane_2plane_selected]
 	uint32_t max_decimation_table_bytes;      // largest DecimationInfo::table_bytes (LDS staging size)

@@ -1204,7 +1204,9 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 	r->off_cos_table = off_cos;
 	{
 		const uint32_t n = (uint32_t)SINCOS_STEPS * (uint32_t)ANGULAR_STEPS;
-		uint32_t off_cs = blob.alloc((size_t)n * 2 * sizeof(float), 8);
+		// (one more row, all +0.0: the angular search points the slots past a grid's last weight at it -- adding it leaves
+		// the sums as they are)
+		uint32_t off_cs = blob.alloc((size_t)(n + (uint32_t)ANGULAR_STEPS) * 2 * sizeof(float), 8);
 		for (uint32_t i = 0; i < n; i++)
 		{
 			*blob.at<float>((uint32_t)(off_cs + (2 * i) * sizeof(float))) = *blob.at<float>((uint32_t)(off_cos + i * sizeof(float)));

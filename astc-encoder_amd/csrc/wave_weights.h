@@ -335,6 +335,11 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		}
 		a.out[0] = min_weight;
 		a.out[1] = max_weight;
+		// The slots between the set's last weight and the next multiple of four (they belong to the set: the packing is in
+		// fours) select the table's all-zero row: phase 1 walks the weights four at a time and needs no tail handling in
+		// its sum of cosines / sines.
+		static_assert(ASTC_ANG_GROUP <= 4, "the padding of a set's slots is to a multiple of four");
+		for (int j = a.wcount; j < ((a.wcount + 3) & ~3); j++) const_cast<uint8_t*>(a.rows)[j] = (uint8_t)SINCOS_STEPS;
 	}
 	WV_SYNC();
 
@@ -382,7 +387,7 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				float cs[ASTC_ANG_GROUP], sn[ASTC_ANG_GROUP];
 				uint32_t row[ASTC_ANG_GROUP];
 				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++) { const int j = j0 + u < W ? j0 + u : 0; row[u] = rows[j]; }
+				for (int u = 0; u < ASTC_ANG_GROUP; u++) { row[u] = rows[j0 + u]; }      // (past W: the all-zero row, see the pre-pass)
 				#pragma unroll
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
@@ -394,13 +399,9 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				#pragma unroll
 				for (int u = 0; u < ASTC_ANG_GROUP; u++)
 				{
-					// past the set's last weight the table values are replaced by +0.0, which leaves the sums as they are (they
-					// are never -0.0: they start at +0.0), as a multiplication by 1.0 / 0.0 (exact: the products are cs, sn or a
-					// signed zero), so that what stays live across the table loads is a vector register per slot, not a lane mask
-					// in a scalar register pair
-					const float keep = wv_opaque_f(j0 + u < W ? 1.0f : 0.0f);
-					anglesum_x += cs[u] * keep;
-					anglesum_y += sn[u] * keep;
+					// (past the set's last weight: +0.0 from the table's zero row; the sums start at +0.0 and are never -0.0)
+					anglesum_x += cs[u];
+					anglesum_y += sn[u];
 				}
 			}
 			float angle = ref_atan2(anglesum_y, anglesum_x);
