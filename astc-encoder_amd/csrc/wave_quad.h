@@ -110,7 +110,11 @@ WV_FN void q_store_i32(int* p, qi a) { p[Q_CH] = a.v; }
 
 #else // ------------------------------------------------------------------------------------------------------
 
+#if defined(ASTC_EMU_REVERSE_LANES)
+#define WV_QUADS(p, n) for (int p = (int)(n) - 1; p >= 0; p--)
+#else
 #define WV_QUADS(p, n) for (int p = 0; p < (int)(n); p++)
+#endif
 #define WV_QUADS16(p, n) WV_QUADS(p, wv_checked_count((int)(n), 16))
 
 struct qf { float v[4]; };

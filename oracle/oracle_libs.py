@@ -18,3 +18,5 @@ LIB_REF_AVX2 = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2.so")
 LIB_REF_AVX2_GATHERS = os.path.join(REPO, "oracle", "_ref", "libastcenc-avx2-gathers.so")
 LIB_REF_DIAG = os.path.join(REPO, "oracle", "_ref", "libastcenc-diag.so")
 LIB_EMU = os.path.join(REPO, "oracle", "emu", "_build", "libastcenc_emu.so")
+# ... with the lanes of every lane loop in reverse order (oracle/emu/Makefile: `make reverse`), the lane-order race check
+LIB_EMU_REVERSE = os.path.join(REPO, "oracle", "emu", "_build", "libastcenc_emu_reverse.so")
