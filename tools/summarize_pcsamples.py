@@ -17,7 +17,7 @@ for f in files:
             by_line[(m.group(1), int(m.group(2))) if m else ("?", 0)] += 1
 print("total samples", total)
 print("--- top opcodes")
-for k, v in by_inst.most_common(25): print("%8d %5.1f%% %s" % (v, 100.0 * v / max(total, 1), k))
+for k, v in by_inst.most_common(80): print("%8d %5.1f%% %s" % (v, 100.0 * v / max(total, 1), k))
 print("--- top source lines")
 for k, v in by_line.most_common(120): print("%8d %5.1f%% %s:%d" % (v, 100.0 * v / max(total, 1), k[0], k[1]))
 by_file = collections.Counter()
