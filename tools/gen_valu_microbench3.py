@@ -33,8 +33,8 @@ for sb in (False, True):
 row("v_sub_f32", "v_sub_f32 {d}, {a}, {d}")
 row("v_fmac_f32", "v_fmac_f32 {d}, {a}, {b}")
 row("v_min_f32", "v_min_f32 {d}, {a}, {d}")
-row("v_cmp_lt_f32 vcc + v_cndmask_b32 vcc (2)", "v_cmp_lt_f32 vcc, {a}, {d}\n v_cndmask_b32 {d}, {d}, {b}, vcc", n=2)
-row("v_cmp_lt_f32_e64 + v_cndmask_b32_e64 (2)", "v_cmp_lt_f32_e64 s[22:23], {a}, {d}\n v_cndmask_b32_e64 {d}, {d}, {b}, s[22:23]", n=2)
+row("v_cmp_lt_f32 vcc + v_cndmask_b32 vcc (2)", "v_cmp_lt_f32 vcc, {a}, {d}\\n v_cndmask_b32 {d}, {d}, {b}, vcc", n=2)
+row("v_cmp_lt_f32_e64 + v_cndmask_b32_e64 (2)", "v_cmp_lt_f32_e64 s[22:23], {a}, {d}\\n v_cndmask_b32_e64 {d}, {d}, {b}, s[22:23]", n=2)
 row("v_cmp_lt_f32 vcc alone", "v_cmp_lt_f32 vcc, {a}, {d}")
 row("v_cvt_f32_i32", "v_cvt_f32_i32 {d}, {d}")
 row("v_cvt_i32_f32", "v_cvt_i32_f32 {d}, {d}")
@@ -68,9 +68,9 @@ row("v_sqrt_f32", "v_sqrt_f32 {d}, {d}")
 row("v_pk_add_f32", "v_pk_add_f32 {D}, {A}, {D}")
 row("v_pk_mul_f32", "v_pk_mul_f32 {D}, {A}, {D}")
 row("v_pk_fma_f32", "v_pk_fma_f32 {D}, {A}, {B}, {D}")
-row("v_add_f32 + v_max_f32 alternating (2)", "v_add_f32 {d}, {a}, {d}\n v_max_f32 {d}, {b}, {d}", n=2)
-row("v_add_f32 + v_cvt_f32_i32 alternating (2)", "v_add_f32 {d}, {a}, {d}\n v_cvt_f32_i32 {d}, {d}", n=2)
-row("v_add_f32 + s_and_b64 alternating (1 valu)", "v_add_f32 {d}, {a}, {d}\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=1)
+row("v_add_f32 + v_max_f32 alternating (2)", "v_add_f32 {d}, {a}, {d}\\n v_max_f32 {d}, {b}, {d}", n=2)
+row("v_add_f32 + v_cvt_f32_i32 alternating (2)", "v_add_f32 {d}, {a}, {d}\\n v_cvt_f32_i32 {d}, {d}", n=2)
+row("v_add_f32 + s_and_b64 alternating (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=1)
 row("v_add_f32 dependent chain (1 chain)", "v_add_f32 v32, {a}, v32")
 row("v_max_f32 dependent chain (1 chain)", "v_max_f32 v32, {a}, v32")
 row("v_fma_f32 dependent chain (1 chain)", "v_fma_f32 v32, {a}, {b}, v32")
@@ -90,7 +90,7 @@ def body(tmpl, same_bank):
             A = "v[16:17]" if i % 2 == 0 else "v[18:19]"
             B = "v[18:19]" if i % 2 == 0 else "v[16:17]"
             out.append(tmpl.format(d="v%d" % d, a="v%d" % a, b="v%d" % b, D=D, A=A, B=B))
-    return "\n ".join(out)
+    return "\\n ".join(out)
 
 HDR = r'''// SPDX-License-Identifier: Apache-2.0
 // GENERATED by tools/gen_valu_microbench3.py -- do not edit.  VALU issue cost per wave64 instruction on gfx950,
