@@ -199,6 +199,26 @@ WV_FN float f_max(float p, float q) { return p > q ? p : q; }
 WV_FN int   i_min(int p, int q) { return p < q ? p : q; }
 WV_FN int   i_max(int p, int q) { return p > q ? p : q; }
 
+/* `x < m ? x : m` / `x > m ? x : m` for a running minimum / maximum m that is never NaN and values that are never -0
+ * (the compare-select keeps m when x is NaN; so does the hardware's IEEE minimum / maximum, which returns the operand
+ * that is a number): one instruction on the device instead of a compare and a select. */
+WV_FN float f_run_min(float x, float m)
+{
+#if WV_DEVICE
+	float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m)); return r;
+#else
+	return x < m ? x : m;
+#endif
+}
+WV_FN float f_run_max(float x, float m)
+{
+#if WV_DEVICE
+	float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m)); return r;
+#else
+	return x > m ? x : m;
+#endif
+}
+
 /* astc::clamp (ref: astcenc_mathlib.h:271) */
 WV_FN float f_clamp(float v, float mn, float mx)
 {

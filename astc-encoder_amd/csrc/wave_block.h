@@ -15,6 +15,7 @@
 #include "wave_format.h"
 #include "wave_color.h"
 #include "wave_refine.h"
+#include "wave_batch.h"
 #include "wave_partition.h"
 #include "wave_pack.h"
 
@@ -405,6 +406,73 @@ WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_co
 	WV_SYNC();
 }
 
+/* A candidate that passed the test on the error of its (batched) first step takes its turn: what the step left for
+ * it (wave_batch.h: CandState) becomes the working block, endpoints and decoded endpoints, and the candidate's tables
+ * are staged for the steps that follow (as refine_candidate_setup does for the one-candidate path). */
+WV_OUT void refine_candidate_restore(bool dual, int partition_count, int partition_packed, int plane2_component, int candidate, int slot,
+                                     int stage_dm, int stage_wq, int color_quant_level, int block_mode_packed)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component); candidate = wv_uniform(candidate); slot = wv_uniform(slot);
+	stage_dm = wv_uniform(stage_dm); stage_wq = wv_uniform(stage_wq); color_quant_level = wv_uniform(color_quant_level);
+	block_mode_packed = wv_uniform(block_mode_packed);
+	TrialInfo& tr = c.tr();
+	Scb& workscb = c.wscb();
+	{
+		// (first: the record of a batch's first candidate lies in the scratch that the staged tables are about to overwrite)
+		const BatchView bv = batch_view(c, dual, partition_count);
+		const CandState st = batch_state(c, bv, slot);
+		WV_FOR64(k, partition_count * 4)
+		{
+			(&tr.wep0[0][0])[k] = st.wep0[k];
+			(&tr.wep1[0][0])[k] = st.wep1[k];
+		}
+		WV_FOR64(k, partition_count * 8) { workscb.color_values[k >> 3][k & 7] = st.colors[k]; }
+		WV_FOR64(j, partition_count) { workscb.color_formats[j] = st.formats[j]; }
+		{
+			const uint32_t* src = reinterpret_cast<const uint32_t*>(c.candw(candidate));
+			uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
+			WV_FOR(k, 16) { dst[k] = src[k]; }
+		}
+		const int formats_matched = wv_uniform((int)st.meta[1]);
+		const int quant_mode = wv_uniform((int)st.meta[0]);
+		const bool rgbm_error = wv_uniform((int)st.meta[2]) != 0;
+		WV_ONE
+		{
+			// the header of the working block (as refine_pack writes it); an RGBM block whose M decodes to zero is an
+			// error block from here on (ref: :612-616)
+			uint32_t* head = reinterpret_cast<uint32_t*>(&workscb);
+			head[0] = (uint32_t)(rgbm_error ? SYM_BTYPE_ERROR : SYM_BTYPE_NONCONST) | ((uint32_t)partition_count << 8) |
+			          ((uint32_t)formats_matched << 16) | ((uint32_t)((dual ? plane2_component : -1) & 0xFF) << 24);
+			head[1] = (uint32_t)block_mode_packed | ((uint32_t)partition_packed << 16);
+			workscb.quant_mode = (uint8_t)quant_mode;
+		}
+		WV_SYNC();
+	}
+	if (stage_dm >= 0)
+	{
+		const DecimationInfo& dinfo = c.dec_info(stage_dm);
+		stage_quads_nosync(c.lds + c.L->dtab, reinterpret_cast<const uint8_t*>(&dinfo), (int)sizeof(DecimationInfo));
+		stage_quads_nosync(c.lds + c.L->dtab + DTAB_RECORD_BYTES, c.table(dinfo.off_texel_weights), (int)dinfo.table_bytes);
+	}
+	if (stage_wq >= 0)
+	{
+		stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(stage_wq)), (int)(sizeof(QuantXfer) / 4));
+	}
+	stage_color_rows(c, color_quant_level);      // ends with a sync
+	// the decoded endpoints of the packed values, where the scoring and realignment steps expect them
+	WV_FOR64(p, partition_count)
+	{
+		i4 e0, e1;
+		unpack_color_endpoints(c.cfg->profile, workscb.color_formats[p], workscb.color_values[p], e0, e1);
+		int* o = &tr.ibox[p * 8];
+		o[0] = e0.x; o[1] = e0.y; o[2] = e0.z; o[3] = e0.w;
+		o[4] = e1.x; o[5] = e1.y; o[6] = e1.z; o[7] = e1.w;
+	}
+	WV_SYNC();
+}
+
 /* One refinement step's front half, part 1: least-squares endpoints for the current weights
  * (ref: :542-555, :925-931).  Three out-of-line variants -- the single-partition case is by far the most
  * frequent and should not carry the register needs of the other two. */
@@ -446,8 +514,8 @@ WV_OUT void refine_pack_hdr(int partition_count, int candidate, int to_scratch, 
 	uint8_t* tries = reinterpret_cast<uint8_t*>(tr.fbox);             // (the re-fit's sums are consumed by now)
 	static_assert(sizeof(tr.fbox) >= 4 * HDR_TRY_LANES * HDR_TRY_BYTES, "sub-mode records do not fit the mailbox");
 	WV_FOR64(j, partition_count) { if (!to_scratch && endpoint_format_is_hdr(tr.cand_formats[candidate][j])) have_decoded[j] = 0; }
-	pack_endpoints_hdr(c, partition_count, tr.cand_formats[candidate], to_scratch ? colorvals : &workscb.color_values[0][0],
-	                   to_scratch ? fmts : workscb.color_formats, quant_level, tries);
+	pack_endpoints_hdr(color_tabs(c, quant_level), &tr.wep0[0][0], &tr.wep1[0][0], &tr.rgbo[0][0], partition_count, tr.cand_formats[candidate],
+	                   to_scratch ? colorvals : &workscb.color_values[0][0], to_scratch ? fmts : workscb.color_formats, tries);
 }
 #endif
 
@@ -613,41 +681,95 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 
 	DUP_STAGE(c, DUP_CAND_QUANTIZE, refine_quantize_candidates(dual, partition_count, partition_packed));
 
-	int staged_dm = -1, staged_wq = -1;                 // what the candidate tables in LDS currently hold
-	for (int i = 0; i < candidate_count; i++)
+	// The first step of every candidate -- re-fit, pack, decode and score -- runs for a batch of candidates at once
+	// (wave_batch.h); then each candidate of the batch takes its turn in the reference's order: the test on that first
+	// error, and for a candidate that passes it the rest of its refinement, one candidate at a time.
+	const int batch_max = wv_uniform((int)c.L->bat_max[dual ? 1 : 0]);
+	bool stop_all = false;
+	for (int first = 0; first < candidate_count && !stop_all; first += batch_max)
 	{
-		const int bm_packed_index = wv_uniform(tr.cand_block_mode[i]);
-		const BlockMode& qw_bm = c.block_mode(bm_packed_index);
-		const int color_quant_level = wv_uniform((int)tr.cand_quant[i]);
-		const int color_quant_level_mod = wv_uniform((int)tr.cand_quant_mod[i]);
-		const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
-		const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
+		const int batch = i_min(batch_max, candidate_count - first);
+		DUP_STAGE(c, DUP_BATCH_PREPARE, batch_prepare(dual, partition_count, partition_packed, first, batch));
+		DUP_STAGE(c, DUP_BATCH_SUMS, batch_sums(dual, partition_count, partition_packed, plane2_component, batch));
+		DUP_STAGE(c, DUP_BATCH_SOLVE, batch_solve(dual, partition_count, partition_packed, plane2_component, batch));
+		DUP_STAGE(c, DUP_BATCH_PACK, batch_pack(dual, partition_count, first, batch));
+		DUP_STAGE(c, DUP_BATCH_SCORE, batch_score(dual, partition_count, partition_packed, plane2_component, batch));
+		// (the step's scratch is the region the staged candidate tables live in)
+		int staged_dm = -1, staged_wq = -1;
+		WV_ONE { tr.staged_color_quant[0] = -1; }
+		WV_SYNC();
 
-		TRACE_PUT(c, TR_CANDIDATE, (float)cand_wq);
-		DUP_STAGE(c, DUP_CAND_SETUP, refine_candidate_setup(dual, partition_count, plane2_component, i, cand_dm != staged_dm ? cand_dm : -1,
-		                       cand_wq != staged_wq ? cand_wq : -1, color_quant_level));
-		staged_dm = cand_dm;
-		staged_wq = cand_wq;
-
-		bool stop_all = false;
-		for (int l = 0; l < refinement_limit; l++)
+		for (int slot = 0; slot < batch; slot++)
 		{
-			DUP_STAGE(c, DUP_RECOMPUTE, {
-			if (dual) refine_recompute_2planes(cand_dm, plane2_component);
-			else if (partition_count == 1) refine_recompute_1partition(cand_dm);
-			else refine_recompute_partitions(partition_count, partition_packed, cand_dm); });
-			DUP_STAGE(c, DUP_PACK, refine_pack(dual, partition_count, partition_packed, plane2_component, i,
-			            color_quant_level, color_quant_level_mod, bm_packed_index));
+			const int i = first + slot;
+			const int bm_packed_index = wv_uniform(tr.cand_block_mode[i]);
+			const BlockMode& qw_bm = c.block_mode(bm_packed_index);
+			const int color_quant_level = wv_uniform((int)tr.cand_quant[i]);
+			const int color_quant_level_mod = wv_uniform((int)tr.cand_quant_mod[i]);
+			const int cand_dm = wv_uniform((int)qw_bm.decimation_mode);
+			const int cand_wq = wv_uniform((int)qw_bm.quant_mode);
 
-			if (l == 0)
+			TRACE_PUT(c, TR_CANDIDATE, (float)cand_wq);
 			{
-				float errorval;
-				DUP_STAGE(c, DUP_DIFF, errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm)));
+				// the first step's error (ref: :600-640)
+				const BatchView bv = batch_view(c, dual, partition_count);
+				const float errorval = wv_uniform(*batch_state(c, bv, slot).errorval);
 				TRACE_PUT(c, TR_ERR_PRE, errorval);
 				best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
 
-				int iters_remaining = refinement_limit - l;
-				float threshold = (0.045f * (float)iters_remaining) + 1.08f;
+				const float threshold = (0.045f * (float)refinement_limit) + 1.08f;
+				if (errorval > (threshold * best_errorval_in_scb)) continue;
+
+				DUP_STAGE(c, DUP_CAND_SETUP, refine_candidate_restore(dual, partition_count, partition_packed, plane2_component, i, slot,
+				                       cand_dm != staged_dm ? cand_dm : -1, cand_wq != staged_wq ? cand_wq : -1, color_quant_level, bm_packed_index));
+				staged_dm = cand_dm;
+				staged_wq = cand_wq;
+
+				if (errorval < best_errorval_in_scb)
+				{
+					best_errorval_in_scb = errorval;
+					refine_accept(errorval);
+					if (errorval < tune_errorval_threshold)
+					{
+						stop_all = true;
+						break;
+					}
+				}
+			}
+
+			for (int l = 0; l < refinement_limit; l++)
+			{
+				if (l > 0)
+				{
+					DUP_STAGE(c, DUP_RECOMPUTE, {
+					if (dual) refine_recompute_2planes(cand_dm, plane2_component);
+					else if (partition_count == 1) refine_recompute_1partition(cand_dm);
+					else refine_recompute_partitions(partition_count, partition_packed, cand_dm); });
+					DUP_STAGE(c, DUP_PACK, refine_pack(dual, partition_count, partition_packed, plane2_component, i,
+					            color_quant_level, color_quant_level_mod, bm_packed_index));
+				}
+
+#if defined(ASTC_DUPSTAGE)
+				// (realignment changes the weights: for the doubled run they are put back first)
+				uint32_t saved_weights = 0;
+				if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN)
+				{
+					WV_FOR(k, 16) { saved_weights = reinterpret_cast<const uint32_t*>(c.wscb().weights)[k]; }
+					(void)refine_realign(partition_count, partition_packed, cand_dm);
+					WV_SYNC();
+					WV_FOR(k, 16) { reinterpret_cast<uint32_t*>(c.wscb().weights)[k] = saved_weights; }
+					WV_SYNC();
+				}
+#endif
+				const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
+
+				float errorval;
+				DUP_STAGE(c, DUP_DIFF, errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm)));
+				TRACE_PUT(c, TR_ERR_POST, errorval);
+				best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
+
+				int iters_remaining = refinement_limit - 1 - l;
+				float threshold = (0.045f * (float)iters_remaining) + 1.0f;
 				if (errorval > (threshold * best_errorval_in_scb))
 				{
 					break;
@@ -663,51 +785,14 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 						break;
 					}
 				}
-			}
 
-#if defined(ASTC_DUPSTAGE)
-			// (realignment changes the weights: for the doubled run they are put back first)
-			uint32_t saved_weights = 0;
-			if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN)
-			{
-				WV_FOR(k, 16) { saved_weights = reinterpret_cast<const uint32_t*>(c.wscb().weights)[k]; }
-				(void)refine_realign(partition_count, partition_packed, cand_dm);
-				WV_SYNC();
-				WV_FOR(k, 16) { reinterpret_cast<uint32_t*>(c.wscb().weights)[k] = saved_weights; }
-				WV_SYNC();
-			}
-#endif
-			const bool adjustments = wv_uniform(refine_realign(partition_count, partition_packed, cand_dm));
-
-			float errorval;
-			DUP_STAGE(c, DUP_DIFF, errorval = wv_uniform(refine_difference(partition_count, partition_packed, cand_dm)));
-			TRACE_PUT(c, TR_ERR_POST, errorval);
-			best_errorval_in_mode = wv_uniform(f_min(errorval, best_errorval_in_mode));
-
-			int iters_remaining = refinement_limit - 1 - l;
-			float threshold = (0.045f * (float)iters_remaining) + 1.0f;
-			if (errorval > (threshold * best_errorval_in_scb))
-			{
-				break;
-			}
-
-			if (errorval < best_errorval_in_scb)
-			{
-				best_errorval_in_scb = errorval;
-				refine_accept(errorval);
-				if (errorval < tune_errorval_threshold)
+				if (!adjustments)
 				{
-					stop_all = true;
 					break;
 				}
 			}
-
-			if (!adjustments)
-			{
-				break;
-			}
+			if (stop_all) break;
 		}
-		if (stop_all) break;
 	}
 	return best_errorval_in_mode;
 }

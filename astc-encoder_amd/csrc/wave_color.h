@@ -426,9 +426,8 @@ struct QPacked {
 /* One partition's endpoints -> bytes, LDR formats (ref: pack_color_endpoints :1909; the HDR formats are coded by
  * pack_endpoints_hdr in wave_color_hdr.h).  colour0 / colour1 are the real-valued endpoints (0 .. 65535), rgbs the
  * RGB + scale vector.  output: 8 bytes. */
-WV_FN QPacked pack_endpoints_quad(const Ctx& c, qf colour0, qf colour1, qf rgbs, int format, uint8_t* output, int quant_level)
+WV_FN QPacked pack_endpoints_quad(const ColorTabs& t, qf colour0, qf colour1, qf rgbs, int format, uint8_t* output, int quant_level)
 {
-	const ColorTabs t = color_tabs(c, quant_level);
 	QPacked r;
 	r.format = format;
 	r.decoded_valid = false;
@@ -550,6 +549,12 @@ WV_FN QPacked pack_endpoints_quad(const Ctx& c, qf colour0, qf colour1, qf rgbs,
 	return r;
 }
 
+/* ... with the rows of the candidate being refined (staged by stage_color_rows). */
+WV_FN QPacked pack_endpoints_quad(const Ctx& c, qf colour0, qf colour1, qf rgbs, int format, uint8_t* output, int quant_level)
+{
+	return pack_endpoints_quad(color_tabs(c, quant_level), colour0, colour1, rgbs, format, output, quant_level);
+}
+
 /* The endpoint formats coded by pack_endpoints_hdr. */
 WV_FN bool endpoint_format_is_hdr(int format)
 {
@@ -562,21 +567,19 @@ WV_FN bool endpoint_format_is_hdr(int format)
  * :2076-2140).  requested[p] = format asked for; values + 8 p receives the bytes, formats_out[p] the format used.
  * Partitions with an LDR format are left alone (pack_endpoints_quad codes those).  `tries`: LDS scratch,
  * 4 * HDR_TRY_LANES * HDR_TRY_BYTES bytes. */
-WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* requested, uint8_t* values, uint8_t* formats_out,
-                              int quant_level, uint8_t* tries)
+WV_FN void pack_endpoints_hdr(const ColorTabs& t, const float* wep0, const float* wep1, const float* rgbo_in,
+                              int partition_count, const uint8_t* requested, uint8_t* values, uint8_t* formats_out, uint8_t* tries)
 {
-	const TrialInfo& tr = c.tr();
-	const ColorTabs t = color_tabs(c, quant_level);
 	// the sub-modes, side by side
 	WV_FOR64(k, partition_count * HDR_TRY_LANES)
 	{
 		const int p = k / HDR_TRY_LANES, lane = k % HDR_TRY_LANES;
 		const int format = requested[p];
 		uint8_t* rec = tries + k * HDR_TRY_BYTES;
-		const f4 low = v4_clamp(0.0f, 65535.0f, load4(tr.wep0[p])), high = v4_clamp(0.0f, 65535.0f, load4(tr.wep1[p]));
+		const f4 low = v4_clamp(0.0f, 65535.0f, load4(wep0 + 4 * p)), high = v4_clamp(0.0f, 65535.0f, load4(wep1 + 4 * p));
 		if (format == FMT_HDR_RGB_SCALE)
 		{
-			if (lane < 5) hdr_try_rgbo(t, load4(tr.rgbo[p]), lane, rec);                       // preference: sub-mode 0 first
+			if (lane < 5) hdr_try_rgbo(t, load4(rgbo_in + 4 * p), lane, rec);                       // preference: sub-mode 0 first
 		}
 		else if (format == FMT_HDR_RGB || format == FMT_HDR_RGB_LDR_ALPHA || format == FMT_HDR_RGBA)
 		{
@@ -592,7 +595,7 @@ WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* 
 		if (!endpoint_format_is_hdr(format)) continue;
 		uint8_t* out = values + p * 8;
 		const uint8_t* recs = tries + p * HDR_TRY_LANES * HDR_TRY_BYTES;
-		const f4 low = v4_clamp(0.0f, 65535.0f, load4(tr.wep0[p])), high = v4_clamp(0.0f, 65535.0f, load4(tr.wep1[p]));
+		const f4 low = v4_clamp(0.0f, 65535.0f, load4(wep0 + 4 * p)), high = v4_clamp(0.0f, 65535.0f, load4(wep1 + 4 * p));
 		auto first_fit = [recs](int begin, int end) {
 			for (int m = begin; m < end; m++) if (recs[m * HDR_TRY_BYTES]) return m;
 			return -1;
@@ -602,7 +605,7 @@ WV_FN void pack_endpoints_hdr(const Ctx& c, int partition_count, const uint8_t* 
 		{
 			const int m = first_fit(0, 5);
 			if (m >= 0) { for (int i = 0; i < 4; i++) out[i] = recs[m * HDR_TRY_BYTES + 1 + i]; }
-			else hdr_escape_rgbo(t, load4(tr.rgbo[p]), out);
+			else hdr_escape_rgbo(t, load4(rgbo_in + 4 * p), out);
 		}
 		else if (format == FMT_HDR_LUMINANCE_SMALL_RANGE || format == FMT_HDR_LUMINANCE_LARGE_RANGE)
 		{

@@ -135,6 +135,11 @@ struct LdsLayout {
 	uint32_t mode_chunk; // block modes scored per pass of score_block_modes (descriptors + quantized weights + texel terms fit `uni`)
 	uint32_t mode_wcap[2];     // weights per plane the scoring passes provide lanes for, per trial class (1-plane, 2-plane)
 	uint32_t mode_wcap_inv[2]; // ceil(2^16 / mode_wcap): k / wcap == (k * inv) >> 16
+	// refine: the first refinement step of a trial's candidates runs for several of them at once (wave_batch.h)
+	uint32_t bat;              // scratch of that step: the whole refine region up to `cstate`
+	uint32_t cstate;           // what the step leaves for the candidates' own turns: one record per candidate but the first
+	uint32_t cstate_stride;    // bytes per record (cand_state_bytes)
+	uint32_t bat_max[2];       // candidates per batch in a 1-plane / 2-plane trial (1: nothing to gain, still the same code)
 	uint32_t total;
 };
 
@@ -166,6 +171,23 @@ WV_FN uint32_t part_scratch_bytes(uint32_t max_partitionings, uint32_t max_index
 	uint32_t n = (max_partitionings + 3u) & ~3u;
 	uint32_t lim = max_index_limit < n ? max_index_limit : n;
 	return 256 + n * 2 + lim * 8 + n;
+}
+
+/* Per-candidate record of the batched first refinement step (wave_batch.h: CandState): the endpoints of every partition
+ * as floats, the packed colour bytes, formats, flags, the step's error. */
+WV_FN uint32_t cand_state_bytes(uint32_t partition_limit)
+{
+	const uint32_t P = partition_limit < 1 ? 1u : partition_limit > 4 ? 4u : partition_limit;
+	return (2u * P * 16u + P * 8u + 4u + 4u + 4u + 15u) & ~15u;
+}
+/* Bytes of the step's scratch for `nb` candidates (BatchView, wave_batch.h): seven shared texel rows, then per candidate
+ * the expanded weights (float and integer, per plane), the sums of every partition, the decoded endpoints, the error
+ * terms, the colour quantization rows (one set more for the matched-format retry), a small record, the first state. */
+WV_FN uint32_t batch_scratch_bytes(uint32_t nb, uint32_t planes, uint32_t pc, uint32_t Tp, uint32_t state_bytes)
+{
+	const uint32_t iw = (nb * planes * Tp + 15u) & ~15u;
+	const uint32_t Ts = (uint32_t)lds_row_stride((int)Tp);
+	return 7u * Ts * 4u + nb * planes * Ts * 4u + iw + nb * pc * 112u + nb * pc * 32u + nb * Ts * 4u + (nb + 1u) * 512u + nb * 32u + nb * 4u * 32u + state_bytes;
 }
 
 WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayout& L)
@@ -229,6 +251,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	}
 	L.tsc_r = take(2 * Tp * 4);                                  // expanded weights of plane 0 / 1
 	L.wsc = take(2 * 64 * 4);
+	const uint32_t classic_end = o;
 	if (o > end) end = o;
 	// The hardware hands out LDS in units of LDS_ALLOC_GRANULE bytes (measured on MI355X, DESIGN.md section 6: the
 	// workgroups per CU step at multiples of 1280 B): what the largest phase leaves of its last unit costs no occupancy.
@@ -267,10 +290,30 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		L.part_tabs = take(chunk * rec);
 	}
 	if (o > end) end = o;
-#if defined(ASTC_LDS_PAD)
-	end += ASTC_LDS_PAD;   // occupancy experiments only
-#endif
 	L.total = end;
+	// The batched first refinement step: its scratch is the refine region itself (nothing of a candidate's own turn is live
+	// while it runs), the records it leaves behind sit between the end of that region and the end of the allocation --
+	// as many candidates per batch as both allow.
+	{
+		L.bat = begin;
+		L.cstate = classic_end;
+		L.cstate_stride = cand_state_bytes(cfg.tune_partition_count_limit);
+		const uint32_t room = L.total - classic_end;
+		const uint32_t pcl = cfg.tune_partition_count_limit < 1 ? 1u : cfg.tune_partition_count_limit;
+		for (int cls = 0; cls < 2; cls++)
+		{
+			uint32_t nb = 1u + room / L.cstate_stride;
+			if (nb > cfg.tune_candidate_limit) nb = cfg.tune_candidate_limit;
+			if (nb > (uint32_t)MAX_TRIAL_CANDIDATES) nb = (uint32_t)MAX_TRIAL_CANDIDATES;
+			if (nb * (cls ? 1u : pcl) > 16u) nb = 16u / (cls ? 1u : pcl);        // (one quad per (candidate, partition) in one trip)
+			while (nb > 1u && batch_scratch_bytes(nb, cls ? 2u : 1u, cls ? 1u : pcl, Tp, L.cstate_stride) > classic_end - begin) nb--;
+			if (nb < 1u) nb = 1u;
+			L.bat_max[cls] = nb;
+			// (a footprint whose one-candidate scratch outgrows the refine region: the region grows)
+			const uint32_t need = batch_scratch_bytes(nb, cls ? 2u : 1u, cls ? 1u : pcl, Tp, L.cstate_stride);
+			if (begin + need > L.cstate) { L.cstate = (begin + need + 15u) & ~15u; if (L.cstate > L.total) L.total = L.cstate; }
+		}
+	}
 }
 
 /* wv_uniform(v): `v` is the same on every lane (a value read from LDS or from a table looks lane-variant to the
@@ -468,7 +511,7 @@ WV_FN void trace_put(const Ctx& c, uint32_t tag, float value)
  * instruction count -- a per-stage VALU / SALU / LDS / VMEM profile without PC sampling (tools/gpu_stage_counts.sh). */
 enum { DUP_IDEAL = 1, DUP_DECIMATE, DUP_ANGULAR, DUP_MODES, DUP_MODES_FORMATS, DUP_CAND_QUANTIZE, DUP_CAND_SETUP, DUP_RECOMPUTE,
        DUP_PACK, DUP_DIFF, DUP_PART_ORDER, DUP_PART_SCORE, DUP_PART_SELECT, DUP_STATS, DUP_LOAD, DUP_PHYSICAL, DUP_ACCEPT,
-       DUP_REALIGN };
+       DUP_REALIGN, DUP_BATCH_PREPARE, DUP_BATCH_SUMS, DUP_BATCH_SOLVE, DUP_BATCH_PACK, DUP_BATCH_SCORE };
 #if defined(ASTC_DUPSTAGE)
 #define DUP_STAGE(c, id, call) do { call; if ((c).cfg->debug_dup_stage == (uint32_t)(id)) { call; } } while (0)
 #else

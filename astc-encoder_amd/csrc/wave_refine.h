@@ -89,6 +89,171 @@ WV_FN PlaneSolve solve_plane(f4 left_sum, f4 middle_sum, f4 right_sum, f4 color_
 	return r;
 }
 
+/* The re-fit's solve for one (partition, channel) of a one-plane candidate (ref: recompute_ideal_colors_1plane :1271-1340;
+ * every quantity is channel-wise in the reference's vector code, the per-partition scalars are simply recomputed by the
+ * four lanes of a partition).  `s`: the partition's sums -- 0 wmin 1 wmax 2 scale_min 3 scale_max 4-6 left / middle / right
+ * 7 weight_weight_sum 8-11 color_vec_x 12-15 color_vec_y 16-17 scale_vec; ep0 / ep1: in = the endpoints so far (kept when
+ * the solve is degenerate), out = the new ones; rgbs: lane ch of the RGB + scale vector. */
+WV_FN void refit_solve_1plane(const float* s, const BlkInfo& blk, float scale_dir, int texels, float ls_weight, int ch,
+                              float& ep0, float& ep1, float& rgbs)
+{
+	const float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
+	const float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6];
+	const float color_weight = blk.cw[ch];
+	const float cwn = color_weight * (float)texels;
+	const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
+
+	const float left_sum = left_sum_s * color_weight;
+	const float middle_sum = middle_sum_s * color_weight;
+	const float right_sum = right_sum_s * color_weight;
+	const float lm_x = left_sum_s * ls_weight, lm_y = middle_sum_s * ls_weight, lm_z = right_sum_s * ls_weight;
+
+	const float color_vec_x = s[8 + ch] * color_weight;
+	const float color_vec_y = s[12 + ch] * color_weight;
+
+	float scalediv = scale_min / f_max(scale_max, 1e-10f);
+	scalediv = f_clamp1(scalediv);
+	// lane ch of rgbs: scale_dir * scale for RGB, the scale ratio for A
+	rgbs = ch < 3 ? scale_dir * scale_max : scalediv;
+
+	if (wmin1 >= wmax1 * 0.999f)
+	{
+		// all weights (nearly) equal: both endpoints become the mean
+		const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+		if (avg == avg) { ep0 = avg; ep1 = avg; }
+		if (ch == 3) rgbs = 1.0f;
+	}
+	else
+	{
+		// (ref: solve as in solve_plane(), one channel)
+		const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
+		const float color_rdet1 = 1.0f / color_det1;
+		const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
+		const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
+		const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
+		if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
+
+		const float scale_vec0 = s[16], scale_vec1 = s[17];
+		const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
+		const float ls_rdet1 = 1.0f / ls_det1;
+		const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
+		const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
+		const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
+
+		if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
+		{
+			rgbs = ch < 3 ? scale_dir * scale_ep1 : scale_ep0 / scale_ep1;
+		}
+	}
+}
+
+/* The HDR RGB + offset vector of one partition of a one-plane candidate (ref: :1342-1364); v0 / v1: the new endpoints. */
+WV_FN f4 refit_rgbo_1plane(const float* s, const BlkInfo& blk, int texels, f4 v0, f4 v1)
+{
+	const float right_sum_s = s[6], weight_weight_sum_s = s[7];
+	f4 color_weight = load4(blk.cw);
+	f4 rgba_weight_sum = v4_max(color_weight * (float)texels, splat4(1e-17f));
+	f4 color_vec_x = load4(&s[8]) * color_weight, color_vec_y = load4(&s[12]) * color_weight;
+	f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
+	float psum = right_sum_s * hadd_rgb_s(color_weight);
+	f4 rgbq_sum = color_vec_x + color_vec_y;
+	rgbq_sum.w = hadd_rgb_s(color_vec_y);
+	f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
+	if (f_isnan(dot_s(rgbovec, rgbovec)))
+	{
+		float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
+		avgdif = f_max(avgdif, 0.0f);
+		f4 avg = (v0 + v1) * 0.5f;
+		f4 e0 = avg - splat4(avgdif) * 0.5f;
+		rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
+	}
+	return rgbovec;
+}
+
+/* The same for one channel of a two-plane candidate (ref: recompute_ideal_colors_2planes :1514-1612).  `s`: 0 wmin1 1 wmax1
+ * 2 wmin2 3 wmax2 4 scale_min 5 scale_max 6-8 left / middle / right of plane 1, 9-11 of plane 2, 12-15 color_vec_x
+ * 16-19 color_vec_y 20-21 scale_vec 22-25 weight_weight_sum. */
+WV_FN void refit_solve_2planes(const float* s, const BlkInfo& blk, float scale_dir_ch, int T, float ls_weight, int ch, int plane2_component,
+                               float& ep0, float& ep1, float& rgbs)
+{
+	const bool second = ch == plane2_component;
+	const float wmin1 = s[0], wmax1 = s[1], scale_min = s[4], scale_max = s[5];
+	const float wmin = second ? s[2] : wmin1, wmax = second ? s[3] : wmax1;
+	const float color_weight = blk.cw[ch];
+	const float cwn = color_weight * (float)T;
+	const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
+	const float left_sum = (second ? s[9] : s[6]) * color_weight;
+	const float middle_sum = (second ? s[10] : s[7]) * color_weight;
+	const float right_sum = (second ? s[11] : s[8]) * color_weight;
+	const float color_vec_x = s[12 + ch] * color_weight;
+	const float color_vec_y = s[16 + ch] * color_weight;
+
+	if (wmin >= wmax * 0.999f)
+	{
+		// all weights of the channel's plane (nearly) equal: both endpoints become the mean
+		const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
+		if (avg == avg) { ep0 = avg; ep1 = avg; }
+	}
+	else
+	{
+		const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
+		const float color_rdet1 = 1.0f / color_det1;
+		const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
+		const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
+		const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
+		if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
+	}
+
+	// the RGB + scale vector follows plane 1 (lane ch: scale_dir * scale for RGB, the scale ratio for A)
+	float scalediv = scale_min / f_max(scale_max, 1e-10f);
+	scalediv = f_clamp1(scalediv);
+	rgbs = ch < 3 ? scale_dir_ch * scale_max : scalediv;
+	if (wmin1 >= wmax1 * 0.999f)
+	{
+		if (ch == 3) rgbs = 1.0f;
+	}
+	else
+	{
+		const float lm_x = s[6] * ls_weight, lm_y = s[7] * ls_weight, lm_z = s[8] * ls_weight;
+		const float scale_vec0 = s[20], scale_vec1 = s[21];
+		const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
+		const float ls_rdet1 = 1.0f / ls_det1;
+		const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
+		const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
+		const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
+		if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
+		{
+			rgbs = ch < 3 ? scale_dir_ch * scale_ep1 : scale_ep0 / scale_ep1;
+		}
+	}
+}
+
+/* ... and its HDR RGB + offset vector (ref: :1614-1640). */
+WV_FN f4 refit_rgbo_2planes(const float* s, const BlkInfo& blk, int T, int plane2_component, f4 v0, f4 v1)
+{
+	const f4 color_weight = load4(blk.cw);
+	const f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
+	const f4 right1_sum = splat4(s[8]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
+	const f4 color_vec_x = load4(&s[12]) * color_weight;
+	const f4 color_vec_y = load4(&s[16]) * color_weight;
+	const f4 weight_weight_sum = load4(&s[22]) * color_weight;
+	f4 sel = mk4(plane2_component == 0 ? right2_sum.x : right1_sum.x, plane2_component == 1 ? right2_sum.y : right1_sum.y,
+	             plane2_component == 2 ? right2_sum.z : right1_sum.z, plane2_component == 3 ? right2_sum.w : right1_sum.w);
+	float psum = dot3_s(sel, color_weight);
+	f4 rgbq_sum = color_vec_x + color_vec_y;
+	rgbq_sum.w = hadd_rgb_s(color_vec_y);
+	f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
+	if (f_isnan(dot_s(rgbovec, rgbovec)))
+	{
+		float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
+		avgdif = f_max(avgdif, 0.0f);
+		f4 avg = (v0 + v1) * 0.5f;
+		f4 e0 = avg - splat4(avgdif) * 0.5f;
+		rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
+	}
+	return rgbovec;
+}
+
 /* Scale direction of every partition of the trial (ref: recompute_ideal_colors_1plane :1198-1219, _2planes :1433-1437):
  * the normalised colour sum of the partition's texels.  It depends on the block and the partitioning only, not on
  * the weights, so it is computed once per trial (the reference recomputes the same values in every refinement step)
@@ -231,59 +396,8 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	WV_FOR64(k, pc * 4)
 	{
 		const int p = k >> 2, ch = k & 3;
-		const float* s = &tr.fbox[p * 24];
-		const float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
-		const float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6];
-		const float color_weight = blk.cw[ch];
-		const float scale_dir = tr.pm_dir[p][ch];
-		const float cwn = color_weight * (float)pv.cnt(p);
-		const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
-
-		const float left_sum = left_sum_s * color_weight;
-		const float middle_sum = middle_sum_s * color_weight;
-		const float right_sum = right_sum_s * color_weight;
-		const float lm_x = left_sum_s * ls_weight, lm_y = middle_sum_s * ls_weight, lm_z = right_sum_s * ls_weight;
-
-		const float color_vec_x = s[8 + ch] * color_weight;
-		const float color_vec_y = s[12 + ch] * color_weight;
-
-		float scalediv = scale_min / f_max(scale_max, 1e-10f);
-		scalediv = f_clamp1(scalediv);
-		// lane ch of rgbs: scale_dir * scale for RGB, the scale ratio for A
-		float rgbs = ch < 3 ? scale_dir * scale_max : scalediv;
-
-		float ep0 = tr.wep0[p][ch], ep1 = tr.wep1[p][ch];
-
-		if (wmin1 >= wmax1 * 0.999f)
-		{
-			// all weights (nearly) equal: both endpoints become the mean
-			const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
-			if (avg == avg) { ep0 = avg; ep1 = avg; }
-			if (ch == 3) rgbs = 1.0f;
-		}
-		else
-		{
-			// (ref: solve as in solve_plane(), one channel)
-			const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
-			const float color_rdet1 = 1.0f / color_det1;
-			const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
-			const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
-			const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
-			if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
-
-			const float scale_vec0 = s[16], scale_vec1 = s[17];
-			const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
-			const float ls_rdet1 = 1.0f / ls_det1;
-			const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
-			const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
-			const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
-
-			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
-			{
-				rgbs = ch < 3 ? scale_dir * scale_ep1 : scale_ep0 / scale_ep1;
-			}
-		}
-
+		float ep0 = tr.wep0[p][ch], ep1 = tr.wep1[p][ch], rgbs;
+		refit_solve_1plane(&tr.fbox[p * 24], blk, tr.pm_dir[p][ch], pv.cnt(p), ls_weight, ch, ep0, ep1, rgbs);
 		tr.wep0[p][ch] = ep0;
 		tr.wep1[p][ch] = ep1;
 		tr.rgbs[p][ch] = rgbs;
@@ -293,26 +407,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	{
 		WV_FOR64(p, pc)
 		{
-			const float* s = &tr.fbox[p * 24];
-			const float right_sum_s = s[6], weight_weight_sum_s = s[7];
-			f4 color_weight = load4(blk.cw);
-			f4 rgba_weight_sum = v4_max(color_weight * (float)pv.cnt(p), splat4(1e-17f));
-			f4 color_vec_x = load4(&s[8]) * color_weight, color_vec_y = load4(&s[12]) * color_weight;
-			f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
-			float psum = right_sum_s * hadd_rgb_s(color_weight);
-			f4 rgbq_sum = color_vec_x + color_vec_y;
-			rgbq_sum.w = hadd_rgb_s(color_vec_y);
-			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
-			if (f_isnan(dot_s(rgbovec, rgbovec)))
-			{
-				f4 v0 = load4(tr.wep0[p]), v1 = load4(tr.wep1[p]);
-				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
-				avgdif = f_max(avgdif, 0.0f);
-				f4 avg = (v0 + v1) * 0.5f;
-				f4 e0 = avg - splat4(avgdif) * 0.5f;
-				rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
-			}
-			store4(tr.rgbo[p], rgbovec);
+			store4(tr.rgbo[p], refit_rgbo_1plane(&tr.fbox[p * 24], blk, pv.cnt(p), load4(tr.wep0[p]), load4(tr.wep1[p])));
 		}
 		WV_SYNC();
 	}
@@ -395,60 +490,8 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	// component, else to plane 1
 	WV_FOR(ch, 4)
 	{
-		const float* s = tr.fbox;
-		const bool second = ch == plane2_component;
-		const float wmin1 = s[0], wmax1 = s[1], scale_min = s[4], scale_max = s[5];
-		const float wmin = second ? s[2] : wmin1, wmax = second ? s[3] : wmax1;
-		const float color_weight = blk.cw[ch];
-		const float cwn = color_weight * (float)T;
-		const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
-		const float left_sum = (second ? s[9] : s[6]) * color_weight;
-		const float middle_sum = (second ? s[10] : s[7]) * color_weight;
-		const float right_sum = (second ? s[11] : s[8]) * color_weight;
-		const float color_vec_x = s[12 + ch] * color_weight;
-		const float color_vec_y = s[16 + ch] * color_weight;
-
-		float ep0 = tr.wep0[0][ch], ep1 = tr.wep1[0][ch];
-		if (wmin >= wmax * 0.999f)
-		{
-			// all weights of the channel's plane (nearly) equal: both endpoints become the mean
-			const float avg = (color_vec_x + color_vec_y) / rgba_weight_sum;
-			if (avg == avg) { ep0 = avg; ep1 = avg; }
-		}
-		else
-		{
-			const float color_det1 = (left_sum * right_sum) - (middle_sum * middle_sum);
-			const float color_rdet1 = 1.0f / color_det1;
-			const float color_mss1 = (left_sum * left_sum) + (2.0f * middle_sum * middle_sum) + (right_sum * right_sum);
-			const float e0 = (right_sum * color_vec_x - middle_sum * color_vec_y) * color_rdet1;
-			const float e1 = (left_sum * color_vec_y - middle_sum * color_vec_x) * color_rdet1;
-			if ((f_abs(color_det1) > (color_mss1 * 1e-4f)) && (e0 == e0) && (e1 == e1)) { ep0 = e0; ep1 = e1; }
-		}
-
-		// the RGB + scale vector follows plane 1 (lane ch: scale_dir * scale for RGB, the scale ratio for A)
-		const float scale_dir_ch = tr.pm_dir[0][ch];
-		float scalediv = scale_min / f_max(scale_max, 1e-10f);
-		scalediv = f_clamp1(scalediv);
-		float rgbs = ch < 3 ? scale_dir_ch * scale_max : scalediv;
-		if (wmin1 >= wmax1 * 0.999f)
-		{
-			if (ch == 3) rgbs = 1.0f;
-		}
-		else
-		{
-			const float lm_x = s[6] * ls_weight, lm_y = s[7] * ls_weight, lm_z = s[8] * ls_weight;
-			const float scale_vec0 = s[20], scale_vec1 = s[21];
-			const float ls_det1 = (lm_x * lm_z) - (lm_y * lm_y);
-			const float ls_rdet1 = 1.0f / ls_det1;
-			const float ls_mss1 = (lm_x * lm_x) + (2.0f * lm_y * lm_y) + (lm_z * lm_z);
-			const float scale_ep0 = (lm_z * scale_vec0 - lm_y * scale_vec1) * ls_rdet1;
-			const float scale_ep1 = (lm_x * scale_vec1 - lm_y * scale_vec0) * ls_rdet1;
-			if (f_abs(ls_det1) > (ls_mss1 * 1e-4f) && scale_ep0 == scale_ep0 && scale_ep1 == scale_ep1 && scale_ep0 < scale_ep1)
-			{
-				rgbs = ch < 3 ? scale_dir_ch * scale_ep1 : scale_ep0 / scale_ep1;
-			}
-		}
-
+		float ep0 = tr.wep0[0][ch], ep1 = tr.wep1[0][ch], rgbs;
+		refit_solve_2planes(tr.fbox, blk, tr.pm_dir[0][ch], T, ls_weight, ch, plane2_component, ep0, ep1, rgbs);
 		tr.wep0[0][ch] = ep0;
 		tr.wep1[0][ch] = ep1;
 		tr.rgbs[0][ch] = rgbs;
@@ -460,32 +503,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	// i.e. a scratch frame, for them).
 	if (kHdr && (blk.rgb_lns || blk.alpha_lns))
 	{
-		WV_ONE
-		{
-			const float* s = tr.fbox;
-			const f4 color_weight = load4(blk.cw);
-			const f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
-			const f4 right1_sum = splat4(s[8]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
-			const f4 color_vec_x = load4(&s[12]) * color_weight;
-			const f4 color_vec_y = load4(&s[16]) * color_weight;
-			const f4 weight_weight_sum = load4(&s[22]) * color_weight;
-			f4 sel = mk4(plane2_component == 0 ? right2_sum.x : right1_sum.x, plane2_component == 1 ? right2_sum.y : right1_sum.y,
-			             plane2_component == 2 ? right2_sum.z : right1_sum.z, plane2_component == 3 ? right2_sum.w : right1_sum.w);
-			float psum = dot3_s(sel, color_weight);
-			f4 rgbq_sum = color_vec_x + color_vec_y;
-			rgbq_sum.w = hadd_rgb_s(color_vec_y);
-			f4 rgbovec = compute_rgbo_vector(rgba_weight_sum, weight_weight_sum, rgbq_sum, psum);
-			if (f_isnan(dot_s(rgbovec, rgbovec)))
-			{
-				f4 v0 = load4(tr.wep0[0]), v1 = load4(tr.wep1[0]);
-				float avgdif = hadd_rgb_s(v1 - v0) * (1.0f / 3.0f);
-				avgdif = f_max(avgdif, 0.0f);
-				f4 avg = (v0 + v1) * 0.5f;
-				f4 e0 = avg - splat4(avgdif) * 0.5f;
-				rgbovec = mk4(e0.x, e0.y, e0.z, avgdif);
-			}
-			store4(tr.rgbo[0], rgbovec);
-		}
+		WV_ONE { store4(tr.rgbo[0], refit_rgbo_2planes(tr.fbox, blk, T, plane2_component, load4(tr.wep0[0]), load4(tr.wep1[0]))); }
 		WV_SYNC();
 	}
 }

@@ -40,9 +40,9 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	{
 		const LdsLayout& L = b->layout;
 		const TableRoot& r = *reinterpret_cast<const TableRoot*>(blob);
-		fprintf(stderr, "lds layout: total %u | data %u blk %u scb %u trial %u ei_w %u ei_wes %u ptab %u candw %u | phase begin %u | search: dwi %u lowhigh %u modes %u uni %u (+%u) | refine: dtab %u ctab %u qtab %u rsc %u tsc_r %u wsc %u | part: part %u tsc_p %u part_tabs %u (chunk %u) | max_dec_table %u realign_rt %u\n",
+		fprintf(stderr, "lds layout: total %u | data %u blk %u scb %u trial %u ei_w %u ei_wes %u ptab %u candw %u | phase begin %u | search: dwi %u lowhigh %u modes %u uni %u (+%u) | refine: dtab %u ctab %u qtab %u rsc %u tsc_r %u wsc %u | part: part %u tsc_p %u part_tabs %u (chunk %u) | max_dec_table %u realign_rt %u | batch: cstate %u stride %u per batch %u / %u\n",
 		        L.total, L.data, L.blk, L.scb, L.trial, L.ei_w, L.ei_wes, L.ptab, L.candw, L.dwi, L.dwi, L.lowhigh, L.modes, L.uni, L.uni_bytes,
-		        L.dtab, L.ctab, L.qtab, L.rsc, L.tsc_r, L.wsc, L.part, L.tsc_p, L.part_tabs, L.part_chunk, r.max_decimation_table_bytes, r.realign_rt_floats);
+		        L.dtab, L.ctab, L.qtab, L.rsc, L.tsc_r, L.wsc, L.part, L.tsc_p, L.part_tabs, L.part_chunk, r.max_decimation_table_bytes, r.realign_rt_floats, L.cstate, L.cstate_stride, L.bat_max[0], L.bat_max[1]);
 	}
 	*status = 0;
 	return b;

@@ -107,7 +107,7 @@ int main(int argc, char** argv)
 					for (int k = 0; k < 4; k++) { tr.wep0[0][k] = e0[k]; tr.wep1[0][k] = e1[k]; tr.rgbo[0][k] = rgbo[k]; }
 					uint8_t requested[4] = { (uint8_t)format, 0, 0, 0 }, formats_out[4] = { 0 };
 					uint8_t tries[4 * astcd::HDR_TRY_LANES * astcd::HDR_TRY_BYTES];
-					astcd::pack_endpoints_hdr(c, 1, requested, got, formats_out, q, tries);
+					astcd::pack_endpoints_hdr(astcd::color_tabs(c, q), &tr.wep0[0][0], &tr.wep1[0][0], &tr.rgbo[0][0], 1, requested, got, formats_out, tries);
 					got_format = formats_out[0];
 					// coverage: which sub-mode record won
 					auto first = [&tries](int begin, int end) { for (int m = begin; m < end; m++) if (tries[m * astcd::HDR_TRY_BYTES]) return m - begin; return end - begin; };

@@ -2,8 +2,9 @@
 """Per-stage instruction counts from the runs of tools/gpu_stage_counts.sh (stage doubled minus plain run)."""
 import csv, glob, os, sys
 NAMES = {1: "ideal endpoints+weights", 2: "decimate (all grids)", 3: "angular bounds", 4: "mode scoring", 5: "mode scoring + formats",
-         6: "candidate quantize", 7: "candidate setup/staging", 8: "recompute endpoints", 9: "pack endpoints", 10: "difference (decode+score)",
-         11: "partition order (k-means)", 12: "partition score", 13: "partition select", 14: "block statistics", 15: "load block", 16: "physical", 18: "weight realignment"}
+         6: "candidate quantize", 7: "candidate restore/staging", 8: "recompute endpoints", 9: "pack endpoints", 10: "difference (decode+score)",
+         11: "partition order (k-means)", 12: "partition score", 13: "partition select", 14: "block statistics", 15: "load block", 16: "physical", 18: "weight realignment",
+         19: "batch: rows + weights", 20: "batch: sums", 21: "batch: solve", 22: "batch: pack", 23: "batch: score"}
 d = sys.argv[1]
 def load(i):
     tot = {}
