@@ -7,6 +7,10 @@
 // All control flow here is wave-uniform: every decision is taken on values read back from LDS.
 #pragma once
 #include <stddef.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 #include "wave_ctx.h"
 #include "wave_quad.h"
 #include "wave_load.h"
@@ -886,7 +890,10 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 			}
 		}
 	}
-	// list of the grids this trial uses, largest weight count first (the order the search batches them in)
+	// list of the grids this trial uses, largest weight count first (the order the search batches them in).  Only grids with
+	// a block mode at a quant level that HAS angular bounds (<= QUANT_12, ref: weight_align.cpp:404-422) and that this trial
+	// may use: the reference also runs the search for grids whose every mode is above QUANT_12 and never reads the result.
+	const uint16_t ang_mask = (uint16_t)(ref_mask & ((1u << (MAX_ANGULAR_QUANT + 1)) - 1u));
 	const uint8_t* by_weights = c.table(c.root->off_dm_by_weights);
 	const int all_dms = (int)c.root->decimation_mode_count_selected;
 #if WV_DEVICE
@@ -901,7 +908,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 			{
 				i = by_weights[k];
 				const DecimationMode& m = c.dec_mode(i);
-				used = i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask) != 0;
+				used = i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ang_mask) != 0;
 			}
 			const unsigned long long mask = __ballot(used);
 			if (used) tr.dm_list[n + __popcll(mask & ((1ull << WV_LANE) - 1ull))] = (uint8_t)i;
@@ -916,7 +923,7 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		{
 			const int i = by_weights[k];
 			const DecimationMode& m = c.dec_mode(i);
-			if (i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ref_mask)) tr.dm_list[n++] = (uint8_t)i;
+			if (i < max_decimation_modes && ((dual ? m.refprec_2planes : m.refprec_1plane) & ang_mask)) tr.dm_list[n++] = (uint8_t)i;
 		}
 		tr.dm_count = n;
 	}
@@ -940,6 +947,10 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 		return a;
 	};
 	PROF_SCOPE(c, PS_ANGULAR);
+#if !WV_DEVICE
+	if (getenv("ASTC_EMU_DUMP_ANG")) { fprintf(stderr, "ang: dual %d pc %d maxwq %d sets %d:", (int)dual, partition_count, max_weight_quant, tr.dm_count * (dual ? 2 : 1));
+		for (int s = 0; s < tr.dm_count * (dual ? 2 : 1); s++) { AngSet a = get_set(s); fprintf(stderr, " (w%d q%d u%x)", a.wcount, a.maxq, a.used); } fprintf(stderr, "\n"); }
+#endif
 	angular_endpoints(c, tr.dm_count * (dual ? 2 : 1), get_set);
 }
 

@@ -102,11 +102,23 @@ WV_FN float q_hmin(qf a)
 	o = q_perm_f<Q_SWAP2>(v); v = o < v ? o : v;
 	return v;
 }
+/* largest component (finite values) */
+WV_FN float q_hmax(qf a)
+{
+	float v = a.v;
+	float o = q_perm_f<Q_SWAP1>(v); v = o > v ? o : v;
+	o = q_perm_f<Q_SWAP2>(v); v = o > v ? o : v;
+	return v;
+}
 /* stores: component ch of `a` to p[ch * stride] for ch < count */
 WV_FN void q_store_u8(uint8_t* p, int stride, qi a, int count) { if (Q_CH < count) p[Q_CH * stride] = (uint8_t)a.v; }
 WV_FN void q_store_i32(int* p, qi a) { p[Q_CH] = a.v; }
 /* executed by one lane of the quad (scalar results: formats, flags) */
 #define Q_ONCE if (Q_CH == 0)
+/* Per-component code with loops and state of its own (a running sum per component, each over its own index sequence):
+ * Q_LANES(l) { ... QV(a, l) ... } runs the body for component l = this lane's on the device, for l = 0 .. 3 in turn on the CPU. */
+#define Q_LANES(l) for (int l = Q_CH, q_once_##l = 1; q_once_##l; q_once_##l = 0)
+#define QV(a, l) ((a).v)
 
 #else // ------------------------------------------------------------------------------------------------------
 
@@ -152,9 +164,12 @@ WV_FN int q_sum_rgb(qi a) { return a.v[0] + a.v[1] + a.v[2]; }
 WV_FN float q_hadd_rgb(qf a) { return (a.v[0] + a.v[1]) + a.v[2]; }
 WV_FN float q_hadd(qf a) { return (a.v[0] + a.v[2]) + (a.v[1] + a.v[3]); }
 WV_FN float q_hmin(qf a) { float m = a.v[0]; for (int k = 1; k < 4; k++) m = a.v[k] < m ? a.v[k] : m; return m; }
+WV_FN float q_hmax(qf a) { float m = a.v[0]; for (int k = 1; k < 4; k++) m = a.v[k] > m ? a.v[k] : m; return m; }
 WV_FN void q_store_u8(uint8_t* p, int stride, qi a, int count) { for (int k = 0; k < count; k++) p[k * stride] = (uint8_t)a.v[k]; }
 WV_FN void q_store_i32(int* p, qi a) { for (int k = 0; k < 4; k++) p[k] = a.v[k]; }
 #define Q_ONCE if (true)
+#define Q_LANES(l) for (int l = 0; l < 4; l++)
+#define QV(a, l) ((a).v[l])
 
 #endif
 

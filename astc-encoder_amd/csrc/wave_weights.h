@@ -413,27 +413,26 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 			float errval = 0.0f, cut_low = 0.0f, cut_high = 0.0f;
 			float minidx = f_round(min_weight * rcp_stepsize - offset);
 			float maxidx = f_round(max_weight * rcp_stepsize - offset);
-			for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
+			// (four weights per round trip while four are left, then the tail one by one: every lane walks exactly its own
+			//  set's weights -- the sets of a batch are sorted by weight count, so the lanes mostly stop together -- and a
+			//  weight costs its sixteen operations, nothing for masking slots past the end)
+			auto one_weight = [&](float w)
 			{
-				float wj[ASTC_ANG_GROUP];
-				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++) wj[u] = wv[j0 + u < W ? j0 + u : 0];
-				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++)
+				float sval = w * rcp_stepsize - offset;
+				float svalrte = f_round(sval);
+				float diff = sval - svalrte;
+				errval += diff * diff;
+				if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
+				if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+			};
+			{
+				int j = 0;
+				for (; j + 4 <= W; j += 4)
 				{
-					// past the set's last weight (wj is a copy of weight 0 there): the squared difference is multiplied by 0.0
-					// (+0.0 added to a sum that is >= +0.0: exact) and the rounded value is pushed out of the index range so
-					// that neither cut test fires -- arithmetic on a 1.0 / 0.0 flag in a vector register instead of a branch
-					// or a lane mask per slot (eight of those do not fit the scalar registers of an out-of-line stage)
-					const float keep = wv_opaque_f(j0 + u < W ? 1.0f : 0.0f);
-					float sval = wj[u] * rcp_stepsize - offset;
-					float svalrte = f_round(sval);
-					float diff = sval - svalrte;
-					errval += (diff * diff) * keep;
-					const float key = svalrte + (1.0f - keep) * 1e30f;       // == svalrte for a real weight
-					if (key == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
-					if (key == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+					const float w0 = wv[j], w1 = wv[j + 1], w2 = wv[j + 2], w3 = wv[j + 3];
+					one_weight(w0); one_weight(w1); one_weight(w2); one_weight(w3);
 				}
+				for (; j < W; j++) one_weight(wv[j]);
 			}
 			int max_quant_steps = steps;
 			int span = (int)(maxidx - minidx + 1.0f);
