@@ -9,6 +9,7 @@
 //                                                     compute_error_of_weight_set_{1plane,2planes} :688-842
 #pragma once
 #include "wave_ctx.h"
+#include "wave_quad.h"
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
@@ -305,43 +306,73 @@ struct AngSet {
 	uint16_t used;          // quant levels <= QUANT_12 that a block mode of this grid uses (bit mask)
 };
 
+/* What the search keeps per set while it runs (in the trial's float mailbox, 64 sets at a time): the phases read this
+ * one 8-byte record instead of walking decimation mode -> decimation info -> layout again (get_set) on every lane of
+ * every phase. */
+struct AngRec {
+	uint16_t w_off;     // the set's ideal weights: float index from the start of LDS
+	uint16_t out_off;   // ... its (low, high) pairs
+	uint8_t wcount, maxq, used, steps;
+};
+static_assert(sizeof(AngRec) == 8, "64 records fill the 512-byte mailbox");
+
 template <typename SetFn>
-WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
+WV_FN void angular_endpoints(const Ctx& c, int nsets_all, SetFn get_set)
 {
 	float* ang = c.ang();               // [64][ANG_PAIR_STRIDE]: offset, lowest, span, err, cut_low, cut_high
 	TrialInfo& tr = c.tr();
 	struct CosSin { float cs, sn; };
 	const CosSin* cos_sin_table = reinterpret_cast<const CosSin*>(c.table(c.root->off_cos_sin_table));
-
-	// steps of every set, one per lane: the batching below then needs no memory access per set
-	LaneArray128 steps_of;
-	steps_of.clear();
-	WV_FOR(s, nsets) { steps_of.set(s, steps_for_quant_level(get_set(s).maxq)); }
+	float* ldsf = reinterpret_cast<float*>(c.lds);
+	AngRec* recs = reinterpret_cast<AngRec*>(tr.fbox);
+	static_assert(sizeof(tr.fbox) >= 64 * sizeof(AngRec), "set records do not fit the mailbox");
+	const int row_bias = (int)(c.L->dwi >> 2);       // isample()[k] belongs to the weight at float index row_bias + k
 	uint8_t* pair_set = reinterpret_cast<uint8_t*>(&tr.ibox[32]);      // [64] batch-local set of each (set, step) pair
 	uint8_t* set_steps = reinterpret_cast<uint8_t*>(&tr.ibox[48]);     // [32] steps of each set of the batch
 
-	// Lowest and highest weight of every set (ref: compute_angular_offsets keeps them per step, :104-127: they are the same
-	// for every step of a set), one lane per set, parked in the first two floats of the set's output row until the
-	// set's own phase 2 overwrites them with the bounds of quant level 0.
-	WV_FOR(s, nsets)
+	for (int g0 = 0; g0 < nsets_all; g0 += 64)
 	{
-		const AngSet a = get_set(s);
-		float min_weight = 3.402823466e+38f, max_weight = -3.402823466e+38f;
-		for (int j = 0; j < a.wcount; j++)
+	const int nsets = i_min(64, nsets_all - g0);
+	// Per set: its record, and the lowest and highest weight (ref: compute_angular_offsets keeps them per step, :104-127:
+	// they are the same for every step of a set) -- one QUAD per set, lane l looks at weights l, l + 4, ... (exact: the
+	// weights are finite) -- parked in the first two floats of the set's output row until the set's own phase 2 overwrites
+	// them with the bounds of quant level 0.
+	WV_QUADS(s, nsets)
+	{
+		const AngSet a = get_set(g0 + s);
+		qf mn = q_splat(3.402823466e+38f), mx = q_splat(-3.402823466e+38f);
+		Q_LANES(l)
 		{
-			const float w = a.weights[j];
-			min_weight = w < min_weight ? w : min_weight;
-			max_weight = w > max_weight ? w : max_weight;
+			for (int j = l; j < a.wcount; j += 4)
+			{
+				const float w = a.weights[j];
+				QV(mn, l) = w < QV(mn, l) ? w : QV(mn, l);
+				QV(mx, l) = w > QV(mx, l) ? w : QV(mx, l);
+			}
 		}
-		a.out[0] = min_weight;
-		a.out[1] = max_weight;
-		// The slots between the set's last weight and the next multiple of four (they belong to the set: the packing is in
-		// fours) select the table's all-zero row: phase 1 walks the weights four at a time and needs no tail handling in
-		// its sum of cosines / sines.
-		static_assert(ASTC_ANG_GROUP <= 4, "the padding of a set's slots is to a multiple of four");
-		for (int j = a.wcount; j < ((a.wcount + 3) & ~3); j++) const_cast<uint8_t*>(a.rows)[j] = (uint8_t)SINCOS_STEPS;
+		const float min_weight = q_hmin(mn), max_weight = q_hmax(mx);
+		Q_ONCE
+		{
+			a.out[0] = min_weight;
+			a.out[1] = max_weight;
+			// The slots between the set's last weight and the next multiple of four (they belong to the set: the packing is
+			// in fours) select the table's all-zero row: phase 1 walks the weights four at a time and needs no tail handling
+			// in its sum of cosines / sines.
+			static_assert(ASTC_ANG_GROUP <= 4, "the padding of a set's slots is to a multiple of four");
+			for (int j = a.wcount; j < ((a.wcount + 3) & ~3); j++) const_cast<uint8_t*>(a.rows)[j] = (uint8_t)SINCOS_STEPS;
+			AngRec r;
+			r.w_off = (uint16_t)(a.weights - ldsf);
+			r.out_off = (uint16_t)(a.out - ldsf);
+			r.wcount = (uint8_t)a.wcount; r.maxq = (uint8_t)a.maxq; r.used = (uint8_t)a.used;
+			r.steps = (uint8_t)steps_for_quant_level(a.maxq);
+			recs[s] = r;
+		}
 	}
 	WV_SYNC();
+	// steps of every set, one per lane: the batching below then needs no memory access per set
+	LaneArray128 steps_of;
+	steps_of.clear();
+	WV_FOR64(s, nsets) { steps_of.set(s, recs[s].steps); }
 
 	int s0 = 0;
 	while (s0 < nsets)
@@ -369,15 +400,15 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		{
 			// (set, step) of pair k
 			const int sl = pair_set[k];
-			const int s = s0 + sl;
 			const int base = tr.ibox[sl];
-			const AngSet a = get_set(s);
-			const int steps = steps_for_quant_level(a.maxq);
+			const AngRec a = recs[s0 + sl];
+			const int steps = a.steps;
 			int sp = k - base;
 			const int W = a.wcount;
-			const float* wv = a.weights;
-			const uint8_t* rows = a.rows;
-			const float min_weight = a.out[0], max_weight = a.out[1];
+			const float* wv = ldsf + a.w_off;
+			const uint8_t* rows = c.isample() + ((int)a.w_off - row_bias);
+			const float* aout = ldsf + a.out_off;
+			const float min_weight = aout[0], max_weight = aout[1];
 
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
@@ -454,10 +485,11 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 		WV_FOR(k, (s1 - s0) * 8)
 		{
 			int s = s0 + (k >> 3), qi = k & 7;
-			AngSet a = get_set(s);
+			const AngRec a = recs[s];
+			float* aout = ldsf + a.out_off;
 			if (qi <= a.maxq && ((a.used >> qi) & 1u))
 			{
-				int steps = steps_for_quant_level(a.maxq);
+				int steps = a.steps;
 				const float* base = ang + tr.ibox[s - s0] * (int)ANG_PAIR_STRIDE;
 				int q = steps_for_quant_level(qi);
 
@@ -490,12 +522,13 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets, SetFn get_set)
 				float hwi = lwi + (float)q - 1.0f;
 				float stepsize = 1.0f / (1.0f + (float)bsi);
 				const int slot = popcount32((uint32_t)a.used & ((1u << qi) - 1u));
-				a.out[slot * 2 + 0] = (r[0] + lwi) * stepsize;
-				a.out[slot * 2 + 1] = (r[0] + hwi) * stepsize;
+				aout[slot * 2 + 0] = (r[0] + lwi) * stepsize;
+				aout[slot * 2 + 1] = (r[0] + hwi) * stepsize;
 			}
 		}
 		WV_SYNC();
 		s0 = s1;
+	}
 	}
 }
 
