@@ -29,8 +29,10 @@ Rank 0 prints ONE JSON line with the driver's fields plus:
                    between, plus the 1-thread rate, the rate per host core-second, and the host's CPU model / cgroup
                    quota / load; then a byte comparison of the crop against the GPU output.  N = 1 only.
   extra_configs  : BASELINE configs[2] (8192^2 8x8 -thorough) and configs[3] (4096^2 RGBA16F HDR 6x6 -medium):
-                   kernel time, Mtexels/s, roofline, byte parity of a block-aligned crop and of the clamped image
-                   tail against the reference, and (HDR) mPSNR / log RMSE from the on-device comparison.
+                   kernel time, Mtexels/s, roofline, byte parity of the WHOLE stream against the reference (crop + tail if
+                   a probe says that would take more than a minute of host time), and (HDR) mPSNR / log RMSE from the
+                   on-device comparison; and `photo`: the reference's Khronos test images tiled to 4096^2, 6x6 -medium,
+                   with the reference's AVX2 rate on the same image and a whole-stream byte comparison.
 """
 import argparse
 import ctypes
@@ -261,6 +263,83 @@ def parity_crops(cfg, img, gpu_blocks, budget_s):
     return res
 
 
+def parity_whole_or_crops(cfg, img, gpu_blocks, budget_s):
+    """Every block of the image against the reference when a probe says that fits `budget_s` of host time (it does on the
+    GPU boxes seen so far), else the crop + tail comparison."""
+    if not os.path.exists(O.LIB_REF_AVX2):
+        return None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    bx, by = cfg["block"]
+    probe = 256 // by * by, 256 // bx * bx
+    dt, _ = reference_threads(A.Library(O.LIB_REF_AVX2), cfg, np.ascontiguousarray(img[:probe[0], :probe[1]]), cores, 1)
+    estimate = dt * img.shape[0] * img.shape[1] / (probe[0] * probe[1])
+    if estimate <= budget_s:
+        res = parity_full(cfg, img, gpu_blocks, cores, 0)
+        res["coverage"] = "whole stream"
+        return res
+    res = parity_crops(cfg, img, gpu_blocks, budget_s / 4.0)
+    res["coverage"] = "crop + tail (a whole-stream run was estimated at %.0f s of host time)" % estimate
+    return res
+
+
+def khronos_mosaic(size=4096):
+    """The reference's Khronos test images (tests/corpus/_images, fetched by tests/corpus/make_corpus.py) tiled into one
+    size x size RGBA8 image: the 2048^2 diffuse map in two quadrants, the 1024^2 maps (emissive, metal-roughness, base
+    colour, specular-glossiness, normal, occlusion) in the other two.  None when the corpus is not there."""
+    from PIL import Image
+    d = os.path.join(ROOT, "tests", "corpus", "_images", "Khronos")
+    names = ["LDR-RGB/ldr-rgb-diffuse.png", "LDR-RGB/ldr-rgb-emissive.png", "LDR-RGB/ldr-rgb-metalrough.png", "LDR-RGBA/ldr-rgba-base.png",
+             "LDR-RGBA/ldr-rgba-diffuse.png", "LDR-RGBA/ldr-rgba-specgloss.png", "LDR-XY/ldr-xy-normal1.png", "LDR-L/ldr-l-occlusion.png"]
+    if not all(os.path.exists(os.path.join(d, n)) for n in names):
+        return None
+    tiles = [np.array(Image.open(os.path.join(d, n)).convert("RGBA")) for n in names]
+    big, small = tiles[0], tiles[1:]
+    canvas = np.zeros((size, size, 4), dtype=np.uint8)
+    q = size // 2
+    k = 0
+    for qy in range(2):
+        for qx in range(2):
+            if qx == qy:
+                reps = (q + big.shape[0] - 1) // big.shape[0]
+                canvas[qy * q:(qy + 1) * q, qx * q:(qx + 1) * q] = np.tile(big, (reps, reps, 1))[:q, :q]
+            else:
+                for ty in range(0, q, 1024):
+                    for tx in range(0, q, 1024):
+                        canvas[qy * q + ty: qy * q + ty + 1024, qx * q + tx: qx * q + tx + 1024] = small[k % len(small)][:min(1024, q - ty), :min(1024, q - tx)]
+                        k += 1
+    return np.ascontiguousarray(canvas)
+
+
+def run_photo_config(lib, dev, steps, warmup):
+    """Photographic content (VERDICT r03 "missing" 2: real content takes the early exits that noise never takes): the
+    Khronos set tiled to 4096^2, 6x6 -medium, device-resident like the headline; the reference's AVX2 build on the same
+    image beside it (whole stream, byte-compared)."""
+    img = khronos_mosaic()
+    if img is None:
+        return {"config": "photo", "skipped": "tests/corpus/_images not present (tests/corpus/make_corpus.py needs /root/reference)"}
+    cfg = dict(CONFIGS["c2"], size=img.shape[0], label="Khronos test images tiled to %dx%d RGBA8 LDR, 6x6 block, -medium" % img.shape[:2])
+    ctx = make_context(lib, cfg)
+    d_img = to_device(img, dev)
+    nbx, nby = block_grid(cfg)
+    d_out = torch.zeros(nbx * nby * 16, dtype=torch.uint8, device=dev)
+    elapsed, kms = time_device_resident(lib, ctx, cfg, d_img, d_out, dev, steps, warmup, lambda: torch.cuda.synchronize(dev))
+    gpu_blocks = d_out.cpu().numpy()
+    texels = img.shape[0] * img.shape[1]
+    value = texels * steps / elapsed / 1e6
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    par = parity_full(cfg, img, gpu_blocks, cores, 0)
+    res = {"config": "photo", "workload": cfg["label"], "data": "reference Test/Images/Khronos", "value": round(value, 3), "unit": "Mtexels/s",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "blocks_per_image": nbx * nby,
+           "kernel_ms": round(sum(kms) / len(kms), 3), "parity_vs_reference": par,
+           "quality": device_quality(lib, ctx, cfg, d_img, d_out, dev)}
+    if par:
+        res["cpu_baseline"] = {"value": par["reference_mtexels_s_whole_image"], "unit": "Mtexels/s", "cores": par["threads"], "kind": "reference",
+                               "sample": "astcenc-avx2 (oracle/_ref) on the whole mosaic, one run"}
+        res["speedup_vs_cpu_baseline"] = round(value / max(par["reference_mtexels_s_whole_image"], 1e-9), 2)
+    lib.context_free(ctx)
+    return res
+
+
 def decoded_psnr(cfg, img, gpu_blocks):
     """PSNR (dB, RGBA, reference definition astcenccli_error_metrics.cpp:240-346) of the GPU's blocks
     decoded by the independent plain-C decoder in oracle/ (checker only, never timed)."""
@@ -387,7 +466,15 @@ def roofline_of(cfg, kernel_s, hdr_kernel, name):
                             "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_S,
                             "what": "wave-level VALU instructions per block x blocks / kernel time of this run, against 1024 SIMDs x 2.4 GHz / 2 "
                                     "clocks; active_lanes = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (of 64)"}
-        for key in ("salu_insts_per_block", "lds_insts_per_block", "valu_issue_frac", "valu_busy_frac_of_kernel_time"):
+            if "valu_issue_cycles_per_block" in counters:
+                # Sum over the opcode classes of (count x measured issue cost) / (kernel time x SIMDs x clock): how busy the
+                # vector pipes are by the costs of tools/valu_microbench3.hip instead of the spec's 2 clocks; a range, since
+                # the hardware's class counters leave two fifths of the instructions unclassified (tools/summarize_evidence.py)
+                simd_cycles = kernel_s * 1024 * 2.4e9
+                cyc = counters["valu_issue_cycles_per_block"]
+                roof["valu"]["issue_frac_measured"] = {"low": round(cyc["low"] * nbx * nby / simd_cycles, 4), "high": round(cyc["high"] * nbx * nby / simd_cycles, 4),
+                                                       "class_insts_per_block": counters.get("valu_class_insts_per_block"), "costs": cyc.get("costs")}
+        for key in ("salu_insts_per_block", "lds_insts_per_block", "wait_any_frac_of_wave_cycles", "lds_bank_conflict_frac"):
             if key in counters:
                 roof[key] = counters[key]
     return roof
@@ -408,7 +495,7 @@ def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
            "value": round(texels * steps / elapsed / 1e6, 3), "unit": "Mtexels/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "blocks_per_image": nbx * nby,
            "roofline": roofline_of(cfg, kernel_s, cfg["hdr"], name),
-           "parity_vs_reference": parity_crops(cfg, img, gpu_blocks, budget_s),
+           "parity_vs_reference": parity_whole_or_crops(cfg, img, gpu_blocks, budget_s),
            "quality": device_quality(lib, ctx, cfg, d_img, d_out, dev)}
     lib.context_free(ctx)
     del d_img, d_out
@@ -544,7 +631,8 @@ def main():
             extra = []
             for name in ("c3", "c4"):
                 shared = img_host if name == "c3" else None           # c3 is the same RGBA8 image, other footprint / preset
-                extra.append(run_extra_config(lib, name, dev, 2, 1, shared, 8.0))
+                extra.append(run_extra_config(lib, name, dev, 2, 1, shared, 60.0))
+            extra.append(run_photo_config(lib, dev, 3, 1))
             out["extra_configs"] = extra
         print(json.dumps(out), flush=True)
 

@@ -14,7 +14,7 @@ out = {"configs": {}, "method": "rocprofv3 --pmc over `bench.py --config <c> --s
 for c in configs:
     tot, n = defaultdict(float), defaultdict(int)
     kernel = None
-    for p in range(1, 5):
+    for p in range(1, 6):
         for f in glob.glob(os.path.join(d, "%s_pmc%d" % (c, p), "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = row.get("Kernel_Name", "")
@@ -37,11 +37,6 @@ for c in configs:
                 e[key] = round(per(counter) / waves, 2)
     if per("SQ_THREAD_CYCLES_VALU") and per("SQ_ACTIVE_INST_VALU"):
         e["active_lanes_avg"] = round(per("SQ_THREAD_CYCLES_VALU") / per("SQ_ACTIVE_INST_VALU"), 2)
-    if per("SQ_ACTIVE_INST_VALU") and per("SQ_WAVE_CYCLES"):
-        # both tick in units of 4 clocks; 4 waves share a SIMD (c2, c4; config 3 runs 10 blocks per CU = 2.5 per SIMD, see
-        # valu_busy_frac_of_kernel_time below), so wave residency / 4 = SIMD time.  Every VALU instruction counts as
-        # one 4-clock slot whatever its real issue cost: an upper bound of the VALU pipe's busy fraction
-        e["valu_issue_frac"] = round(per("SQ_ACTIVE_INST_VALU") / (per("SQ_WAVE_CYCLES") / 4.0), 4)
     if per("SQ_WAIT_ANY") and per("SQ_WAVE_CYCLES"):
         e["wait_any_frac_of_wave_cycles"] = round(per("SQ_WAIT_ANY") / per("SQ_WAVE_CYCLES"), 4)
     if per("SQ_LDS_BANK_CONFLICT") and per("SQ_ACTIVE_INST_LDS"):
@@ -52,10 +47,21 @@ for c in configs:
             if "astc_compress" in row.get("Name", ""):
                 e["rocprofv3_kernel_avg_ms"] = round(float(row["AverageNs"]) / 1e6, 3)
                 e["rocprofv3_kernel_calls"] = int(row["Calls"])
-    if per("SQ_ACTIVE_INST_VALU") and e.get("rocprofv3_kernel_avg_ms"):
-        # occupancy-independent form of the same bound: VALU slots (4 clocks each) against the launch's wall time on 1024 SIMDs at the
-        # nominal 2.4 GHz (the PMC pass and the traced pass run the same command line)
-        e["valu_busy_frac_of_kernel_time"] = round(per("SQ_ACTIVE_INST_VALU") * 4.0 / (e["rocprofv3_kernel_avg_ms"] * 1e6 * 2.4 * 1024.0), 4)
+    # The VALU opcode classes the hardware counts, per block, and what they cost to issue: SIMD cycles per wave64
+    # instruction measured with hand-written asm loops at 4 to 8 waves per SIMD (tools/valu_microbench3.hip,
+    # profiles/r04a/valu_microbench3.txt): fp32 add / sub / mul 2.2; VOP3 fma 2.4; conversions 4.3; transcendentals 8.3.
+    # INT32 mixes both classes (add / sub / and / or / lshr 2.2; lshl, mul, mad, bfe, min / max, compares 4.3) and so does
+    # what no class counter sees (v_mov 2.2; v_cmp, v_cndmask, fp32 min / max, DPP forms, lane reads 4.3): the sum is given
+    # as a range, every unclassified instruction at 2.2 / at 4.3.
+    if waves and per("SQ_INSTS_VALU_ADD_F32") is not None and per("SQ_INSTS_VALU"):
+        cls = {k: per("SQ_INSTS_VALU_" + k) / waves for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64")}
+        total = per("SQ_INSTS_VALU") / waves
+        known = cls["ADD_F32"] * 2.2 + cls["MUL_F32"] * 2.2 + cls["FMA_F32"] * 2.4 + cls["TRANS_F32"] * 8.3 + cls["CVT"] * 4.3
+        mixed = cls["INT32"] + cls["INT64"] + max(0.0, total - sum(cls.values()))
+        e["valu_class_insts_per_block"] = {k.lower(): round(v, 1) for k, v in cls.items()}
+        e["valu_class_insts_per_block"]["unclassified"] = round(max(0.0, total - sum(cls.values())), 1)
+        e["valu_issue_cycles_per_block"] = {"low": round(known + mixed * 2.2, 0), "high": round(known + mixed * 4.3, 0),
+                                            "costs": "profiles/r04a/valu_microbench3.txt"}
     out["configs"][c] = e
     print("== %s" % c)
     for k, v in e.items():
