@@ -315,11 +315,27 @@ void backend_destroy(Backend* b)
 
 int backend_device_count(const Backend* b) { return (int)b->slots.size(); }
 
+static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress);
+
 /* The blocks of `job` on one slot.  Returns 0 ok, 1 out of memory, 2 device failure, 3 bad argument. */
 static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress)
 {
 	std::lock_guard<std::mutex> busy(s->busy);
 	HIP_TRY(hipSetDevice(s->device), return 2);
+	const int rc = compress_on_slot_locked(b, s, job, progress);
+	if (rc != 0)
+	{
+		// A failed call may leave asynchronous copies of the banded pipeline in flight that read or write the pinned
+		// staging buffers; the next call refills (or regrows and frees) those buffers without waiting for band 0 and 1.
+		// Drain both streams before anybody can get there (best effort: the device may be the thing that failed).
+		(void)hipStreamSynchronize(s->copy_stream);
+		(void)hipStreamSynchronize(s->stream);
+	}
+	return rc;
+}
+
+static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress)
+{
 
 	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y, bsz = b->root.dim_z;
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
@@ -401,6 +417,11 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		a.swz_a = job.swz[3]; a.radius = job.a_scale_radius; a.stream = stream;
 		a.d_scratch = nullptr; a.scratch_workgroups = 0;
 		const size_t scratch = astc_alpha_scratch_bytes(job.dim_x, job.dim_y, dim_z, job.a_scale_radius, &a.scratch_workgroups);
+		if (scratch == (size_t)-1)
+		{
+			fprintf(stderr, "astcenc_amd: a_scale_radius %u needs more than 1 GiB of pre-pass scratch per tile: refused\n", job.a_scale_radius);
+			return 1;
+		}
 		if (scratch)
 		{
 			if (s->alpha_scratch_cap < scratch)
@@ -415,6 +436,14 @@ static int compress_on_slot(Backend* b, DeviceSlot* s, const CompressJob& job, P
 		int arc = astc_alpha_launch(a);
 		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
 		img.alpha_avg = s->d_alpha;
+		// (a large scratch is not kept for the life of the context: the pre-pass runs once per call, its scratch goes back
+		//  as soon as the stream is past the kernel -- hipFree waits for that)
+		if (s->alpha_scratch_cap > ((size_t)64 << 20))
+		{
+			(void)hipStreamSynchronize(stream);
+			(void)hipFree(s->d_alpha_scratch);
+			s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
+		}
 	}
 
 	// Chunks bound the time between cancel checks / progress callbacks on huge images; a chunk is

@@ -39,8 +39,12 @@ size_t astc_alpha_scratch_bytes(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, 
 	if (bytes <= ALPHA_LDS_LIMIT) return 0;
 	const uint32_t tile = (uint32_t)alpha_tile_size(job);
 	const uint32_t tiles = ((dim_x + tile - 1) / tile) * ((dim_y + tile - 1) / tile);
-	// enough workgroups to occupy the chip, but no more scratch than ~1 GiB
-	uint32_t wg = tiles < 1024u ? tiles : 1024u;
+	// One workgroup's summed-area table must stay below 1 GiB: the tile arithmetic of alpha_average_tile (plane sizes,
+	// row offsets) is 32-bit, good for 2^28 floats; a radius beyond that (about 8000 texels on one slice, a few hundred
+	// on a stack of slices) is refused -- the reference would be asking its allocator for the same gigabytes per thread.
+	if (bytes > ((size_t)1 << 30)) return (size_t)-1;
+	// two workgroups per CU keep a bandwidth-bound gather busy; no more scratch than ~1 GiB in total
+	uint32_t wg = tiles < 512u ? tiles : 512u;
 	while (wg > 1 && (size_t)wg * bytes > ((size_t)1 << 30)) wg /= 2;
 	*workgroups = wg;
 	return (size_t)wg * bytes;

@@ -84,7 +84,11 @@
 	// (the sequential build checks what the device build relies on: a count above the promised bound stops the run)
 	WV_FN int wv_checked_count(int n, int bound) { if (n > bound) __builtin_trap(); return n; }
 	#define WV_FOR64(i, n) WV_FOR(i, wv_checked_count((int)(n), 64))
-	#define WV_FOR_T(i, n) WV_FOR(i, n)
+	// ... and the texel loops: one trip in the device builds for footprints of at most 64 texels, where loops such as
+	// WV_FOR_T(k, groups * rows) lean on host-table invariants (slots x rows <= 64); the backend of the sequential build
+	// sets this flag for such footprints so that a table change that breaks an invariant stops the run here
+	extern thread_local bool g_wave_one_trip_texel_loops;
+	#define WV_FOR_T(i, n) WV_FOR(i, (g_wave_one_trip_texel_loops ? wv_checked_count((int)(n), 64) : (int)(n)))
 	#define WV_ONE if (true)
 #endif
 

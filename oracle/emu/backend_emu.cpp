@@ -19,6 +19,9 @@
 namespace astcd {
 
 inline namespace ASTC_VARIANT { thread_local const Ctx* g_wave_ctx = nullptr; }
+}
+thread_local bool g_wave_one_trip_texel_loops = false;
+namespace astcd {
 
 struct Backend {
 	std::vector<uint8_t> blob;      // tables + DeviceConfig + LdsLayout, like the device copy
@@ -73,6 +76,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.Ts = lds_row_stride(c.Tp);
 	c.prof = nullptr;
 	g_wave_ctx = &c;
+	g_wave_one_trip_texel_loops = root->texel_count <= 64;      // what kernel_{ldr,hdr}64.hip assume (wave.h: WV_FOR_T)
 
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
 	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * (job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16);

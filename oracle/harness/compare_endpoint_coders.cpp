@@ -16,6 +16,7 @@
 #include <vector>
 
 namespace astcd { inline namespace ASTC_VARIANT { thread_local const Ctx* g_wave_ctx = nullptr; } }
+thread_local bool g_wave_one_trip_texel_loops = false;
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd()
