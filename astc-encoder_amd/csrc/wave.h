@@ -45,12 +45,8 @@
 	// order, so a cross-lane hand-off through LDS needs no s_barrier and no s_waitcnt: it only needs
 	// the compiler not to move or cache LDS accesses across this point.  (__syncthreads() would add
 	// an `s_waitcnt lgkmcnt(0)` LDS round trip at every one of the thousands of hand-offs per block.)
-	#if defined(ASTC_SYNC_WAITCNT)
-	#define WV_SYNC() __syncthreads()
-	#else
 	#define WV_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
 	                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-	#endif
 	#define WV_FOR(i, n) for (int i = WV_LANE; i < (int)(n); i += 64)
 	#define WV_ONE if (WV_LANE == 0)
 	// WV_FOR for a count that is known to be at most 64 (the weights of a grid, partitions x channels, candidates ...): one

@@ -1017,11 +1017,6 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 	}
 	WV_SYNC();
 
-	// (profiling builds only: -DDEC_EXP=3 / 2 / 1 stop after the headers / the symbol phases / the endpoints, which
-	//  is how the phase split quoted in DESIGN.md was measured)
-#if defined(DEC_EXP) && DEC_EXP >= 3
-	return;
-#endif
 	// ---- weights and colour values: one lane per (block, BISE group), as many lanes per block as the fullest block needs ----
 	int wmax_part = 0, cmax_part = 0;                 // per-lane partial maxima (lane k looked at block k), folded below
 	WV_FOR(k, count)
@@ -1077,9 +1072,6 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 		}
 	}
 	WV_SYNC();
-#if defined(DEC_EXP) && DEC_EXP >= 2
-	return;
-#endif
 	// ---- endpoints: one lane per (block, partition) ----
 	WV_FOR(j, count * 4)
 	{
@@ -1105,9 +1097,6 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 	}
 	WV_SYNC();
 
-#if defined(DEC_EXP) && DEC_EXP >= 1
-	return;
-#endif
 	// ---- texels: one lane per (block, texel) ----
 	const bool small_block = T < 31;
 	const uint32_t t_inv = img.t_inv24;

@@ -752,7 +752,6 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			const f4 color_offset_1 = uniform4(load4(&tr.fbox[4]));
 			const f4 color_base_1 = uniform4(load4(&tr.fbox[0]));
 			const bool speculative = di.later != nullptr;
-#if !defined(ASTC_REALIGN_GROUP_SPECULATION)
 			// The one-lane-per-weight evaluator (below) keeps, per texel, what every weight reaching the texel would compute
 			// again: the decoded colour at the current weights minus the source colour, and the texel's endpoint step.  The
 			// term rows of the group evaluator are not used on that path; the three arrays take their place.
@@ -778,37 +777,28 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					store4_aligned(&tdiff[t * 4], color - orig_color);
 				}
 			};
-#else
-			auto refresh_texel = [&](int t) { wb[t] = two_taps ? infill2(uqf, tw, tcf, T, t) : infill4(uqf, tw, tcf, T, t); };
-#endif
 			{ PROF_SCOPE(c, PS_Y4);
 			WV_FOR_T(t, T) { refresh_texel(t); }
 			WV_SYNC(); }
 
-			// Two drivers feed ONE group evaluator (a single call site keeps a single copy of it in the kernel):
+			// Two ways through a grid's weights (ref: the one-by-one sweep of realign_weights_decimated :188-338):
 			//
-			// * the level schedule (DecimationInfo::off_realign_order): the reference visits the weights one by one; a
-			//   weight's verdict only depends on earlier weights that share a texel with it, so the host-built
-			//   schedule groups weights that touch disjoint texels and a whole group is evaluated and moved at once;
+			// * speculation (every grid whose later-neighbour lists fit, i.e. every 2D grid): all weights are evaluated
+			//   against the current state, one lane or one quad each; then, in index order, the first weight whose verdict is
+			//   "move" is moved for real and only the later weights that share a texel with it
+			//   (DecimationInfo::off_realign_later) are evaluated again.  A verdict only depends on the weight itself and on
+			//   the weights it shares texels with, moves are applied in index order, and every verdict a move could
+			//   invalidate is recomputed before it is looked at: the outcome is the reference's sweep.  (On the bench content
+			//   1.5 to 3.5 weights of ~26 move per call.)
 			//
-			// * long schedules (grids decimated in two dimensions: groups of one to three weights) are replaced by
-			//   speculation: every weight is evaluated against the current state, `slots` weights at a time; then, in
-			//   index order, the first weight whose verdict is "move" is moved for real and only the later weights that
-			//   share a texel with it (DecimationInfo::off_realign_later) are evaluated again.  A verdict only depends
-			//   on the weight itself and on the weights it shares texels with, moves are applied in index order, and
-			//   every verdict a move could invalidate is recomputed before it is looked at: the outcome is the
-			//   reference's one-by-one sweep.  (On the bench content 1.5 to 3.5 weights of ~26 move per call.)
+			// * the level schedule (DecimationInfo::off_realign_order; some 3D grids): a weight's verdict only depends on
+			//   earlier weights that share a texel with it, so the host-built schedule groups weights that touch disjoint
+			//   texels and a whole group is evaluated -- one lane per (weight, texel) -- and moved at once.
 			uint8_t* verdict = reinterpret_cast<uint8_t*>(&tr.ibox[40]);    // [W <= 64] new quantized value, 255 = stays
 			const uint8_t* order = di.ro;
 			const uint8_t* group_count = di.rc;
-			const int slots = di.slots;
-			enum { LEVELS, SPEC_ALL, SPEC_LATER };
-			int phase = speculative ? SPEC_ALL : LEVELS;
-			int lv = 0, pos = 0;                          // LEVELS: next group of the schedule
-			int next = 0;                                 // SPEC_ALL: next weight to evaluate; SPEC_LATER: next entry of the mover's list
-			int start = 0, later_count = 0;               // SPEC_LATER: verdicts below `start` are final
-			uint8_t* later = reinterpret_cast<uint8_t*>(&tr.ibox[56]);    // [REALIGN_LATER_MAX] the mover's list, copied to LDS
-#if !defined(ASTC_REALIGN_GROUP_SPECULATION)
+			int lv = 0, pos = 0;                          // level schedule: next group
+			int start = 0;                                // speculation: verdicts below `start` are final
 			// Speculative grids (decimated in two dimensions: every weight reaches a dozen texels or more, and no two
 			// neighbours can be decided together): ONE LANE PER WEIGHT walks the weight's texels, keeps the twelve running
 			// sums in registers in the reference's order and decides on the spot -- all weights in a single pass, no term
@@ -981,66 +971,19 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 #undef REALIGN_LATER_ENTRY
 				continue;                                   // (next plane)
 			}
-#endif
 			for (;;)
 			{
-				// ---- which weights next: `gn` of them, weight of slot s = src[s] (kind 0, 2) or base + s (kind 1) ----
-				int gn, base = 0;
-				const uint8_t* src = nullptr;
-				if (phase == LEVELS)
-				{
-					if (lv >= di.levels) break;
-					gn = group_count[lv];
-					src = order + pos;
-				}
-				else if (phase == SPEC_ALL)
-				{
-					if (next >= W) { phase = SPEC_LATER; next = 0; later_count = 0; continue; }
-					gn = i_min(slots, W - next);
-					base = next;
-				}
-				else
-				{
-					if (next >= later_count)
-					{
-						const int mover = wv_find_first(W, [&](int w) { return w >= start && verdict[w] != 255; });
-						if (mover < 0) break;
-						adjustments = true;
-						const int new_value = wv_uniform((int)verdict[mover]);
-						WV_ONE
-						{
-							uq[mover] = (uint8_t)new_value;
-							uqf[mover] = (float)new_value;
-						}
-						WV_SYNC();
-						WV_FOR_T(te, (int)wtc[mover])
-						{
-							const int texel = wt[te * W + mover];
-							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
-						}
-						WV_SYNC();
-						// the later weights that share a texel with the mover see different infilled weights now
-						{
-							const uint32_t* list = reinterpret_cast<const uint32_t*>(di.later + mover * REALIGN_LATER_MAX);
-							WV_FOR(k, REALIGN_LATER_MAX / 4) { reinterpret_cast<uint32_t*>(later)[k] = list[k]; }
-							WV_SYNC();
-						}
-						later_count = 0;
-						while (later_count < REALIGN_LATER_MAX && later[later_count] != 255) later_count++;
-						start = mover + 1;
-						next = 0;
-						if (later_count == 0) continue;
-					}
-					gn = i_min(slots, later_count - next);
-					src = later + next;
-				}
+				// ---- the next group of the schedule: `gn` weights, weight of slot s = src[s] ----
+				if (lv >= di.levels) break;
+				const int gn = group_count[lv];
+				const uint8_t* src = order + pos;
 
 				// ---- evaluate the group: one lane per (weight of the group, texel row of that weight) writes the squared
 				//      differences for the current / next lower / next higher quantized value, 4 channels each ----
 				WV_FOR_T(k, gn * rs)
 				{
 					const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
-					const int we = src ? (int)src[slot] : base + slot;
+					const int we = (int)src[slot];
 					if (te >= (int)wtc[we]) continue;
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
@@ -1078,18 +1021,18 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				WV_FOR(k, gn * 12)
 				{
 					const int slot = k / 12;
-					const int n = wtc[src ? (int)src[slot] : base + slot];
+					const int n = wtc[(int)src[slot]];
 					float* v = rt + k * rs;                   // == rt + slot * 12 * rs + (k % 12) * rs
 					float acc = 0.0f;
 					for (int te = 0; te < n; te++) acc += v[te];
 					v[0] = acc;
 				}
 				WV_SYNC();
-				// one lane per weight decides (ref: :250-316); under the level schedule the move happens right away
+				// one lane per weight decides (ref: :250-316) and moves right away
 				bool moved_here = false;                  // per lane on the device; wv_any() folds the lanes
 				WV_FOR64(slot, gn)
 				{
-					const int we = src ? (int)src[slot] : base + slot;
+					const int we = (int)src[slot];
 					const int uqw = uq[we];
 					const uint32_t prev_and_next = pn[we];
 					const float* sm = rt + wv_opaque(slot * 12) * rs;
@@ -1100,7 +1043,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
 					else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
 					verdict[we] = (uint8_t)(new_value < 0 ? 255 : new_value);
-					if (phase == LEVELS && new_value >= 0)
+					if (new_value >= 0)
 					{
 						uqf[we] = (float)new_value;
 						uq[we] = (uint8_t)new_value;
@@ -1109,29 +1052,22 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 				}
 				WV_SYNC();
 
-				// ---- what the driver does with the verdicts ----
-				if (phase == LEVELS)
+				// ---- the texels of the weights that moved see different infilled weights now ----
+				if (wv_any(moved_here))
 				{
-					if (wv_any(moved_here))
+					adjustments = true;
+					WV_FOR_T(k, gn * rs)
 					{
-						adjustments = true;
-						WV_FOR_T(k, gn * rs)
-						{
-							const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
-							const int we = order[pos + slot];
-							if (verdict[we] == 255 || te >= (int)wtc[we]) continue;
-							int texel = wt[te * W + we];
-							wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
-						}
-						WV_SYNC();
+						const int slot = (int)(((uint32_t)k * rs_inv) >> 16), te = k - slot * rs;
+						const int we = order[pos + slot];
+						if (verdict[we] == 255 || te >= (int)wtc[we]) continue;
+						int texel = wt[te * W + we];
+						wb[texel] = two_taps ? infill2(uqf, tw, tcf, T, texel) : infill4(uqf, tw, tcf, T, texel);
 					}
-					pos += gn;
-					lv++;
+					WV_SYNC();
 				}
-				else
-				{
-					next += gn;
-				}
+				pos += gn;
+				lv++;
 			}
 		}
 	}
