@@ -28,6 +28,10 @@ struct CompressJob {
 	void (*progress)(float);   // optional; called with a monotonically increasing percentage
 	uint32_t fast_load_slice0; // multi-slice RGBA8 / LDR / identity-swizzle input with a 2D footprint: 1 = every slice reads
 	                           // slice 0 like the reference's fast loader (astcenc_image.cpp:304), 0 = each slice reads itself
+	// A block-row shard of a 2D host image with the alpha-scale pre-pass: host_slices[0] starts halo_above texel rows
+	// above the shard's first row and halo_below rows follow its last one (dim_y counts the shard's own rows only).  The
+	// pre-pass runs over all of them, the blocks of the shard's own rows are compressed (backend_compress sets these).
+	uint32_t halo_above, halo_below;
 };
 
 struct DecompressJob {

@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <sched.h>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,7 @@ struct DeviceSlot {
 	size_t trace_cap;             // bytes at d_prof in ASTC_TRACE builds
 	double* d_sums;               // totals of the image comparison kernel
 	std::mutex busy;              // one call at a time per slot: the staging buffers and events are shared state
+	std::vector<int> local_cpus;  // host CPUs on the device's NUMA node (Linux sysfs); empty: unknown, no binding
 };
 
 struct Backend {
@@ -111,6 +113,53 @@ void slot_destroy(DeviceSlot* s)
 	delete s;
 }
 
+/* The host CPUs next to `device` (Linux: /sys/bus/pci/devices/<bus id>/local_cpulist, e.g. "0-31,128-159").  A shard's
+ * worker thread runs on them (bind_worker_to_device), so the pinned staging buffers it allocates on first use -- pinned
+ * pages are placed by first touch -- and the memcpy into them stay on the device's NUMA node: on an 8-GPU node the
+ * other placement sends every band across the inter-socket link twice.  Empty when the platform does not say. */
+static std::vector<int> device_local_cpus(int device)
+{
+	std::vector<int> cpus;
+	char bus[64] = { 0 };
+	if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return cpus;
+	for (char* p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+	char path[160];
+	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+	FILE* f = fopen(path, "r");
+	if (!f) return cpus;
+	char line[1024] = { 0 };
+	if (fgets(line, (int)sizeof(line), f))
+	{
+		for (char* p = line; *p && *p != '\n'; )
+		{
+			char* end = nullptr;
+			long a = strtol(p, &end, 10);
+			if (end == p) break;
+			long bnd = a;
+			p = end;
+			if (*p == '-') { bnd = strtol(p + 1, &end, 10); p = end; }
+			for (long c = a; c <= bnd && c < 4096; c++) cpus.push_back((int)c);
+			if (*p == ',') p++;
+		}
+	}
+	fclose(f);
+	return cpus;
+}
+
+/* Called on a shard's worker thread (never on the caller's own thread: its affinity is the caller's business).
+ * ASTCENC_AMD_NUMA_BIND=0 switches it off. */
+static void bind_worker_to_device(const DeviceSlot* s)
+{
+	static const bool enabled = []() { const char* e = getenv("ASTCENC_AMD_NUMA_BIND"); return !(e && e[0] == '0'); }();
+	if (!enabled || s->local_cpus.empty()) return;
+	cpu_set_t allowed, want;
+	CPU_ZERO(&want);
+	if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+	int n = 0;
+	for (int c : s->local_cpus) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); n++; }
+	if (n > 0) (void)sched_setaffinity(0, sizeof(want), &want);        // (best effort: a container may forbid it)
+}
+
 /* One slot on `device`: uploads the tables, sets the kernels' dynamic-LDS attribute there, creates streams
  * and events.  Every failure leaves through slot_destroy (the record starts zeroed). status: 1 = out of
  * memory, 2 = anything else. */
@@ -155,6 +204,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	SLOT_TRY(hipMemset(s->d_prof, 0, 2 * PS_COUNT * sizeof(unsigned long long)), 2);
 #endif
 #undef SLOT_TRY
+	s->local_cpus = device_local_cpus(device);
 	*status = 0;
 	return s;
 }
@@ -344,7 +394,11 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	const uint32_t blocks_z = (dim_z + bsz - 1) / bsz;
 	const size_t nblocks = (size_t)blocks_x * blocks_y * blocks_z;
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
-	const size_t slice_bytes = (size_t)job.dim_x * job.dim_y * texel_bytes;
+	// (a shard of the alpha-scale split carries halo rows around its own: they are uploaded and averaged, not compressed)
+	const uint32_t halo_above = dim_z == 1 && job.a_scale_radius != 0 ? job.halo_above : 0u;
+	const uint32_t halo_below = dim_z == 1 && job.a_scale_radius != 0 ? job.halo_below : 0u;
+	const uint32_t rows_with_halo = job.dim_y + halo_above + halo_below;
+	const size_t slice_bytes = (size_t)job.dim_x * rows_with_halo * texel_bytes;
 	const size_t image_bytes = slice_bytes * dim_z;
 	const size_t out_bytes = nblocks * 16;
 
@@ -389,7 +443,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	if (!d_image || !d_out) return 2;
 
 	ImageDesc img;
-	img.data = d_image;
+	img.data = static_cast<const uint8_t*>(d_image) + (size_t)halo_above * job.dim_x * texel_bytes;
 	img.dim_x = job.dim_x; img.dim_y = job.dim_y;
 	img.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = job.swz[i];
@@ -403,7 +457,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	img.a_scale_radius = job.a_scale_radius;
 	if (job.a_scale_radius != 0)
 	{
-		const size_t need = (size_t)job.dim_x * job.dim_y * sizeof(float);
+		const size_t need = (size_t)job.dim_x * rows_with_halo * sizeof(float);
 		if (s->alpha_cap < need)
 		{
 			if (s->d_alpha) (void)hipFree(s->d_alpha);
@@ -413,10 +467,10 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 		}
 		AlphaLaunch a;
 		a.d_image = d_image; a.d_averages = s->d_alpha;
-		a.dim_x = job.dim_x; a.dim_y = job.dim_y; a.dim_z = dim_z; a.data_type = job.data_type;
+		a.dim_x = job.dim_x; a.dim_y = rows_with_halo; a.dim_z = dim_z; a.data_type = job.data_type;
 		a.swz_a = job.swz[3]; a.radius = job.a_scale_radius; a.stream = stream;
 		a.d_scratch = nullptr; a.scratch_workgroups = 0;
-		const size_t scratch = astc_alpha_scratch_bytes(job.dim_x, job.dim_y, dim_z, job.a_scale_radius, &a.scratch_workgroups);
+		const size_t scratch = astc_alpha_scratch_bytes(job.dim_x, rows_with_halo, dim_z, job.a_scale_radius, &a.scratch_workgroups);
 		if (scratch == (size_t)-1)
 		{
 			fprintf(stderr, "astcenc_amd: a_scale_radius %u needs more than 1 GiB of pre-pass scratch per tile: refused\n", job.a_scale_radius);
@@ -435,7 +489,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 		}
 		int arc = astc_alpha_launch(a);
 		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
-		img.alpha_avg = s->d_alpha;
+		img.alpha_avg = s->d_alpha + (size_t)halo_above * job.dim_x;
 		// (a large scratch is not kept for the life of the context: the pre-pass runs once per call, its scratch goes back
 		//  as soon as the stream is past the kernel -- hipFree waits for that)
 		if (s->alpha_scratch_cap > ((size_t)64 << 20))
@@ -635,15 +689,18 @@ int backend_compress(Backend* b, const CompressJob& job)
 	// Host images: contiguous ranges of block rows (2D) or of block layers (volumes, stacks of slices), one per device,
 	// each running its own pipeline on its own streams from its own host thread; the caller's thread takes the first
 	// shard and joins the rest (ref: the block loop of compress_image, astcenc_entry.cpp:1009-1038 -- blocks are
-	// independent, so the split needs no exchange).  The alpha-scale pre-pass (which reads a halo around each block)
-	// stays on one device.
+	// independent, so the split needs no exchange).  With the alpha-scale pre-pass (ref: the same split over the
+	// worker threads, astcenc_entry.cpp:1190-1211, astcenc_compute_variance.cpp:507) a shard also takes the texel rows its
+	// averages reach into: enough rows above and below for every 32 x 32 tile of the pre-pass that touches the shard to
+	// see exactly the texels it sees in the whole image -- same tiles, same summed-area arithmetic, same floats.
 	const uint32_t bsy = b->root.dim_y, bsz = b->root.dim_z;
 	const uint32_t blocks_x = (job.dim_x + b->root.dim_x - 1) / b->root.dim_x;
 	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
 	const uint32_t dim_z = job.dim_z ? job.dim_z : 1u;
 	const uint32_t blocks_z = (dim_z + bsz - 1) / bsz;
 	size_t ndev = b->slots.size();
-	if (job.a_scale_radius != 0 || !job.host_out) ndev = 1;
+	// (a stack of slices with the alpha-scale pre-pass averages around slice 0 for the whole stack: one device)
+	if ((job.a_scale_radius != 0 && dim_z > 1) || !job.host_out) ndev = 1;
 	const size_t by_size = progress.total / MIN_BLOCKS_PER_DEVICE;
 	if (ndev > by_size) ndev = by_size < 1 ? 1 : by_size;
 	// a 2D image is cut into block rows, a volume / stack of slices into layers of blocks
@@ -675,7 +732,21 @@ int backend_compress(Backend* b, const CompressJob& job)
 		{
 			const uint32_t y0 = u0 * bsy;
 			const uint32_t y1 = u1 * bsy < job.dim_y ? u1 * bsy : job.dim_y;
-			sh.slices.push_back(static_cast<const uint8_t*>(job.host_slices[0]) + (size_t)y0 * job.dim_x * texel_bytes);
+			uint32_t first_row = y0;
+			if (job.a_scale_radius != 0)
+			{
+				// tiles of the pre-pass start at multiples of ALPHA_TILE from the image origin; a tile's summed-area table
+				// takes in radius + 1 rows above its first row and radius rows below its last
+				const uint32_t tile = 32u, r = job.a_scale_radius;
+				const uint32_t tile_top = y0 / tile * tile, tile_bottom = (y1 + tile - 1) / tile * tile;
+				const uint32_t want_top = tile_top > r + 1 ? (tile_top - (r + 1)) / tile * tile : 0u;
+				const uint64_t want_bottom = (uint64_t)tile_bottom + r + 1;
+				first_row = want_top;
+				const uint32_t last_row = want_bottom < job.dim_y ? (uint32_t)want_bottom : job.dim_y;
+				sh.job.halo_above = y0 - first_row;
+				sh.job.halo_below = last_row - y1;
+			}
+			sh.slices.push_back(static_cast<const uint8_t*>(job.host_slices[0]) + (size_t)first_row * job.dim_x * texel_bytes);
 			sh.job.dim_y = y1 - y0;
 			sh.job.host_out = job.host_out + (size_t)u0 * blocks_x * 16;
 		}
@@ -696,7 +767,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	std::vector<size_t> inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
 	{
-		try { workers.emplace_back([&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); }); }
+		try { workers.emplace_back([&, g]() { bind_worker_to_device(b->slots[g]); shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); }); }
 		catch (...) { inline_shards.push_back(g); }
 	}
 	shards[0].rc = compress_on_slot(b, b->slots[0], shards[0].job, &progress);
@@ -804,7 +875,7 @@ int backend_decompress(Backend* bk, const DecompressJob& job)
 	std::vector<size_t> inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
 	{
-		try { workers.emplace_back([&, g]() { shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); }); }
+		try { workers.emplace_back([&, g]() { bind_worker_to_device(bk->slots[g]); shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); }); }
 		catch (...) { inline_shards.push_back(g); }
 	}
 	shards[0].rc = decompress_on_slot(bk, bk->slots[0], shards[0].job);

@@ -219,3 +219,40 @@ def test_volumes_and_slice_stacks_are_dealt_by_layers(product, ref, A):
     want = ref.compress(stack8, (4, 4), A.PRE_FASTEST)
     with _Devices("0,0,0"):
         assert np.array_equal(product.compress(stack8, (4, 4), A.PRE_FASTEST), want)
+
+
+@pytest.mark.parametrize("radius,slots", [(1, "0,0"), (3, "0,0,0"), (9, "0,0,0,0,0"), (40, "0,0,0")])
+def test_alpha_scale_prepass_is_sharded_with_a_halo(product, ref, A, radius, slots):
+    """a_scale_radius != 0 (the CLI's -a): every shard runs the alpha-average pre-pass over its own rows plus the rows its
+    averages reach into (ref: the reference deals the same pre-pass to its worker threads, astcenc_entry.cpp:1190-1211,
+    astcenc_compute_variance.cpp:507).  The tiles of the pre-pass keep their places, so the averages -- and the blocks the
+    test on them skips -- are the same floats as on one device, and the stream equals the reference's."""
+    w, h, block = 1500, 2300, (6, 6)                     # 96 000 blocks: enough for five shards
+    img = images.noisy(w, h, 21)
+    # transparent bands and islands whose edges fall near the shard seams and on / off tile boundaries
+    img[:, :, 3] = 255
+    for y0, y1 in ((250, 520), (690, 705), (930, 1190), (1500, 1560), (1830, 1930)):
+        img[y0:y1, :, 3] = 0
+    img[300:420, 100:400, 3] = 7
+    img[1000:1003, 500:503, 3] = 1
+    img[1535:1538, 40:1400, 3] = 2
+
+    def run(devices):
+        old = os.environ.get("ASTCENC_AMD_DEVICES")
+        os.environ["ASTCENC_AMD_DEVICES"] = devices
+        try:
+            return product.compress(img, block, A.PRE_FAST, flags=A.FLG_USE_ALPHA_WEIGHT, tweak=lambda c: setattr(c, "a_scale_radius", radius))
+        finally:
+            if old is None:
+                del os.environ["ASTCENC_AMD_DEVICES"]
+            else:
+                os.environ["ASTCENC_AMD_DEVICES"] = old
+
+    one = run("0")
+    many = run(slots)
+    assert np.array_equal(one, many), "the %s split differs from one device at radius %d" % (slots, radius)
+    if radius == 3:
+        want = ref.compress(img, block, A.PRE_FAST, flags=A.FLG_USE_ALPHA_WEIGHT, tweak=lambda c: setattr(c, "a_scale_radius", radius))
+        assert np.array_equal(want, many)
+    plain = product.compress(img, block, A.PRE_FAST, flags=A.FLG_USE_ALPHA_WEIGHT)
+    assert (plain != many).any(), "the test image must contain blocks that the alpha test skips"
