@@ -119,10 +119,13 @@ struct DecimationMode {
 
 // Everything the decimation sweeps need about one packed ideal-weight slot (TableRoot::off_dwi_slots):
 // one 16-byte load per lane instead of walking owner -> decimation mode -> decimation info.
-struct DwiTap { uint32_t texel; float contrib; };     // one tap of a weight: weight_texels[j][i], weight_contribs[j][i]
+// The taps of a weight -- weight_texels[j][i], weight_contribs[j][i] -- two bytes each (texel index, the contribution: an
+// integer 0 .. 16), eight to a 16-byte group: tap k of a group = bytes 2k, 2k + 1.  The last group of a weight is padded
+// with (texel 0, contribution 0), which adds +0.0 to every sum of the sweeps.
+struct DwiTap8 { uint32_t w[4]; };
 struct DwiSlot {
-	uint32_t wt_off;        // blob offset of the weight's DwiTap records, taps in order, 16-byte aligned and padded to an even count
-	                        // with zero contributions: a sweep fetches two taps with one 128-bit load
+	uint32_t wt_off;        // blob offset of the weight's DwiTap8 groups, taps in order, 16-byte aligned: a sweep fetches eight taps
+	                        // with one 128-bit load
 	uint32_t wc_off;        // (unused)
 	uint16_t refprec;       // quant levels (bit mask) of the block modes using this grid in this trial class
 	uint8_t  weight_count;

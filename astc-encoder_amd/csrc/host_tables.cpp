@@ -1012,23 +1012,25 @@ bool build_tables(unsigned int tx, unsigned int ty, unsigned int tz, unsigned in
 		}
 	}
 
-	// the taps of every weight as consecutive DwiTap records (see DwiSlot::wt_off)
+	// the taps of every weight as packed DwiTap8 groups (see DwiSlot::wt_off): two bytes per tap -- texel index, integer
+	// contribution 0 .. 16 -- eight taps per 16-byte group, the last group padded with (texel 0, contribution 0)
 	std::vector<uint32_t> weight_taps_off(dms.size(), 0), weight_taps_stride(dms.size(), 0);
 	for (size_t i = 0; i < dms.size(); i++)
 	{
 		const DecimationInfo di = *blob.at<DecimationInfo>((uint32_t)(off_di + i * sizeof(DecimationInfo)));
-		const uint32_t W = di.weight_count, rows = di.max_weight_texel_count, rows2 = (rows + 1u) & ~1u;
-		const uint32_t off = blob.alloc((size_t)std::max<uint32_t>(W * rows2, 2u) * sizeof(DwiTap), 16);
+		const uint32_t W = di.weight_count, rows = di.max_weight_texel_count, rows8 = (rows + 7u) & ~7u;
+		const uint32_t off = blob.alloc((size_t)std::max<uint32_t>(W * rows8, 8u) * 2u, 16);
 		for (uint32_t w = 0; w < W; w++)
-			for (uint32_t j = 0; j < rows2; j++)
+			for (uint32_t j = 0; j < rows8; j++)
 			{
-				DwiTap tap;
-				tap.texel = j < rows ? *blob.at<uint8_t>((uint32_t)(di.off_weight_texels + j * W + w)) : 0u;
-				tap.contrib = j < rows ? *blob.at<float>((uint32_t)(di.off_weight_contribs + (j * W + w) * sizeof(float))) : 0.0f;
-				*blob.at<DwiTap>((uint32_t)(off + (w * rows2 + j) * sizeof(DwiTap))) = tap;
+				uint8_t* tap = blob.at<uint8_t>((uint32_t)(off + (w * rows8 + j) * 2u));
+				const float contrib = j < rows ? *blob.at<float>((uint32_t)(di.off_weight_contribs + (j * W + w) * sizeof(float))) : 0.0f;
+				tap[0] = j < rows && contrib != 0.0f ? *blob.at<uint8_t>((uint32_t)(di.off_weight_texels + j * W + w)) : (uint8_t)0;
+				tap[1] = (uint8_t)(int)contrib;      // (integer valued: ref block_sizes.cpp weights_texel_contribs)
+				if ((float)tap[1] != contrib) abort();
 			}
 		weight_taps_off[i] = off;
-		weight_taps_stride[i] = rows2 * (uint32_t)sizeof(DwiTap);
+		weight_taps_stride[i] = rows8 * 2u;
 	}
 
 	// per-slot / per-set records of the decimation sweeps (see DwiSlot, InfillSet), in packing order

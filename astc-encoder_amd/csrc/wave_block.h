@@ -1215,7 +1215,8 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 	for (int i = start_trial; i < 2 && !done; i++)
 	{
 		const float errorval_mult = i == 0 ? 1.0f / cfg.tune_mse_overshoot : 1.0f;
-		float errorval = compress_block_1plane(c, i == 0, error_threshold * errorval_mult * errorval_overshoot, 1, 0, QUANT_32);
+		float errorval;
+		DUP_STAGE(c, i == 0 ? DUP_TRIAL_A0 : DUP_TRIAL_A1, errorval = compress_block_1plane(c, i == 0, error_threshold * errorval_mult * errorval_overshoot, 1, 0, QUANT_32));
 		WV_SYNC();
 		if (scb.block_type != SYM_BTYPE_ERROR)
 		{
@@ -1238,7 +1239,8 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 			if (blk.grayscale && i != 3) continue;
 			if (is_constant_channel(blk, i)) continue;
 
-			float errorval = compress_block_2planes(c, trial_threshold, i, quant_limit);
+			float errorval;
+			DUP_STAGE(c, DUP_TRIAL_2PLANES, errorval = compress_block_2planes(c, trial_threshold, i, quant_limit));
 			WV_SYNC();
 			if (errorval > (best_errorval_prev_pcount * 1.85f)) break;
 			if (errorval < error_threshold) done = true;
@@ -1273,8 +1275,9 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 
 			for (int i = 0; i < actual_trials; i++)
 			{
-				float errorval = compress_block_1plane(c, false, trial_threshold,
-				                                       partition_count, partition_indices.get(i), quant_limit);
+				float errorval;
+				DUP_STAGE(c, DUP_TRIAL_2PARTITIONS + (partition_count - 2), errorval = compress_block_1plane(c, false, trial_threshold,
+				                                       partition_count, partition_indices.get(i), quant_limit));
 				WV_SYNC();
 				best_error = wv_uniform(f_min(best_error, errorval));
 

@@ -68,10 +68,14 @@ WV_FN uint8_t angular_sample_row(float weight)
 	return (uint8_t)(int)(sample + 0.5f);
 }
 
+/* Tap k (0 .. 7) of a packed group: texel index and contribution. */
+WV_FN uint32_t dwi_tap_texel(const DwiTap8& g, int k) { return (g.w[k >> 1] >> (16 * (k & 1))) & 0xFFu; }
+WV_FN float dwi_tap_contrib(const DwiTap8& g, int k) { return (float)(int)((g.w[k >> 1] >> (16 * (k & 1) + 8)) & 0xFFu); }
+
 /* One slot of sweep 1: initial guess for weight `sl.index` of its grid (ref: :877-905; direct grids copy, :858-866).
- * Two taps per round trip: the pair's (texel, contribution) records arrive with one 128-bit load, then both gathers
- * are issued, then the (strictly ordered) accumulation runs. */
-struct DwiTapPair { uint32_t texel0; float contrib0; uint32_t texel1; float contrib1; };
+ * Eight taps per round trip to the table: the group's (texel, contribution) pairs arrive with one 128-bit load, then all
+ * gathers are issued, then the (strictly ordered) accumulation runs.  The padding taps of the last group have
+ * contribution 0: they add +0.0 to both sums (which are never -0), i.e. nothing. */
 WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 {
 	const int plane = (sl.flags >> 1) & 1;
@@ -83,21 +87,30 @@ WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 	float weight_weight = 1e-10f;
 	float initial_weight = 0.0f;
 	const int cnt = sl.taps;
-	for (int j0 = 0; j0 < cnt; j0 += 2)
+	for (int j0 = 0; j0 < cnt; j0 += 8)
 	{
-		const DwiTapPair tp = table_at_byte<DwiTapPair>(c.tab, sl.wt_off + (uint32_t)j0 * (uint32_t)sizeof(DwiTap));
-		const float iw0 = eiw[tp.texel0], iw1 = eiw[tp.texel1];
-		const float es0 = constant_wes ? wes0 : eiwes[tp.texel0], es1 = constant_wes ? wes0 : eiwes[tp.texel1];
+		const DwiTap8 g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
+		// (in two halves: most weights of the larger grids have four taps or fewer, and the second half of their only group
+		//  is all padding)
+		#pragma unroll
+		for (int h = 0; h < 8; h += 4)
 		{
-			float contrib_weight = tp.contrib0 * es0;
-			weight_weight += contrib_weight;
-			initial_weight += iw0 * contrib_weight;
-		}
-		if (j0 + 1 < cnt)
-		{
-			float contrib_weight = tp.contrib1 * es1;
-			weight_weight += contrib_weight;
-			initial_weight += iw1 * contrib_weight;
+			if (h != 0 && j0 + h >= cnt) break;
+			float iw[4], es[4];
+			#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const uint32_t t = dwi_tap_texel(g, h + k);
+				iw[k] = eiw[t];
+				es[k] = constant_wes ? wes0 : eiwes[t];
+			}
+			#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const float contrib_weight = dwi_tap_contrib(g, h + k) * es[k];
+				weight_weight += contrib_weight;
+				initial_weight += iw[k] * contrib_weight;
+			}
 		}
 	}
 	return initial_weight / weight_weight;
@@ -114,22 +127,30 @@ WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf
 	float error_change0 = 1e-10f;
 	float error_change1 = 0.0f;
 	const int cnt = sl.taps;
-	for (int j0 = 0; j0 < cnt; j0 += 2)
+	for (int j0 = 0; j0 < cnt; j0 += 8)
 	{
-		const DwiTapPair tp = table_at_byte<DwiTapPair>(c.tab, sl.wt_off + (uint32_t)j0 * (uint32_t)sizeof(DwiTap));
-		const float iw0 = eiw[tp.texel0], iw1 = eiw[tp.texel1];
-		const float ow0 = inf[tp.texel0], ow1 = inf[tp.texel1];
-		const float es0 = constant_wes ? wes0 : eiwes[tp.texel0], es1 = constant_wes ? wes0 : eiwes[tp.texel1];
+		const DwiTap8 g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
+		#pragma unroll
+		for (int h = 0; h < 8; h += 4)
 		{
-			float scale = es0 * tp.contrib0;
-			error_change0 += tp.contrib0 * scale;
-			error_change1 += (ow0 - iw0) * scale;
-		}
-		if (j0 + 1 < cnt)
-		{
-			float scale = es1 * tp.contrib1;
-			error_change0 += tp.contrib1 * scale;
-			error_change1 += (ow1 - iw1) * scale;
+			if (h != 0 && j0 + h >= cnt) break;
+			float iw[4], ow[4], es[4];
+			#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const uint32_t t = dwi_tap_texel(g, h + k);
+				iw[k] = eiw[t];
+				ow[k] = inf[t];
+				es[k] = constant_wes ? wes0 : eiwes[t];
+			}
+			#pragma unroll
+			for (int k = 0; k < 4; k++)
+			{
+				const float contrib = dwi_tap_contrib(g, h + k);
+				const float scale = es[k] * contrib;
+				error_change0 += contrib * scale;
+				error_change1 += (ow[k] - iw[k]) * scale;
+			}
 		}
 	}
 	float step = (error_change1 * -16.0f) / error_change0;
