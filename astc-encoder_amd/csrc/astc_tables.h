@@ -53,6 +53,7 @@ enum {
 // kernel will use.
 constexpr uint32_t MODE_DESC_BYTES = 16 + 2 * 32;   // ModeHdr + ModeQ[2], see score_block_modes (wave_block.h)
 constexpr uint32_t MODE_WEIGHT_BYTES = 64;          // quantized weights of one block mode (second plane at + 32)
+constexpr uint32_t MODE_Q2U_BYTES = 12 * 32;        // mode scoring's LDS copy of the quant_to_unquant rows of the weight quant levels (tail of `uni`)
 constexpr uint32_t FMT_QUANT_ROWS = 17;
 ASTC_HD inline uint32_t fmt_comb_cols(uint32_t partition_limit) { return partition_limit <= 1 ? 0u : partition_limit == 2 ? 7u : partition_limit == 3 ? 10u : 13u; }
 ASTC_HD inline uint32_t fmt_scratch_bytes(uint32_t partition_limit)

@@ -124,6 +124,17 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
 	const uint32_t t_inv = c.L->t_inv24;                                      // k / T == (k * t_inv) >> 24 for k < 2^24 / T
 
+	// The unquantized value of every weight quant level's steps (QuantXfer::quant_to_unquant, 12 x 32 bytes) goes to the
+	// tail of the scratch region once per call: pass A looks two of them up per weight, and from the blob every chunk
+	// would wait for one more round trip to L2.
+	const uint32_t q2u_lds = c.L->uni + c.L->uni_bytes - MODE_Q2U_BYTES;
+	WV_FOR(k, (int)(MODE_Q2U_BYTES / 4))
+	{
+		const uint32_t level = (uint32_t)k >> 3, w = (uint32_t)k & 7u;
+		reinterpret_cast<uint32_t*>(c.lds + q2u_lds)[k] = table_at_byte<uint32_t>(c.tab, c.root->off_quant_xfer + level * (uint32_t)sizeof(QuantXfer) + 4u * w);
+	}
+	// (visible to pass A after the descriptor pass's hand-off)
+
 	// Windows of 64 block modes.  Only the modes that are legal under this trial's weight quant limit
 	// (less than half of them, typically, once trial A has set the limit) are scored: their window
 	// positions are compacted through a validity bit mask into chunks of descriptor slots.
@@ -134,12 +145,19 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 	const int free_bits = dual ? 109 : partition_count == 1 ? 111 : partition_count == 2 ? 97 : partition_count == 3 ? 94 : 91;   // (ref: mode_bitcount)
 	unsigned long long vmask = 0;
 #if WV_DEVICE
+	// the record of window mode `lane`: read once, kept in registers (as scalars: a struct indexed by the plane would live
+	// in scratch memory) for every chunk's descriptor pass
+	uint32_t my_tw_off = 0, my_tcf_off = 0, my_dwi = 0, my_lh = 0, my_misc = 0;
 	{
 		bool ok = false;
 		if (WV_LANE < nwin)
 		{
 			const ModeStatic ms = table_at(mstat, (uint32_t)(base + WV_LANE));
 			ok = ms.quant_mode <= max_weight_quant && (dual || free_bits - (int)ms.weight_bits > 0);
+			my_tw_off = ms.tw_off; my_tcf_off = ms.tcf_off;
+			my_dwi = (uint32_t)ms.dwi_off[0] | ((uint32_t)ms.dwi_off[1] << 16);
+			my_lh = (uint32_t)ms.lh_off[0] | ((uint32_t)ms.lh_off[1] << 16);
+			my_misc = (uint32_t)ms.taps | ((uint32_t)ms.weights << 8) | ((uint32_t)ms.quant_mode << 16);
 		}
 		vmask = __ballot(ok);
 	}
@@ -158,39 +176,46 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 		const int nm = i_min(chunk_modes, nvalid - first);
 
 		{ PROF_SCOPE(c, PS_MODE3);
-		WV_FOR(k, nwin * 2)
+		WV_FOR64(i, nwin)
 		{
-			const int i = k >> 1, plane = k & 1;
-			if (!((vmask >> i) & 1ull) || plane >= planes) continue;
+			if (!((vmask >> i) & 1ull)) continue;
 			const int m = popcount64(vmask & ((1ull << i) - 1ull)) - first;       // descriptor slot of window mode i
 			if (m < 0 || m >= nm) continue;
+#if !WV_DEVICE
 			const ModeStatic ms = table_at(mstat, (uint32_t)(base + i));
-			if (plane == 0)
+			const uint32_t my_tw_off = ms.tw_off, my_tcf_off = ms.tcf_off, my_dwi = (uint32_t)ms.dwi_off[0] | ((uint32_t)ms.dwi_off[1] << 16);
+			const uint32_t my_lh = (uint32_t)ms.lh_off[0] | ((uint32_t)ms.lh_off[1] << 16);
+			const uint32_t my_misc = (uint32_t)ms.taps | ((uint32_t)ms.weights << 8) | ((uint32_t)ms.quant_mode << 16);
+#endif
+			const int quant_mode = (int)(my_misc >> 16);
+			ModeHdr h;
+			h.tw_off = my_tw_off;
+			h.tcf_off = my_tcf_off;
+			h.taps = (int16_t)(my_misc & 0xFFu);
+			h.weights = (int16_t)((my_misc >> 8) & 0xFFu);
+			h.mode = base + i;
+			hdr[m] = h;
+			for (int plane = 0; plane < planes; plane++)
 			{
-				ModeHdr h;
-				h.tw_off = ms.tw_off;
-				h.tcf_off = ms.tcf_off;
-				h.taps = (int16_t)ms.taps;
-				h.weights = (int16_t)ms.weights;
-				h.mode = base + i;
-				hdr[m] = h;
+				// the mode's weight range (ref: compress_symbolic.cpp:459-462, :819-827; the same as mode_weight_bounds())
+				const uint32_t lh_off = plane ? my_lh >> 16 : my_lh & 0xFFFFu;
+				const uint32_t dwi_off = plane ? my_dwi >> 16 : my_dwi & 0xFFFFu;
+				float low = 0.0f, high = 1.0f;
+				if (lh_off != 0xFFFF)
+				{
+					const float* lh = reinterpret_cast<const float*>(c.lds + c.L->lowhigh) + lh_off;
+					low = lh[0];
+					high = lh[1];
+				}
+				if (high > 1.02f * c.tr().min_wt_cutoff[plane]) high = 1.0f;
+				QuantParams qp = quant_params(low, high, quant_mode);
+				ModeQ q;
+				q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
+				q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
+				q.q2u_off = q2u_lds + (uint32_t)quant_mode * 32u;                 // (LDS byte offset of the level's 32 entries)
+				q.dwi_off = (c.L->dwi >> 2) + dwi_off;
+				mq[m * 2 + plane] = q;
 			}
-			// the mode's weight range (ref: compress_symbolic.cpp:459-462, :819-827; the same as mode_weight_bounds())
-			float low = 0.0f, high = 1.0f;
-			if (ms.lh_off[plane] != 0xFFFF)
-			{
-				const float* lh = reinterpret_cast<const float*>(c.lds + c.L->lowhigh) + ms.lh_off[plane];
-				low = lh[0];
-				high = lh[1];
-			}
-			if (high > 1.02f * c.tr().min_wt_cutoff[plane]) high = 1.0f;
-			QuantParams qp = quant_params(low, high, ms.quant_mode);
-			ModeQ q;
-			q.scale = qp.scale; q.scaled_low_bound = qp.scaled_low_bound; q.quant_level_m1 = qp.quant_level_m1;
-			q.rscale = qp.rscale; q.low_bound = qp.low_bound; q.steps_m1 = qp.steps_m1;
-			q.q2u_off = c.root->off_quant_xfer + (uint32_t)ms.quant_mode * (uint32_t)sizeof(QuantXfer);
-			q.dwi_off = (c.L->dwi >> 2) + (uint32_t)ms.dwi_off[plane];
-			mq[m * 2 + plane] = q;
 		}
 		WV_SYNC(); }
 
@@ -213,8 +238,8 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				const float ix1 = ix * q.quant_level_m1;
 				const int weightl = (int)ix1;
 				const int weighth = i_min(weightl + 1, q.steps_m1);
-				const int ixli = c.tab[q.q2u_off + (uint32_t)weightl];
-				const int ixhi = c.tab[q.q2u_off + (uint32_t)weighth];
+				const int ixli = c.lds[q.q2u_off + (uint32_t)weightl];
+				const int ixhi = c.lds[q.q2u_off + (uint32_t)weighth];
 				const bool up = ((float)ixli + (float)ixhi) < (128.0f * ix);
 				uqw[m * (int)MODE_WEIGHT_BYTES + plane * PLANE2_OFFSET + i] = (uint8_t)(up ? ixhi : ixli);
 			}
