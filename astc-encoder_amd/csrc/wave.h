@@ -219,12 +219,27 @@ WV_FN float f_run_max(float x, float m)
 #endif
 }
 
+/* The median of (v, mn, mx) in ONE instruction on the device.  For mn <= mx that are numbers it equals both clamp forms
+ * of the reference below bit for bit -- NaN gives mn, -0 against a +0 bound gives +0 -- as tools/minmax_semantics.hip
+ * checks on the hardware (v_med3_f32 returns the minimum of the numbers when an operand is NaN and orders -0 below +0);
+ * the compare-select forms are two compares and two selects, four instructions of the slow issue class. */
+#if WV_DEVICE
+WV_FN float f_med3(float v, float mn, float mx)
+{
+	float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(mn), "v"(mx)); return r;
+}
+#endif
+
 /* astc::clamp (ref: astcenc_mathlib.h:271) */
 WV_FN float f_clamp(float v, float mn, float mx)
 {
+#if WV_DEVICE
+	return f_med3(v, mn, mx);
+#else
 	if (v > mx) return mx;
 	if (v > mn) return v;
 	return mn;
+#endif
 }
 WV_FN int i_clamp(int v, int mn, int mx)
 {
@@ -238,8 +253,12 @@ WV_FN float f_clamp255(float v) { return f_clamp(v, 0.0f, 255.0f); }
 /* vector-lane clamp: min(max(a, lo), hi) with compare-select (ref: vecmathlib_common_4.h:225) */
 WV_FN float v_clamp(float lo, float hi, float a)
 {
+#if WV_DEVICE
+	return f_med3(a, lo, hi);
+#else
 	float t = a > lo ? a : lo;
 	return t < hi ? t : hi;
+#endif
 }
 WV_FN float v_clampzo(float a) { return v_clamp(0.0f, 1.0f, a); }
 
@@ -320,7 +339,7 @@ WV_FN float dot_s(f4 a, f4 b) { return hadd_s(a * b); }
 WV_FN float dot3_s(f4 a, f4 b) { f4 m = a * b; return m.x + m.y + m.z; }
 WV_FN f4 v4_min(f4 a, f4 b) { return mk4(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z, a.w < b.w ? a.w : b.w); }
 WV_FN f4 v4_max(f4 a, f4 b) { return mk4(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z, a.w > b.w ? a.w : b.w); }
-WV_FN f4 v4_clamp(float lo, float hi, f4 a) { return v4_min(v4_max(a, splat4(lo)), splat4(hi)); }
+WV_FN f4 v4_clamp(float lo, float hi, f4 a) { return mk4(v_clamp(lo, hi, a.x), v_clamp(lo, hi, a.y), v_clamp(lo, hi, a.z), v_clamp(lo, hi, a.w)); }
 WV_FN f4 v4_abs(f4 a) { return mk4(f_abs(a.x), f_abs(a.y), f_abs(a.z), f_abs(a.w)); }
 WV_FN f4 v4_sqrt(f4 a) { return mk4(f_sqrt(a.x), f_sqrt(a.y), f_sqrt(a.z), f_sqrt(a.w)); }
 WV_FN f4 load4(const float* p) { return mk4(p[0], p[1], p[2], p[3]); }

@@ -369,6 +369,16 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		for (int i = 0; i < Tp; i += 4)
 		{
 			const uint32_t ot = ot4[i >> 2];
+			float member[3][4];
+			#pragma unroll
+			for (int p = 0; p < 3; p++)
+			{
+				if (p >= pc - 1) break;
+				member[p][0] = (int)(ot & 0xFF) == p ? 1.0f : 0.0f;
+				member[p][1] = (int)((ot >> 8) & 0xFF) == p ? 1.0f : 0.0f;
+				member[p][2] = (int)((ot >> 16) & 0xFF) == p ? 1.0f : 0.0f;
+				member[p][3] = (int)(ot >> 24) == p ? 1.0f : 0.0f;
+			}
 			#pragma unroll
 			for (int ch = 0; ch < 4; ch++)
 			{
@@ -379,10 +389,12 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 				for (int p = 0; p < 3; p++)
 				{
 					if (p >= pc - 1) break;
-					acc[p][ch][0] = acc[p][ch][0] + ((int)(ot & 0xFF) == p ? d0 : 0.0f);
-					acc[p][ch][1] = acc[p][ch][1] + ((int)((ot >> 8) & 0xFF) == p ? d1 : 0.0f);
-					acc[p][ch][2] = acc[p][ch][2] + ((int)((ot >> 16) & 0xFF) == p ? d2 : 0.0f);
-					acc[p][ch][3] = acc[p][ch][3] + ((int)(ot >> 24) == p ? d3 : 0.0f);
+					// (`acc + (in partition p ? d : 0)` as acc + d * m with m = 1.0 / 0.0: d * 1 = d, d * 0 = +0 for the
+					//  non-negative texel data -- the same sum, in multiplies and adds (the fast issue class) instead of selects)
+					acc[p][ch][0] = acc[p][ch][0] + d0 * member[p][0];
+					acc[p][ch][1] = acc[p][ch][1] + d1 * member[p][1];
+					acc[p][ch][2] = acc[p][ch][2] + d2 * member[p][2];
+					acc[p][ch][3] = acc[p][ch][3] + d3 * member[p][3];
 				}
 			}
 		}
@@ -435,10 +447,12 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		{
 			int t = tix[i];
 			f4 d = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], n == 4 ? c.data(3)[t] : 0.0f) - average;
-			sum[0] = select4(d.x > 0.0f, sum[0] + d, sum[0]);
-			sum[1] = select4(d.y > 0.0f, sum[1] + d, sum[1]);
-			sum[2] = select4(d.z > 0.0f, sum[2] + d, sum[2]);
-			if (n == 4) sum[3] = select4(d.w > 0.0f, sum[3] + d, sum[3]);
+			// (`above ? sum + d : sum` as sum + d * m, m = 1.0 / 0.0: d is finite -- every searched partitioning has texels in
+			//  all its partitions, so the average is a number -- and a sum is never -0, so adding d * 0 = +-0 changes nothing)
+			sum[0] = sum[0] + d * (d.x > 0.0f ? 1.0f : 0.0f);
+			sum[1] = sum[1] + d * (d.y > 0.0f ? 1.0f : 0.0f);
+			sum[2] = sum[2] + d * (d.z > 0.0f ? 1.0f : 0.0f);
+			if (n == 4) sum[3] = sum[3] + d * (d.w > 0.0f ? 1.0f : 0.0f);
 		}
 		f4 best_vector = sum[0];
 		float best_sum = dot_s(sum[0], sum[0]);
