@@ -781,7 +781,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 #if defined(ASTC_DUPSTAGE)
 				// (realignment changes the weights: for the doubled run they are put back first)
 				uint32_t saved_weights = 0;
-				if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN)
+				if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN || (dual && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_2PLANES))
 				{
 					WV_FOR(k, 16) { saved_weights = reinterpret_cast<const uint32_t*>(c.wscb().weights)[k]; }
 					(void)refine_realign(partition_count, partition_packed, cand_dm);

@@ -632,6 +632,262 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 // Weight realignment
 // ---------------------------------------------------------------------------------------------
 
+/* realign_weights() for a TWO-PLANE candidate on a grid that is walked speculatively (every 2D grid; two planes: at most
+ * 32 weights each, one partition).  The reference does one plane after the other (ref: the `pl` loop of
+ * realign_weights_decimated, astcenc_weight_align... astcenc_compress_symbolic.cpp:188-338); the planes share nothing --
+ * a plane's endpoint step is zero on the other plane's channels, so its verdicts only read its own weights -- and so
+ * both run side by side here: one first pass over the weights of both planes, then per round the first mover of EACH plane
+ * moves and the later neighbours of both are looked at again on the sixteen quads of the wave.  Same verdicts, same moves,
+ * half the passes.  State per plane pp: endpoints fbox[pp*8 ..], prev/next and float weights at [pp*32 + weight],
+ * infilled weights wb[pp*Tp + texel], colour differences tdiff[(pp*Tp + texel)*4 ..], verdicts verdict[pp*32 + weight]. */
+WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantXfer& qat)
+{
+	Scb& scb = c.wscb();
+	TrialInfo& tr = c.tr();
+	const BlkInfo& blk = c.blk();
+	const int T = c.T, Tp = c.Tp;
+	const int W = di.W;
+	const int p2c = wv_uniform((int)scb.plane2_component);
+	const uint8_t* wtc = di.wtc;
+	const uint8_t* wt = di.wt;
+	const float* tcw = di.tcw;
+	const uint8_t* tw = di.tw;
+	const float* tcf = di.tcf;
+	const bool two_taps = di.max_texel_weight_count <= 2;
+	const int last_row = di.rows - 1;
+
+	uint32_t* pn = reinterpret_cast<uint32_t*>(c.rsc(0));   // [2][32]
+	float* uqf = reinterpret_cast<float*>(pn + 64);         // [2][32]
+	float* wb = uqf + 64;                                   // [2][Tp]
+	float* tdiff = wb + 2 * Tp;                             // [2][Tp][4]
+	uint8_t* verdict = reinterpret_cast<uint8_t*>(&tr.ibox[40]);    // [2][32] new quantized value, 255 = stays
+	uint8_t* items = reinterpret_cast<uint8_t*>(&tr.ibox[32]);      // [32] weights to evaluate: plane * 32 + weight
+
+	// (the decoded endpoints are in tr.ibox[0 .. 7]: refine_pack() unpacks them once per packing)
+	WV_FOR64(k, 8)
+	{
+		const int pp = k >> 2, ch = k & 3;
+		const int* e = &tr.ibox[0];
+		const bool masked = (pp == 0) ? (ch == p2c) : (ch != p2c);
+		const int epd = masked ? 0 : e[4 + ch] - e[ch];
+		tr.fbox[pp * 8 + ch] = (float)e[ch];
+		tr.fbox[pp * 8 + 4 + ch] = (float)epd * (1.0f / 64.0f);
+	}
+	WV_FOR64(k, 64)
+	{
+		const int we = k & 31;
+		if (we < W)
+		{
+			const int u = scb.weights[k];                        // (PLANE2_OFFSET == 32: the index is plane * 32 + weight)
+			uqf[k] = (float)u;
+			pn[k] = qat.prev_next_values[u];
+		}
+	}
+	WV_SYNC();
+	auto refresh_texel = [&](int pp, int t)
+	{
+		const float* wts = uqf + pp * 32;
+		const float w = two_taps ? infill2(wts, tw, tcf, T, t) : infill4(wts, tw, tcf, T, t);
+		wb[pp * Tp + t] = w;
+		const f4 color_offset = load4(&tr.fbox[pp * 8 + 4]);
+		const f4 color_base = load4(&tr.fbox[pp * 8]);
+		const f4 color = color_base + color_offset * w;
+		const f4 orig_color = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], c.data(3)[t]);
+		store4_aligned(&tdiff[(pp * Tp + t) * 4], color - orig_color);
+	};
+	WV_FOR(k, 2 * T)
+	{
+		const int pp = k >= T ? 1 : 0;
+		refresh_texel(pp, k - pp * T);
+	}
+	WV_SYNC();
+
+	// ---- first pass: every weight of both planes against the current state ----
+	int count = 2 * W;
+	if (count > 16)
+	{
+		// one lane per weight (see realign_weights: the twelve running sums in registers, the table reads one row ahead)
+		const f4 error_weight = load4(blk.cw);
+		WV_FOR64(k, 64)
+		{
+			const int pp = k >> 5, we = k & 31;
+			if (we >= W) continue;
+			const int uqw = scb.weights[k];
+			const uint32_t prev_and_next = pn[k];
+			const float* wbp = wb + pp * Tp;
+			const float* tdp = tdiff + pp * Tp * 4;
+			const f4 color_offset = load4(&tr.fbox[pp * 8 + 4]);
+			const int n = wtc[we];
+			int texel = wt[we];
+			float tw_base = tcw[we];
+			const float uqw_base = (float)uqw;
+			const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+			const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+			f4 sb = splat4(0.0f), sd = splat4(0.0f), su = splat4(0.0f);
+			for (int te = 0; te < n; te++)
+			{
+				const int row1 = i_min(te + 1, last_row);
+				const int texel_next = wt[row1 * W + we];
+				const float tw_next = tcw[row1 * W + we];
+				const float weight_base = wbp[texel];
+				const float weight_down = weight_base + uqw_diff_down * tw_base - weight_base;
+				const float weight_up = weight_base + uqw_diff_up * tw_base - weight_base;
+				const f4 color_diff = load4_aligned(&tdp[texel * 4]);        // (base + step * weight_base) - source colour
+				const f4 color_down_diff = color_diff + color_offset * weight_down;
+				const f4 color_up_diff = color_diff + color_offset * weight_up;
+				sb = sb + color_diff * color_diff;
+				sd = sd + color_down_diff * color_down_diff;
+				su = su + color_up_diff * color_up_diff;
+				texel = texel_next; tw_base = tw_next;
+			}
+			const float error_base = hadd_s(sb * error_weight);
+			const float error_down = hadd_s(sd * error_weight);
+			const float error_up = hadd_s(su * error_weight);
+			int new_value = 255;
+			if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+			else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+			verdict[k] = (uint8_t)new_value;
+		}
+		count = 0;
+	}
+	else
+	{
+		WV_FOR64(k, count) { items[k] = (uint8_t)(k >= W ? 32 + (k - W) : k); }
+	}
+	WV_SYNC();
+
+	bool adjustments = false;
+	int start0 = 0, start1 = 0;                     // verdicts below these are final
+	for (;;)
+	{
+		// ---- the listed weights, one QUAD per weight, lane = colour channel (see realign_weights) ----
+		if (count != 0)
+		{
+			const qf error_weight_q = q_load(blk.cw);
+			WV_QUADS(k, count)
+			{
+				const int item = items[k];
+				const int pp = item >> 5, we = item & 31;
+				const int uqw = scb.weights[item];
+				const uint32_t prev_and_next = pn[item];
+				const float* wbp = wb + pp * Tp;
+				const float* tdp = tdiff + pp * Tp * 4;
+				const qf color_offset_q = q_load(&tr.fbox[pp * 8 + 4]);
+				const int n = wtc[we];
+				int texel_next = wt[we];
+				float tw_cur = tcw[we];
+				const int row1 = i_min(1, last_row);
+				int texel_ahead = wt[row1 * W + we];
+				float tw_next = tcw[row1 * W + we];
+				const float uqw_base = (float)uqw;
+				const float uqw_diff_down = (float)(prev_and_next & 0xFF) - uqw_base;
+				const float uqw_diff_up = (float)((prev_and_next >> 8) & 0xFF) - uqw_base;
+				qf sb = q_splat(0.0f), sd = q_splat(0.0f), su = q_splat(0.0f);
+				float weight_cur = wbp[texel_next];
+				qf diff_cur = q_load(&tdp[texel_next * 4]);
+				texel_next = texel_ahead;
+				for (int te = 0; te < n; te++)
+				{
+					const int row2 = i_min(te + 2, last_row);
+					texel_ahead = wt[row2 * W + we];
+					const float tw_ahead = tcw[row2 * W + we];
+					const float weight_next = wbp[texel_next];
+					const qf diff_next = q_load(&tdp[texel_next * 4]);
+
+					const float weight_base = weight_cur;
+					const float weight_down = weight_base + uqw_diff_down * tw_cur - weight_base;
+					const float weight_up = weight_base + uqw_diff_up * tw_cur - weight_base;
+					const qf color_diff = diff_cur;
+					const qf color_down_diff = color_diff + color_offset_q * weight_down;
+					const qf color_up_diff = color_diff + color_offset_q * weight_up;
+					sb = sb + color_diff * color_diff;
+					sd = sd + color_down_diff * color_down_diff;
+					su = su + color_up_diff * color_up_diff;
+
+					texel_next = texel_ahead; tw_cur = tw_next; tw_next = tw_ahead;
+					weight_cur = weight_next; diff_cur = diff_next;
+				}
+				const float error_base = q_hadd(sb * error_weight_q);
+				const float error_down = q_hadd(sd * error_weight_q);
+				const float error_up = q_hadd(su * error_weight_q);
+				int new_value = 255;
+				if ((error_up < error_base) && (error_up < error_down) && (uqw < 64)) new_value = (int)((prev_and_next >> 8) & 0xFF);
+				else if ((error_down < error_base) && (uqw > 0)) new_value = (int)(prev_and_next & 0xFF);
+				Q_ONCE { verdict[item] = (uint8_t)new_value; }
+			}
+			WV_SYNC();
+		}
+
+		// ---- per plane: the first weight (in index order) whose verdict is "move" moves; what that invalidates -- the
+		//      later weights sharing a texel with it -- is listed for the next round ----
+		count = 0;
+		for (;;)
+		{
+			int m0, m1, nv0 = 0, nv1 = 0;
+#if WV_DEVICE
+			int entry = 255;
+			{
+				const int we = WV_LANE & 31;
+				const int mine = we < W ? (int)verdict[WV_LANE] : 255;
+				const unsigned long long movers = __ballot(mine != 255 && we >= (WV_LANE < 32 ? start0 : start1));
+				const uint32_t lo = (uint32_t)movers, hi = (uint32_t)(movers >> 32);
+				m0 = lo ? (int)__builtin_ctz(lo) : -1;
+				m1 = hi ? (int)__builtin_ctz(hi) : -1;
+				if (m0 < 0 && m1 < 0) break;
+				if (m0 >= 0) nv0 = __builtin_amdgcn_readlane(mine, m0);
+				if (m1 >= 0) nv1 = __builtin_amdgcn_readlane(mine, 32 + m1);
+				// the movers' later neighbours (global memory): requested now, needed after the moves
+				const int m = WV_LANE < 16 ? m0 : m1;
+				if (WV_LANE < 32 && m >= 0) entry = di.later[m * REALIGN_LATER_MAX + (WV_LANE & 15)];
+			}
+#else
+			m0 = wv_find_first(W, [&](int w) { return w >= start0 && verdict[w] != 255; });
+			m1 = wv_find_first(W, [&](int w) { return w >= start1 && verdict[32 + w] != 255; });
+			if (m0 < 0 && m1 < 0) break;
+			if (m0 >= 0) nv0 = verdict[m0];
+			if (m1 >= 0) nv1 = verdict[32 + m1];
+#endif
+			adjustments = true;
+			WV_FOR64(k, 2)
+			{
+				const int m = k ? m1 : m0, nv = k ? nv1 : nv0;
+				if (m >= 0)
+				{
+					scb.weights[k * 32 + m] = (uint8_t)nv;
+					uqf[k * 32 + m] = (float)nv;
+				}
+			}
+			WV_SYNC();
+			WV_FOR(k, 2 * di.rows)
+			{
+				const int pp = k >= di.rows ? 1 : 0;
+				const int te = k - pp * di.rows;
+				const int m = pp ? m1 : m0;
+				if (m >= 0 && te < (int)wtc[m]) refresh_texel(pp, (int)wt[te * W + m]);
+			}
+			if (m0 >= 0) start0 = m0 + 1;
+			if (m1 >= 0) start1 = m1 + 1;
+			int count0 = 0, count1 = 0;
+#if WV_DEVICE
+			{
+				const unsigned long long listed = __ballot(entry != 255);
+				count0 = (int)__builtin_popcount((uint32_t)listed & 0xFFFFu);
+				count1 = (int)__builtin_popcount((uint32_t)listed >> 16);
+				if (entry != 255) items[(WV_LANE < 16 ? 0 : count0) + (WV_LANE & 15)] = (uint8_t)((WV_LANE < 16 ? 0 : 32) + entry);
+			}
+#else
+			if (m0 >= 0) { const uint8_t* row = di.later + m0 * REALIGN_LATER_MAX; while (count0 < REALIGN_LATER_MAX && row[count0] != 255) { items[count0] = row[count0]; count0++; } }
+			if (m1 >= 0) { const uint8_t* row = di.later + m1 * REALIGN_LATER_MAX; while (count1 < REALIGN_LATER_MAX && row[count1] != 255) { items[count0 + count1] = (uint8_t)(32 + row[count1]); count1++; } }
+#endif
+			WV_SYNC();
+			count = count0 + count1;
+			if (count != 0) break;
+		}
+		if (count == 0) break;
+	}
+	return adjustments;
+}
+
 /* (ref: realign_weights_undecimated :69, realign_weights_decimated :188).  Operates on wscb();
  * uniform return: true if any weight moved. */
 WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, const QuantXfer& qat)
@@ -647,6 +903,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	const bool decimated = W != T;
 
 	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
+	if (max_plane == 1 && decimated && pc == 1 && di.later != nullptr && W <= 32) return realign_weights_2planes(c, di, qat);
 
 	bool adjustments = false;
 	// wave-uniform values read from LDS: keep them in scalar registers
