@@ -175,32 +175,16 @@ WV_OUT void batch_prepare(bool dual, int partition_count, int partition_packed, 
 		for (int plane = 0; plane < bv.planes; plane++)
 		{
 			const uint8_t* u = uq + plane * PLANE2_OFFSET;
-			float xf;
-			int wi;
-			if (m.taps == 1)
-			{
-				wi = u[t];
-				xf = (float)wi * (1.0f / 64.0f);
-			}
-			else
-			{
-				const TexelTaps tp = texel_taps_at(c.tab, m.tw_off, m.tcf_off, (uint32_t)t);
-				const int u0 = u[tp.idx & 0xFFu], u1 = u[(tp.idx >> 8) & 0xFFu];
-				const float g0 = (float)u0 * (1.0f / 64.0f), g1 = (float)u1 * (1.0f / 64.0f);
-				int sum = 8 + u0 * (int)(tp.c0 * 16.0f) + u1 * (int)(tp.c1 * 16.0f);
-				if (m.taps == 2)
-				{
-					xf = g0 * tp.c0 + g1 * tp.c1;
-				}
-				else
-				{
-					const int u2 = u[(tp.idx >> 16) & 0xFFu], u3 = u[tp.idx >> 24];
-					const float g2 = (float)u2 * (1.0f / 64.0f), g3 = (float)u3 * (1.0f / 64.0f);
-					xf = (g0 * tp.c0 + g1 * tp.c1) + (g2 * tp.c2 + g3 * tp.c3);
-					sum += u2 * (int)(tp.c2 * 16.0f) + u3 * (int)(tp.c3 * 16.0f);
-				}
-				wi = sum >> 4;
-			}
+			// (every grid through the four-tap form: a tap a grid does not have has index 0 and factor 0 in its records, which
+			//  leaves both values as the shorter forms give them -- x + (0 + 0) is x, (8 + 16 w) >> 4 is w -- and the lanes of
+			//  a wave, which belong to two candidates with different grids, do not branch apart)
+			const TexelTaps tp = texel_taps_at(c.tab, m.tw_off, m.tcf_off, (uint32_t)t);
+			const int u0 = u[tp.idx & 0xFFu], u1 = u[(tp.idx >> 8) & 0xFFu], u2 = u[(tp.idx >> 16) & 0xFFu], u3 = u[tp.idx >> 24];
+			const float g0 = (float)u0 * (1.0f / 64.0f), g1 = (float)u1 * (1.0f / 64.0f);
+			const float g2 = (float)u2 * (1.0f / 64.0f), g3 = (float)u3 * (1.0f / 64.0f);
+			const float xf = (g0 * tp.c0 + g1 * tp.c1) + (g2 * tp.c2 + g3 * tp.c3);
+			const int sum = 8 + u0 * (int)(tp.c0 * 16.0f) + u1 * (int)(tp.c1 * 16.0f) + u2 * (int)(tp.c2 * 16.0f) + u3 * (int)(tp.c3 * 16.0f);
+			const int wi = sum >> 4;
 			bv.x(ci, plane)[i] = xf;
 			bv.iw(ci, plane)[i] = (uint8_t)wi;
 		}
