@@ -476,7 +476,7 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		// squared distance to both lines; accumulators run on across partitions, lane = position
 		// within the partition mod 4 (ref: :778-831, :892-937)
 		float lo = 1e10f, hi = -1e10f;
-		for (int i = 0; i < cnt; i++)
+		auto one_texel = [&](int i, float& ua, float& sa)
 		{
 			int t = tix[i];
 			float r = c.data(0)[t], g = c.data(1)[t], b = c.data(2)[t];
@@ -505,14 +505,20 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 				float s0 = sp * sb.x - r, s1 = sp * sb.y - g, s2 = sp * sb.z - b;
 				se = (blk.cw[0] * s0 * s0) + (blk.cw[1] * s1 * s1) + (blk.cw[2] * s2 * s2);
 			}
-			lo = uncor_param < lo ? uncor_param : lo;
-			hi = uncor_param > hi ? uncor_param : hi;
-			// accumulator lane = position mod 4 (kept in named registers, no indexed array)
-			int l = i & 3;
-			if (l == 0) { ua0 += ue; sa0 += se; }
-			else if (l == 1) { ua1 += ue; sa1 += se; }
-			else if (l == 2) { ua2 += ue; sa2 += se; }
-			else { ua3 += ue; sa3 += se; }
+			// (the hardware minimum / maximum: they differ from the reference's compare-selects in the sign of a zero only
+			//  -- the data are numbers -- and hi - lo goes through max(., 1e-7) below, which is blind to that)
+			lo = f_run_min(uncor_param, lo);
+			hi = f_run_max(uncor_param, hi);
+			ua += ue; sa += se;
+		};
+		// accumulator lane = position mod 4: four texels per trip, each into its own pair of accumulators (one loop over i
+		// with the accumulator picked by i & 3 compiles to a chain of scalar branches and register moves per texel)
+		for (int i = 0; i < cnt; i += 4)
+		{
+			one_texel(i, ua0, sa0);
+			if (i + 1 < cnt) one_texel(i + 1, ua1, sa1);
+			if (i + 2 < cnt) one_texel(i + 2, ua2, sa2);
+			if (i + 3 < cnt) one_texel(i + 3, ua3, sa3);
 		}
 		float linelen = hi - lo;
 		line_len[p] = f_max(linelen, 1e-7f);
