@@ -903,7 +903,11 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 	const bool decimated = W != T;
 
 	// (the decoded endpoints of every partition are in tr.ibox[p * 8 ..]: refine_pack() unpacks them once per packing)
+	// (not in the device build for footprints of more than 64 texels: inlined next to that build's general texel loops the
+	//  kernel body would need a scratch frame; the sequential build runs it for every footprint)
+#if !WV_DEVICE || defined(ASTC_TEXELS_LE_64)
 	if (max_plane == 1 && decimated && pc == 1 && di.later != nullptr && W <= 32) return realign_weights_2planes(c, di, qat);
+#endif
 
 	bool adjustments = false;
 	// wave-uniform values read from LDS: keep them in scalar registers
