@@ -228,7 +228,7 @@ struct QuantXfer {
 // kernel or stage function that knows the blob pointer reaches them without a dependent load:
 //   blob - CTX_LAYOUT_BACK : LdsLayout      blob - CTX_CONFIG_BACK : DeviceConfig
 constexpr uint32_t CTX_CONFIG_BACK = 256;
-constexpr uint32_t CTX_LAYOUT_BACK = 512;
+constexpr uint32_t CTX_LAYOUT_BACK = 1024;
 
 // Root record at blob offset 0.
 struct TableRoot {

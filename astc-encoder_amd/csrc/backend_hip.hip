@@ -178,7 +178,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 #define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
 	SLOT_TRY(hipSetDevice(device), 2);
 	{
-		uint8_t layout[256]; uint32_t layout_bytes = 0, lds_bytes = 0;
+		uint8_t layout[CTX_LAYOUT_BACK - CTX_CONFIG_BACK]; uint32_t layout_bytes = 0, lds_bytes = 0;
 		int prc = kernel_prepare(b, &lds_bytes, layout, &layout_bytes);
 		if (prc != 0)
 		{
@@ -314,7 +314,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(&b->root, blob, sizeof(TableRoot));
 	b->hdr = cfg.profile >= 2;
 	b->lds_bytes = 0;
-	uint8_t layout[256];
+	uint8_t layout[CTX_LAYOUT_BACK - CTX_CONFIG_BACK];
 	uint32_t layout_bytes = 0;
 	{
 		// layout record of the block's LDS working set (the kernels' dynamic-LDS attribute is per device: slot_create)

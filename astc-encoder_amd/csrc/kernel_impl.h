@@ -41,13 +41,22 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	uint32_t bz = img.blocks_z > 1 ? row / img.blocks_y : 0u;
 	uint32_t by = row - bz * img.blocks_y;
 
+	// one scalar base for the layout, the config and the tables: every field is then a non-negative immediate offset of
+	// it (fields of `tab - CTX_LAYOUT_BACK` written as such cost a 64-bit subtraction per field)
+	// (through an integer the optimiser cannot see through, and back as a pointer to constant memory -- a generic pointer
+	//  would make every table read a flat load)
+	typedef const __attribute__((address_space(4))) uint8_t* constant_bytes;
+	uintptr_t base_bits = reinterpret_cast<uintptr_t>(tab) - CTX_LAYOUT_BACK;
+	asm volatile("" : "+s"(base_bits));
+	const uint8_t* const base = (const uint8_t*)(constant_bytes)base_bits;
+	tab = base + CTX_LAYOUT_BACK;
 	Ctx c;
 	c.tab = tab;
 	c.root = reinterpret_cast<const TableRoot*>(tab);
-	c.cfg = reinterpret_cast<const DeviceConfig*>(tab - CTX_CONFIG_BACK);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(base + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
 	c.lds = lds;
-	c.L = reinterpret_cast<const LdsLayout*>(tab - CTX_LAYOUT_BACK);
-	c.T = wv_uniform((int)c.root->texel_count);
+	c.L = reinterpret_cast<const LdsLayout*>(base);
+	c.T = (int)c.L->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
 #if defined(ASTC_TRACE)
@@ -60,7 +69,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	WV_ONE
 	{
 		LdsHeader* h = reinterpret_cast<LdsHeader*>(lds);
-		h->tab = tab;
+		h->base = base;
 		h->prof = prof;
 		c.blk().block_index = b;
 	}
@@ -84,7 +93,7 @@ int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* 
 	if (const char* pad = getenv("ASTC_LDS_PAD_RT")) L.total += (uint32_t)atoi(pad);
 #endif
 	*lds_bytes = L.total;
-	static_assert(sizeof(LdsLayout) <= 256, "layout record grew past the space the backend reserves");
+	static_assert(sizeof(LdsLayout) <= CTX_LAYOUT_BACK - CTX_CONFIG_BACK, "layout record grew past the space the backend reserves");
 	memcpy(layout_out, &L, sizeof(L));
 	*layout_bytes = (uint32_t)sizeof(L);
 	return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(ASTC_KERNEL_NAME),

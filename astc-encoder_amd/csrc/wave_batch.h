@@ -93,16 +93,9 @@ WV_FN BatchView batch_view(const Ctx& c, bool dual, int pc)
 	v.Tp = c.Tp;
 	v.Ts = c.Ts;
 	v.P = i_max(1, i_min(4, (int)c.cfg->tune_partition_count_limit));
-	uint32_t o = 7u * (uint32_t)v.Ts * 4u;
-	v.o_x = o;     o += (uint32_t)(v.nb * v.planes * v.Ts) * 4u;
-	v.o_iw = o;    o += ((uint32_t)(v.nb * v.planes * v.Tp) + 15u) & ~15u;
-	v.o_sum = o;   o += (uint32_t)(v.nb * pc) * 112u;
-	v.o_dec = o;   o += (uint32_t)(v.nb * pc) * 32u;
-	v.o_term = o;  o += (uint32_t)(v.nb * v.Ts) * 4u;
-	v.o_ctab = o;  o += (uint32_t)(v.nb + 1) * 512u;
-	v.o_cand = o;  o += (uint32_t)v.nb * 32u;
-	v.o_vec = o;   o += (uint32_t)(v.nb * v.P) * 32u;
-	v.o_state0 = o;
+	const BatchOffsets& o = c.L->batview[dual ? 1 : 0][pc - 1];      // (host-computed: batch_offsets, wave_ctx.h)
+	v.o_x = o.o_x; v.o_iw = o.o_iw; v.o_sum = o.o_sum; v.o_dec = o.o_dec; v.o_term = o.o_term;
+	v.o_ctab = o.o_ctab; v.o_cand = o.o_cand; v.o_vec = o.o_vec; v.o_state0 = o.o_state0;
 	return v;
 }
 

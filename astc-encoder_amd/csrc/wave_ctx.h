@@ -95,9 +95,14 @@ struct ModeRec {
 
 /* First bytes of every workgroup's LDS: what an out-of-line stage function needs to rebuild its Ctx. */
 struct LdsHeader {
-	const uint8_t* tab;
+	const uint8_t* base;        // start of [LdsLayout][DeviceConfig][table blob] in device memory (blob = base + CTX_LAYOUT_BACK):
+	                            // every field of the three is then a non-negative immediate offset of one scalar base
 	unsigned long long* prof;
 };
+
+/* The offsets inside the scratch of the batched first refinement step (BatchView, wave_batch.h), per trial class and
+ * partition count: computed once on the host instead of in the prologue of each of the step's stages. */
+struct BatchOffsets { uint32_t o_x, o_iw, o_sum, o_dec, o_term, o_ctab, o_cand, o_vec, o_state0; };
 
 struct LdsLayout {
 	uint32_t hdr;        // LdsHeader (offset 0)
@@ -141,6 +146,8 @@ struct LdsLayout {
 	uint32_t cstate_stride;    // bytes per record (cand_state_bytes)
 	uint32_t bat_max[2];       // candidates per batch in a 1-plane / 2-plane trial (1: nothing to gain, still the same code)
 	uint32_t total;
+	uint32_t texel_count;      // (TableRoot::texel_count as a 32-bit word: a scalar load in the stages' prologues)
+	BatchOffsets batview[2][4];   // [2-plane trial][partition count - 1]
 };
 
 /* Staged copy of a grid's tables in LDS (LdsLayout::dtab): its DecimationInfo record first (the refinement steps then
@@ -188,6 +195,24 @@ WV_FN uint32_t batch_scratch_bytes(uint32_t nb, uint32_t planes, uint32_t pc, ui
 	const uint32_t iw = (nb * planes * Tp + 15u) & ~15u;
 	const uint32_t Ts = (uint32_t)lds_row_stride((int)Tp);
 	return 7u * Ts * 4u + nb * planes * Ts * 4u + iw + nb * pc * 112u + nb * pc * 32u + nb * Ts * 4u + (nb + 1u) * 512u + nb * 32u + nb * 4u * 32u + state_bytes;
+}
+
+/* Where the parts of the step's scratch start (bytes from LdsLayout::bat), in the order batch_scratch_bytes() adds them up. */
+WV_FN BatchOffsets batch_offsets(uint32_t nb, uint32_t planes, uint32_t pc, uint32_t Tp, uint32_t P)
+{
+	const uint32_t Ts = (uint32_t)lds_row_stride((int)Tp);
+	BatchOffsets v;
+	uint32_t o = 7u * Ts * 4u;
+	v.o_x = o;     o += nb * planes * Ts * 4u;
+	v.o_iw = o;    o += (nb * planes * Tp + 15u) & ~15u;
+	v.o_sum = o;   o += nb * pc * 112u;
+	v.o_dec = o;   o += nb * pc * 32u;
+	v.o_term = o;  o += nb * Ts * 4u;
+	v.o_ctab = o;  o += (nb + 1u) * 512u;
+	v.o_cand = o;  o += nb * 32u;
+	v.o_vec = o;   o += nb * P * 32u;
+	v.o_state0 = o;
+	return v;
 }
 
 WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayout& L)
@@ -313,7 +338,12 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 			const uint32_t need = batch_scratch_bytes(nb, cls ? 2u : 1u, cls ? 1u : pcl, Tp, L.cstate_stride);
 			if (begin + need > L.cstate) { L.cstate = (begin + need + 15u) & ~15u; if (L.cstate > L.total) L.total = L.cstate; }
 		}
+		const uint32_t P = pcl > 4u ? 4u : pcl;
+		for (uint32_t cls = 0; cls < 2; cls++)
+			for (uint32_t pc = 1; pc <= 4; pc++)
+				L.batview[cls][pc - 1] = batch_offsets(L.bat_max[cls], cls ? 2u : 1u, pc, Tp, P);
 	}
+	L.texel_count = r.texel_count;
 }
 
 /* wv_uniform(v): `v` is the same on every lane (a value read from LDS or from a table looks lane-variant to the
@@ -408,21 +438,30 @@ extern __shared__ __attribute__((aligned(16))) uint8_t astc_lds[];
 template <bool SCALAR_TABLES>
 WV_FN Ctx ctx_make_as()
 {
-	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(astc_lds);
+	// The kernels use dynamic LDS only, so it starts at LDS address 0 (tests/test_code_object.py checks that the static
+	// size stays 0).  Naming `astc_lds` in a function that is not a kernel costs a look-up of the caller's static LDS size
+	// in a table in memory (nine scalar instructions and a load per stage call); an integer the optimiser cannot see
+	// through (a literal 0 would fold to the null pointer, which is -1 in this address space) costs one.
+	typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
+	uint32_t lds_zero = 0;
+	asm volatile("" : "+s"(lds_zero));
+	uint8_t* const lds = (uint8_t*)(lds_bytes)(uintptr_t)lds_zero;
+	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(lds);
 	Ctx c;
 	// A pointer rebuilt from integers would be a generic (flat) pointer to the compiler: go through
 	// explicit address-space pointers so that table reads stay s_load / global_load.
 	typedef const __attribute__((address_space(1))) uint8_t* global_bytes;
 	typedef const __attribute__((address_space(4))) uint8_t* constant_bytes;
 	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
-	const uintptr_t tab = (uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->tab));
-	c.tab = SCALAR_TABLES ? (const uint8_t*)(constant_bytes)tab : (const uint8_t*)(global_bytes)tab;
+	const uintptr_t base = (uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->base));
+	const uint8_t* const b = SCALAR_TABLES ? (const uint8_t*)(constant_bytes)base : (const uint8_t*)(global_bytes)base;
+	c.tab = b + CTX_LAYOUT_BACK;
 	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
 	c.root = reinterpret_cast<const TableRoot*>(c.tab);
-	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
-	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
-	c.lds = astc_lds;
-	c.T = wv_uniform((int)c.root->texel_count);
+	c.cfg = reinterpret_cast<const DeviceConfig*>(b + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
+	c.L = reinterpret_cast<const LdsLayout*>(b);
+	c.lds = lds;
+	c.T = (int)c.L->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
 	return c;
