@@ -109,15 +109,10 @@ WV_FN CandState batch_state(const Ctx& c, const BatchView& bv, int ci)
 // ---------------------------------------------------------------------------------------------
 // Stage 1: shared texel rows, the candidates' expanded weights, their colour quantization rows
 // ---------------------------------------------------------------------------------------------
-WV_OUT void batch_prepare(bool dual, int partition_count, int partition_packed, int first, int count)
+WV_FN void batch_prepare_body(const Ctx& c, const BatchView& bv, const PartView& pv, bool dual, int partition_count, int first, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
-	first = wv_uniform(first); count = wv_uniform(count);
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
-	const BatchView bv = batch_view(c, dual, partition_count);
-	const PartView pv = partition_count == 1 ? part_view_lds(c, 1, 0) : part_view_lds(c, partition_count, partition_packed);
 	const int T = c.T;
 	const ModeStatic* mstat = reinterpret_cast<const ModeStatic*>(c.table(c.root->off_mode_static));
 
@@ -245,13 +240,8 @@ WV_FN SumLane sum_lane_2planes(const BatchView& bv, int ci, int r, int plane2_co
 	return s;
 }
 
-WV_OUT void batch_sums(bool dual, int partition_count, int partition_packed, int plane2_component, int count)
+WV_FN void batch_sums_body(const Ctx& c, const BatchView& bv, const PartView& pv, bool dual, int partition_count, int plane2_component, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
-	plane2_component = wv_uniform(plane2_component); count = wv_uniform(count);
-	const BatchView bv = batch_view(c, dual, partition_count);
-	const PartView pv = partition_count == 1 ? part_view_lds(c, 1, 0) : part_view_lds(c, partition_count, partition_packed);
 	const int rows = dual ? 19 : 15;
 	const int per_cand = partition_count * rows;
 	const bool uniform_walk = dual || partition_count == 1;
@@ -310,15 +300,10 @@ WV_OUT void batch_sums(bool dual, int partition_count, int partition_packed, int
 // ---------------------------------------------------------------------------------------------
 // Stage 3: the solve, one lane per (candidate, partition, channel)
 // ---------------------------------------------------------------------------------------------
-WV_OUT void batch_solve(bool dual, int partition_count, int partition_packed, int plane2_component, int count)
+WV_FN void batch_solve_body(const Ctx& c, const BatchView& bv, const PartView& pv, bool dual, int partition_count, int plane2_component, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
-	plane2_component = wv_uniform(plane2_component); count = wv_uniform(count);
 	const TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
-	const BatchView bv = batch_view(c, dual, partition_count);
-	const PartView pv = partition_count == 1 ? part_view_lds(c, 1, 0) : part_view_lds(c, partition_count, partition_packed);
 	const float ls_weight = hadd_rgb_s(load4(blk.cw));
 	const int pc4 = partition_count * 4;
 	// (the endpoints a candidate starts from are the trial's ideal ones, merged across the planes: ref :497-540)
@@ -351,6 +336,20 @@ WV_OUT void batch_solve(bool dual, int partition_count, int partition_packed, in
 	}
 }
 
+/* Stages 1 to 3 as one out-of-line stage (a stage call costs some fifty instructions of call sequence and context
+ * rebuild; the three share the views). */
+WV_OUT void batch_refit(bool dual, int partition_count, int partition_packed, int plane2_component, int first, int count)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component); first = wv_uniform(first); count = wv_uniform(count);
+	const BatchView bv = batch_view(c, dual, partition_count);
+	const PartView pv = partition_count == 1 ? part_view_lds(c, 1, 0) : part_view_lds(c, partition_count, partition_packed);
+	DUP_STAGE(c, DUP_BATCH_PREPARE, batch_prepare_body(c, bv, pv, dual, partition_count, first, count));
+	DUP_STAGE(c, DUP_BATCH_SUMS, batch_sums_body(c, bv, pv, dual, partition_count, plane2_component, count));
+	DUP_STAGE(c, DUP_BATCH_SOLVE, batch_solve_body(c, bv, pv, dual, partition_count, plane2_component, count));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 4: pack the endpoints, one quad per (candidate, partition); the matched-format retry; decoded endpoints
 // (ref: compress_symbolic.cpp:561-598 around pack_color_endpoints, astcenc_color_quantize.cpp:1909)
@@ -377,6 +376,34 @@ WV_OUT void batch_pack_hdr(bool dual, int partition_count, int first, int ci, in
 	pack_endpoints_hdr(t, st.wep0, st.wep1, bv.rgbo(ci), partition_count, tr.cand_formats[first + ci], retry ? colorvals : st.colors,
 	                   retry ? fmts : st.formats, tries);
 	WV_SYNC();
+}
+#endif
+
+/* Which candidates get the retry at the quant level that matched formats allow (ref: :571-598). */
+WV_FN void batch_pack_decide_body(const Ctx& c, const BatchView& bv, bool dual, int partition_count, int count)
+{
+	WV_FOR64(ci, count)
+	{
+		const CandState st = batch_state(c, bv, ci);
+		BatchCand& m = bv.cand(ci);
+		bool retry = !dual && partition_count >= 2 && m.color_quant != m.color_quant_mod;
+		for (int j = 1; j < partition_count; j++) retry = retry && st.formats[j] == st.formats[0];
+		m.retry = retry ? 1 : 0;
+		st.meta[0] = (uint8_t)m.color_quant;
+		st.meta[1] = 0;
+		st.meta[2] = 0;
+		st.meta[3] = 0;
+	}
+	WV_SYNC();
+}
+
+#if ASTC_ENABLE_HDR
+/* (builds with HDR formats: the HDR packing stages run between the first packing and this) */
+WV_OUT void batch_pack_decide(bool dual, int partition_count, int count)
+{
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); count = wv_uniform(count);
+	batch_pack_decide_body(c, batch_view(c, dual, partition_count), dual, partition_count, count);
 }
 #endif
 
@@ -410,27 +437,9 @@ WV_OUT void batch_pack_first(bool dual, int partition_count, int first, int coun
 		}
 	}
 	WV_SYNC();
-}
-
-/* Which candidates get the retry at the quant level that matched formats allow (ref: :571-598). */
-WV_OUT void batch_pack_decide(bool dual, int partition_count, int count)
-{
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); count = wv_uniform(count);
-	const BatchView bv = batch_view(c, dual, partition_count);
-	WV_FOR64(ci, count)
-	{
-		const CandState st = batch_state(c, bv, ci);
-		BatchCand& m = bv.cand(ci);
-		bool retry = !dual && partition_count >= 2 && m.color_quant != m.color_quant_mod;
-		for (int j = 1; j < partition_count; j++) retry = retry && st.formats[j] == st.formats[0];
-		m.retry = retry ? 1 : 0;
-		st.meta[0] = (uint8_t)m.color_quant;
-		st.meta[1] = 0;
-		st.meta[2] = 0;
-		st.meta[3] = 0;
-	}
-	WV_SYNC();
+#if !ASTC_ENABLE_HDR
+	batch_pack_decide_body(c, bv, dual, partition_count, count);      // (same stage: nothing runs in between in the LDR builds)
+#endif
 }
 
 /* The retry of candidate `ci` at the higher quant level, into the retry buffers ... */
@@ -481,11 +490,8 @@ WV_OUT void batch_pack_retry_finish(int partition_count, int ci)
 }
 
 /* The decoded endpoints the packing did not leave behind. */
-WV_OUT void batch_decode(bool dual, int partition_count, int count)
+WV_FN void batch_decode_body(const Ctx& c, const BatchView& bv, int partition_count, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); count = wv_uniform(count);
-	const BatchView bv = batch_view(c, dual, partition_count);
 	const int profile = c.cfg->profile;
 	const uint32_t pc_inv = (65536u + (uint32_t)partition_count - 1u) / (uint32_t)partition_count;
 	WV_FOR64(k, count * partition_count)
@@ -510,7 +516,9 @@ __attribute__((always_inline)) WV_FN void batch_pack(bool dual, int partition_co
 #if ASTC_ENABLE_HDR
 	for (int ci = 0; ci < count; ci++) batch_pack_hdr(dual, partition_count, first, ci, 0);
 #endif
+#if ASTC_ENABLE_HDR
 	batch_pack_decide(dual, partition_count, count);
+#endif
 	if (!dual && partition_count >= 2)
 	{
 		const Ctx c = ctx_make();
@@ -525,20 +533,15 @@ __attribute__((always_inline)) WV_FN void batch_pack(bool dual, int partition_co
 			batch_pack_retry_finish(partition_count, ci);
 		}
 	}
-	batch_decode(dual, partition_count, count);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Stage 5: decode and score, one lane per (candidate, texel) (ref: compute_symbolic_block_difference_*,
 // decompress_symbolic.cpp:313-505) -> CandState::errorval
 // ---------------------------------------------------------------------------------------------
-WV_OUT void batch_score_terms(bool dual, int partition_count, int partition_packed, int plane2_component, int count)
+WV_FN void batch_score_terms_body(const Ctx& c, const BatchView& bv, bool dual, int partition_count, int partition_packed, int plane2_component, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
-	plane2_component = wv_uniform(plane2_component); count = wv_uniform(count);
 	const BlkInfo& blk = c.blk();
-	const BatchView bv = batch_view(c, dual, partition_count);
 	const PartView pv = partition_count == 1 ? part_view_lds(c, 1, 0) : part_view_lds(c, partition_count, partition_packed);
 	const int T = c.T;
 	const int profile = c.cfg->profile;
@@ -599,11 +602,8 @@ WV_OUT void batch_score_terms(bool dual, int partition_count, int partition_pack
 }
 
 /* ... and the sums of the terms, in the reference's order. */
-WV_OUT void batch_score_sums(bool dual, int partition_count, int count)
+WV_FN void batch_score_sums_body(const Ctx& c, const BatchView& bv, bool dual, int partition_count, int count)
 {
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); count = wv_uniform(count);
-	const BatchView bv = batch_view(c, dual, partition_count);
 	const int T = c.T;
 	const bool rgbm = (c.cfg->flags & (1u << 6)) != 0;
 	const bool fast_1p = !dual && partition_count == 1 && !rgbm;
@@ -634,10 +634,16 @@ WV_OUT void batch_score_sums(bool dual, int partition_count, int count)
 	WV_SYNC();
 }
 
-WV_FN void batch_score(bool dual, int partition_count, int partition_packed, int plane2_component, int count)
+/* One stage for the three steps (a stage call costs some fifty instructions of call sequence and context rebuild). */
+WV_OUT void batch_score(bool dual, int partition_count, int partition_packed, int plane2_component, int count)
 {
-	batch_score_terms(dual, partition_count, partition_packed, plane2_component, count);
-	batch_score_sums(dual, partition_count, count);
+	const Ctx c = ctx_make();
+	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
+	plane2_component = wv_uniform(plane2_component); count = wv_uniform(count);
+	const BatchView bv = batch_view(c, dual, partition_count);
+	batch_decode_body(c, bv, partition_count, count);
+	batch_score_terms_body(c, bv, dual, partition_count, partition_packed, plane2_component, count);
+	batch_score_sums_body(c, bv, dual, partition_count, count);
 }
 
 } } // namespace astcd::ASTC_VARIANT

@@ -692,9 +692,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 	for (int first = 0; first < candidate_count && !stop_all; first += batch_max)
 	{
 		const int batch = i_min(batch_max, candidate_count - first);
-		DUP_STAGE(c, DUP_BATCH_PREPARE, batch_prepare(dual, partition_count, partition_packed, first, batch));
-		DUP_STAGE(c, DUP_BATCH_SUMS, batch_sums(dual, partition_count, partition_packed, plane2_component, batch));
-		DUP_STAGE(c, DUP_BATCH_SOLVE, batch_solve(dual, partition_count, partition_packed, plane2_component, batch));
+		batch_refit(dual, partition_count, partition_packed, plane2_component, first, batch);
 		DUP_STAGE(c, DUP_BATCH_PACK, batch_pack(dual, partition_count, first, batch));
 		DUP_STAGE(c, DUP_BATCH_SCORE, batch_score(dual, partition_count, partition_packed, plane2_component, batch));
 		// (the step's scratch is the region the staged candidate tables live in)
@@ -985,13 +983,8 @@ WV_OUT void stage_formats(bool dual, int partition_count, int partition_packed, 
 		compute_ideal_endpoint_formats(c, part_view_lds(c, 1, 0), dual ? &tr.rgbs[1] : tr.ep0[0], dual ? &tr.rgbs[2] : tr.ep1[0], start, end);
 	else
 		compute_ideal_endpoint_formats(c, pv, tr.ep0[0], tr.ep1[0], start, end);
-}
-
-WV_OUT void stage_format_select(int partition_count, int start, int end)
-{
-	const Ctx c = ctx_make();
-	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
-	PROF_SCOPE(c, PS_FORMATS);
+	// (the candidate selection in the same stage: a stage call costs some fifty instructions of call sequence and context
+	//  rebuild, and the selection shares this stage's uniform values)
 	select_candidate_modes(c, partition_count, start, end);
 }
 
@@ -1035,8 +1028,7 @@ __attribute__((always_inline)) WV_FN float compress_trial(const Ctx& c, bool dua
 	// (the format search adds to the mode records in place, so it is doubled together with the scoring that resets them)
 	DUP_STAGE(c, DUP_MODES_FORMATS, {
 	DUP_STAGE(c, DUP_MODES, stage_modes(partition_count, mode_start, mode_end, max_weight_quant, dual));
-	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end);
-	stage_format_select(partition_count, mode_start, mode_end); });
+	stage_formats(dual, partition_count, partition_packed, plane2_component, mode_start, mode_end); });
 	return wv_uniform(stage_refine(partition_count, partition_packed, dual ? plane2_component : -1, tune_errorval_threshold));
 }
 
