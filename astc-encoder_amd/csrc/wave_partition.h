@@ -273,49 +273,65 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	// ---- stable counting sort (ref: :412-446) ----
 #if WV_DEVICE
 	{
-		// Lane b owns bin b.  Elements are taken 64 at a time; within a chunk the distinct mismatch
-		// values are peeled off one by one with ballots, which gives every element its rank among the
-		// equal-valued elements before it (stability) without any memory traffic.
+		// Elements are taken 64 at a time, one per lane.  A lane's rank among the equal keys before it in its chunk -- what
+		// makes the sort stable -- comes from the mask of the lanes that hold the same key: six ballots, one per key bit
+		// (a mismatch count is below 64), each narrowing the mask to the lanes that agree in that bit; the lowest lane of a
+		// mask speaks for its key when the bins (64 counters in the trial's integer mailbox) are updated.  (Peeling the
+		// distinct keys of a chunk off one by one, as before, costs a dozen instructions per distinct key and pass.)
 		const int lane = WV_LANE;
-		const unsigned long long lt_mask = (1ull << lane) - 1ull;
 		const uint8_t* mm = ps.mismatch();
 		uint16_t* ord = ps.ordering();
-		int hist = 0;
+		int* bins = &tr.ibox[0];
+		bins[lane] = 0;
+		WV_SYNC();
+		auto same_key_lanes = [](int m, bool valid) -> unsigned long long
+		{
+			unsigned long long mask = __ballot(valid);
+			#pragma unroll
+			for (int k = 0; k < 6; k++)
+			{
+				const bool bit = ((m >> k) & 1) != 0;
+				const unsigned long long with_bit = __ballot(bit);
+				mask &= bit ? with_bit : ~with_bit;
+			}
+			return mask;
+		};
+		auto lanes_below = [](unsigned long long mask) -> int      // popcount(mask & lanes below this one)
+		{
+			return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+		};
 		for (int first = 0; first < count; first += 64)
 		{
 			const int i = first + lane;
-			const int m = i < count ? (int)mm[i] : -1;
-			unsigned long long todo = __ballot(m >= 0);
-			while (todo)
-			{
-				const int v = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
-				const unsigned long long same = __ballot(m == v);
-				if (lane == v) hist += __popcll(same);
-				todo &= ~same;
-			}
+			const bool valid = i < count;
+			const int m = valid ? (int)mm[i] : 0;
+			const unsigned long long same = same_key_lanes(m, valid);
+			if (valid && lanes_below(same) == 0) bins[m] += (int)__popcll(same);      // (one lane per distinct key: no two lanes write one bin)
 		}
+		WV_SYNC();
 		// exclusive prefix over the bins (integer adds: any order is exact)
-		int base = hist;
-		for (int d = 1; d < 64; d <<= 1)
 		{
-			int up = __shfl_up(base, d);
-			if (lane >= d) base += up;
+			const int hist = bins[lane];
+			int base = hist;
+			for (int d = 1; d < 64; d <<= 1)
+			{
+				int up = __shfl_up(base, d);
+				if (lane >= d) base += up;
+			}
+			bins[lane] = base - hist;
 		}
-		base -= hist;
+		WV_SYNC();
 		for (int first = 0; first < count; first += 64)
 		{
 			const int i = first + lane;
-			const int m = i < count ? (int)mm[i] : -1;
-			unsigned long long todo = __ballot(m >= 0);
-			while (todo)
-			{
-				const int v = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
-				const unsigned long long same = __ballot(m == v);
-				const int start = __builtin_amdgcn_readlane(base, v);
-				if (m == v) ord[start + __popcll(same & lt_mask)] = (uint16_t)i;
-				if (lane == v) base += __popcll(same);
-				todo &= ~same;
-			}
+			const bool valid = i < count;
+			const int m = valid ? (int)mm[i] : 0;
+			const unsigned long long same = same_key_lanes(m, valid);
+			const int rank = lanes_below(same);
+			const int start = bins[m];
+			if (valid) ord[start + rank] = (uint16_t)i;
+			// (the wave's LDS operations complete in order: every lane has its `start` before the bin moves on)
+			if (valid && rank == 0) bins[m] = start + (int)__popcll(same);
 		}
 		(void)texels_to_process;
 	}
