@@ -390,16 +390,45 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets_all, SetFn get_set)
 		}
 	}
 	WV_SYNC();
-	// steps of every set, one per lane: the batching below then needs no memory access per set
+	// Batches of sets: as many consecutive sets as give at most 64 (set, step) pairs (and at most 32 sets).
+	// ibox[s - s0] = first pair slot of set s.  On the device lane s holds the steps of set s and their running total, so a
+	// batch boundary is one ballot and every set of the batch writes its own two entries -- no loop over the sets.
+#if WV_DEVICE
+	const int my_steps = WV_LANE < nsets ? (int)recs[WV_LANE].steps : 0;
+	int steps_through = my_steps;                  // steps of sets 0 .. lane (integers: any order of adding is exact)
+	for (int d = 1; d < 64; d <<= 1)
+	{
+		const int up = __shfl_up(steps_through, d);
+		if (WV_LANE >= d) steps_through += up;
+	}
+	int steps_before_batch = 0;
+#else
 	LaneArray128 steps_of;
 	steps_of.clear();
 	WV_FOR64(s, nsets) { steps_of.set(s, recs[s].steps); }
+#endif
 
 	int s0 = 0;
 	while (s0 < nsets)
 	{
 		// batch [s0, s1): total steps <= 64; ibox[s - s0] = first pair slot of set s
-		int s1 = s0, pairs = 0;
+		int s1, pairs;
+#if WV_DEVICE
+		{
+			const bool fits = WV_LANE >= s0 && WV_LANE < nsets && WV_LANE - s0 < 32 && steps_through - steps_before_batch <= 64;
+			const unsigned long long run = __ballot(fits) >> s0;                 // (the running total only grows: a run of ones from bit 0)
+			const int n = ~run ? (int)__builtin_ctzll(~run) : 64;
+			s1 = s0 + n;
+			pairs = __builtin_amdgcn_readlane(steps_through, s1 - 1) - steps_before_batch;
+			if (WV_LANE >= s0 && WV_LANE < s1)
+			{
+				tr.ibox[WV_LANE - s0] = steps_through - my_steps - steps_before_batch;
+				set_steps[WV_LANE - s0] = (uint8_t)my_steps;
+			}
+			steps_before_batch += pairs;
+		}
+#else
+		s1 = s0; pairs = 0;
 		while (s1 < nsets && s1 - s0 < 32)
 		{
 			int steps = steps_of.get(s1);
@@ -408,12 +437,32 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets_all, SetFn get_set)
 			pairs += steps;
 			s1++;
 		}
+#endif
 		WV_SYNC();
+#if WV_DEVICE
+		{
+			// the set of every pair slot: each set marks its first slot, the running maximum fills in the rest (every set
+			// has at least two steps, so no two sets start in one slot)
+			pair_set[WV_LANE] = 0;
+			WV_SYNC();
+			if (WV_LANE < s1 - s0) pair_set[tr.ibox[WV_LANE]] = (uint8_t)WV_LANE;
+			WV_SYNC();
+			int v = pair_set[WV_LANE];
+			for (int d = 1; d < 64; d <<= 1)
+			{
+				const int up = __shfl_up(v, d);
+				if (WV_LANE >= d) v = i_max(v, up);
+			}
+			WV_SYNC();
+			pair_set[WV_LANE] = (uint8_t)v;
+		}
+#else
 		WV_FOR64(sl, s1 - s0)
 		{
 			const int base = tr.ibox[sl], steps = set_steps[sl];
 			for (int j = 0; j < steps; j++) pair_set[base + j] = (uint8_t)sl;
 		}
+#endif
 		WV_SYNC();
 
 		{ PROF_SCOPE(c, PS_ANG1);
