@@ -1187,6 +1187,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 		c.tr().staged_color_quant[1] = -1;
 		c.tr().eci1_valid = 0;
 		c.tr().ideal_1p1p_valid = 0;
+		c.tr().dirsum1_mask = 0;
 	}
 	WV_SYNC();
 

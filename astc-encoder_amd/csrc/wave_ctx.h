@@ -73,6 +73,11 @@ struct TrialInfo {
 	int   eci1_valid;
 	float eci1[4];            // rgb_scale, rgb_luma, luminance, alpha_drop of partition 0 of 1
 	int   ideal_1p1p_valid;   // ei_w / ei_wes / ep0 / ep1 / is_constant_wes hold the 1-partition 1-plane result
+	// ... and the direction sums of the one-partition "partitioning" (compute_avgs_and_dirs): entry [which][j] -- the sum of
+	// channel j's offsets from the block mean over the texels whose channel `which` is above its mean -- depends on the two
+	// channels only, so the one-plane trial's 3 x 3 or 4 x 4 entries serve the channel subsets of the two-plane trials
+	uint32_t dirsum1_mask;    // bit which * 4 + j: dirsum1[which][j] is valid
+	float dirsum1[4][4];
 	// the staged partitioning's per-partition start / size bytes (PartView::offsets / counts): every refinement step
 	// builds a view of it, and two dependent L2 round trips for the header each time would be most of such a step's latency
 	uint32_t part_offsets, part_counts;

@@ -77,6 +77,20 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 	WV_SYNC();
 
 	// sum of offsets over the texels whose component `which` is above the mean (ref: :409-433)
+	// (one partition: the entries are the block's, whatever the trial -- TrialInfo::dirsum1)
+	uint32_t needed = 0;
+	for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) needed |= 1u << (cs.comp(a) * 4 + cs.comp(b));
+	const bool cached = pc == 1 && (wv_uniform(tr.dirsum1_mask) & needed) == needed;
+	if (cached)
+	{
+		WV_FOR64(k, n * n)
+		{
+			const uint32_t n_inv = n == 4 ? 64u : n == 3 ? 86u : n == 2 ? 128u : 256u;
+			const int which = (int)(((uint32_t)k * n_inv) >> 8), j = k - which * n;
+			tr.fbox[which * 4 + j] = tr.dirsum1[cs.comp(which)][cs.comp(j)];
+		}
+	}
+	else
 	WV_FOR64(k, pc * n * n)
 	{
 		// (n is 2, 3 or 4: divisions by multiply-shift, exact for k < 128 -- the device has no integer divide)
@@ -97,7 +111,9 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 			sum = sum + (dat_w > 0.0f ? dat_j : 0.0f);
 		}
 		tr.fbox[(p * 4 + which) * 4 + j] = sum;
+		if (pc == 1) tr.dirsum1[cs.comp(which)][cs.comp(j)] = sum;
 	}
+	if (pc == 1 && !cached) { WV_ONE { tr.dirsum1_mask |= needed; } }
 	WV_SYNC();
 
 	WV_FOR64(p, pc)
