@@ -558,7 +558,8 @@ enum { DUP_IDEAL = 1, DUP_DECIMATE, DUP_ANGULAR, DUP_MODES, DUP_MODES_FORMATS, D
        DUP_REALIGN, DUP_BATCH_PREPARE, DUP_BATCH_SUMS, DUP_BATCH_SOLVE, DUP_BATCH_PACK, DUP_BATCH_SCORE,
        // whole trials by class (a second run of a trial finds nothing better than its first and changes nothing)
        DUP_TRIAL_A0, DUP_TRIAL_A1, DUP_TRIAL_2PLANES, DUP_TRIAL_2PARTITIONS, DUP_TRIAL_3PARTITIONS, DUP_TRIAL_4PARTITIONS,
-       DUP_REALIGN_2PLANES };        // the realignment of two-plane candidates only
+       DUP_REALIGN_2PLANES,          // the realignment of two-plane candidates only
+       DUP_REALIGN_FIRST_PASS };     // the first evaluation of all weights inside every realignment (idempotent)
 #if defined(ASTC_DUPSTAGE)
 #define DUP_STAGE(c, id, call) do { call; if ((c).cfg->debug_dup_stage == (uint32_t)(id)) { call; } } while (0)
 #else

@@ -704,6 +704,10 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 
 	// ---- first pass: every weight of both planes against the current state ----
 	int count = 2 * W;
+#if defined(ASTC_DUPSTAGE)
+	bool dup_done = false;
+	for (int rep = 0; rep < (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS ? 2 : 1); rep++)
+#endif
 	if (count > 16)
 	{
 		// one lane per weight (see realign_weights: the twelve running sums in registers, the table reads one row ahead)
@@ -816,6 +820,9 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 				Q_ONCE { verdict[item] = (uint8_t)new_value; }
 			}
 			WV_SYNC();
+#if defined(ASTC_DUPSTAGE)
+			if (!dup_done && !adjustments && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
+#endif
 		}
 
 		// ---- per plane: the first weight (in index order) whose verdict is "move" moves; what that invalidates -- the
@@ -1069,6 +1076,9 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 			{
 				int items = W;                              // pass 1: every weight; then: the later neighbours of each mover
 				bool all = true;
+#if defined(ASTC_DUPSTAGE)
+				bool dup_done = false;
+#endif
 				const int last_row = di.rows - 1;
 				// the mover's later neighbours: on the device entry k sits in a register of the lanes of quad k
 				const uint8_t* later_row = di.later;
@@ -1182,6 +1192,9 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						}
 					}
 					WV_SYNC(); }
+#if defined(ASTC_DUPSTAGE)
+					if (all && !dup_done && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
+#endif
 					PROF_SCOPE(c, PS_Y7);
 					// the first weight (in index order) whose verdict is "move" moves; what it invalidates is evaluated again
 					int mover, later_count = 0;

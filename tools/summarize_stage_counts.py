@@ -5,7 +5,7 @@ NAMES = {1: "ideal endpoints+weights", 2: "decimate (all grids)", 3: "angular bo
          6: "candidate quantize", 7: "candidate restore/staging", 8: "recompute endpoints", 9: "pack endpoints", 10: "difference (decode+score)",
          11: "partition order (k-means)", 12: "partition score", 13: "partition select", 14: "block statistics", 15: "load block", 16: "physical", 18: "weight realignment",
          19: "batch: rows + weights", 20: "batch: sums", 21: "batch: solve", 22: "batch: pack", 23: "batch: score",
-         24: "TRIALS: A0 (1 partition, always modes)", 25: "TRIALS: A1 (1 partition, all modes)", 26: "TRIALS: two planes", 27: "TRIALS: 2 partitions", 28: "TRIALS: 3 partitions", 29: "TRIALS: 4 partitions", 30: "  realignment of two-plane candidates"}
+         24: "TRIALS: A0 (1 partition, always modes)", 25: "TRIALS: A1 (1 partition, all modes)", 26: "TRIALS: two planes", 27: "TRIALS: 2 partitions", 28: "TRIALS: 3 partitions", 29: "TRIALS: 4 partitions", 30: "  realignment of two-plane candidates", 31: "  realignment: first pass over all weights"}
 d = sys.argv[1]
 def load(i):
     tot = {}
