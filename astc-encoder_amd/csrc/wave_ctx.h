@@ -346,7 +346,14 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		const uint32_t P = pcl > 4u ? 4u : pcl;
 		for (uint32_t cls = 0; cls < 2; cls++)
 			for (uint32_t pc = 1; pc <= 4; pc++)
+			{
 				L.batview[cls][pc - 1] = batch_offsets(L.bat_max[cls], cls ? 2u : 1u, pc, Tp, P);
+#if !WV_DEVICE
+				// (the two descriptions of the scratch -- where its parts start, how much is set aside -- must agree: the second
+				//  counts the vector rows of four partitions whatever the partition limit)
+				if (pc <= (cls ? 1u : pcl) && L.batview[cls][pc - 1].o_state0 + L.cstate_stride > batch_scratch_bytes(L.bat_max[cls], cls ? 2u : 1u, pc, Tp, L.cstate_stride)) __builtin_trap();
+#endif
+			}
 	}
 	L.texel_count = r.texel_count;
 }

@@ -46,6 +46,10 @@ def test_kernel_descriptors(tmp_path):
     for name in ("astc_compress_blocks_ldrEP", "astc_compress_blocks_hdrEP"):
         big = next(d for n, d in by_short.items() if n.startswith(name))
         assert big["private_segment_fixed_size"] == 0 and big["vgpr_spill_count"] == 0 and big["vgpr_count"] <= 128, (name, big)
+    # the stages of the compression kernels address LDS from 0 (ctx_make, wave_ctx.h): the kernels must use dynamic LDS only
+    for n, d in by_short.items():
+        if n.startswith("astc_compress_blocks"):
+            assert d["group_segment_fixed_size"] == 0, (n, d)
     assert any(n.startswith("astc_decompress_blocks") for n in by_short)
     assert any(n.startswith("astc_alpha_averages") for n in by_short)
     assert sum(n.startswith("astc_compare_") for n in by_short) == 3
