@@ -18,7 +18,7 @@ AVX2 library (byte-identical to the scalar build by the reference's invariance g
     0.05 dB that later reference releases themselves moved by.
 Default matrix: every image at 6x6 -medium, plus one more (block size, preset) of 4x4 / 6x6 / 8x8 x -fast / -medium /
 -thorough per image of the Small set in rotation and 8x8 -thorough for the large sets; ASTC_CORPUS_FULL=1 runs every image x 3 block sizes
-x 3 presets (tools/gpu_corpus.sh; profiles/ holds the log of a full run)."""
+x 3 presets (`ASTC_CORPUS_FULL=1 python -m pytest tests/test_corpus.py`: 382 cases; profiles/r04z/corpus_full.log is the log of such a run)."""
 import json
 import os
 import re
