@@ -363,55 +363,10 @@ WV_OUT void refine_quantize_candidates(bool dual, int partition_count, int parti
 	WV_SYNC();
 }
 
-/* Per candidate: stage what the refinement loop reads in serial, latency-bound code into LDS (grid tables
- * and quant transfer table only when they differ from what is there), set up the working endpoints and
- * weights (ref: :497-540). */
-WV_OUT void refine_candidate_setup(bool dual, int partition_count, int plane2_component, int candidate,
-                                   int stage_dm, int stage_wq, int color_quant_level)
-{
-	const Ctx c = ctx_make();
-	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); plane2_component = wv_uniform(plane2_component);
-	candidate = wv_uniform(candidate); stage_dm = wv_uniform(stage_dm); stage_wq = wv_uniform(stage_wq);
-	color_quant_level = wv_uniform(color_quant_level);
-	TrialInfo& tr = c.tr();
-	Scb& workscb = c.wscb();
-	{
-		PROF_SCOPE(c, PS_X0);
-		if (stage_dm >= 0)
-		{
-			const DecimationInfo& dinfo = c.dec_info(stage_dm);
-			// (the record and the tables are 16-byte aligned in the blob: 128-bit copies)
-			stage_quads_nosync(c.lds + c.L->dtab, reinterpret_cast<const uint8_t*>(&dinfo), (int)sizeof(DecimationInfo));
-			stage_quads_nosync(c.lds + c.L->dtab + DTAB_RECORD_BYTES, c.table(dinfo.off_texel_weights), (int)dinfo.table_bytes);
-		}
-		if (stage_wq >= 0)
-		{
-			stage_words_nosync(c.lds + c.L->qtab, reinterpret_cast<const uint8_t*>(&c.qxfer(stage_wq)), (int)(sizeof(QuantXfer) / 4));
-		}
-		stage_color_rows(c, color_quant_level);      // ends with a sync
-	}
-
-	// workep = ideal endpoints (merged across planes for dual plane); quantized weights come from
-	// refine_quantize_candidates()
-	PROF_SCOPE(c, PS_Y1);
-	WV_FOR64(k, partition_count * 4)
-	{
-		int p = k >> 2, ch = k & 3;
-		int plane = (dual && ch == plane2_component) ? 1 : 0;
-		tr.wep0[p][ch] = tr.ep0[plane][p][ch];
-		tr.wep1[p][ch] = tr.ep1[plane][p][ch];
-	}
-	{
-		const uint32_t* src = reinterpret_cast<const uint32_t*>(c.candw(candidate));
-		uint32_t* dst = reinterpret_cast<uint32_t*>(workscb.weights);
-		WV_FOR(k, 16) { dst[k] = src[k]; }
-	}
-	WV_SYNC();
-}
-
 /* A candidate that passed the test on the error of its (batched) first step takes its turn: what the step left for
  * it (wave_batch.h: CandState) becomes the working block, endpoints and decoded endpoints, and the candidate's tables
- * are staged for the steps that follow (as refine_candidate_setup does for the one-candidate path). */
+ * are staged for the steps that follow -- the grid's tables and the quant transfer table only when they differ from
+ * what is staged (ref: :497-540). */
 WV_OUT void refine_candidate_restore(bool dual, int partition_count, int partition_packed, int plane2_component, int candidate, int slot,
                                      int stage_dm, int stage_wq, int color_quant_level, int block_mode_packed)
 {

@@ -16,7 +16,7 @@ struct ColorTabs {
 
 /* The rows of the colour quant level staged in LDS by stage_color_rows(): pack_color_endpoints does ~50 dependent
  * lookups per call, and a pointer that could be LDS or HBM would make each of them a flat load with 64-bit address
- * arithmetic.  The caller stages the level it packs at (refine_candidate_setup; refine_pack for its retry level). */
+ * arithmetic.  The caller stages the level it packs at (refine_candidate_restore; refine_pack for its retry level). */
 WV_FN ColorTabs color_tabs(const Ctx& c, int quant_level)
 {
 	ColorTabs t;

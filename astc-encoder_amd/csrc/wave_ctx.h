@@ -746,7 +746,7 @@ WV_FN DecView dec_view_global(const Ctx& c, int dm)
 	return dec_view_at(di, c.table(di.off_texel_weights));
 }
 
-/* The staged view (after refine_candidate_setup staged the grid): sizes, offsets and tables all come from LDS. */
+/* The staged view (after refine_candidate_restore staged the grid): sizes, offsets and tables all come from LDS. */
 WV_FN DecView dec_view_lds(const Ctx& c, int dm)
 {
 	(void)dm;
