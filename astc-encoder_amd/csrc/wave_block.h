@@ -102,27 +102,24 @@ WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* tab, float ideal)
 /* Quantize-and-score every block mode in [start, end) (ref: compress_symbolic.cpp:438-485 / :806-860 with
  * compute_quantized_weights_for_decimation + compute_error_of_weight_set_{1plane,2planes}).
  *
- * The reference walks the modes one by one.  Here a chunk of modes is scored at once: one lane per
- * (mode, plane) prepares the mode's quantization parameters; one lane per (mode, texel) quantizes the
- * <= 4 grid weights that texel interpolates (same arithmetic on the same inputs as a per-weight pass
- * would use) and writes the texel's error term; then four lanes per mode run the reference's 4
- * interleaved accumulators over the terms in texel order. */
+ * The reference walks the modes one by one.  Here a chunk of up to sixteen modes is scored at once: one lane per
+ * mode prepares the mode's quantization parameters; one lane per (mode, weight) quantizes the grid weights; one
+ * quad per mode runs the reference's four interleaved accumulators, each lane forming its texels' error terms itself
+ * (the infill of the <= 4 quantized weights the texel interpolates) in texel order. */
 WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
 {
 	ModeRec* modes = c.modes(start);
-	const int T = c.T, Tp = c.Ts;                       // (Tp: the stride of the term rows below)
+	const int T = c.T;
 	const int planes = dual ? 2 : 1;
 	const int chunk_modes = (int)c.L->mode_chunk;
 	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);
 	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
-	float* buf = reinterpret_cast<float*>(c.lds + c.L->uni + (uint32_t)chunk_modes * MODE_DESC_BYTES);
-	uint8_t* uqw = c.lds + c.L->uni + (uint32_t)chunk_modes * (MODE_DESC_BYTES + (uint32_t)Tp * 4);   // [mode][MODE_WEIGHT_BYTES]
+	uint8_t* uqw = c.lds + c.L->uni + (uint32_t)chunk_modes * MODE_DESC_BYTES;   // [mode][MODE_WEIGHT_BYTES]
 	const int wcap = (int)c.L->mode_wcap[dual ? 1 : 0];
 	const uint32_t wcap_inv = c.L->mode_wcap_inv[dual ? 1 : 0];
 	const float* ldsf = reinterpret_cast<const float*>(c.lds);
 	const float* eiw0 = c.ei_w(0); const float* eiwes0 = c.ei_wes(0);
 	const float* eiw1 = c.ei_w(1); const float* eiwes1 = c.ei_wes(1);
-	const uint32_t t_inv = c.L->t_inv24;                                      // k / T == (k * t_inv) >> 24 for k < 2^24 / T
 
 	// The unquantized value of every weight quant level's steps (QuantXfer::quant_to_unquant, 12 x 32 bytes) goes to the
 	// tail of the scratch region once per call: pass A looks two of them up per weight, and from the blob every chunk
@@ -246,60 +243,52 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 		}
 		WV_SYNC(); }
 
-		// Pass B: one lane per (mode, texel): infill the quantized weights and take the squared difference to the
-		// ideal weight of the texel (ref: compute_error_of_weight_set_{1plane,2planes} :688-842)
+		// Pass B: one QUAD per mode, lane l of it = the reference's accumulator l: the lane infills the quantized weights at
+		// its texels l, l + 4, ... , takes the squared difference to the texel's ideal weight and adds the terms up in that
+		// order (ref: compute_error_of_weight_set_{1plane,2planes} :688-842, four interleaved sums folded (a0 + a2) + (a1 + a3)).
+		// (Until round 4 one lane per (mode, texel) wrote the terms to a row per mode and a second pass summed them: the rows
+		//  were most of a mode's LDS, i.e. set the modes per chunk -- 10 for 6x6, 7 for 8x8, now 16 -- and every chunk pays
+		//  the descriptor pass and four hand-offs.)
 		{ PROF_SCOPE(c, PS_MODE1);
-		WV_FOR(k, nm * T)
+		WV_QUADS16(m, nm)
 		{
-			int m = (int)(((uint32_t)k * t_inv) >> 24), t = k - m * T;
 			const ModeHdr h = hdr[m];
-			float term = 0.0f;
+			const uint8_t* uq = uqw + m * (int)MODE_WEIGHT_BYTES;
+			const ModeQ q0 = mq[m * 2], q1 = mq[m * 2 + 1];
+			qf acc = q_splat(0.0f);
+			Q_LANES(l)
 			{
-				// (the texel's record of the mode's grid: one 32-bit and one 128-bit load, whatever the tap count)
-				const TexelTaps taps = texel_taps_at(c.tab, h.tw_off, h.tcf_off, (uint32_t)t);
-				const uint8_t* uq = uqw + m * (int)MODE_WEIGHT_BYTES;
-				// Every grid through the four-tap form: a tap a grid does not have has index 0 and factor 0.0f in the tables
-				// (ref: init_decimation_info_2d fills the unused entries with zeros), and (v0 + v1) + (0 + 0) is v0 + v1, so
-				// this is the value of the two-tap and the undecimated forms -- but the (mode, texel) lanes of a wave, which
-				// belong to two or three modes with different grids, no longer take their own branch one after the other
-				// (config 2 +1.6 %, config 3 +2 %).
-				const int i0 = (int)(taps.idx & 0xFFu), i1 = (int)((taps.idx >> 8) & 0xFFu), i2 = (int)((taps.idx >> 16) & 0xFFu), i3 = (int)(taps.idx >> 24);
-				const float c0 = taps.c0, c1 = taps.c1, c2 = taps.c2, c3 = taps.c3;
-				for (int plane = 0; plane < planes; plane++)
+				float sum = 0.0f;
+				for (int t = l; t < T; t += 4)
 				{
-					const ModeQ q = mq[m * 2 + plane];
-					const uint8_t* u = uq + plane * PLANE2_OFFSET;
-					const float v0 = ((float)(int)u[i0] * q.rscale + q.low_bound) * c0;
-					const float v1 = ((float)(int)u[i1] * q.rscale + q.low_bound) * c1;
-					const float v2 = ((float)(int)u[i2] * q.rscale + q.low_bound) * c2;
-					const float v3 = ((float)(int)u[i3] * q.rscale + q.low_bound) * c3;
-					float current = (v0 + v1) + (v2 + v3);
-					float diff = current - (plane ? eiw1[t] : eiw0[t]);
-					float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
-					term = plane ? term + e : e;
+					// (the texel's record of the mode's grid: one 32-bit and one 128-bit load, whatever the tap count.  Every
+					//  grid goes through the four-tap form: a tap a grid does not have has index 0 and factor 0.0f in the tables
+					//  (ref: init_decimation_info_2d fills the unused entries with zeros), and (v0 + v1) + (0 + 0) is v0 + v1)
+					const TexelTaps taps = texel_taps_at(c.tab, h.tw_off, h.tcf_off, (uint32_t)t);
+					const int i0 = (int)(taps.idx & 0xFFu), i1 = (int)((taps.idx >> 8) & 0xFFu), i2 = (int)((taps.idx >> 16) & 0xFFu), i3 = (int)(taps.idx >> 24);
+					const float c0 = taps.c0, c1 = taps.c1, c2 = taps.c2, c3 = taps.c3;
+					float term = 0.0f;
+					for (int plane = 0; plane < planes; plane++)
+					{
+						const ModeQ& q = plane ? q1 : q0;
+						const uint8_t* u = uq + plane * PLANE2_OFFSET;
+						const float v0 = ((float)(int)u[i0] * q.rscale + q.low_bound) * c0;
+						const float v1 = ((float)(int)u[i1] * q.rscale + q.low_bound) * c1;
+						const float v2 = ((float)(int)u[i2] * q.rscale + q.low_bound) * c2;
+						const float v3 = ((float)(int)u[i3] * q.rscale + q.low_bound) * c3;
+						float current = (v0 + v1) + (v2 + v3);
+						float diff = current - (plane ? eiw1[t] : eiw0[t]);
+						float e = diff * diff * (plane ? eiwes1[t] : eiwes0[t]);
+						term = plane ? term + e : e;
+					}
+					sum += term;
 				}
+				QV(acc, l) = sum;
 			}
-			buf[m * Tp + t] = term;
+			const float error = q_hadd(acc);
+			Q_ONCE { modes[h.mode].error = error; }
 		}
 		WV_SYNC(); }
-
-		// 4 interleaved accumulators per mode, in place (lane l only touches indices = l mod 4)
-		{ PROF_SCOPE(c, PS_MODE2);
-		WV_FOR64(k, nm * 4)                              // (nm <= mode_chunk <= 16)
-		{
-			int m = k >> 2, l = k & 3;
-			float* v = buf + m * Tp;
-			float acc = 0.0f;
-			for (int i = l; i < T; i += 4) acc += v[i];
-			v[l] = acc;
-		}
-		WV_SYNC(); }
-
-		WV_FOR64(m, nm)
-		{
-			modes[hdr[m].mode].error = (buf[m * Tp] + buf[m * Tp + 2]) + (buf[m * Tp + 1] + buf[m * Tp + 3]);
-		}
-		WV_SYNC();
 	}
 	}
 }

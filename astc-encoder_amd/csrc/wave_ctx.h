@@ -255,8 +255,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	}
 	L.uni_bytes = uni_region_bytes(r.texel_count, cfg.tune_partition_count_limit);
 	L.t_inv24 = ((1u << 24) + (uint32_t)r.texel_count - 1u) / (uint32_t)r.texel_count;
-	const uint32_t Ts = (uint32_t)lds_row_stride((int)Tp);
-	L.mode_chunk = (L.uni_bytes - MODE_Q2U_BYTES) / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Ts * 4);
+	L.mode_chunk = (L.uni_bytes - MODE_Q2U_BYTES) / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES);
 	if (L.mode_chunk > 16u) L.mode_chunk = 16u;
 	for (int cls = 0; cls < 2; cls++)
 	{
@@ -292,7 +291,7 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 		if (rounded <= 64u * 1024u)
 		{
 			L.uni_bytes = (rounded - L.uni) & ~15u;
-			L.mode_chunk = (L.uni_bytes - MODE_Q2U_BYTES) / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Ts * 4);
+			L.mode_chunk = (L.uni_bytes - MODE_Q2U_BYTES) / (MODE_DESC_BYTES + MODE_WEIGHT_BYTES);
 			if (L.mode_chunk > 16u) L.mode_chunk = 16u;       // (four accumulator lanes per mode of a chunk: one wave-trip, score_block_modes)
 			end = rounded;
 		}
