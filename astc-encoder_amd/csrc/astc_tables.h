@@ -52,7 +52,7 @@ enum {
 // and the partition-count limit, so the table builder can cut the decimation sweeps into the same chunks the
 // kernel will use.
 constexpr uint32_t MODE_DESC_BYTES = 16 + 2 * 32;   // ModeHdr + ModeQ[2], see score_block_modes (wave_block.h)
-constexpr uint32_t MODE_WEIGHT_BYTES = 64;          // quantized weights of one block mode (second plane at + 32)
+constexpr uint32_t MODE_WEIGHT_BYTES = 68;          // quantized weights of one block mode (second plane at + 32); 17 words: the quads of a chunk's modes read their records side by side, in different LDS banks
 constexpr uint32_t MODE_Q2U_BYTES = 12 * 32;        // mode scoring's LDS copy of the quant_to_unquant rows of the weight quant levels (tail of `uni`)
 constexpr uint32_t FMT_QUANT_ROWS = 17;
 ASTC_HD inline uint32_t fmt_comb_cols(uint32_t partition_limit) { return partition_limit <= 1 ? 0u : partition_limit == 2 ? 7u : partition_limit == 3 ? 10u : 13u; }
@@ -69,7 +69,7 @@ ASTC_HD inline uint32_t uni_region_bytes(uint32_t texel_count, uint32_t partitio
 {
 	const uint32_t Tp = (texel_count + 3u) & ~3u;
 	uint32_t bytes = 64 * ANG_PAIR_STRIDE * 4;                     // angular batch
-	if (8u * (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4) > bytes) bytes = 8u * (MODE_DESC_BYTES + MODE_WEIGHT_BYTES + Tp * 4);   // mode scoring: descriptors, quantized weights, texel terms of 8 modes
+	if (8u * (MODE_DESC_BYTES + 64u + Tp * 4) > bytes) bytes = 8u * (MODE_DESC_BYTES + 64u + Tp * 4);   // (what mode scoring needed while it kept a row of texel terms per mode; it takes less now -- make_lds_layout fits the modes per chunk to the region -- but the decimation sweeps' sets per chunk are sized by this too)
 	if (fmt_scratch_bytes(partition_limit) > bytes) bytes = fmt_scratch_bytes(partition_limit);
 	if (5 * Tp * 4 > bytes) bytes = 5 * Tp * 4;                    // encoding-choice rows
 	return (bytes + 15u) & ~15u;
