@@ -72,7 +72,6 @@ row("v_add_f32 + v_max_f32 alternating (2)", "v_add_f32 {d}, {a}, {d}\\n v_max_f
 row("v_add_f32 + v_cvt_f32_i32 alternating (2)", "v_add_f32 {d}, {a}, {d}\\n v_cvt_f32_i32 {d}, {d}", n=2)
 row("v_add_f32 + s_and_b64 alternating (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=1)
 row("v_max_f32 + s_and_b64 alternating (1 valu)", "v_max_f32 {d}, {a}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=1)
-row("v_add_f32 + 2 x s_and_b64 (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]\\n s_or_b64 s[30:31], s[30:31], s[20:21]", n=1)
 row("v_add_f32 + s_waitcnt lgkmcnt(0) (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_waitcnt lgkmcnt(0)", n=1)
 row("v_add_f32 + s_nop 0 (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_nop 0", n=1)
 row("v_add_f32 + s_nop 1 (1 valu)", "v_add_f32 {d}, {a}, {d}\\n s_nop 1", n=1)
