@@ -716,6 +716,11 @@ int astcenc_amd_context_device_count(const astcenc_context* ctx)
 	return ctx && ctx->backend ? backend_device_count(ctx->backend) : 0;
 }
 
+const char* astcenc_amd_context_kernel_name(const astcenc_context* ctx)
+{
+	return ctx && ctx->backend ? backend_kernel_name(ctx->backend) : "";
+}
+
 astcenc_error astcenc_amd_context_set_option(astcenc_context* ctx, astcenc_amd_option option, int value)
 {
 	if (!ctx) return ASTCENC_ERR_BAD_CONTEXT;

@@ -104,6 +104,17 @@ int astc_kernel_prepare_ldr64(const TableRoot& root, const DeviceConfig& cfg, ui
 int astc_kernel_prepare_hdr64(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes);
 int astc_kernel_launch_ldr64(const KernelLaunch& k);
 int astc_kernel_launch_hdr64(const KernelLaunch& k);
+// ... and the fixed-context builds (kernel_ldr_6x6m.hip, kernel_ldr_8x8t.hip, kernel_hdr_6x6m.hip): `prepare` returns
+// ASTC_PREPARE_NOT_THIS_CONTEXT when the context is not the one the build was compiled for
+constexpr int ASTC_PREPARE_NOT_THIS_CONTEXT = -1;
+#define ASTC_DECLARE_KERNEL_VARIANT(tag) \
+	int astc_kernel_prepare_##tag(const TableRoot& root, const DeviceConfig& cfg, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes); \
+	int astc_kernel_launch_##tag(const KernelLaunch& k);
+ASTC_DECLARE_KERNEL_VARIANT(ldr_6x6m)
+ASTC_DECLARE_KERNEL_VARIANT(ldr_8x8t)
+ASTC_DECLARE_KERNEL_VARIANT(hdr_6x6m)
+#undef ASTC_DECLARE_KERNEL_VARIANT
+const char* backend_kernel_name(const Backend* b);   // the build of the compression kernel this context launches
 
 /* Alpha-average pre-pass launch (kernel_alpha.hip).  The padded tile of a region lives in LDS while it fits
  * (ALPHA_LDS_LIMIT) and otherwise in d_scratch: astc_alpha_scratch_bytes() says how much of it and for how many

@@ -53,6 +53,7 @@ struct Backend {
 	uint32_t lds_bytes;
 	bool hdr;
 	TableRoot root;
+	int variant;                      // index into kernel_variants (chosen by the first kernel_prepare)
 };
 
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
@@ -77,21 +78,47 @@ struct DeviceGuard {
 	~DeviceGuard() { if (ok) (void)hipSetDevice(saved); }
 };
 
-/* Four builds of the compression kernel: LDR / HDR coders x footprints of at most 64 texels (whose texel loops make one
- * trip, kernel_ldr64.hip) / the larger ones. */
-int kernel_prepare(const Backend* b, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes)
+/* The builds of the compression kernel.  Generic ones: LDR / HDR coders x footprints of at most 64 texels (whose texel
+ * loops make one trip, kernel_ldr64.hip) / the larger ones.  Fixed-context ones (kernel_ldr_6x6m.hip, ...): compiled for
+ * one named context each, its LDS layout, configuration and table root as constants; their `prepare` returns
+ * ASTC_PREPARE_NOT_THIS_CONTEXT unless the live context is that one, record for record.  The first variant that accepts
+ * the context is used (fixed ones first); ASTCENC_AMD_KERNEL=generic in the environment skips the fixed ones. */
+struct KernelVariant {
+	const char* name;
+	bool fixed, hdr, small;
+	int (*prepare)(const TableRoot&, const DeviceConfig&, uint32_t*, void*, uint32_t*);
+	int (*launch)(const KernelLaunch&);
+};
+const KernelVariant kernel_variants[] = {
+	{ "astc_compress_blocks_ldr_6x6m", true, false, true, astc_kernel_prepare_ldr_6x6m, astc_kernel_launch_ldr_6x6m },
+	{ "astc_compress_blocks_ldr_8x8t", true, false, true, astc_kernel_prepare_ldr_8x8t, astc_kernel_launch_ldr_8x8t },
+	{ "astc_compress_blocks_hdr_6x6m", true, true, true, astc_kernel_prepare_hdr_6x6m, astc_kernel_launch_hdr_6x6m },
+	{ "astc_compress_blocks_ldr64", false, false, true, astc_kernel_prepare_ldr64, astc_kernel_launch_ldr64 },
+	{ "astc_compress_blocks_hdr64", false, true, true, astc_kernel_prepare_hdr64, astc_kernel_launch_hdr64 },
+	{ "astc_compress_blocks_ldr", false, false, false, astc_kernel_prepare_ldr, astc_kernel_launch_ldr },
+	{ "astc_compress_blocks_hdr", false, true, false, astc_kernel_prepare_hdr, astc_kernel_launch_hdr },
+};
+/* Picks the context's variant (b->variant < 0: not chosen yet) and prepares it on the current device. */
+int kernel_prepare(Backend* b, uint32_t* lds_bytes, void* layout_out, uint32_t* layout_bytes)
 {
+	if (b->variant >= 0) return kernel_variants[b->variant].prepare(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
 	const bool small = b->root.texel_count <= 64;
-	if (b->hdr) return small ? astc_kernel_prepare_hdr64(b->root, b->cfg, lds_bytes, layout_out, layout_bytes)
-	                         : astc_kernel_prepare_hdr(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
-	return small ? astc_kernel_prepare_ldr64(b->root, b->cfg, lds_bytes, layout_out, layout_bytes)
-	             : astc_kernel_prepare_ldr(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
+	const char* want = getenv("ASTCENC_AMD_KERNEL");
+	const bool generic_only = want && strcmp(want, "generic") == 0;
+	for (int i = 0; i < (int)(sizeof(kernel_variants) / sizeof(kernel_variants[0])); i++)
+	{
+		const KernelVariant& v = kernel_variants[i];
+		if (v.hdr != b->hdr || v.small != small || (v.fixed && generic_only)) continue;
+		const int rc = v.prepare(b->root, b->cfg, lds_bytes, layout_out, layout_bytes);
+		if (rc == ASTC_PREPARE_NOT_THIS_CONTEXT) continue;
+		if (rc == 0) b->variant = i;
+		return rc;
+	}
+	return (int)hipErrorInvalidDeviceFunction;
 }
 int kernel_launch(const Backend* b, const KernelLaunch& k)
 {
-	const bool small = b->root.texel_count <= 64;
-	if (b->hdr) return small ? astc_kernel_launch_hdr64(k) : astc_kernel_launch_hdr(k);
-	return small ? astc_kernel_launch_ldr64(k) : astc_kernel_launch_ldr(k);
+	return kernel_variants[b->variant].launch(k);
 }
 
 void slot_destroy(DeviceSlot* s)
@@ -314,6 +341,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(&b->root, blob, sizeof(TableRoot));
 	b->hdr = cfg.profile >= 2;
 	b->lds_bytes = 0;
+	b->variant = -1;
 	uint8_t layout[CTX_LAYOUT_BACK - CTX_CONFIG_BACK];
 	uint32_t layout_bytes = 0;
 	{
@@ -364,6 +392,7 @@ void backend_destroy(Backend* b)
 }
 
 int backend_device_count(const Backend* b) { return (int)b->slots.size(); }
+const char* backend_kernel_name(const Backend* b) { return b->variant >= 0 ? kernel_variants[b->variant].name : ""; }
 
 static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress);
 

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
 ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
                  uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
 {
-	uint8_t* lds = astc_lds;
+	uint8_t* lds = lds_base();
 
 	uint32_t b = xcd_block_remap(blockIdx.x, num_blocks) + first_block;
 	// raster block order: x fastest, then y, then z (ref: astcenc_entry.cpp:961-966)
@@ -52,10 +52,17 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	tab = base + CTX_LAYOUT_BACK;
 	Ctx c;
 	c.tab = tab;
+	c.lds = lds;
+#if ASTC_FIXED
+	// (a fixed-context build: the three records are constants of this translation unit, wave_ctx.h)
+	c.root = &kFixedRoot;
+	c.cfg = &kFixedConfig;
+	c.L = &kFixedLayout;
+#else
 	c.root = reinterpret_cast<const TableRoot*>(tab);
 	c.cfg = reinterpret_cast<const DeviceConfig*>(base + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
-	c.lds = lds;
 	c.L = reinterpret_cast<const LdsLayout*>(base);
+#endif
 	c.T = (int)c.L->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
@@ -91,6 +98,16 @@ int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* 
 #if defined(ASTC_DUPSTAGE)
 	// instrumentation builds only: extra LDS per block at run time, to find where the occupancy steps are
 	if (const char* pad = getenv("ASTC_LDS_PAD_RT")) L.total += (uint32_t)atoi(pad);
+#endif
+#if ASTC_FIXED
+	// This build is compiled for ONE context (wave_ctx.h): the live context must be that one, record for record.  (The
+	// instrumentation builds' stage selector is read from the live record, DUP_STAGE_ID.)
+	{
+		DeviceConfig live = cfg;
+		live.debug_dup_stage = kFixedConfig.debug_dup_stage;
+		if (memcmp(&L, &kFixedLayout, sizeof(L)) != 0 || memcmp(&live, &kFixedConfig, sizeof(live)) != 0 || memcmp(&root, &kFixedRoot, sizeof(root)) != 0)
+			return ASTC_PREPARE_NOT_THIS_CONTEXT;
+	}
 #endif
 	*lds_bytes = L.total;
 	static_assert(sizeof(LdsLayout) <= CTX_LAYOUT_BACK - CTX_CONFIG_BACK, "layout record grew past the space the backend reserves");

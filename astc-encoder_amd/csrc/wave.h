@@ -40,7 +40,15 @@
 	#define WV_DEVICE 1
 	#define WV_FN __host__ __device__ inline
 	#define WV_OUT static __host__ __device__ __attribute__((noinline))
-	#define WV_LANE ((int)threadIdx.x)
+	// The lane's index.  WV_LANE names `wv_lane_v`, which at namespace scope is the hardware's value -- ONE value for the whole
+	// kernel, so everything derived from it (a lane's row address, its slot in a table) is loop-invariant everywhere and the
+	// optimiser hoists such terms out of the search loops of compress_block and carries them, in vector registers, across
+	// every trial.  A function that is inlined into the kernel body shadows the name with a local, opaque copy
+	// (WV_LANE_SCOPE as its first statement): what is derived from the lane index is then computed, and dies, inside it.
+	struct WvLaneId { __device__ operator int() const { return (int)threadIdx.x; } };
+	static constexpr WvLaneId wv_lane_v{};
+	#define WV_LANE ((int)wv_lane_v)
+	#define WV_LANE_SCOPE int wv_lane_scope_src = (int)threadIdx.x; asm volatile("" : "+v"(wv_lane_scope_src)); const int wv_lane_v = wv_lane_scope_src
 	// A workgroup is exactly one wavefront, and a wavefront's LDS instructions execute in issue
 	// order, so a cross-lane hand-off through LDS needs no s_barrier and no s_waitcnt: it only needs
 	// the compiler not to move or cache LDS accesses across this point.  (__syncthreads() would add
@@ -86,6 +94,7 @@
 	extern thread_local bool g_wave_one_trip_texel_loops;
 	#define WV_FOR_T(i, n) WV_FOR(i, (g_wave_one_trip_texel_loops ? wv_checked_count((int)(n), 64) : (int)(n)))
 	#define WV_ONE if (true)
+	#define WV_LANE_SCOPE ((void)0)
 #endif
 
 /* True on every lane if `flag` is true on any lane (flags are set inside WV_FOR bodies). */

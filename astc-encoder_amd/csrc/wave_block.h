@@ -471,6 +471,7 @@ WV_OUT void refine_pack_hdr(int partition_count, int candidate, int to_scratch, 
 __attribute__((always_inline)) WV_FN void refine_pack(bool dual, int partition_count, int partition_packed, int plane2_component,
                         int candidate, int quant_level, int quant_level_mod, int block_mode_packed)
 {
+	WV_LANE_SCOPE;
 	const Ctx c = ctx_make();
 	dual = wv_uniform(dual); partition_count = wv_uniform(partition_count); partition_packed = wv_uniform(partition_packed);
 	plane2_component = wv_uniform(plane2_component);
@@ -616,6 +617,7 @@ WV_OUT void refine_accept(float errorval)
 WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_packed,
                               int plane2_component, float tune_errorval_threshold)
 {
+	WV_LANE_SCOPE;
 	TrialInfo& tr = c.tr();
 	const bool dual = plane2_component >= 0;
 
@@ -697,7 +699,7 @@ WV_FN float refine_candidates(const Ctx& c, int partition_count, int partition_p
 #if defined(ASTC_DUPSTAGE)
 				// (realignment changes the weights: for the doubled run they are put back first)
 				uint32_t saved_weights = 0;
-				if (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN || (dual && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_2PLANES))
+				if (DUP_STAGE_ID(c) == (uint32_t)DUP_REALIGN || (dual && DUP_STAGE_ID(c) == (uint32_t)DUP_REALIGN_2PLANES))
 				{
 					WV_FOR(k, 16) { saved_weights = reinterpret_cast<const uint32_t*>(c.wscb().weights)[k]; }
 					(void)refine_realign(partition_count, partition_packed, cand_dm);

@@ -357,6 +357,23 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 	L.texel_count = r.texel_count;
 }
 
+/* FIXED-CONTEXT BUILDS (kernel_*_6x6m.hip, kernel_ldr_8x8t.hip).  A kernel build may be compiled for
+ * ONE named context -- footprint x preset x profile with the default channel weights and flags, i.e. exactly what a BASELINE
+ * config runs: ASTC_FIXED_CONTEXT names a record of fixed_contexts.inc, which holds that context's LdsLayout, DeviceConfig
+ * and TableRoot word for word (generated from the sequential build of this source by tools/gen_fixed_contexts.py,
+ * tests/test_fixed_contexts.py keeps it current).  In such a build the three records are compile-time constants: every LDS
+ * region offset is an immediate of its ds_read / ds_write, every table offset an immediate of its load, the texel count,
+ * the trip counts of the texel loops, the candidate / partition limits and the profile are literals, and a stage
+ * function's prologue shrinks to fetching the blob pointer.  The host side of the same translation unit compares the live
+ * context's three records with the constants byte for byte (ASTC_PREPARE_NAME) and the backend falls back to the generic
+ * build of the footprint class when anything differs. */
+#if defined(ASTC_FIXED_CONTEXT)
+#include "fixed_contexts.inc"      // (the record selected by the translation unit's ASTC_FIXED_<name>: kFixedLayout, kFixedConfig, kFixedRoot)
+#define ASTC_FIXED 1
+#else
+#define ASTC_FIXED 0
+#endif
+
 /* wv_uniform(v): `v` is the same on every lane (a value read from LDS or from a table looks lane-variant to the
  * compiler); returns it in a scalar register, so that control flow on it runs on the scalar unit and addresses built
  * on it use the scalar-base addressing mode. */
@@ -446,32 +463,47 @@ extern __shared__ __attribute__((aligned(16))) uint8_t astc_lds[];
  * through the constant address space: every read at a wave-uniform address then goes through the scalar cache instead
  * of the vector memory pipeline (shorter latency, no vector register).  The values live in scalar registers, though:
  * the two stages that run out of those (mode scoring, decimation) keep the global address space. */
+/* LDS address 0 as a pointer the optimiser can see through.  The kernels use dynamic LDS only, so it starts at LDS
+ * address 0 (tests/test_code_object.py checks that the static size stays 0).  Naming `astc_lds` in a function that is not a
+ * kernel costs a look-up of the caller's static LDS size in a table in memory (nine scalar instructions and a load per stage
+ * call), and a literal 0 cast to a pointer is the null pointer, which is -1 in this address space; 16 - 16 is neither: every
+ * `lds + offset` folds into the offset field of its ds_read / ds_write.  (Until round 5 this was an opaque zero in a scalar
+ * register, added to every LDS address formed.) */
+WV_FN uint8_t* lds_base()
+{
+	typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
+	return (uint8_t*)((lds_bytes)(uintptr_t)16 - 16);
+}
+
 template <bool SCALAR_TABLES>
 WV_FN Ctx ctx_make_as()
 {
-	// The kernels use dynamic LDS only, so it starts at LDS address 0 (tests/test_code_object.py checks that the static
-	// size stays 0).  Naming `astc_lds` in a function that is not a kernel costs a look-up of the caller's static LDS size
-	// in a table in memory (nine scalar instructions and a load per stage call); an integer the optimiser cannot see
-	// through (a literal 0 would fold to the null pointer, which is -1 in this address space) costs one.
-	typedef __attribute__((address_space(3))) uint8_t* lds_bytes;
-	uint32_t lds_zero = 0;
-	asm volatile("" : "+s"(lds_zero));
-	uint8_t* const lds = (uint8_t*)(lds_bytes)(uintptr_t)lds_zero;
+	uint8_t* const lds = lds_base();
 	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(lds);
 	Ctx c;
 	// A pointer rebuilt from integers would be a generic (flat) pointer to the compiler: go through
 	// explicit address-space pointers so that table reads stay s_load / global_load.
 	typedef const __attribute__((address_space(1))) uint8_t* global_bytes;
 	typedef const __attribute__((address_space(4))) uint8_t* constant_bytes;
-	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
 	const uintptr_t base = (uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->base));
 	const uint8_t* const b = SCALAR_TABLES ? (const uint8_t*)(constant_bytes)base : (const uint8_t*)(global_bytes)base;
 	c.tab = b + CTX_LAYOUT_BACK;
+#if defined(ASTC_PROFILE) || defined(ASTC_TRACE)
+	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
 	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
+#else
+	c.prof = nullptr;
+#endif
+	c.lds = lds;
+#if ASTC_FIXED
+	c.root = &kFixedRoot;
+	c.cfg = &kFixedConfig;
+	c.L = &kFixedLayout;
+#else
 	c.root = reinterpret_cast<const TableRoot*>(c.tab);
 	c.cfg = reinterpret_cast<const DeviceConfig*>(b + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
 	c.L = reinterpret_cast<const LdsLayout*>(b);
-	c.lds = lds;
+#endif
 	c.T = (int)c.L->texel_count;
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
@@ -480,6 +512,7 @@ WV_FN Ctx ctx_make_as()
 WV_FN Ctx ctx_make() { return ctx_make_as<true>(); }
 WV_FN Ctx ctx_make_vector_tables() { return ctx_make_as<false>(); }
 #else
+WV_FN uint8_t* lds_base() { return nullptr; }        // (host pass of a kernel translation unit: never executed)
 extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block
 WV_FN Ctx ctx_make() { return *g_wave_ctx; }
 WV_FN Ctx ctx_make_vector_tables() { return *g_wave_ctx; }
@@ -567,7 +600,9 @@ enum { DUP_IDEAL = 1, DUP_DECIMATE, DUP_ANGULAR, DUP_MODES, DUP_MODES_FORMATS, D
        DUP_REALIGN_2PLANES,          // the realignment of two-plane candidates only
        DUP_REALIGN_FIRST_PASS };     // the first evaluation of all weights inside every realignment (idempotent)
 #if defined(ASTC_DUPSTAGE)
-#define DUP_STAGE(c, id, call) do { call; if ((c).cfg->debug_dup_stage == (uint32_t)(id)) { call; } } while (0)
+/* (read from the live context's record: in a fixed-context build c.cfg is the constant record of the named context) */
+#define DUP_STAGE_ID(c) (reinterpret_cast<const DeviceConfig*>((c).tab - CTX_CONFIG_BACK)->debug_dup_stage)
+#define DUP_STAGE(c, id, call) do { call; if (DUP_STAGE_ID(c) == (uint32_t)(id)) { call; } } while (0)
 #else
 #define DUP_STAGE(c, id, call) do { call; } while (0)
 #endif

@@ -368,65 +368,51 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 	const int T = c.T, Tp = c.Tp;
 	const int n = uses_alpha ? 4 : 3;
 
-	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385).
-	// One pass over the texels feeds the accumulators of every (partition, channel); lanes past T read
-	// the zero padding of the texel rows, which adds +0.0 like the reference's masked tail lanes.
+	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385), one partition
+	// at a time -- sixteen accumulators live instead of forty-eight (round 5: the function fits a stage function's
+	// caller-saved registers); lanes past T read the zero padding of the texel rows, which adds +0.0 like the reference's
+	// masked tail lanes.  The last partition's average comes from what the others leave of the block's sums.
 	float avg[4][4];
 	{
-		float acc[3][4][4];
-		#pragma unroll
-		for (int p = 0; p < 3; p++)
-			#pragma unroll
-			for (int ch = 0; ch < 4; ch++)
-				#pragma unroll
-				for (int l = 0; l < 4; l++) acc[p][ch][l] = 0.0f;
-
-		const uint32_t* ot4 = reinterpret_cast<const uint32_t*>(pv.of_texel);
-		for (int i = 0; i < Tp; i += 4)
-		{
-			const uint32_t ot = ot4[i >> 2];
-			float member[3][4];
-			#pragma unroll
-			for (int p = 0; p < 3; p++)
-			{
-				if (p >= pc - 1) break;
-				member[p][0] = (int)(ot & 0xFF) == p ? 1.0f : 0.0f;
-				member[p][1] = (int)((ot >> 8) & 0xFF) == p ? 1.0f : 0.0f;
-				member[p][2] = (int)((ot >> 16) & 0xFF) == p ? 1.0f : 0.0f;
-				member[p][3] = (int)(ot >> 24) == p ? 1.0f : 0.0f;
-			}
-			#pragma unroll
-			for (int ch = 0; ch < 4; ch++)
-			{
-				if (ch >= n) break;
-				const float* d = c.data(ch) + i;
-				const float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
-				#pragma unroll
-				for (int p = 0; p < 3; p++)
-				{
-					if (p >= pc - 1) break;
-					// (`acc + (in partition p ? d : 0)` as acc + d * m with m = 1.0 / 0.0: d * 1 = d, d * 0 = +0 for the
-					//  non-negative texel data -- the same sum, in multiplies and adds (the fast issue class) instead of selects)
-					acc[p][ch][0] = acc[p][ch][0] + d0 * member[p][0];
-					acc[p][ch][1] = acc[p][ch][1] + d1 * member[p][1];
-					acc[p][ch][2] = acc[p][ch][2] + d2 * member[p][2];
-					acc[p][ch][3] = acc[p][ch][3] + d3 * member[p][3];
-				}
-			}
-		}
-
 		float rest[4];
 		#pragma unroll
 		for (int ch = 0; ch < 4; ch++) rest[ch] = blk.data_mean[ch] * (float)T;
+		const uint32_t* ot4 = reinterpret_cast<const uint32_t*>(pv.of_texel);
 		#pragma unroll
 		for (int p = 0; p < 3; p++)
 		{
 			if (p >= pc - 1) break;
+			float acc[4][4];
+			#pragma unroll
+			for (int ch = 0; ch < 4; ch++)
+				#pragma unroll
+				for (int l = 0; l < 4; l++) acc[ch][l] = 0.0f;
+			#pragma nounroll
+			for (int i = 0; i < Tp; i += 4)
+			{
+				const uint32_t ot = ot4[i >> 2];
+				// (`acc + (in partition p ? d : 0)` as acc + d * m with m = 1.0 / 0.0: d * 1 = d, d * 0 = +0 for the
+				//  non-negative texel data -- the same sum, in multiplies and adds (the fast issue class) instead of selects)
+				const float m0 = (int)(ot & 0xFF) == p ? 1.0f : 0.0f;
+				const float m1 = (int)((ot >> 8) & 0xFF) == p ? 1.0f : 0.0f;
+				const float m2 = (int)((ot >> 16) & 0xFF) == p ? 1.0f : 0.0f;
+				const float m3 = (int)(ot >> 24) == p ? 1.0f : 0.0f;
+				#pragma unroll
+				for (int ch = 0; ch < 4; ch++)
+				{
+					if (ch >= n) break;
+					const float* d = c.data(ch) + i;
+					acc[ch][0] = acc[ch][0] + d[0] * m0;
+					acc[ch][1] = acc[ch][1] + d[1] * m1;
+					acc[ch][2] = acc[ch][2] + d[2] * m2;
+					acc[ch][3] = acc[ch][3] + d[3] * m3;
+				}
+			}
 			#pragma unroll
 			for (int ch = 0; ch < 4; ch++)
 			{
 				if (ch >= n) break;
-				float total = hadd4(acc[p][ch][0], acc[p][ch][1], acc[p][ch][2], acc[p][ch][3]);
+				float total = hadd4(acc[ch][0], acc[ch][1], acc[ch][2], acc[ch][3]);
 				rest[ch] = rest[ch] - total;
 				avg[p][ch] = total / (float)pv.cnt(p);
 			}
@@ -443,9 +429,9 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 
 	float ua0 = 0.0f, ua1 = 0.0f, ua2 = 0.0f, ua3 = 0.0f;
 	float sa0 = 0.0f, sa1 = 0.0f, sa2 = 0.0f, sa3 = 0.0f;
-	float tail_uncor = 0.0f, tail_samec = 0.0f;   // accumulated after the texel loop (ref: :660-670)
-	float line_len[4];
-	f4 uncor_b[4], samec_b[4];
+	// what each partition adds after the texel sums (ref: :660-670): formed while the partition's directions are in
+	// registers, added in partition order below
+	float tail_uncor[4], tail_samec[4];
 
 	#pragma unroll
 	for (int p = 0; p < 4; p++)
@@ -486,8 +472,6 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 		f4 sb = normalize_safe4(average, n == 4 ? unit4() : unit3());
 		float dd = n == 4 ? dot_s(average, ub) : dot3_s(average, ub);
 		f4 amod = average - ub * (n == 4 ? splat4(dd) : mk4(dd, dd, dd, 0.0f));
-		uncor_b[p] = ub;
-		samec_b[p] = sb;
 
 		// squared distance to both lines; accumulators run on across partitions, lane = position
 		// within the partition mod 4 (ref: :778-831, :892-937)
@@ -537,31 +521,32 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 			if (i + 3 < cnt) one_texel(i + 3, ua3, sa3);
 		}
 		float linelen = hi - lo;
-		line_len[p] = f_max(linelen, 1e-7f);
+		linelen = f_max(linelen, 1e-7f);
+		{
+			const f4 error_weights = splat4((float)cnt * weight_imprecision_estim);
+			const f4 uncor_vector = ub * linelen;
+			const f4 samec_vector = sb * linelen;
+			if (n == 4)
+			{
+				tail_uncor[p] = dot_s(uncor_vector * uncor_vector, error_weights);
+				tail_samec[p] = dot_s(samec_vector * samec_vector, error_weights);
+			}
+			else
+			{
+				tail_uncor[p] = dot3_s(uncor_vector * uncor_vector, error_weights);
+				tail_samec[p] = dot3_s(samec_vector * samec_vector, error_weights);
+			}
+		}
 	}
 
 	float uncor_error = hadd4(ua0, ua1, ua2, ua3);
 	float samec_error = hadd4(sa0, sa1, sa2, sa3);
-	(void)tail_uncor; (void)tail_samec;
-
 	#pragma unroll
 	for (int p = 0; p < 4; p++)
 	{
 		if (p >= pc) break;
-		float tpp = (float)pv.cnt(p);
-		f4 error_weights = splat4(tpp * weight_imprecision_estim);
-		f4 uncor_vector = uncor_b[p] * line_len[p];
-		f4 samec_vector = samec_b[p] * line_len[p];
-		if (n == 4)
-		{
-			uncor_error += dot_s(uncor_vector * uncor_vector, error_weights);
-			samec_error += dot_s(samec_vector * samec_vector, error_weights);
-		}
-		else
-		{
-			uncor_error += dot3_s(uncor_vector * uncor_vector, error_weights);
-			samec_error += dot3_s(samec_vector * samec_vector, error_weights);
-		}
+		uncor_error += tail_uncor[p];
+		samec_error += tail_samec[p];
 	}
 	uncor_out = uncor_error;
 	samec_out = samec_error;
@@ -611,6 +596,7 @@ WV_FN int partition_search_order(const Ctx& c, int pc)
 /* Step 2: line-fit errors of the first partition_search_limit partitionings of the ordering. */
 WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_limit)
 {
+	WV_LANE_SCOPE;
 	PartScratch& ps = *reinterpret_cast<PartScratch*>(c.part());
 	const BlkInfo& blk = c.blk();
 	const int T = c.T;
@@ -640,8 +626,11 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 			staged[wv_opaque(k)] = table_at_byte<uint32_t>(part_base, (uint32_t)ps.ordering()[first + sl] * part_stride + (uint32_t)w * 4u);
 		}
 		WV_SYNC();
-		WV_FOR64(i, nn)
+		WV_FOR64(i_lane, nn)
 		{
+			// (opaque: the lane's record address and everything derived from it would otherwise be loop-invariant all the way
+			//  out to the search loop of compress_block, hoisted there and carried -- spilled -- across every trial)
+			const int i = wv_opaque(i_lane);
 			const uint8_t* rec = reinterpret_cast<const uint8_t*>(staged + i * rec_words);
 			PartView pv;
 			pv.h = reinterpret_cast<const PartitionHeader*>(rec);

@@ -642,6 +642,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
  * infilled weights wb[pp*Tp + texel], colour differences tdiff[(pp*Tp + texel)*4 ..], verdicts verdict[pp*32 + weight]. */
 WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantXfer& qat)
 {
+	WV_LANE_SCOPE;
 	Scb& scb = c.wscb();
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
@@ -706,7 +707,7 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 	int count = 2 * W;
 #if defined(ASTC_DUPSTAGE)
 	bool dup_done = false;
-	for (int rep = 0; rep < (c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS ? 2 : 1); rep++)
+	for (int rep = 0; rep < (DUP_STAGE_ID(c) == (uint32_t)DUP_REALIGN_FIRST_PASS ? 2 : 1); rep++)
 #endif
 	if (count > 16)
 	{
@@ -821,7 +822,7 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 			}
 			WV_SYNC();
 #if defined(ASTC_DUPSTAGE)
-			if (!dup_done && !adjustments && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
+			if (!dup_done && !adjustments && DUP_STAGE_ID(c) == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
 #endif
 		}
 
@@ -899,6 +900,7 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
  * uniform return: true if any weight moved. */
 WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, const QuantXfer& qat)
 {
+	WV_LANE_SCOPE;
 	Scb& scb = c.wscb();
 	TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
@@ -1193,7 +1195,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 					}
 					WV_SYNC(); }
 #if defined(ASTC_DUPSTAGE)
-					if (all && !dup_done && c.cfg->debug_dup_stage == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
+					if (all && !dup_done && DUP_STAGE_ID(c) == (uint32_t)DUP_REALIGN_FIRST_PASS) { dup_done = true; continue; }
 #endif
 					PROF_SCOPE(c, PS_Y7);
 					// the first weight (in index order) whose verdict is "move" moves; what it invalidates is evaluated again

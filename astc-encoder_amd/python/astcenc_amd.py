@@ -90,7 +90,7 @@ EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_ima
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
 EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
                "astcenc_amd_compare_images_device", "astcenc_amd_backend_name", "astcenc_amd_context_device_count",
-               "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device"]
+               "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device", "astcenc_amd_context_kernel_name"]
 OPT_PER_SLICE_FAST_LOAD = 1
 
 
@@ -180,6 +180,9 @@ class Library:
             L.astcenc_amd_context_device_count.restype = C.c_int
             L.astcenc_amd_context_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.astcenc_amd_context_set_option.restype = C.c_int
+        if hasattr(L, "astcenc_amd_context_kernel_name"):
+            L.astcenc_amd_context_kernel_name.argtypes = [C.c_void_p]
+            L.astcenc_amd_context_kernel_name.restype = C.c_char_p
         if hasattr(L, "astcenc_amd_compress_volume_device"):
             L.astcenc_amd_compress_volume_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int,
                                                              C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,

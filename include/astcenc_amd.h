@@ -124,6 +124,16 @@ ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
  * whatever the list says. */
 ASTCENC_PUBLIC int astcenc_amd_context_device_count(const struct astcenc_context* context);
 
+/* Name of the build of the compression kernel the context launches (what a rocprofv3 kernel trace shows, without the
+ * namespace).  The library holds generic builds -- "astc_compress_blocks_{ldr,hdr}64" for footprints of at most 64 texels,
+ * "astc_compress_blocks_{ldr,hdr}" for the larger ones -- and builds compiled for one context each, whose LDS layout,
+ * configuration and table root are compile-time constants: "astc_compress_blocks_ldr_6x6m" (6x6 -medium, LDR),
+ * "astc_compress_blocks_ldr_8x8t" (8x8 -thorough, LDR), "astc_compress_blocks_hdr_6x6m" (6x6 -medium, HDR).  A context gets
+ * such a build when its records equal the build's byte for byte (default flags and channel weights), the generic one
+ * otherwise; both produce the same bytes.  ASTCENC_AMD_KERNEL=generic in the environment keeps every context on the
+ * generic builds. */
+ASTCENC_PUBLIC const char* astcenc_amd_context_kernel_name(const struct astcenc_context* context);
+
 /* Behaviour switches that have no counterpart in the reference API. */
 enum astcenc_amd_option {
 	/* Multi-slice RGBA8 input (image.dim_z > 1) with a 2D footprint, LDR profile and identity swizzle: the

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace astcd {
@@ -47,6 +48,35 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		        L.total, L.data, L.blk, L.scb, L.trial, L.ei_w, L.ei_wes, L.ptab, L.candw, L.dwi, L.dwi, L.lowhigh, L.modes, L.uni, L.uni_bytes,
 		        L.dtab, L.ctab, L.qtab, L.rsc, L.tsc_r, L.wsc, L.part, L.tsc_p, L.part_tabs, L.part_chunk, r.max_decimation_table_bytes, r.realign_rt_floats, L.cstate, L.cstate_stride, L.bat_max[0], L.bat_max[1]);
 	}
+	if (const char* path = getenv("ASTC_EMU_DUMP_FIXED_CONTEXT"))
+	{
+		// tools/gen_fixed_contexts.py: the context's three records as the aggregate initializers of fixed_contexts.inc
+		// ("path:name"; appended).  LdsLayout is 32-bit words throughout, TableRoot four bytes and then words.
+		std::string spec(path);
+		const size_t colon = spec.rfind(':');
+		FILE* f = fopen(spec.substr(0, colon).c_str(), "a");
+		if (f)
+		{
+			const TableRoot& r = *reinterpret_cast<const TableRoot*>(blob);
+			fprintf(f, "#if defined(ASTC_FIXED_%s)\n", spec.substr(colon + 1).c_str());
+			static_assert(sizeof(LdsLayout) % 4 == 0 && sizeof(TableRoot) % 4 == 0, "records are word arrays");
+			fprintf(f, "constexpr LdsLayout kFixedLayout = {");
+			for (size_t i = 0; i < sizeof(LdsLayout) / 4; i++) fprintf(f, "%s%uu", i ? ", " : " ", reinterpret_cast<const uint32_t*>(&b->layout)[i]);
+			fprintf(f, " };\n");
+			static_assert(sizeof(DeviceConfig) == 92, "DeviceConfig changed: update this dump");
+			fprintf(f, "constexpr DeviceConfig kFixedConfig = { %d, %uu, { %af, %af, %af, %af }, %af, %uu, { %uu, %uu, %uu }, %uu, %uu, { %uu, %uu, %uu }, %af, %af, { %af, %af }, %af, %af, 0u };\n",
+			        cfg.profile, cfg.flags, cfg.cw[0], cfg.cw[1], cfg.cw[2], cfg.cw[3], cfg.rgbm_m_scale, cfg.tune_partition_count_limit,
+			        cfg.tune_partition_index_limit[0], cfg.tune_partition_index_limit[1], cfg.tune_partition_index_limit[2],
+			        cfg.tune_refinement_limit, cfg.tune_candidate_limit, cfg.tune_partitioning_candidate_limit[0],
+			        cfg.tune_partitioning_candidate_limit[1], cfg.tune_partitioning_candidate_limit[2], cfg.tune_db_limit, cfg.tune_mse_overshoot,
+			        cfg.tune_partition_early_out_limit_factor[0], cfg.tune_partition_early_out_limit_factor[1],
+			        cfg.tune_2plane_early_out_limit_correlation, cfg.tune_search_mode0_enable);
+			fprintf(f, "constexpr TableRoot kFixedRoot = { %u, %u, %u, %u", r.dim_x, r.dim_y, r.texel_count, r.dim_z);
+			for (size_t i = 1; i < sizeof(TableRoot) / 4; i++) fprintf(f, ", %uu", reinterpret_cast<const uint32_t*>(&r)[i]);
+			fprintf(f, " };\n#endif\n");
+			fclose(f);
+		}
+	}
 	*status = 0;
 	return b;
 }
@@ -54,6 +84,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 void backend_destroy(Backend* b) { delete b; }
 int backend_device_count(const Backend*) { return 1; }
 const char* backend_name() { return "emu:cpu"; }
+const char* backend_kernel_name(const Backend*) { return "emu"; }
 
 int backend_compress(Backend* b, const CompressJob& job)
 {

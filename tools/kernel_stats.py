@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "astc-encoder_amd")
 which = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "ldr"
 out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-math-errno -fno-slp-vectorize " \
+FLAGS = os.environ.get("KS_EXTRA", "") + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-math-errno -fno-slp-vectorize " \
         "-fvisibility=hidden -DASTCENC_DYNAMIC_LIBRARY=1 -Icsrc -Wno-unused-function --cuda-device-only -S"
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "k.s")
