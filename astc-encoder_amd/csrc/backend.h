@@ -120,6 +120,9 @@ const char* backend_kernel_name(const Backend* b);   // the build of the compres
  * (ALPHA_LDS_LIMIT) and otherwise in d_scratch: astc_alpha_scratch_bytes() says how much of it and for how many
  * workgroups the launch needs (0 / 0: the LDS kernel is used). */
 constexpr size_t ALPHA_LDS_LIMIT = 160u * 1024u;
+// tile edge of the pre-pass on a single slice (= ALPHA_TILE of wave_alpha.h, kernel_alpha.hip asserts it): the halo rows a
+// block-row shard takes along are counted in these tiles (backend_compress)
+constexpr uint32_t ALPHA_TILE_ROWS_2D = 32;
 struct AlphaLaunch {
 	const void* d_image;
 	float* d_averages;

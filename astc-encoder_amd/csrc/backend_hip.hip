@@ -14,11 +14,28 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
 namespace astcd {
+
+/* The host thread that drives a further device of a sharded call (the calling thread drives the first).  Created with
+ * the context's slot, parked on a condition variable between calls, joined when the context goes: a call on N devices
+ * wakes N - 1 threads instead of creating and joining them (round 5; a 4096^2 image is 26 ms of work per device, a
+ * std::thread launch + join some 50-100 us each).  Concurrent calls on one context take turns per worker (`mu`). */
+struct SlotWorker {
+	std::mutex mu;                    // one task at a time
+	std::mutex state_mu;
+	std::condition_variable wake, done_cv;
+	std::function<void()> task;
+	bool has_task = false, done = true, quit = false, bound = false;
+	std::thread thread;
+	bool started = false;
+};
 
 // Everything that lives on one GPU: the table blob, two streams, events and the staging buffers of the
 // host-pointer API.  A context owns one slot per device it may run on (see backend_create).
@@ -42,6 +59,7 @@ struct DeviceSlot {
 	double* d_sums;               // totals of the image comparison kernel
 	std::mutex busy;              // one call at a time per slot: the staging buffers and events are shared state
 	std::vector<int> local_cpus;  // host CPUs on the device's NUMA node (Linux sysfs); empty: unknown, no binding
+	SlotWorker* worker;           // the slot's parked host thread (slots 1.. of a multi-device context), or null
 };
 
 struct Backend {
@@ -121,9 +139,23 @@ int kernel_launch(const Backend* b, const KernelLaunch& k)
 	return kernel_variants[b->variant].launch(k);
 }
 
+void worker_stop(SlotWorker* w)
+{
+	if (!w) return;
+	if (w->started)
+	{
+		{ std::lock_guard<std::mutex> g(w->state_mu); w->quit = true; }
+		w->wake.notify_one();
+		w->thread.join();
+	}
+	delete w;
+}
+
 void slot_destroy(DeviceSlot* s)
 {
 	if (!s) return;
+	worker_stop(s->worker);
+	s->worker = nullptr;
 	(void)hipSetDevice(s->device);
 	if (s->d_image) (void)hipFree(s->d_image);
 	if (s->d_out) (void)hipFree(s->d_out);
@@ -187,6 +219,58 @@ static void bind_worker_to_device(const DeviceSlot* s)
 	if (n > 0) (void)sched_setaffinity(0, sizeof(want), &want);        // (best effort: a container may forbid it)
 }
 
+/* Hands `task` to the slot's parked thread (started on first use, bound to the device's CPUs once); false when no
+ * thread can be had -- std::system_error must not cross the C ABI -- and the caller runs the task itself.  The worker
+ * stays locked (w->mu) until worker_wait(). */
+static bool worker_run(DeviceSlot* s, std::function<void()> task)
+{
+	SlotWorker* w = s->worker;
+	if (!w) return false;
+	w->mu.lock();
+	if (!w->started)
+	{
+		try
+		{
+			w->thread = std::thread([w, s]()
+			{
+				bind_worker_to_device(s);
+				std::unique_lock<std::mutex> lk(w->state_mu);
+				for (;;)
+				{
+					w->wake.wait(lk, [w]() { return w->has_task || w->quit; });
+					if (w->quit) return;
+					std::function<void()> t = std::move(w->task);
+					w->has_task = false;
+					lk.unlock();
+					t();
+					lk.lock();
+					w->done = true;
+					w->done_cv.notify_all();
+				}
+			});
+			w->started = true;
+		}
+		catch (...) { w->mu.unlock(); return false; }
+	}
+	{
+		std::lock_guard<std::mutex> g(w->state_mu);
+		w->task = std::move(task);
+		w->has_task = true;
+		w->done = false;
+	}
+	w->wake.notify_one();
+	return true;
+}
+static void worker_wait(DeviceSlot* s)
+{
+	SlotWorker* w = s->worker;
+	{
+		std::unique_lock<std::mutex> lk(w->state_mu);
+		w->done_cv.wait(lk, [w]() { return w->done; });
+	}
+	w->mu.unlock();
+}
+
 /* One slot on `device`: uploads the tables, sets the kernels' dynamic-LDS attribute there, creates streams
  * and events.  Every failure leaves through slot_destroy (the record starts zeroed). status: 1 = out of
  * memory, 2 = anything else. */
@@ -202,6 +286,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	s->d_image = nullptr; s->image_cap = 0; s->d_out = nullptr; s->out_cap = 0; s->d_alpha = nullptr; s->alpha_cap = 0;
 	s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
 	s->d_prof = nullptr; s->trace_cap = 0; s->d_sums = nullptr;
+	s->worker = nullptr;
 #define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
 	SLOT_TRY(hipSetDevice(device), 2);
 	{
@@ -376,6 +461,8 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 			fprintf(stderr, "astcenc_amd: device %d not usable, continuing with %zu device(s)\n", device, b->slots.size());
 			continue;
 		}
+		// (every device but the first gets its parked host thread: the record here, the thread itself on first use)
+		if (!b->slots.empty()) s->worker = new (std::nothrow) SlotWorker();
 		b->slots.push_back(s);
 	}
 	*status = 0;
@@ -766,7 +853,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 			{
 				// tiles of the pre-pass start at multiples of ALPHA_TILE from the image origin; a tile's summed-area table
 				// takes in radius + 1 rows above its first row and radius rows below its last
-				const uint32_t tile = 32u, r = job.a_scale_radius;
+				const uint32_t tile = ALPHA_TILE_ROWS_2D, r = job.a_scale_radius;
 				const uint32_t tile_top = y0 / tile * tile, tile_bottom = (y1 + tile - 1) / tile * tile;
 				const uint32_t want_top = tile_top > r + 1 ? (tile_top - (r + 1)) / tile * tile : 0u;
 				const uint64_t want_bottom = (uint64_t)tile_bottom + r + 1;
@@ -792,16 +879,15 @@ int backend_compress(Backend* b, const CompressJob& job)
 	for (Shard& sh : shards) sh.job.host_slices = sh.slices.data();      // (after the vector stopped growing)
 	// one host thread per further shard; a shard whose thread cannot be created (std::system_error must not cross the
 	// C ABI, and the earlier workers must still be joined) runs on the calling thread after its own
-	std::vector<std::thread> workers;
-	std::vector<size_t> inline_shards;
+	std::vector<size_t> on_workers, inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
 	{
-		try { workers.emplace_back([&, g]() { bind_worker_to_device(b->slots[g]); shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); }); }
-		catch (...) { inline_shards.push_back(g); }
+		if (worker_run(b->slots[g], [&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); })) on_workers.push_back(g);
+		else inline_shards.push_back(g);
 	}
 	shards[0].rc = compress_on_slot(b, b->slots[0], shards[0].job, &progress);
 	for (size_t g : inline_shards) shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress);
-	for (std::thread& t : workers) t.join();
+	for (size_t g : on_workers) worker_wait(b->slots[g]);
 	int rc = 0;
 	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
 	return rc;
@@ -900,16 +986,15 @@ int backend_decompress(Backend* bk, const DecompressJob& job)
 		shards.push_back(std::move(sh));
 	}
 	for (Shard& sh : shards) sh.job.host_slices = sh.slices.data();
-	std::vector<std::thread> workers;
-	std::vector<size_t> inline_shards;
+	std::vector<size_t> on_workers, inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
 	{
-		try { workers.emplace_back([&, g]() { bind_worker_to_device(bk->slots[g]); shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); }); }
-		catch (...) { inline_shards.push_back(g); }
+		if (worker_run(bk->slots[g], [&, g]() { shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); })) on_workers.push_back(g);
+		else inline_shards.push_back(g);
 	}
 	shards[0].rc = decompress_on_slot(bk, bk->slots[0], shards[0].job);
 	for (size_t g : inline_shards) shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job);
-	for (std::thread& t : workers) t.join();
+	for (size_t g : on_workers) worker_wait(bk->slots[g]);
 	int rc = 0;
 	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
 	return rc;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 namespace astcd {
+static_assert(ALPHA_TILE == (int)ALPHA_TILE_ROWS_2D, "the backend's shard halo is counted in tiles of the pre-pass");
 
 /* The padded tile in LDS: one workgroup per tile. */
 __global__ void __launch_bounds__(64)

@@ -95,10 +95,6 @@ int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* 
 {
 	LdsLayout L;
 	make_lds_layout(root, cfg, L);
-#if defined(ASTC_DUPSTAGE)
-	// instrumentation builds only: extra LDS per block at run time, to find where the occupancy steps are
-	if (const char* pad = getenv("ASTC_LDS_PAD_RT")) L.total += (uint32_t)atoi(pad);
-#endif
 #if ASTC_FIXED
 	// This build is compiled for ONE context (wave_ctx.h): the live context must be that one, record for record.  (The
 	// instrumentation builds' stage selector is read from the live record, DUP_STAGE_ID.)

@@ -342,6 +342,13 @@ WV_FN void make_lds_layout(const TableRoot& r, const DeviceConfig& cfg, LdsLayou
 			const uint32_t need = batch_scratch_bytes(nb, cls ? 2u : 1u, cls ? 1u : pcl, Tp, L.cstate_stride);
 			if (begin + need > L.cstate) { L.cstate = (begin + need + 15u) & ~15u; if (L.cstate > L.total) L.total = L.cstate; }
 		}
+		// (a class processed later may have moved cstate up: the records of a class with more than one candidate per batch
+		//  -- (bat_max - 1) of them from cstate on -- must still end inside the allocation)
+		{
+			const uint32_t nbmax = L.bat_max[0] > L.bat_max[1] ? L.bat_max[0] : L.bat_max[1];
+			const uint32_t state_end = L.cstate + (nbmax - 1u) * L.cstate_stride;
+			if (state_end > L.total) L.total = (state_end + 15u) & ~15u;
+		}
 		const uint32_t P = pcl > 4u ? 4u : pcl;
 		for (uint32_t cls = 0; cls < 2; cls++)
 			for (uint32_t pc = 1; pc <= 4; pc++)

@@ -307,6 +307,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 			const int m = valid ? (int)mm[i] : 0;
 			const unsigned long long same = same_key_lanes(m, valid);
 			if (valid && lanes_below(same) == 0) bins[m] += (int)__popcll(same);      // (one lane per distinct key: no two lanes write one bin)
+			WV_SYNC();      // (the next chunk's lanes read the bins this chunk's rank-0 lanes wrote; a fence, no instruction)
 		}
 		WV_SYNC();
 		// exclusive prefix over the bins (integer adds: any order is exact)
@@ -332,6 +333,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 			if (valid) ord[start + rank] = (uint16_t)i;
 			// (the wave's LDS operations complete in order: every lane has its `start` before the bin moves on)
 			if (valid && rank == 0) bins[m] = start + (int)__popcll(same);
+			WV_SYNC();
 		}
 		(void)texels_to_process;
 	}

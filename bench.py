@@ -202,12 +202,22 @@ def cpu_reference_baseline(cfg, img, gpu_blocks, budget_s=30.0):
         mismatch += int((want != out_g.reshape(-1, 16)).any(axis=1).sum())
         if gathers["1"] > best_rate:
             best_rate, used_gathers = gathers["1"], 1
+    # ... and through the link-time optimised build (the reference's release setting for its command line tool,
+    # Source/cmake_core.cmake:258-262)
+    lto = None
+    if os.path.exists(O.LIB_REF_AVX2_LTO):
+        dt, out_l = reference_threads(A.Library(O.LIB_REF_AVX2_LTO), cfg, crop, best_threads, 3)
+        lto = round(side * side / dt / 1e6, 3)
+        mismatch += int((want != out_l.reshape(-1, 16)).any(axis=1).sum())
+        if lto > best_rate:
+            best_rate, used_gathers = lto, 0
     quota = host.get("cgroup_cpu_max", "").split()
     cpus_allowed = min(cores, float(quota[0]) / float(quota[1])) if len(quota) == 2 and quota[0] != "max" else float(cores)
     return {"value": round(best_rate, 3), "unit": "Mtexels/s", "cores": best_threads, "kind": "reference",
             "sample": "astcenc-avx2 (oracle/_ref), %dx%d top-left crop of the bench image, best of 3 per thread count with "
                       "astcenc_compress_reset in between; 1-thread figure on a %dx%d crop" % (side, side, small.shape[1], small.shape[0]),
-            "x86_gathers_mtexels_s": gathers, "x86_gathers_used": used_gathers,
+            "x86_gathers_mtexels_s": gathers, "x86_gathers_used": used_gathers, "lto_build_mtexels_s": lto,
+            "build": "g++ -O3 -mavx2 shared library from /root/reference/Source (oracle/Makefile); fastest of {no gathers, hardware gathers, -flto}",
             "cpus_allowed": round(cpus_allowed, 2), "mtexels_per_core_second": round(best_rate / max(min(cpus_allowed, best_threads), 1e-9), 4),
             "threads_at_best": best_threads, "value_1thread": round(rate1, 4), "per_thread_at_best": round(best_rate / best_threads, 4),
             "thread_sweep_mtexels_s": sweep, "cpu_model": host.get("cpu_model"), "nproc": host["nproc"], "affinity": host["affinity"],
@@ -445,12 +455,18 @@ def time_device_resident(lib, ctx, cfg, d_img, d_out, dev, steps, warmup, barrie
     return time.perf_counter() - t0, kms
 
 
-def roofline_of(cfg, kernel_s, hdr_kernel, name):
+def kernel_name_of(lib, ctx):
+    """The build of the compression kernel the context launches (include/astcenc_amd.h: a fixed-context build for the BASELINE
+    contexts, a generic one otherwise)."""
+    return "astcd::" + lib.lib.astcenc_amd_context_kernel_name(ctx).decode()
+
+
+def roofline_of(cfg, kernel_s, kernel_name, name):
     algo = algorithmic_bytes(cfg)
     achieved = algo / kernel_s / 1e9
     roof = {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
-            "kernel": "astcd::astc_compress_blocks_%s%s" % ("hdr" if hdr_kernel else "ldr", "64" if cfg["block"][0] * cfg["block"][1] <= 64 else ""), "kernel_ms": round(kernel_s * 1e3, 3),
+            "kernel": kernel_name, "kernel_ms": round(kernel_s * 1e3, 3),
             "algorithmic_bytes_per_launch": algo}
     counters, src = measured_counters(name)
     if counters:
@@ -494,7 +510,7 @@ def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
     res = {"config": name, "baseline_config_index": cfg["index"], "workload": cfg["label"],
            "value": round(texels * steps / elapsed / 1e6, 3), "unit": "Mtexels/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "blocks_per_image": nbx * nby,
-           "roofline": roofline_of(cfg, kernel_s, cfg["hdr"], name),
+           "roofline": roofline_of(cfg, kernel_s, kernel_name_of(lib, ctx), name),
            "parity_vs_reference": parity_whole_or_crops(cfg, img, gpu_blocks, budget_s),
            "quality": device_quality(lib, ctx, cfg, d_img, d_out, dev)}
     lib.context_free(ctx)
@@ -589,13 +605,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # (the group is done with: what rank 0 adds to its line below -- quality figures, the CPU baseline -- happens after
+        #  the timed region and after the other ranks have left, so it neither perturbs their timing nor keeps a collective open)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
     if rank == 0:
         texels = cfg["size"] * cfg["size"]
         value = world * texels * args.steps / elapsed / 1e6
         kernel_s = sum(kms) / len(kms) / 1e3
         gpu_blocks = d_out.cpu().numpy()
-        roof = roofline_of(cfg, kernel_s, cfg["hdr"], args.config)
+        roof = roofline_of(cfg, kernel_s, kernel_name_of(lib, ctx), args.config)
         out = {
             "metric": "Mtexels/s + PSNR-dB, 8192x8192 RGBA8 LDR 6x6 -medium" if args.config == "c2" else "Mtexels/s, " + cfg["label"],
             "value": round(value, 3), "unit": "Mtexels/s",
@@ -615,16 +635,20 @@ def main():
             out["value_host_api"] = {"value": round(rate, 3), "unit": "Mtexels/s", "devices": ndev,
                                      "what": "astcenc_compress_image, pageable host buffers, H2D + kernels + D2H, best of 2",
                                      "identical_to_device_path": bool(np.array_equal(host_blocks, gpu_blocks))}
-        if world == 1 and not args.no_quality:
+        if not args.no_quality:
             q = decoded_psnr(cfg, img_host, gpu_blocks) or {}
             q.update(device_quality(lib, ctx, cfg, d_img, d_out, dev))
             out["quality"] = q
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (N > 1: timed on rank 0 once the other ranks are done, i.e. on the same idle host as at N = 1; the ratio below
+            #  stays "one GPU's share against the host": the whole job's value / N)
             base = cpu_reference_baseline(cfg, img_host, gpu_blocks)
             if base:
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = round(value / base["value"], 2)
-                if args.config == "c2" and not args.no_parity_full:
+                if world > 1:
+                    out["speedup_vs_cpu_baseline_per_gpu"] = round(value / world / base["value"], 2)
+                if world == 1 and args.config == "c2" and not args.no_parity_full:
                     out["parity_full"] = parity_full(cfg, img_host, gpu_blocks, base["threads_at_best"], base["x86_gathers_used"])
         if world == 1 and not args.no_extra and args.config == "c2":
             del d_img, d_out
@@ -637,8 +661,6 @@ def main():
         print(json.dumps(out), flush=True)
 
     lib.context_free(ctx)
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 def single_process(lib, cfg, args):

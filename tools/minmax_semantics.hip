@@ -39,5 +39,19 @@ int main()
 		bad_min += m1; bad_max += m2; if (i % 7 == 0) bad_med += m3;
 	}
 	printf("differences from the compare-select forms: v_min %d, v_max %d, v_med3 clamp %d (of %d / %d / 7 cases)\n", bad_min, bad_max, bad_med, n, n);
-	return 0;
+	// What wave.h relies on (tests/test_hw_semantics.py runs this on the GPU box and checks the exit status):
+	//   f_clamp / v_clamp: v_med3_f32(x, 0, 1) has the bits of the compare-select clamp for EVERY x, NaN and -0 included;
+	//   f_run_min / f_run_max: with a running value y that is a number, and no -0 on either side, v_min_f32 / v_max_f32
+	//   have the bits of `x < y ? x : y` / `x > y ? x : y` -- for a NaN x that is y.
+	int contract = bad_med;
+	for (int i = 0; i < n; i++)
+	{
+		const float x = ha[i], y = hb[i];
+		if (y != y || bits(x) == 0x80000000u || bits(y) == 0x80000000u) continue;
+		const float sel_min = x < y ? x : y, sel_max = x > y ? x : y;
+		contract += bits(ho[3 * i]) != bits(sel_min);
+		contract += bits(ho[3 * i + 1]) != bits(sel_max);
+	}
+	printf("violations of the contract wave.h relies on: %d\n", contract);
+	return contract == 0 ? 0 : 1;
 }
