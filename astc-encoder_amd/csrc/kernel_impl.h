@@ -52,6 +52,7 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	tab = base + CTX_LAYOUT_BACK;
 	Ctx c;
 	c.tab = tab;
+	c.tab_constant = true;
 	c.lds = lds;
 #if ASTC_FIXED
 	// (a fixed-context build: the three records are constants of this translation unit, wave_ctx.h)

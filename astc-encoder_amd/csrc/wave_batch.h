@@ -128,7 +128,7 @@ WV_FN void batch_prepare_body(const Ctx& c, const BatchView& bv, const PartView&
 	}
 	// the texel rows every candidate's sums read, in visiting order: partition by partition for a one-plane trial
 	// (ref: recompute_ideal_colors_1plane :1241), texel order for a two-plane one (:1474)
-	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	const float ls_weight = hadd_rgb_s(cw4_of(blk));
 	WV_FOR_T(i, T)
 	{
 		const int t = dual ? i : (int)pv.sorted[i];
@@ -304,7 +304,7 @@ WV_FN void batch_solve_body(const Ctx& c, const BatchView& bv, const PartView& p
 {
 	const TrialInfo& tr = c.tr();
 	const BlkInfo& blk = c.blk();
-	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	const float ls_weight = hadd_rgb_s(cw4_of(blk));
 	const int pc4 = partition_count * 4;
 	// (the endpoints a candidate starts from are the trial's ideal ones, merged across the planes: ref :497-540)
 	WV_FOR(k, count * pc4)
@@ -589,11 +589,11 @@ WV_FN void batch_score_terms_body(const Ctx& c, const BatchView& bv, bool dual, 
 		float term;
 		if (fast_1p)
 		{
-			term = err[0] * blk.cw[0] + err[1] * blk.cw[1] + err[2] * blk.cw[2] + err[3] * blk.cw[3];
+			term = err[0] * cw_of(blk, 0) + err[1] * cw_of(blk, 1) + err[2] * cw_of(blk, 2) + err[3] * cw_of(blk, 3);
 		}
 		else
 		{
-			const float d = hadd4(err[0] * blk.cw[0], err[1] * blk.cw[1], err[2] * blk.cw[2], err[3] * blk.cw[3]);
+			const float d = hadd4(err[0] * cw_of(blk, 0), err[1] * cw_of(blk, 1), err[2] * cw_of(blk, 2), err[3] * cw_of(blk, 3));
 			term = d < ERROR_CALC_DEFAULT ? d : ERROR_CALC_DEFAULT;
 		}
 		bv.term(ci)[i] = term;

@@ -1006,7 +1006,7 @@ WV_FN float prepare_block_statistics(const Ctx& c)
 		float acc = 0.0f;
 		for (int i = 0; i < T; i++)
 		{
-			float weight = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) / 4.0f;
+			float weight = hadd4(cw_of(blk, 0), cw_of(blk, 1), cw_of(blk, 2), cw_of(blk, 3)) / 4.0f;
 			if (k == 0) acc += weight;
 			else
 			{
@@ -1119,7 +1119,7 @@ __attribute__((always_inline)) WV_FN void search_block(const Ctx& c)
 	bool block_is_la = blk_is_luminancealpha(blk);
 	float block_is_la_scale = block_is_la ? 1.0f / 1.05f : 1.0f;
 
-	float error_weight_sum = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) * (float)T;
+	float error_weight_sum = hadd4(cw_of(blk, 0), cw_of(blk, 1), cw_of(blk, 2), cw_of(blk, 3)) * (float)T;
 	// (driver state of the whole block: wave-uniform, kept in scalar registers -- values derived from LDS or table
 	//  loads look lane-variant to the compiler and would be carried, and spilled, as vector registers)
 	const float error_threshold = wv_uniform(cfg.tune_db_limit * error_weight_sum * block_is_l_scale * block_is_la_scale);

@@ -412,6 +412,7 @@ WV_FN uint64_t wv_uniform(uint64_t v) { return v; }
 /* Uniform per-wave context. */
 struct Ctx {
 	const uint8_t* tab;          // table blob (HBM, read-only)
+	bool tab_constant;           // read through the constant address space (scalar cache) rather than the global one
 	const TableRoot* root;
 	const DeviceConfig* cfg;
 	uint8_t* lds;
@@ -423,7 +424,27 @@ struct Ctx {
 
 	// a table of the blob at byte offset `off` (an offset read from the blob): scalar base pointer, so that lane-variant
 	// indexing costs one 32-bit offset per access instead of 64-bit pointer arithmetic
-	WV_FN const uint8_t* table(uint32_t off) const { return tab + wv_uniform(off); }
+	WV_FN const uint8_t* table(uint32_t off) const
+	{
+#if ASTC_FIXED && WV_DEVICE
+		// `off` is a literal here (a field of the constant TableRoot).  Left to itself the compiler adds it to every lane's
+		// address -- scalar base + 32-bit lane offset + a constant too large for the load's immediate field becomes a 64-bit
+		// vector addition per access (v_lshl_add_u64, v_add_co_u32, v_addc_co_u32: four instructions where the generic
+		// build has one).  Formed once on the scalar unit and handed on as an opaque scalar pair, the table's base is a
+		// scalar register pair again and the load keeps the scalar-base + vector-offset form.
+		typedef const __attribute__((address_space(1))) uint8_t* global_bytes;
+		typedef const __attribute__((address_space(4))) uint8_t* constant_bytes;
+		if (__builtin_constant_p(off))
+		{
+			uintptr_t p = (uintptr_t)wv_uniform((uint64_t)(reinterpret_cast<uintptr_t>(tab) + off));
+			asm("" : "+s"(p));
+			return tab_constant ? (const uint8_t*)(constant_bytes)p : (const uint8_t*)(global_bytes)p;
+		}
+		return tab + wv_uniform(off);
+#else
+		return tab + wv_uniform(off);
+#endif
+	}
 	// typed views
 	WV_FN float* data(int c) const { return reinterpret_cast<float*>(lds + L->data) + c * Tp; }
 	WV_FN BlkInfo& blk() const { return *reinterpret_cast<BlkInfo*>(lds + L->blk); }
@@ -495,6 +516,7 @@ WV_FN Ctx ctx_make_as()
 	const uintptr_t base = (uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->base));
 	const uint8_t* const b = SCALAR_TABLES ? (const uint8_t*)(constant_bytes)base : (const uint8_t*)(global_bytes)base;
 	c.tab = b + CTX_LAYOUT_BACK;
+	c.tab_constant = SCALAR_TABLES;
 #if defined(ASTC_PROFILE) || defined(ASTC_TRACE)
 	typedef __attribute__((address_space(1))) unsigned long long* global_u64;
 	c.prof = (unsigned long long*)(global_u64)(uintptr_t)wv_uniform((uint64_t)reinterpret_cast<uintptr_t>(h->prof));
@@ -524,6 +546,25 @@ extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation back
 WV_FN Ctx ctx_make() { return *g_wave_ctx; }
 WV_FN Ctx ctx_make_vector_tables() { return *g_wave_ctx; }
 #endif
+
+/* The block's channel weights (BlkInfo::cw; ref: image_block::channel_weight).  They are the context's weights unless
+ * ASTCENC_FLG_USE_ALPHA_WEIGHT scales them by the block's alpha (load_block) -- so in a fixed-context build whose context has
+ * the flag clear they are literals (1, 1, 1, 1 for the BASELINE contexts: every `x * cw` then IS x, the multiplication by one
+ * is exact and the compiler drops it), and everything else reads the block's record. */
+WV_FN float cw_of(const BlkInfo& blk, int k)
+{
+#if ASTC_FIXED
+	if ((kFixedConfig.flags & (1u << 2)) == 0) return k == 0 ? kFixedConfig.cw[0] : k == 1 ? kFixedConfig.cw[1] : k == 2 ? kFixedConfig.cw[2] : kFixedConfig.cw[3];
+#endif
+	return blk.cw[k];
+}
+WV_FN f4 cw4_of(const BlkInfo& blk)
+{
+#if ASTC_FIXED
+	if ((kFixedConfig.flags & (1u << 2)) == 0) return mk4(kFixedConfig.cw[0], kFixedConfig.cw[1], kFixedConfig.cw[2], kFixedConfig.cw[3]);
+#endif
+	return load4(blk.cw);
+}
 
 /* Lowest index i in [0, n), n <= 64, for which pred(i) holds, or -1; the same value on every lane. */
 template <typename Pred>

@@ -144,7 +144,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 
 		// per-texel error terms in partition order (ref: :124-201)
 		const float default_a = blk_default_alpha(blk);
-		const float ew0 = blk.cw[0], ew1 = blk.cw[1], ew2 = blk.cw[2];
+		const float ew0 = cw_of(blk, 0), ew1 = cw_of(blk, 1), ew2 = cw_of(blk, 2);
 		WV_FOR_T(i, T)
 		{
 			int t = pv.sorted[i];
@@ -200,7 +200,7 @@ WV_FN void compute_encoding_choice_errors(const Ctx& c, const PartView& pv, cons
 		}
 		else
 		{
-			float a_drop = s[0] * blk.cw[3];
+			float a_drop = s[0] * cw_of(blk, 3);
 			float uncor = s[1], samec = s[2], rgbl = s[3], lum = s[4];
 			e_scale = (samec - uncor) * 0.7f;
 			e_luma = (rgbl - uncor) * 1.5f;
@@ -261,7 +261,7 @@ WV_FN void color_error_for_quant_level(const Ctx& c, const PartView& pv, int p, 
 	uint8_t* fmt = fs.format_of_choice(p, i);
 
 	f4 ep0 = load4(ep0p), ep1 = load4(ep1p);
-	f4 ew = load4(blk.cw);
+	f4 ew = cw4_of(blk);
 
 	float ep1_min = hmin4(ep1.x, ep1.y, ep1.z, ep1.x);
 	ep1_min = f_max(ep1_min, 0.0f);

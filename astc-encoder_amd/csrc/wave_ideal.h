@@ -145,7 +145,7 @@ WV_FN void ideal_colors_and_weights_1comp(const Ctx& c, const PartView& pv, int 
 	const float* d = c.data(component);
 	float* w = c.ei_w(plane);
 	float* wes = c.ei_wes(plane);
-	float error_weight = blk.cw[component];
+	float error_weight = cw_of(blk, component);
 
 	// (one partition -- the only case on the search path, the second plane of a two-plane trial -- : the channel's range
 	//  over the block by a wave reduction; minimum / maximum of finite values are exact whatever the order)
@@ -343,12 +343,12 @@ WV_FN void ideal_colors_and_weights_1plane(const Ctx& c, const PartView& pv)
 	if (uses_alpha)
 	{
 		cs.ncomp = 4; cs.set(0, 1, 2, 3);
-		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], blk.cw[3]) / 4.0f;
+		ew = hadd4(cw_of(blk, 0), cw_of(blk, 1), cw_of(blk, 2), cw_of(blk, 3)) / 4.0f;
 	}
 	else
 	{
 		cs.ncomp = 3; cs.set(0, 1, 2, 0);
-		ew = hadd4(blk.cw[0], blk.cw[1], blk.cw[2], 0.0f) * (1.0f / 3.0f);
+		ew = hadd4(cw_of(blk, 0), cw_of(blk, 1), cw_of(blk, 2), 0.0f) * (1.0f / 3.0f);
 	}
 	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
 }
@@ -371,10 +371,10 @@ WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, in
 		float a, b, d;
 		switch (plane2_component)
 		{
-		case 0: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[2]; break;
-		case 1: a = blk.cw[0]; b = blk.cw[2]; d = blk.cw[3]; break;
-		case 2: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[3]; break;
-		default: a = blk.cw[0]; b = blk.cw[1]; d = blk.cw[2]; break;
+		case 0: a = cw_of(blk, 0); b = cw_of(blk, 1); d = cw_of(blk, 2); break;
+		case 1: a = cw_of(blk, 0); b = cw_of(blk, 2); d = cw_of(blk, 3); break;
+		case 2: a = cw_of(blk, 0); b = cw_of(blk, 1); d = cw_of(blk, 3); break;
+		default: a = cw_of(blk, 0); b = cw_of(blk, 1); d = cw_of(blk, 2); break;
 		}
 		ew = hadd4(a, b, d, 0.0f) * (1.0f / 3.0f);
 	}
@@ -384,7 +384,7 @@ WV_FN void ideal_colors_and_weights_2planes(const Ctx& c, const PartView& pv, in
 		// the two colour channels other than plane2_component (0..2), ascending
 		const int c0 = plane2_component == 0 ? 1 : 0, c1 = plane2_component <= 1 ? 2 : 1;
 		cs.set(c0, c1, 0, 0);
-		ew = hadd4(blk.cw[c0], blk.cw[c1], 0.0f, 0.0f) / 2.0f;
+		ew = hadd4(cw_of(blk, c0), cw_of(blk, c1), 0.0f, 0.0f) / 2.0f;
 	}
 	ideal_colors_and_weights_ncomp(c, pv, 0, cs, ew);
 	ideal_colors_and_weights_1comp(c, pv, 1, plane2_component);

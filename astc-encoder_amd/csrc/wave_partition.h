@@ -76,7 +76,7 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
 	const int T = c.T;
 	float* dist = c.tsc_p(0);
 	float* assign = c.tsc_p(1);          // partition of texel, as float
-	const f4 cw = load4(blk.cw);
+	const f4 cw = cw4_of(blk);
 	float* centers = &tr.fbox[0];      // [4][4]
 
 	// ---- kmeans_init (ref: :60-135): sequential prefix scans, run by all lanes uniformly ----
@@ -491,10 +491,10 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 				float d1 = (amod.y - g) + (uncor_param * ub.y);
 				float d2 = (amod.z - b) + (uncor_param * ub.z);
 				float d3 = (amod.w - a) + (uncor_param * ub.w);
-				ue = (blk.cw[0] * d0 * d0) + (blk.cw[1] * d1 * d1) + (blk.cw[2] * d2 * d2) + (blk.cw[3] * d3 * d3);
+				ue = (cw_of(blk, 0) * d0 * d0) + (cw_of(blk, 1) * d1 * d1) + (cw_of(blk, 2) * d2 * d2) + (cw_of(blk, 3) * d3 * d3);
 				float sp = (r * sb.x) + (g * sb.y) + (b * sb.z) + (a * sb.w);
 				float s0 = sp * sb.x - r, s1 = sp * sb.y - g, s2 = sp * sb.z - b, s3 = sp * sb.w - a;
-				se = (blk.cw[0] * s0 * s0) + (blk.cw[1] * s1 * s1) + (blk.cw[2] * s2 * s2) + (blk.cw[3] * s3 * s3);
+				se = (cw_of(blk, 0) * s0 * s0) + (cw_of(blk, 1) * s1 * s1) + (cw_of(blk, 2) * s2 * s2) + (cw_of(blk, 3) * s3 * s3);
 			}
 			else
 			{
@@ -502,10 +502,10 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool use
 				float d0 = (amod.x - r) + (uncor_param * ub.x);
 				float d1 = (amod.y - g) + (uncor_param * ub.y);
 				float d2 = (amod.z - b) + (uncor_param * ub.z);
-				ue = (blk.cw[0] * d0 * d0) + (blk.cw[1] * d1 * d1) + (blk.cw[2] * d2 * d2);
+				ue = (cw_of(blk, 0) * d0 * d0) + (cw_of(blk, 1) * d1 * d1) + (cw_of(blk, 2) * d2 * d2);
 				float sp = (r * sb.x) + (g * sb.y) + (b * sb.z);
 				float s0 = sp * sb.x - r, s1 = sp * sb.y - g, s2 = sp * sb.z - b;
-				se = (blk.cw[0] * s0 * s0) + (blk.cw[1] * s1 * s1) + (blk.cw[2] * s2 * s2);
+				se = (cw_of(blk, 0) * s0 * s0) + (cw_of(blk, 1) * s1 * s1) + (cw_of(blk, 2) * s2 * s2);
 			}
 			// (the hardware minimum / maximum: they differ from the reference's compare-selects in the sign of a zero only
 			//  -- the data are numbers -- and hi - lo goes through max(., 1e-7) below, which is blind to that)

@@ -16,6 +16,7 @@
 // broadcast with q_get, i.e. it is the same on the four lanes.
 #pragma once
 #include "wave.h"
+#include "wave_ctx.h"
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
@@ -199,5 +200,8 @@ WV_FN bool q_any_rgb_outside(qi a, int lo, int hi) { return q_any_rgb(q_test(a, 
 /* component 3 replaced by that of `w` / by a constant */
 WV_FN qi q_with_w(qi a, qi w) { return q_zipi_ch(a, w, [](int ch, int x, int y) { return ch == 3 ? y : x; }); }
 WV_FN qi q_with_w(qi a, int w) { return q_mapi_ch(a, [w](int ch, int x) { return ch == 3 ? w : x; }); }
+
+/* the block's channel weights as a quad vector (cw4_of, wave_ctx.h: literals in a fixed-context build) */
+WV_FN qf q_cw_of(const BlkInfo& blk) { const f4 w = cw4_of(blk); return q_make(w.x, w.y, w.z, w.w); }
 
 } } // namespace astcd::ASTC_VARIANT

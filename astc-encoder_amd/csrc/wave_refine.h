@@ -99,7 +99,7 @@ WV_FN void refit_solve_1plane(const float* s, const BlkInfo& blk, float scale_di
 {
 	const float wmin1 = s[0], wmax1 = s[1], scale_min = s[2], scale_max = s[3];
 	const float left_sum_s = s[4], middle_sum_s = s[5], right_sum_s = s[6];
-	const float color_weight = blk.cw[ch];
+	const float color_weight = cw_of(blk, ch);
 	const float cwn = color_weight * (float)texels;
 	const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
 
@@ -151,7 +151,7 @@ WV_FN void refit_solve_1plane(const float* s, const BlkInfo& blk, float scale_di
 WV_FN f4 refit_rgbo_1plane(const float* s, const BlkInfo& blk, int texels, f4 v0, f4 v1)
 {
 	const float right_sum_s = s[6], weight_weight_sum_s = s[7];
-	f4 color_weight = load4(blk.cw);
+	f4 color_weight = cw4_of(blk);
 	f4 rgba_weight_sum = v4_max(color_weight * (float)texels, splat4(1e-17f));
 	f4 color_vec_x = load4(&s[8]) * color_weight, color_vec_y = load4(&s[12]) * color_weight;
 	f4 weight_weight_sum = splat4(weight_weight_sum_s) * color_weight;
@@ -179,7 +179,7 @@ WV_FN void refit_solve_2planes(const float* s, const BlkInfo& blk, float scale_d
 	const bool second = ch == plane2_component;
 	const float wmin1 = s[0], wmax1 = s[1], scale_min = s[4], scale_max = s[5];
 	const float wmin = second ? s[2] : wmin1, wmax = second ? s[3] : wmax1;
-	const float color_weight = blk.cw[ch];
+	const float color_weight = cw_of(blk, ch);
 	const float cwn = color_weight * (float)T;
 	const float rgba_weight_sum = cwn > 1e-17f ? cwn : 1e-17f;
 	const float left_sum = (second ? s[9] : s[6]) * color_weight;
@@ -231,7 +231,7 @@ WV_FN void refit_solve_2planes(const float* s, const BlkInfo& blk, float scale_d
 /* ... and its HDR RGB + offset vector (ref: :1614-1640). */
 WV_FN f4 refit_rgbo_2planes(const float* s, const BlkInfo& blk, int T, int plane2_component, f4 v0, f4 v1)
 {
-	const f4 color_weight = load4(blk.cw);
+	const f4 color_weight = cw4_of(blk);
 	const f4 rgba_weight_sum = v4_max(color_weight * (float)T, splat4(1e-17f));
 	const f4 right1_sum = splat4(s[8]) * color_weight, right2_sum = splat4(s[11]) * color_weight;
 	const f4 color_vec_x = load4(&s[12]) * color_weight;
@@ -288,8 +288,8 @@ WV_FN void trial_scale_directions(const Ctx& c, const PartView& pv, bool dual)
 	WV_SYNC();
 	WV_FOR64(p, pc)
 	{
-		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * load4(blk.cw);
-		f4 rgba_weight_sum = v4_max(load4(blk.cw) * (float)pv.cnt(p), splat4(1e-17f));
+		f4 rgba_sum = load4(&tr.fbox[96 + p * 4]) * cw4_of(blk);
+		f4 rgba_weight_sum = v4_max(cw4_of(blk) * (float)pv.cnt(p), splat4(1e-17f));
 		f4 scale_dir = normalize4(xyz0(rgba_sum / rgba_weight_sum));
 		store4(tr.pm_dir[p], scale_dir);
 	}
@@ -310,7 +310,7 @@ WV_FN void recompute_ideal_colors_1plane(const Ctx& c, const PartView& pv, const
 	// pass 2 (ref: :1241-1269): the reference accumulates 15 running sums per partition in partition-texel order.
 	// Per-texel terms are produced lane-parallel (row r, position i in the partition-sorted order), then each chain
 	// is summed sequentially -- additions only -- by its own lane.
-	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	const float ls_weight = hadd_rgb_s(cw4_of(blk));
 	// Running minima / maxima of the weights and of the scale projection (ref: :1230-1235, :1247-1253).  With a single
 	// partition they are wave-wide reductions of per-lane partials (exact: the values are finite); with several
 	// partitions the chain lanes of rows 0 and 1 pick them up below.
@@ -424,7 +424,7 @@ WV_FN void recompute_ideal_colors_2planes(const Ctx& c, const DecView& di, int p
 	expand_weights(c, di, c.wscb().weights, c.wsc(0), undec1);
 	expand_weights(c, di, c.wscb().weights + PLANE2_OFFSET, c.wsc(1), undec2);
 
-	const float ls_weight = hadd_rgb_s(load4(blk.cw));
+	const float ls_weight = hadd_rgb_s(cw4_of(blk));
 	const f4 scale_dir = load4(tr.pm_dir[0]);              // trial_scale_directions()
 
 	// running minima / maxima (ref: :1455-1462): per-lane partials, reduced over the wave after the texel pass
@@ -598,11 +598,11 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 
 		if (fast_1p)
 		{
-			term[i] = err[0] * blk.cw[0] + err[1] * blk.cw[1] + err[2] * blk.cw[2] + err[3] * blk.cw[3];
+			term[i] = err[0] * cw_of(blk, 0) + err[1] * cw_of(blk, 1) + err[2] * cw_of(blk, 2) + err[3] * cw_of(blk, 3);
 		}
 		else
 		{
-			float d = hadd4(err[0] * blk.cw[0], err[1] * blk.cw[1], err[2] * blk.cw[2], err[3] * blk.cw[3]);
+			float d = hadd4(err[0] * cw_of(blk, 0), err[1] * cw_of(blk, 1), err[2] * cw_of(blk, 2), err[3] * cw_of(blk, 3));
 			term[i] = d < ERROR_CALC_DEFAULT ? d : ERROR_CALC_DEFAULT;
 		}
 	}
@@ -712,7 +712,7 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 	if (count > 16)
 	{
 		// one lane per weight (see realign_weights: the twelve running sums in registers, the table reads one row ahead)
-		const f4 error_weight = load4(blk.cw);
+		const f4 error_weight = cw4_of(blk);
 		WV_FOR64(k, 64)
 		{
 			const int pp = k >> 5, we = k & 31;
@@ -768,7 +768,7 @@ WV_FN bool realign_weights_2planes(const Ctx& c, const DecView& di, const QuantX
 		// ---- the listed weights, one QUAD per weight, lane = colour channel (see realign_weights) ----
 		if (count != 0)
 		{
-			const qf error_weight_q = q_load(blk.cw);
+			const qf error_weight_q = q_cw_of(blk);
 			WV_QUADS(k, count)
 			{
 				const int item = items[k];
@@ -927,7 +927,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 		return v;
 #endif
 	};
-	const f4 error_weight = uniform4(load4(blk.cw));
+	const f4 error_weight = uniform4(cw4_of(blk));
 
 	for (int pl = 0; pl <= max_plane; pl++)
 	{
@@ -1101,7 +1101,7 @@ WV_FN bool realign_weights(const Ctx& c, const PartView& pv, const DecView& di, 
 						// Up to sixteen weights (every pass after a move, and the first pass of the small grids): one QUAD per
 						// weight, lane = colour channel.  The three running sums are one register each, the channel arithmetic one
 						// instruction instead of four, and the error is the quad's hadd in the reference's order.
-						const qf error_weight_q = q_load(blk.cw);
+						const qf error_weight_q = q_cw_of(blk);
 						const qf color_offset_q = q_load(&tr.fbox[4]);
 						WV_QUADS16(k, items)
 						{

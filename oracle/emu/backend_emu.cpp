@@ -91,6 +91,7 @@ int backend_compress(Backend* b, const CompressJob& job)
 	const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data() + CTX_LAYOUT_BACK);
 	Ctx c;
 	c.tab = b->blob.data() + CTX_LAYOUT_BACK;
+	c.tab_constant = false;
 	c.root = root;
 	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
 	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
