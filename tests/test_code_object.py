@@ -58,3 +58,9 @@ def test_kernel_descriptors(tmp_path):
     assert ldr["vgpr_count"] <= 128 and ldr["max_flat_workgroup_size"] == 64, ldr
     # ... and so does the HDR variant
     assert hdr["private_segment_fixed_size"] == 0 and hdr["vgpr_spill_count"] == 0 and hdr["vgpr_count"] <= 128, hdr
+    # ... and the fixed-context builds (what BASELINE configs[1..3] actually run: kernel_ldr_6x6m.hip, kernel_ldr_8x8t.hip,
+    # kernel_hdr_6x6m.hip)
+    for name in ("astc_compress_blocks_ldr_6x6m", "astc_compress_blocks_ldr_8x8t", "astc_compress_blocks_hdr_6x6m"):
+        d = next(d for n, d in by_short.items() if n.startswith(name))
+        assert d["private_segment_fixed_size"] == 0 and d["vgpr_spill_count"] == 0, (name, d)
+        assert d["vgpr_count"] <= 128 and d["max_flat_workgroup_size"] == 64, (name, d)
