@@ -58,6 +58,11 @@ WV_FN float infill_taps_at(const float* wts, const uint8_t* tab, uint32_t idx_of
 #ifndef ASTC_ANG_GROUP
 #define ASTC_ANG_GROUP 4
 #endif
+// ... and whether the next group's table loads are requested before the current group is added up (measured: +-0 in every
+// build, profiles/r05h; off)
+#ifndef ASTC_ANG_PREFETCH
+#define ASTC_ANG_PREFETCH 0
+#endif
 
 /* Row of the sin/cos tables an ideal weight selects in the angular search (ref: compute_angular_offsets,
  * weight_align.cpp:110-118).  It depends on the weight only, not on the angular step, so it is computed once when
@@ -482,27 +487,40 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets_all, SetFn get_set)
 
 			// compute_angular_offsets (ref: weight_align.cpp:94-140)
 			float anglesum_x = 0.0f, anglesum_y = 0.0f;
-			// groups of ASTC_ANG_GROUP weights: LDS reads, then all table loads, then the ordered accumulation
-			for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
+			// groups of ASTC_ANG_GROUP weights: LDS reads, then all table loads, then the ordered accumulation -- the next group's
+			// (cos, sin) pairs are requested before this group's are added up (they come from L2: one such round trip per group,
+			// one after the other, was most of this loop's time)
 			{
 				float cs[ASTC_ANG_GROUP], sn[ASTC_ANG_GROUP];
-				uint32_t row[ASTC_ANG_GROUP];
-				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++) { row[u] = rows[j0 + u]; }      // (past W: the all-zero row, see the pre-pass)
-				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++)
+				auto fetch = [&](int j0)
 				{
-					const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
-					const CosSin both = table_at(cos_sin_table, at);      // one 64-bit load
-					cs[u] = both.cs;
-					sn[u] = both.sn;
-				}
-				#pragma unroll
-				for (int u = 0; u < ASTC_ANG_GROUP; u++)
+					uint32_t row[ASTC_ANG_GROUP];
+					#pragma unroll
+					for (int u = 0; u < ASTC_ANG_GROUP; u++) { row[u] = rows[j0 + u]; }      // (past W: the all-zero row, see the pre-pass)
+					#pragma unroll
+					for (int u = 0; u < ASTC_ANG_GROUP; u++)
+					{
+						const uint32_t at = row[u] * (uint32_t)ANGULAR_STEPS + (uint32_t)sp;
+						const CosSin both = table_at(cos_sin_table, at);      // one 64-bit load
+						cs[u] = both.cs;
+						sn[u] = both.sn;
+					}
+				};
+				if (ASTC_ANG_PREFETCH && W > 0) fetch(0);
+				for (int j0 = 0; j0 < W; j0 += ASTC_ANG_GROUP)
 				{
-					// (past the set's last weight: +0.0 from the table's zero row; the sums start at +0.0 and are never -0.0)
-					anglesum_x += cs[u];
-					anglesum_y += sn[u];
+					float c_now[ASTC_ANG_GROUP], s_now[ASTC_ANG_GROUP];
+					if (!ASTC_ANG_PREFETCH) fetch(j0);
+					#pragma unroll
+					for (int u = 0; u < ASTC_ANG_GROUP; u++) { c_now[u] = cs[u]; s_now[u] = sn[u]; }
+					if (ASTC_ANG_PREFETCH && j0 + ASTC_ANG_GROUP < W) fetch(j0 + ASTC_ANG_GROUP);
+					#pragma unroll
+					for (int u = 0; u < ASTC_ANG_GROUP; u++)
+					{
+						// (past the set's last weight: +0.0 from the table's zero row; the sums start at +0.0 and are never -0.0)
+						anglesum_x += c_now[u];
+						anglesum_y += s_now[u];
+					}
 				}
 			}
 			float angle = ref_atan2(anglesum_y, anglesum_x);

@@ -18,7 +18,7 @@ for c in $CONFIGS; do
   find $O/${c}_trace -name '*kernel_stats*' | head -1 | xargs -r cat | cut -c1-160 | head -4
   ONE="python $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --no-quality --no-extra --no-host-api"
   timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/${c}_pmc1 -o pmc -- $ONE > $O/${c}_pmc1.log 2>&1
-  timeout 600 rocprofv3 --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY -d $O/${c}_pmc2 -o pmc -- $ONE > $O/${c}_pmc2.log 2>&1
+  timeout 600 rocprofv3 --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES -d $O/${c}_pmc2 -o pmc -- $ONE > $O/${c}_pmc2.log 2>&1
   timeout 600 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_BRANCH -d $O/${c}_pmc5 -o pmc -- $ONE > $O/${c}_pmc5.log 2>&1
   timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/${c}_pmc3 -o pmc -- $ONE > $O/${c}_pmc3.log 2>&1
   timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/${c}_pmc4 -o pmc -- $ONE > $O/${c}_pmc4.log 2>&1
