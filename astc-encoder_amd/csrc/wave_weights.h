@@ -60,6 +60,9 @@ WV_FN float infill_taps_at(const float* wts, const uint8_t* tab, uint32_t idx_of
 #endif
 // ... and whether the next group's table loads are requested before the current group is added up (measured: +-0 in every
 // build, profiles/r05h; off)
+#ifndef ASTC_DWI_PREFETCH
+#define ASTC_DWI_PREFETCH 1
+#endif
 #ifndef ASTC_ANG_PREFETCH
 #define ASTC_ANG_PREFETCH 0
 #endif
@@ -92,9 +95,19 @@ WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 	float weight_weight = 1e-10f;
 	float initial_weight = 0.0f;
 	const int cnt = sl.taps;
+	// (the next group of eight taps is requested before this group's gathers and sums: a weight of a coarse grid on a large
+	//  footprint has up to six groups, each an L2 round trip)
+	DwiTap8 g_next = {};
+	if (ASTC_DWI_PREFETCH) g_next = table_at_byte<DwiTap8>(c.tab, sl.wt_off);
 	for (int j0 = 0; j0 < cnt; j0 += 8)
 	{
-		const DwiTap8 g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
+		DwiTap8 g;
+		if (ASTC_DWI_PREFETCH)
+		{
+			g = g_next;
+			if (j0 + 8 < cnt) g_next = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)(j0 + 8) * 2u);
+		}
+		else g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
 		// (in two halves: most weights of the larger grids have four taps or fewer, and the second half of their only group
 		//  is all padding)
 		#pragma unroll
@@ -132,9 +145,17 @@ WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf
 	float error_change0 = 1e-10f;
 	float error_change1 = 0.0f;
 	const int cnt = sl.taps;
+	DwiTap8 g_next = {};
+	if (ASTC_DWI_PREFETCH) g_next = table_at_byte<DwiTap8>(c.tab, sl.wt_off);
 	for (int j0 = 0; j0 < cnt; j0 += 8)
 	{
-		const DwiTap8 g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
+		DwiTap8 g;
+		if (ASTC_DWI_PREFETCH)
+		{
+			g = g_next;
+			if (j0 + 8 < cnt) g_next = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)(j0 + 8) * 2u);
+		}
+		else g = table_at_byte<DwiTap8>(c.tab, sl.wt_off + (uint32_t)j0 * 2u);
 		#pragma unroll
 		for (int h = 0; h < 8; h += 4)
 		{
