@@ -39,9 +39,11 @@ for c in configs:
         e["active_lanes_avg"] = round(per("SQ_THREAD_CYCLES_VALU") / per("SQ_ACTIVE_INST_VALU"), 2)
     if per("SQ_WAIT_ANY") and per("SQ_WAVE_CYCLES"):
         e["wait_any_frac_of_wave_cycles"] = round(per("SQ_WAIT_ANY") / per("SQ_WAVE_CYCLES"), 4)
-    # measured occupancy: wave-cycles per busy CU-cycle (both in quad-cycles, the same pass), a CU has four SIMDs
+    # measured occupancy: wave-cycles per busy CU-cycle.  SQ_WAVE_CYCLES counts in units of four cycles, SQ_BUSY_CU_CYCLES in
+    # cycles, a CU has four SIMDs: the two factors cancel (config 3, whose LDS allows 10 workgroups per CU = 2.5 per SIMD,
+    # reads 2.47 this way)
     if per("SQ_BUSY_CU_CYCLES") and per("SQ_WAVE_CYCLES"):
-        e["waves_per_simd_measured"] = round(per("SQ_WAVE_CYCLES") / per("SQ_BUSY_CU_CYCLES") / 4.0, 3)
+        e["waves_per_simd_measured"] = round(per("SQ_WAVE_CYCLES") / per("SQ_BUSY_CU_CYCLES"), 3)
     if per("SQ_LDS_BANK_CONFLICT") and per("SQ_ACTIVE_INST_LDS"):
         e["lds_bank_conflict_frac"] = round(per("SQ_LDS_BANK_CONFLICT") / per("SQ_ACTIVE_INST_LDS"), 4)
     # kernel time of the same command under --kernel-trace --stats
