@@ -45,10 +45,13 @@
 	// optimiser hoists such terms out of the search loops of compress_block and carries them, in vector registers, across
 	// every trial.  A function that is inlined into the kernel body shadows the name with a local, opaque copy
 	// (WV_LANE_SCOPE as its first statement): what is derived from the lane index is then computed, and dies, inside it.
-	struct WvLaneId { __device__ operator int() const { return (int)threadIdx.x; } };
+	// (a workgroup is one wavefront: the index is below 64.  A kernel knows that from its launch bounds; a stage function reads
+	//  the index out of the packed work-item register and would otherwise test `lane < 64` -- a compare, three exec-mask
+	//  instructions -- around every one-trip loop over 64 items: the texel loops of an 8x8 block, the weight loops of two planes)
+	struct WvLaneId { __device__ operator int() const { const unsigned l = threadIdx.x; __builtin_assume(l < 64u); return (int)l; } };
 	static constexpr WvLaneId wv_lane_v{};
 	#define WV_LANE ((int)wv_lane_v)
-	#define WV_LANE_SCOPE int wv_lane_scope_src = (int)threadIdx.x; asm volatile("" : "+v"(wv_lane_scope_src)); const int wv_lane_v = wv_lane_scope_src
+	#define WV_LANE_SCOPE int wv_lane_scope_src = (int)threadIdx.x; asm volatile("" : "+v"(wv_lane_scope_src)); __builtin_assume((unsigned)wv_lane_scope_src < 64u); const int wv_lane_v = wv_lane_scope_src
 	// A workgroup is exactly one wavefront, and a wavefront's LDS instructions execute in issue
 	// order, so a cross-lane hand-off through LDS needs no s_barrier and no s_waitcnt: it only needs
 	// the compiler not to move or cache LDS accesses across this point.  (__syncthreads() would add

@@ -110,6 +110,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 {
 	ModeRec* modes = c.modes(start);
 	const int T = c.T;
+	(void)T;        // (the fixed-context builds use the literal)
 	const int planes = dual ? 2 : 1;
 	const int chunk_modes = (int)c.L->mode_chunk;
 	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);
@@ -290,7 +291,8 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				constexpr int kTrips = ((int)kFixedRoot.texel_count + 3) >> 2;
 				constexpr int kLast = (int)kFixedRoot.texel_count - 1;
 				TexelTaps next = texel_taps_at(c.tab, h.tw_off, h.tcf_off, (uint32_t)i_min(l, kLast));
-				#pragma unroll(kTrips <= 9 ? 3 : 4)
+				constexpr int kUnroll = kTrips <= 9 ? 3 : 4;
+				#pragma unroll kUnroll
 				for (int trip = 0; trip < kTrips; trip++)
 				{
 					const int t = l + 4 * trip;

@@ -14,7 +14,7 @@ out = {"configs": {}, "method": "rocprofv3 --pmc over `bench.py --config <c> --s
 for c in configs:
     tot, n = defaultdict(float), defaultdict(int)
     kernel = None
-    for p in range(1, 6):
+    for p in range(1, 7):
         for f in glob.glob(os.path.join(d, "%s_pmc%d" % (c, p), "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 k = row.get("Kernel_Name", "")
@@ -44,6 +44,10 @@ for c in configs:
     # reads 2.47 this way)
     if per("SQ_BUSY_CU_CYCLES") and per("SQ_WAVE_CYCLES"):
         e["waves_per_simd_measured"] = round(per("SQ_WAVE_CYCLES") / per("SQ_BUSY_CU_CYCLES"), 3)
+    # (SQ_INST_CYCLES_SALU turned out to be four cycles per scalar instruction, i.e. the instruction count again, and
+    #  SQ_INST_CYCLES_VALU is not delivered next to it on this stack: no issue-cycle figure from the counters)
+    if waves and per("SQ_INSTS_SMEM") is not None:
+        e["smem_insts_per_block"] = round(per("SQ_INSTS_SMEM") / waves, 2)
     if per("SQ_LDS_BANK_CONFLICT") and per("SQ_ACTIVE_INST_LDS"):
         e["lds_bank_conflict_frac"] = round(per("SQ_LDS_BANK_CONFLICT") / per("SQ_ACTIVE_INST_LDS"), 4)
     # kernel time of the same command under --kernel-trace --stats
