@@ -613,7 +613,7 @@ WV_FN void batch_score_sums_body(const Ctx& c, const BatchView& bv, bool dual, i
 		WV_QUADS(ci, count)
 		{
 			const float* v = bv.term(ci);
-			const qf acc = q_map_ch(q_splat(0.0f), [v, T](int l, float a) { for (int i = l; i < T; i += 4) a += v[i]; return a; });
+			const qf acc = q_map_ch(q_splat(0.0f), [v, T](int l, float a) { for_texels_of_quarter(l, T, [&](int i) { a += v[i]; }); return a; });
 			const float total = q_hadd(acc);
 			Q_ONCE { *batch_state(c, bv, ci).errorval = total; }
 		}

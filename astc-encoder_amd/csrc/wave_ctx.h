@@ -566,6 +566,28 @@ WV_FN f4 cw4_of(const BlkInfo& blk)
 	return load4(blk.cw);
 }
 
+/* for (i = l; i < T; i += 4) body(i), T = the block's texel count, l = 0 .. 3 (an accumulator lane of a quad walking its
+ * texels).  With a lane-dependent start the compiler cannot tell the trip count even when T is a literal and builds a
+ * divergent loop (an exec-mask exit test per trip, the LDS reads one after the other); in a fixed-context build the trips are
+ * ceil(T / 4) for every l, unrolled, the tail trip masked when T is not a multiple of four. */
+template <typename Body>
+WV_FN void for_texels_of_quarter(int l, int T, Body body)
+{
+#if ASTC_FIXED
+	(void)T;
+	constexpr int kT = (int)kFixedRoot.texel_count, kTrips = (kT + 3) >> 2;
+	#pragma unroll
+	for (int trip = 0; trip < kTrips; trip++)
+	{
+		const int i = l + 4 * trip;
+		if ((kT & 3) != 0 && i >= kT) continue;
+		body(i);
+	}
+#else
+	for (int i = l; i < T; i += 4) body(i);
+#endif
+}
+
 /* Lowest index i in [0, n), n <= 64, for which pred(i) holds, or -1; the same value on every lane. */
 template <typename Pred>
 WV_FN int wv_find_first(int n, Pred pred)

@@ -45,11 +45,11 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 			int l = k & 3, p = (int)((((uint32_t)k >> 2) * n_inv) >> 8), j = (k >> 2) - p * n;
 			const float* d = c.data(cs.comp(j));
 			float acc = 0.0f;
-			for (int i = l; i < T; i += 4)
+			for_texels_of_quarter(l, T, [&](int i)
 			{
 				float v = pv.of_texel[i] == p ? d[i] : 0.0f;
 				acc = acc + v;
-			}
+			});
 			tr.fbox[k] = acc;
 		}
 		WV_SYNC();

@@ -364,11 +364,14 @@ WV_FN int kmeans_partition_ordering(const Ctx& c, int pc, PartScratch& ps)
  * record staged in LDS (a lane per candidate reading its own record from global memory would touch
  * a different cache line per lane on every access).
  * (ref: compute_avgs_and_dirs_{4_comp,3_comp_rgb} + compute_error_squared_{rgba,rgb} + :660-670 / :726-738) */
-WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, bool uses_alpha, float weight_imprecision_estim, float& uncor_out, float& samec_out)
+template <bool USES_ALPHA>
+WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, float weight_imprecision_estim, float& uncor_out, float& samec_out)
 {
 	const BlkInfo& blk = c.blk();
 	const int T = c.T, Tp = c.Tp;
-	const int n = uses_alpha ? 4 : 3;
+	// (three or four channels: a template parameter -- as a run-time value it was a wave-uniform branch around every texel of
+	//  both texel loops)
+	constexpr int n = USES_ALPHA ? 4 : 3;
 
 	// partition averages: 4-accumulator masked sums in texel order (ref: averages_and_directions.cpp:47-385), one partition
 	// at a time -- sixteen accumulators live instead of forty-eight (round 5: the function fits a stage function's
@@ -650,7 +653,8 @@ WV_FN void partition_search_score(const Ctx& c, int pc, int partition_search_lim
 				}
 			}
 			float ue, se;
-			score_partitioning(c, pc, pv, uses_alpha, weight_imprecision_estim, ue, se);
+			if (uses_alpha) score_partitioning<true>(c, pc, pv, weight_imprecision_estim, ue, se);
+			else score_partitioning<false>(c, pc, pv, weight_imprecision_estim, ue, se);
 			ps.uncor_err()[first + i] = ue;
 			ps.samec_err()[first + i] = se;
 		}

@@ -610,7 +610,7 @@ WV_FN float compute_symbolic_block_difference(const Ctx& c, const PartView& pv, 
 
 	if (fast_1p)
 	{
-		return wv_sum4(term, T);
+		return wv_sum4_texels(term, T);
 	}
 	// (the reference leaves its texel loop with the sentinel at the first texel whose M is zero, ref: :366-394, :470-480:
 	//  whichever texel that is, the result is the same)

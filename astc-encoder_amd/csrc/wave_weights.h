@@ -706,6 +706,27 @@ WV_FN float sum4(const float* v, int n)
 	return (a0 + a2) + (a1 + a3);
 }
 
+/* wv_sum4() over the T per-texel terms of a block (wave_ctx.h: for_texels_of_quarter). */
+WV_FN float wv_sum4_texels(const float* v, int T)
+{
+#if WV_DEVICE
+	float acc = 0.0f;
+	if (WV_LANE < 4) for_texels_of_quarter(WV_LANE, T, [&](int i) { acc += v[i]; });
+	const int bits = float_as_int(acc);
+	const float a0 = int_as_float(__builtin_amdgcn_readlane(bits, 0)), a1 = int_as_float(__builtin_amdgcn_readlane(bits, 1));
+	const float a2 = int_as_float(__builtin_amdgcn_readlane(bits, 2)), a3 = int_as_float(__builtin_amdgcn_readlane(bits, 3));
+	return (a0 + a2) + (a1 + a3);
+#else
+	float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+	int i = 0;
+	for (; i + 3 < T; i += 4) { a0 += v[i]; a1 += v[i + 1]; a2 += v[i + 2]; a3 += v[i + 3]; }
+	if (i < T) a0 += v[i];
+	if (i + 1 < T) a1 += v[i + 1];
+	if (i + 2 < T) a2 += v[i + 2];
+	return (a0 + a2) + (a1 + a3);
+#endif
+}
+
 /* The same sum as a wave-level operation: the four accumulators run side by side on lanes 0..3 (a quarter of the
  * dependent additions of the one-lane form), then (acc0 + acc2) + (acc1 + acc3).  Uniform result; v must be visible to
  * all lanes (a WV_SYNC() after it was written). */
@@ -713,7 +734,7 @@ WV_FN float wv_sum4(const float* v, int n)
 {
 #if WV_DEVICE
 	float acc = 0.0f;
-	if (WV_LANE < 4) for (int i = WV_LANE; i < n; i += 4) acc += v[i];
+	if (WV_LANE < 4) for (int i = WV_LANE; i < n; i += 4) acc += v[i];      // (n is not always the texel count: see wv_sum4_texels)
 	const int bits = float_as_int(acc);
 	const float a0 = int_as_float(__builtin_amdgcn_readlane(bits, 0)), a1 = int_as_float(__builtin_amdgcn_readlane(bits, 1));
 	const float a2 = int_as_float(__builtin_amdgcn_readlane(bits, 2)), a3 = int_as_float(__builtin_amdgcn_readlane(bits, 3));
