@@ -47,7 +47,9 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 			float acc = 0.0f;
 			for_texels_of_quarter(l, T, [&](int i)
 			{
-				float v = pv.of_texel[i] == p ? d[i] : 0.0f;
+				// (`in partition p ? d : 0` as d * (1 or 0): the texel data are non-negative numbers, so d * 0 is +0 like the
+				//  reference's masked lane -- and the read is not hidden behind a lane mask)
+				float v = d[i] * (pv.of_texel[i] == p ? 1.0f : 0.0f);
 				acc = acc + v;
 			});
 			tr.fbox[k] = acc;

@@ -90,8 +90,9 @@ WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 	const float* eiw = c.ei_w(plane);
 	const float* eiwes = c.ei_wes(plane);
 	if (sl.flags & 1) return eiw[sl.index];
-	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
-	const float wes0 = eiwes[0];
+	// (ref: :872-905 reads one scale for every texel when the trial's scales are all equal, is_constant_weight_error_scale; the
+	//  per-texel row holds that same value in every entry then (ideal_colors_and_weights_*), so reading the row gives the same
+	//  bits -- and a select per tap on a lane-variant flag, the plane's, cost more than the read it saved)
 	float weight_weight = 1e-10f;
 	float initial_weight = 0.0f;
 	const int cnt = sl.taps;
@@ -120,7 +121,7 @@ WV_FN float dwi_initial_weight(const Ctx& c, const DwiSlot& sl)
 			{
 				const uint32_t t = dwi_tap_texel(g, h + k);
 				iw[k] = eiw[t];
-				es[k] = constant_wes ? wes0 : eiwes[t];
+				es[k] = eiwes[t];
 			}
 			#pragma unroll
 			for (int k = 0; k < 4; k++)
@@ -140,8 +141,6 @@ WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf
 	const int plane = (sl.flags >> 1) & 1;
 	const float* eiw = c.ei_w(plane);
 	const float* eiwes = c.ei_wes(plane);
-	const bool constant_wes = c.tr().is_constant_wes[plane] != 0;
-	const float wes0 = eiwes[0];
 	float error_change0 = 1e-10f;
 	float error_change1 = 0.0f;
 	const int cnt = sl.taps;
@@ -167,7 +166,7 @@ WV_FN float dwi_refined_weight(const Ctx& c, const DwiSlot& sl, const float* inf
 				const uint32_t t = dwi_tap_texel(g, h + k);
 				iw[k] = eiw[t];
 				ow[k] = inf[t];
-				es[k] = constant_wes ? wes0 : eiwes[t];
+				es[k] = eiwes[t];
 			}
 			#pragma unroll
 			for (int k = 0; k < 4; k++)
