@@ -80,8 +80,13 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 
 	// sum of offsets over the texels whose component `which` is above the mean (ref: :409-433)
 	// (one partition: the entries are the block's, whatever the trial -- TrialInfo::dirsum1)
+	// (bit a * 4 + b for every pair of the trial's components: the columns once, then one shifted copy per row)
 	uint32_t needed = 0;
-	for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) needed |= 1u << (cs.comp(a) * 4 + cs.comp(b));
+	{
+		uint32_t cols = 0;
+		for (int b = 0; b < n; b++) cols |= 1u << cs.comp(b);
+		for (int a = 0; a < n; a++) needed |= cols << (cs.comp(a) * 4);
+	}
 	const bool cached = pc == 1 && (wv_uniform(tr.dirsum1_mask) & needed) == needed;
 	if (cached)
 	{
