@@ -106,12 +106,16 @@ WV_FN float quantize_weight_q(const ModeQ& q, const uint8_t* tab, float ideal)
  * mode prepares the mode's quantization parameters; one lane per (mode, weight) quantizes the grid weights; one
  * quad per mode runs the reference's four interleaved accumulators, each lane forming its texels' error terms itself
  * (the infill of the <= 4 quantized weights the texel interpolates) in texel order. */
-WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant, bool dual)
+template <bool DUAL>
+WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int end, int max_weight_quant)
 {
+	// (one or two weight planes: a template parameter -- as a run-time flag the second plane was a wave-uniform branch in
+	//  every trip of the three passes' inner loops)
+	constexpr bool dual = DUAL;
 	ModeRec* modes = c.modes(start);
 	const int T = c.T;
 	(void)T;        // (the fixed-context builds use the literal)
-	const int planes = dual ? 2 : 1;
+	constexpr int planes = DUAL ? 2 : 1;
 	const int chunk_modes = (int)c.L->mode_chunk;
 	ModeHdr* hdr = reinterpret_cast<ModeHdr*>(c.lds + c.L->uni);
 	ModeQ* mq = reinterpret_cast<ModeQ*>(c.lds + c.L->uni + (uint32_t)chunk_modes * sizeof(ModeHdr));
@@ -291,7 +295,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				constexpr int kTrips = ((int)kFixedRoot.texel_count + 3) >> 2;
 				constexpr int kLast = (int)kFixedRoot.texel_count - 1;
 				TexelTaps next = texel_taps_at(c.tab, h.tw_off, h.tcf_off, (uint32_t)i_min(l, kLast));
-				constexpr int kUnroll = kTrips <= 9 ? 3 : 4;
+				constexpr int kUnroll = DUAL ? (kTrips <= 9 ? 2 : 1) : 3;      // (two planes: twice the values in flight per trip)
 				#pragma unroll kUnroll
 				for (int trip = 0; trip < kTrips; trip++)
 				{
@@ -938,13 +942,28 @@ WV_OUT void stage_angular(bool dual, int partition_count, int plane2_component, 
 	angular_endpoints(c, tr.dm_count * (dual ? 2 : 1), get_set);
 }
 
-WV_OUT void stage_modes(int partition_count, int start, int end, int max_weight_quant, bool dual)
+/* (one stage function per plane count: each gets its own register allocation -- the two-plane copy's loops keep twice the
+ *  values in flight) */
+WV_OUT void stage_modes_1plane(int partition_count, int start, int end, int max_weight_quant)
 {
 	const Ctx c = ctx_make_vector_tables();
 	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
-	max_weight_quant = wv_uniform(max_weight_quant); dual = wv_uniform(dual);
+	max_weight_quant = wv_uniform(max_weight_quant);
 	PROF_SCOPE(c, PS_MODES);
-	score_block_modes(c, partition_count, start, end, max_weight_quant, dual);
+	score_block_modes<false>(c, partition_count, start, end, max_weight_quant);
+}
+WV_OUT void stage_modes_2planes(int partition_count, int start, int end, int max_weight_quant)
+{
+	const Ctx c = ctx_make_vector_tables();
+	partition_count = wv_uniform(partition_count); start = wv_uniform(start); end = wv_uniform(end);
+	max_weight_quant = wv_uniform(max_weight_quant);
+	PROF_SCOPE(c, PS_MODES);
+	score_block_modes<true>(c, partition_count, start, end, max_weight_quant);
+}
+WV_FN void stage_modes(int partition_count, int start, int end, int max_weight_quant, bool dual)
+{
+	if (dual) stage_modes_2planes(partition_count, start, end, max_weight_quant);
+	else stage_modes_1plane(partition_count, start, end, max_weight_quant);
 }
 
 WV_OUT void stage_formats(bool dual, int partition_count, int partition_packed, int plane2_component, int start, int end)
