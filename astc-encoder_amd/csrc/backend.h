@@ -137,11 +137,16 @@ int astc_alpha_launch(const AlphaLaunch& a);
 struct DecodeLaunch {
 	const uint8_t* d_blocks;
 	void* d_image;
+	const void* d_tables;            // the footprint's decoder tables in HBM (astc_decode_tables_build)
 	uint32_t dim_x, dim_y, dim_z, data_type, swz[4];
 	uint32_t block_x, block_y, block_z, profile;
 	void* stream;
 };
 int astc_decode_launch(const DecodeLaunch& d);
+/* The per-footprint tables of the decoder (block mode field -> weight grid, bit budget -> colour quant level): built on
+ * the host once per context into astc_decode_tables_bytes() bytes, uploaded with the context's other tables. */
+size_t astc_decode_tables_bytes();
+void astc_decode_tables_build(void* out, uint32_t block_x, uint32_t block_y, uint32_t block_z);
 
 /* Image comparison launch (kernel_metrics.hip); d_sums = astc_compare_scratch_doubles() doubles of device memory,
  * the totals arrive in the first ten. */

@@ -43,6 +43,7 @@ struct DeviceSlot {
 	int device;
 	uint8_t* d_base;              // device allocation: context records, then the table blob
 	uint8_t* d_tab;               // the blob inside it
+	uint8_t* d_dectab;            // the decoder's per-footprint tables inside it (after the blob)
 	hipStream_t stream;
 	hipStream_t copy_stream;      // PCIe traffic of the banded host-pointer path
 	hipEvent_t ev0, ev1, ev_copy[2], ev_band, ev_done[3], ev_out[2];
@@ -66,7 +67,8 @@ struct Backend {
 	std::vector<DeviceSlot*> slots;   // the devices host images are sharded over; fixed at backend_create (slot 0 = default device)
 	std::vector<DeviceSlot*> extra;   // slots created on first use for device pointers that live on other GPUs; never sharded over
 	std::mutex slots_mu;              // guards `extra`
-	std::vector<uint8_t> full;        // host copy of [LdsLayout][DeviceConfig][table blob], uploaded to every slot
+	std::vector<uint8_t> full;        // host copy of [LdsLayout][DeviceConfig][table blob][decoder tables], uploaded to every slot
+	size_t dectab_offset;             // of the decoder tables in it
 	DeviceConfig cfg;
 	uint32_t lds_bytes;
 	bool hdr;
@@ -301,6 +303,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	SLOT_TRY(hipMalloc(&s->d_base, b->full.size() + ALLOC_SLACK), 1);
 	SLOT_TRY(hipMemcpy(s->d_base, b->full.data(), b->full.size(), hipMemcpyHostToDevice), 2);
 	s->d_tab = s->d_base + CTX_LAYOUT_BACK;
+	s->d_dectab = s->d_base + b->dectab_offset;
 	SLOT_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), 2);
 	SLOT_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking), 2);
 	SLOT_TRY(hipEventCreateWithFlags(&s->ev_copy[0], hipEventDisableTiming), 2);
@@ -444,8 +447,10 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		delete b; *status = 2; return nullptr;
 	}
 
-	// device allocation = [LdsLayout, 256 B][DeviceConfig, 256 B][table blob]; kernels get the blob pointer
-	b->full.assign(CTX_LAYOUT_BACK + blob_bytes, 0);
+	// device allocation = [LdsLayout, 256 B][DeviceConfig, 256 B][table blob][decoder tables]; kernels get the blob pointer
+	b->dectab_offset = (CTX_LAYOUT_BACK + blob_bytes + 255) & ~(size_t)255;
+	b->full.assign(b->dectab_offset + astc_decode_tables_bytes(), 0);
+	astc_decode_tables_build(b->full.data() + b->dectab_offset, b->root.dim_x, b->root.dim_y, b->root.dim_z);
 	memcpy(b->full.data(), layout, layout_bytes);
 	static_assert(sizeof(DeviceConfig) <= 256, "DeviceConfig outgrew its slot");
 	memcpy(b->full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
@@ -923,6 +928,7 @@ static int decompress_on_slot(Backend* bk, DeviceSlot* b, const DecompressJob& j
 	DecodeLaunch d;
 	d.d_blocks = b->d_out;
 	d.d_image = b->d_image;
+	d.d_tables = b->d_dectab;
 	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = dim_z; d.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
 	d.block_x = bk->root.dim_x; d.block_y = bk->root.dim_y; d.block_z = bk->root.dim_z;
@@ -1013,6 +1019,7 @@ int backend_decompress_device(Backend* bk, const DecompressDeviceJob& job)
 	DecodeLaunch d;
 	d.d_blocks = job.device_blocks;
 	d.d_image = job.device_image;
+	d.d_tables = b->d_dectab;
 	d.dim_x = job.dim_x; d.dim_y = job.dim_y; d.dim_z = job.dim_z ? job.dim_z : 1u; d.data_type = job.data_type;
 	for (int i = 0; i < 4; i++) d.swz[i] = job.swz[i];
 	d.block_x = bk->root.dim_x; d.block_y = bk->root.dim_y; d.block_z = bk->root.dim_z;

@@ -1,6 +1,6 @@
 // SPDX-License-Identifier: Apache-2.0
-// Decompression kernel: one wavefront per ASTC block, texels written straight into the output image
-// in HBM (astcenc_decompress_image; ref: Source/astcenc_entry.cpp:1274-1390).
+// Decompression kernel: one wavefront per run of DECODE_BATCH consecutive blocks of a block row, texels written
+// straight into the output image in HBM (astcenc_decompress_image; ref: Source/astcenc_entry.cpp:1274-1390).
 #define ASTC_VARIANT v_dec
 #define ASTC_ENABLE_HDR 1
 #include "backend.h"
@@ -9,22 +9,30 @@
 
 namespace astcd {
 
-/* One block is a few microseconds of work that keeps under half of a wavefront busy, so every wavefront
- * takes a run of DECODE_BATCH consecutive blocks and decodes them together (decode_block_batch). */
+/* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes a run of
+ * DECODE_BATCH consecutive blocks of one block row and decodes them together (decode_row_batch).  The grid is
+ * (runs per block row, block rows, layers of blocks): a run's place in the image needs no division. */
 __global__ void __launch_bounds__(64)
-astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img, uint32_t num_blocks)
+astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img)
 {
 	__shared__ DecodeBatch batch;
-	const uint32_t first = blockIdx.x * (uint32_t)DECODE_BATCH;
-	if (first >= num_blocks) return;
-	const uint32_t left = num_blocks - first;
-	decode_block_batch(img, blocks, first, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
+	const uint32_t bx0 = blockIdx.x * (uint32_t)DECODE_BATCH;
+	const uint32_t left = img.blocks_x - bx0;
+	decode_row_batch(img, blocks, bx0, blockIdx.y, blockIdx.z, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
+}
+
+size_t astc_decode_tables_bytes() { return sizeof(DecodeTables); }
+
+void astc_decode_tables_build(void* out, uint32_t block_x, uint32_t block_y, uint32_t block_z)
+{
+	decode_tables_build(*static_cast<DecodeTables*>(out), (int)block_x, (int)block_y, (int)block_z);
 }
 
 int astc_decode_launch(const DecodeLaunch& d)
 {
 	DecodeImage img;
 	img.data = d.d_image;
+	img.tabs = static_cast<const DecodeTables*>(d.d_tables);
 	img.dim_x = d.dim_x; img.dim_y = d.dim_y; img.dim_z = d.dim_z;
 	img.data_type = d.data_type;
 	for (int i = 0; i < 4; i++) img.swz[i] = d.swz[i];
@@ -34,8 +42,10 @@ int astc_decode_launch(const DecodeLaunch& d)
 	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
 	decode_image_prepare(img);
-	const uint32_t n = img.blocks_x * img.blocks_y * img.blocks_z;
-	hipLaunchKernelGGL(astc_decompress_blocks, dim3((n + (uint32_t)DECODE_BATCH - 1) / (uint32_t)DECODE_BATCH), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, n);
+	// (grid y / z hold block rows / layers: at most 65535 each, i.e. images of up to 196 605 texels in y at the smallest footprint)
+	if (img.blocks_y > 65535u || img.blocks_z > 65535u) return (int)hipErrorInvalidConfiguration;
+	const dim3 grid((img.blocks_x + (uint32_t)DECODE_BATCH - 1) / (uint32_t)DECODE_BATCH, img.blocks_y, img.blocks_z);
+	hipLaunchKernelGGL(astc_decompress_blocks, grid, dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img);
 	return (int)hipGetLastError();
 }
 

@@ -20,8 +20,11 @@
 
 namespace astcd { inline namespace ASTC_VARIANT {
 
+struct DecodeTables;
+
 struct DecodeImage {
 	void*    data;            // tightly packed RGBA rows of data_type, dim_z slices back to back
+	const DecodeTables* tabs; // per-footprint tables of the batched decoder (decode_tables_build), device memory
 	uint32_t dim_x, dim_y, dim_z;
 	uint32_t data_type;       // astcenc_type
 	uint32_t swz[4];          // astcenc_swz per output channel
@@ -62,10 +65,11 @@ WV_FN uint32_t bits_get(const Bits128& b, int off, int n)
 {
 	// n <= 16, may run past bit 127 (reads zeros there, like the reference's padded buffer)
 	if (n <= 0 || off >= 128) return 0u;
-	int word = off >> 5, sh = off & 31;
-	uint64_t lo = b.w[word];
-	uint64_t hi = word + 1 < 4 ? b.w[word + 1] : 0u;
-	uint64_t v = (lo | (hi << 32)) >> sh;
+	// (the words by selects, not by index: an indexed read of a register array would put the block in scratch memory)
+	const int word = off >> 5, sh = off & 31;
+	const uint32_t lo = word == 0 ? b.w[0] : word == 1 ? b.w[1] : word == 2 ? b.w[2] : b.w[3];
+	const uint32_t hi = word == 0 ? b.w[1] : word == 1 ? b.w[2] : word == 2 ? b.w[3] : 0u;
+	const uint64_t v = ((uint64_t)lo | ((uint64_t)hi << 32)) >> sh;
 	return (uint32_t)v & ((1u << n) - 1u);
 }
 
@@ -80,6 +84,87 @@ WV_FN uint32_t rev32(uint32_t v)
 	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
 	return (v >> 16) | (v << 16);
 #endif
+}
+
+/* a * b (+ c) for factors that fit 24 bits (signed / unsigned): one full-rate instruction each on the device, where a
+ * 32-bit multiply is a quarter-rate one (and where the compiler, left to itself, forms 64-bit multiply-adds).  The device
+ * forms are spelled out because the 24-bit intrinsics are folded back into 32-bit multiplies when an operand's range is unknown. */
+WV_FN int mul24(int a, int b)
+{
+#if WV_DEVICE
+	int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+	return a * b;
+#endif
+}
+WV_FN uint32_t umul24(uint32_t a, uint32_t b)
+{
+#if WV_DEVICE
+	uint32_t r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+#else
+	return a * b;
+#endif
+}
+WV_FN int mad24(int a, int b, int c)
+{
+#if WV_DEVICE
+	int r; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+	return a * b + c;
+#endif
+}
+WV_FN uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
+{
+#if WV_DEVICE
+	uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+#else
+	return a * b + c;
+#endif
+}
+
+/* Four consecutive words at a 16-byte aligned address: one 128-bit LDS read on the device. */
+struct U32x4 { uint32_t x, y, z, w; };
+WV_FN U32x4 load_u32x4_aligned(const uint32_t* p)
+{
+	U32x4 r;
+#if WV_DEVICE
+	typedef uint32_t wv_u32x4 __attribute__((ext_vector_type(4)));
+	const wv_u32x4 v = *reinterpret_cast<const wv_u32x4*>(p);
+	r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+#else
+	r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+#endif
+	return r;
+}
+
+/* Byte permutes (v_perm_b32): byte k of the result is picked by byte k of `sel` out of the eight bytes { hi, lo } -- 0..3 a
+ * byte of lo, 4..7 a byte of hi, 0x0C the constant 0x00, 0x0D the constant 0xFF. */
+WV_FN uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if WV_DEVICE
+	return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+	uint32_t r = 0;
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t s = (sel >> (8 * k)) & 0xFFu;
+		const uint32_t v = s == 0x0Cu ? 0u : s >= 0x0Du ? 255u : s < 4u ? (lo >> (8 * s)) & 0xFFu : (hi >> (8 * (s - 4u))) & 0xFFu;
+		r |= v << (8 * k);
+	}
+	return r;
+#endif
+}
+/* The selector that takes the channels r, g out of the low two bytes of `lo` and b, a out of the low two bytes of `hi`
+ * through a swizzle that picks channels or constants (astcenc_swz 0..5). */
+WV_FN uint32_t swizzle_selector(const uint32_t swz[4])
+{
+	uint32_t sel = 0;
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t s = swz[k] == 4 ? 0x0Cu : swz[k] == 5 ? 0x0Du : swz[k] < 2 ? swz[k] : swz[k] + 2u;
+		sel |= s << (8 * k);
+	}
+	return sel;
 }
 
 /* The weight stream is stored from the top of the block downwards: bit i of it is bit 127 - i. */
@@ -303,6 +388,14 @@ WV_FN int unquant_color_symbol(int v, int quant)
 WV_FN uint32_t trit_group_lut(uint32_t t8) { const uint16_t t[256] = { ASTC_TRIT_LUT_VALUES }; return t[t8]; }
 WV_FN uint32_t quint_group_lut(uint32_t q7) { const uint16_t t[128] = { ASTC_QUINT_LUT_VALUES }; return t[q7]; }
 WV_FN int weight_unquant_lut(int quant, int sym) { const uint8_t t[12 * 32] = { ASTC_WEIGHT_UNQUANT_LUT_VALUES }; return t[quant * 32 + sym]; }
+/* four consecutive entries of the weight table as one word (entry 4 i in the low byte) */
+WV_FN uint32_t weight_unquant_lut_word(int i)
+{
+	alignas(4) const uint8_t t[12 * 32] = { ASTC_WEIGHT_UNQUANT_LUT_VALUES };
+	uint32_t v;
+	__builtin_memcpy(&v, t + 4 * i, 4);
+	return v;
+}
 WV_FN int color_unquant_lut(int quant, int sym) { const uint8_t t[21 * 256] = { ASTC_COLOR_UNQUANT_LUT_VALUES }; return t[quant * 256 + sym]; }
 
 /* (hi:lo) >> sh, low 32 bits; sh in 0..31. */
@@ -366,6 +459,8 @@ WV_FN int ise_symbol_lut(const uint32_t* w, int offset, int bits, int kind, int 
 /* Symbols per lane in the batched decoder: one BISE group (five trits or three quints share packed bits, so the
  * group is the natural unit: its window and its table entry are fetched once), four symbols for plain bit fields. */
 WV_FN int ise_group_size(int kind) { return kind == 1 ? 5 : kind == 2 ? 3 : 4; }
+/* groups of a sequence of `count` symbols (count < 128), without a division */
+WV_FN int ise_group_count(int count, int kind) { return kind == 1 ? ((count + 4) * 205) >> 10 : kind == 2 ? ((count + 2) * 171) >> 9 : (count + 3) >> 2; }
 
 /* The symbols of group `group` of a BISE sequence (same results as ise_symbol_lut for each of them); returns how many
  * of out[0..4] are real (the last group may be short). */
@@ -492,6 +587,44 @@ WV_FN bool decode_block_mode(uint32_t mode, int block_x, int block_y, int block_
 	return wbits >= 24 && wbits <= 96;
 }
 
+/* Per-footprint tables of the batched decoder: what an 11-bit block mode field says for this footprint (the arithmetic of
+ * decode_block_mode and its BISE size, one word per mode) and the colour quant level a bit budget affords (the search of
+ * physical_to_symbolic, astcenc_symbolic_physical.cpp:467-486, one byte per (value pairs, bits)).  Built on the host
+ * by decode_tables_build() from those routines when a context is created and kept in HBM beside its other tables. */
+struct DecodeTables {
+	uint32_t mode[2048];       // bit 31 legal | weight count over both planes << 24 | weight stream bits << 17 | weight quant << 13 | dual << 12 | grid z << 8 | y << 4 | x
+	uint8_t  cquant[9][128];   // [colour value pairs - 1][bits] -> highest quant level whose BISE size fits + 1, 0 = none
+};
+
+inline void decode_tables_build(DecodeTables& t, int block_x, int block_y, int block_z)
+{
+	for (uint32_t mode = 0; mode < 2048u; mode++)
+	{
+		int wx = 0, wy = 0, wz = 1, wquant = 0;
+		bool dual = false;
+		uint32_t e = 0u;
+		if ((mode & 0x1FFu) != 0x1FCu && decode_block_mode(mode, block_x, block_y, block_z, wx, wy, wz, dual, wquant))
+		{
+			const int count = wx * wy * wz * (dual ? 2 : 1);
+			e = 0x80000000u | ((uint32_t)count << 24) | ((uint32_t)ise_bitcount((unsigned)count, wquant) << 17) | ((uint32_t)wquant << 13) |
+			    ((dual ? 1u : 0u) << 12) | ((uint32_t)wz << 8) | ((uint32_t)wy << 4) | (uint32_t)wx;
+		}
+		t.mode[mode] = e;
+	}
+	for (int pairs = 1; pairs <= 9; pairs++)
+	{
+		for (int bits = 0; bits < 128; bits++)
+		{
+			int best = -1;
+			for (int q = 20; q >= 0; q--)
+			{
+				if (best < 0 && (int)ise_bitcount((unsigned)(2 * pairs), q) <= bits) best = q;
+			}
+			t.cquant[pairs - 1][bits] = (uint8_t)(best + 1);
+		}
+	}
+}
+
 /* The partition hash (ref: select_partition / hash52, astcenc_partition_tables.cpp:66-245) in two steps: everything
  * that depends on the block only -- the scrambled seed, its twelve 4-bit multipliers after squaring and shifting, the
  * four offsets -- is packed into four words (x | y << 8 | z << 16 multipliers and the offset << 24 of the a, b, c, d
@@ -560,45 +693,55 @@ WV_FN int unorm16_to_sf16(int p)
 	return v | ((14 - lz) << 10);
 }
 
-/* Write one decoded texel (floats) through the swizzle.  (ref: store_image_block :345-573) */
-WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, uint32_t z, float r, float g, float b, float a)
+/* The swizzle's sources of one decoded texel: r, g, b, a, 0, 1 and the reconstructed normal z. (ref: store_image_block :345-573) */
+WV_FN void swizzle_sources(float r, float g, float b, float a, float src[7])
 {
-	float src[7];
 	src[0] = r; src[1] = g; src[2] = b; src[3] = a; src[4] = 0.0f; src[5] = 1.0f;
+	float xn = (r * 2.0f) - 1.0f;
+	float yn = (a * 2.0f) - 1.0f;
+	float zn = 1.0f - xn * xn - yn * yn;
+	if (zn < 0.0f) zn = 0.0f;
+	src[6] = (f_sqrt(zn) * 0.5f) + 0.5f;
+}
+
+/* One decoded texel (floats) as an RGBA8 pixel through the swizzle; an error texel (NaN) is opaque magenta. */
+WV_FN uint32_t pack_texel_u8(const DecodeImage& img, float r, float g, float b, float a)
+{
+	if (r != r) return 0xFFFF00FFu;
+	float src[7];
+	swizzle_sources(r, g, b, a, src);
+	uint32_t px = 0;
+	for (int k = 0; k < 4; k++)
 	{
-		float xn = (r * 2.0f) - 1.0f;
-		float yn = (a * 2.0f) - 1.0f;
-		float zn = 1.0f - xn * xn - yn * yn;
-		if (zn < 0.0f) zn = 0.0f;
-		src[6] = (f_sqrt(zn) * 0.5f) + 0.5f;
+		uint32_t sw = img.swz[k];
+		int v;
+		if (sw == 4) v = 0;
+		else if (sw == 5) v = 255;
+		else
+		{
+			float f = src[sw];
+			if (sw == 6) f = f < 1.0f ? f : 1.0f;                    // min(z, 1), z is never negative
+			else f = v_clampzo(f);
+			v = (int)(f * 255.0f + 0.5f);
+		}
+		px |= ((uint32_t)v & 0xFFu) << (8 * k);
 	}
-	const size_t at = (((size_t)z * img.dim_y + y) * img.dim_x + x) * 4;
+	return px;
+}
+
+/* Write one decoded texel (floats) through the swizzle; `at` = index of its first component.  (ref: store_image_block :345-573) */
+WV_FN void store_texel_at(const DecodeImage& img, size_t at, float r, float g, float b, float a)
+{
 	if (img.data_type == 0)
 	{
 		// one 32-bit store per texel (the image base is at least 4-byte aligned, rows are tightly packed)
-		uint32_t px = 0xFFFF00FFu;                                       // error colour: magenta, opaque
-		if (!(r != r))
-		{
-			px = 0;
-			for (int k = 0; k < 4; k++)
-			{
-				uint32_t sw = img.swz[k];
-				int v;
-				if (sw == 4) v = 0;
-				else if (sw == 5) v = 255;
-				else
-				{
-					float f = src[sw];
-					if (sw == 6) f = f < 1.0f ? f : 1.0f;                    // min(z, 1), z is never negative
-					else f = v_clampzo(f);
-					v = (int)(f * 255.0f + 0.5f);
-				}
-				px |= ((uint32_t)v & 0xFFu) << (8 * k);
-			}
-		}
+		const uint32_t px = pack_texel_u8(img, r, g, b, a);
 		__builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
+		return;
 	}
-	else if (img.data_type == 1)
+	float src[7];
+	swizzle_sources(r, g, b, a, src);
+	if (img.data_type == 1)
 	{
 		uint16_t h4[4];
 		for (int k = 0; k < 4; k++) h4[k] = float_to_half(src[img.swz[k]]);
@@ -611,22 +754,29 @@ WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, uint32_t 
 	}
 }
 
+WV_FN void store_texel(const DecodeImage& img, uint32_t x, uint32_t y, uint32_t z, float r, float g, float b, float a)
+{
+	store_texel_at(img, (((size_t)z * img.dim_y + y) * img.dim_x + x) * 4, r, g, b, a);
+}
+
 /* Everything the header of a block says (ref: physical_to_symbolic :291-556 up to the ISE decode). */
 struct BlockHeader {
 	bool error, constant, constant_f16;
 	int  const_color[4];      // void-extent colour, raw 16-bit fields
 	int  wx, wy, wz, wquant;  // weight grid and its quant level
+	int  wbits;               // length of the weight stream
 	bool dual;
 	int  parts, seed, plane2;
 	int  fmt[4];              // colour endpoint mode per partition
 	int  nvals, cquant, color_start;
 };
 
-WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_y, int block_z)
+/* tabs: the footprint's DecodeTables (the batched decoder), or null: the mode and the colour quant level by arithmetic. */
+WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_y, int block_z, const DecodeTables* tabs = nullptr)
 {
 	BlockHeader h;
 	h.error = false; h.constant = false; h.constant_f16 = false;
-	h.wx = 0; h.wy = 0; h.wz = 1; h.wquant = 0; h.dual = false;
+	h.wx = 0; h.wy = 0; h.wz = 1; h.wquant = 0; h.wbits = 0; h.dual = false;
 	h.parts = 1; h.seed = 0; h.plane2 = -1;
 	h.nvals = 0; h.cquant = 0; h.color_start = 17;
 	for (int k = 0; k < 4; k++) { h.const_color[k] = 0; h.fmt[k] = 0; }
@@ -654,15 +804,31 @@ WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_
 		for (int k = 0; k < 4; k++) h.const_color[k] = (int)bits_get(blk, 64 + 16 * k, 16);
 		return h;
 	}
-	if (!decode_block_mode(mode, block_x, block_y, block_z, h.wx, h.wy, h.wz, h.dual, h.wquant))
+	int wbits;
+	if (tabs)
 	{
-		h.error = true;
-		return h;
+		const uint32_t e = table_at(tabs->mode, mode);
+		if (!(e >> 31))
+		{
+			h.error = true;
+			return h;
+		}
+		h.wx = (int)(e & 15u); h.wy = (int)((e >> 4) & 15u); h.wz = (int)((e >> 8) & 15u);
+		h.dual = ((e >> 12) & 1u) != 0u;
+		h.wquant = (int)((e >> 13) & 15u);
+		wbits = (int)((e >> 17) & 127u);
 	}
-
-	const int wcount = h.wx * h.wy * h.wz;
-	const int real_wcount = h.dual ? 2 * wcount : wcount;
-	const int wbits = (int)ise_bitcount((unsigned)real_wcount, h.wquant);
+	else
+	{
+		if (!decode_block_mode(mode, block_x, block_y, block_z, h.wx, h.wy, h.wz, h.dual, h.wquant))
+		{
+			h.error = true;
+			return h;
+		}
+		const int wcount = h.wx * h.wy * h.wz;
+		wbits = (int)ise_bitcount((unsigned)(h.dual ? 2 * wcount : wcount), h.wquant);
+	}
+	h.wbits = wbits;
 	h.parts = (int)bits_get(blk, 11, 2) + 1;
 	if (h.dual && h.parts == 4) h.error = true;
 
@@ -706,10 +872,18 @@ WV_FN BlockHeader parse_block_header(const Bits128& blk, int block_x, int block_
 	// the colour stream uses the highest quant level whose BISE size fits the bits left
 	int cbits = below - h.color_start;
 	if (cbits < 0) cbits = 0;
-	h.cquant = -1;
-	for (int q = 20; q >= 0; q--)
+	if (tabs)
 	{
-		if (h.cquant < 0 && (int)ise_bitcount((unsigned)h.nvals, q) <= cbits) h.cquant = q;
+		// (an over-long value count is an error already; the table has rows for the legal counts)
+		h.cquant = h.nvals <= 18 ? (int)table_at(&tabs->cquant[0][0], (uint32_t)((h.nvals >> 1) - 1) * 128u + (uint32_t)cbits) - 1 : -1;
+	}
+	else
+	{
+		h.cquant = -1;
+		for (int q = 20; q >= 0; q--)
+		{
+			if (h.cquant < 0 && (int)ise_bitcount((unsigned)h.nvals, q) <= cbits) h.cquant = q;
+		}
 	}
 	if (h.cquant < QUANT_6) h.error = true;
 	return h;
@@ -726,7 +900,8 @@ WV_FN void endpoint_lns_flags(int profile, int f, bool& rgb_lns, bool& alpha_lns
 }
 
 /* Weights of one texel from the grid (format rule "weight infill"; ref: unpack_weights :89). */
-WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
+/* g0 / g1: grid weight 0 of plane 0 / 1, `stride` bytes from one grid position to the next. */
+WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t* g0, const uint8_t* g1, int stride, int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
 {
 	// ds, dt, dr = (1024 + block / 2) / (block - 1) per axis
 	if (block_z > 1)
@@ -753,12 +928,12 @@ WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t
 		const int v1 = v0 + s1, v2 = v1 + s2, v3 = v0 + NM + N + 1;
 		for (int pl = 0; pl < 2; pl++)
 		{
-			const uint8_t* g = gw[pl];
+			const uint8_t* g = pl ? g1 : g0;
 			int sum = 8;
-			sum += w0 ? g[v0] * w0 : 0;
-			sum += w1 ? g[v1] * w1 : 0;
-			sum += w2 ? g[v2] * w2 : 0;
-			sum += w3 ? g[v3] * w3 : 0;
+			sum += w0 ? g[v0 * stride] * w0 : 0;
+			sum += w1 ? g[v1 * stride] * w1 : 0;
+			sum += w2 ? g[v2 * stride] * w2 : 0;
+			sum += w3 ? g[v3 * stride] * w3 : 0;
 			wp[pl] = sum >> 4;
 		}
 		return;
@@ -778,15 +953,15 @@ WV_FN void infill_texel_weights(int wx, int wy, int wz, bool dual, const uint8_t
 	(void)wcount;
 	for (int pl = 0; pl < (dual ? 2 : 1); pl++)
 	{
-		const uint8_t* g = gw[pl];
-		const int sum = 8 + g[v0] * w00 + g[v0 + 1] * w01 + g[v0 + wx] * w10 + g[v0 + wx + 1] * w11;
+		const uint8_t* g = pl ? g1 : g0;
+		const int sum = 8 + g[v0 * stride] * w00 + g[(v0 + 1) * stride] * w01 + g[(v0 + wx) * stride] * w10 + g[(v0 + wx + 1) * stride] * w11;
 		wp[pl] = sum >> 4;
 	}
 }
 
 WV_FN void infill_texel_weights(const BlockHeader& h, const uint8_t gw[2][64], int ds, int dt, int dr, int block_z, int tx, int ty, int tz, int wp[2])
 {
-	infill_texel_weights(h.wx, h.wy, h.wz, h.dual, gw, ds, dt, dr, block_z, tx, ty, tz, wp);
+	infill_texel_weights(h.wx, h.wy, h.wz, h.dual, gw[0], gw[1], 1, ds, dt, dr, block_z, tx, ty, tz, wp);
 }
 
 /* Unpack weights, colour values and endpoints of a non-constant, legal block into the scratch. */
@@ -917,52 +1092,263 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 }
 
 #if !defined(ASTC_DECODE_NO_LUTS)
-/* A batch of consecutive blocks decoded together by one wavefront.  Decoding one block keeps few lanes
- * busy (a header, <= 64 weights, <= 18 colour values, <= 4 endpoint pairs, T texels, one after the other);
- * over a batch every phase is one flat loop over (block, element) pairs, so the lanes stay filled and
- * the per-block phases cost one pass per batch instead of one per block. */
+/* A run of consecutive blocks of one block row decoded together by one wavefront.  Decoding one block keeps few lanes
+ * busy (a header, <= 64 weights, <= 18 colour values, <= 4 endpoint pairs, T texels, one after the other); over a run
+ * every phase has a lane per (block, element), and the per-block phases cost a pass per run instead of one per block.
+ * The blocks of a run share their rows of the image, so the texel phase walks the image row by row: a lane keeps its
+ * column -- block, texel x, everything the weight infill and the partition hash derive from them -- while the rows go by,
+ * and consecutive lanes store consecutive pixels. */
 #ifndef ASTC_DECODE_BATCH
-#define ASTC_DECODE_BATCH 16
+#define ASTC_DECODE_BATCH 32
 #endif
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
+static_assert(DECODE_BATCH == 32, "the lane maps of decode_row_batch pair lane l with block l & 31");
 
-/* What the element and texel phases need to know about a block, packed so that one 16-byte LDS read fetches it. */
-struct DecodeBlockRec {
-	uint32_t a;          // flags (1 = no payload, 2 = error block, 4 = constant colour) | weight bits << 8 | weight kind << 16 | weight quant << 24
-	uint32_t b;          // colour bits | colour kind << 8 | colour quant << 16 | colour value count << 24
-	uint32_t c;          // weight count over both planes | dual << 8 | first colour bit << 16 | partition count << 24
-	uint32_t d;          // grid x | y << 8 | z << 16 | second plane's component (255 = none) << 24
-	uint32_t origin[3];  // texel coordinates of the block's first texel
-	uint32_t pad;
-	PartitionHash hash;  // multi-partition blocks: the per-block part of the partition hash
+/* Per-wave scratch (LDS).  Strides are chosen so that lanes on neighbouring blocks fall on different banks. */
+struct alignas(16) DecodeBatch {
+	uint32_t rec[DECODE_BATCH][4];       // what the element and texel phases need to know about a block (rec_* below), one 16-byte read
+	uint32_t hash[DECODE_BATCH][4];      // multi-partition blocks: the per-block part of the partition hash (PartitionHash)
+	uint8_t  lns[DECODE_BATCH][4];       // per partition: 1 = rgb, 2 = alpha endpoints are LNS codes
+	uint8_t  fmt[DECODE_BATCH][4];       // colour endpoint mode per partition
+	uint8_t  weights[DECODE_BATCH][76];  // unquantized grid weights in stream order (the two planes of a dual-plane block interleaved), 0..64
+	uint8_t  colors[DECODE_BATCH][28];   // unquantized colour values, 0..255
+	// Endpoints per partition as the interpolation wants them: [0..3] = endpoint0 * 256 + 128, [4..7] = (endpoint1 - endpoint0) * 4
+	// per channel, so that [q] + [4 + q] * weight is the interpolated 16-bit value in bits 8..23 (its top byte in byte 2).
+	// Until the endpoint phase writes them the records of partitions 2 and 3 hold the block's bit streams: [2][0..5] the
+	// block and two zero words (see bits_window), [3][0..3] the weight stream (the block bit-reversed, cut off at its length).
+	// A constant-colour block keeps its four floats in [0][0..3].  (Four pad words: consecutive blocks on different banks.)
+	uint32_t ep[DECODE_BATCH][4 * 8 + 4];
+	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
 };
 
-struct DecodeBatch {
-	DecodeBlockRec rec[DECODE_BATCH];
-	uint32_t    bits[DECODE_BATCH][6];    // the block, then two zero words (see bits_window)
-	uint32_t    rev[DECODE_BATCH][6];     // the same bits reversed: the weight stream
-	float       constant[DECODE_BATCH][4];
-	uint8_t     fmt[DECODE_BATCH][4];     // colour endpoint mode per partition
-	DecodeScratch payload[DECODE_BATCH];
-};
+// rec[0]: bit 0 no payload (error or constant colour), bit 1 error, bit 2 constant colour, bit 3 fast (RGBA8 pixel from integers),
+//         4..6 weight symbol bits, 8..9 weight kind, 12..15 weight quant, 16..21 weight groups, 24..28 bits per weight group
+// rec[1]: 0..3 colour symbol bits, 4..5 colour kind, 8..12 colour quant, 16..20 colour values, 24..28 first colour bit
+// rec[2]: 0..3 grid x, 4..7 y, 8..11 z, 12 dual plane, 13..15 partitions, 16..17 second plane's component, 20..22 colour groups
+// rec[3]: error / constant block with RGBA8 output: the pixel
 
-/* Decode blocks [first, first + count) of the stream (count <= DECODE_BATCH) into the image.  All 64 lanes
- * call this.  Same arithmetic as decode_block(), block by block. */
-WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uint32_t first, int count, DecodeBatch& s)
+WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k] + 16; }
+WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 24; }
+
+/* The symbols of group `g` of a weight stream whose bits past its end are zero (so a short last group needs no mask):
+ * ise_group_lut for the weight levels, whose groups fit a 32-bit window (at most 5 * 3 + 8 bits). */
+WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, uint32_t out[5])
+{
+	const int word = at >> 5, sh = at & 31;
+	const uint32_t g = funnel_shift_right(ws[word + 1], ws[word], sh);
+	const uint32_t low_mask = (1u << bits) - 1u;
+	if (kind == 0)
+	{
+		for (int e = 0; e < 4; e++) out[e] = (g >> (e * bits)) & low_mask;
+		out[4] = 0u;
+	}
+	else if (kind == 1)
+	{
+		const uint32_t t8 = ((g >> bits) & 3u) | (((g >> (2 * bits + 2)) & 3u) << 2) | (((g >> (3 * bits + 4)) & 1u) << 4) |
+		                    (((g >> (4 * bits + 5)) & 3u) << 5) | (((g >> (5 * bits + 7)) & 1u) << 7);
+		const uint32_t trits = trit_group_lut(t8);
+		out[0] = (((trits) & 3u) << bits) | (g & low_mask);
+		out[1] = (((trits >> 2) & 3u) << bits) | ((g >> (bits + 2)) & low_mask);
+		out[2] = (((trits >> 4) & 3u) << bits) | ((g >> (2 * bits + 4)) & low_mask);
+		out[3] = (((trits >> 6) & 3u) << bits) | ((g >> (3 * bits + 5)) & low_mask);
+		out[4] = (((trits >> 8) & 3u) << bits) | ((g >> (4 * bits + 7)) & low_mask);
+	}
+	else
+	{
+		const uint32_t q7 = ((g >> bits) & 7u) | (((g >> (2 * bits + 3)) & 3u) << 3) | (((g >> (3 * bits + 5)) & 3u) << 5);
+		const uint32_t quints = quint_group_lut(q7);
+		out[0] = (((quints) & 7u) << bits) | (g & low_mask);
+		out[1] = (((quints >> 3) & 7u) << bits) | ((g >> (bits + 3)) & low_mask);
+		out[2] = (((quints >> 6) & 7u) << bits) | ((g >> (2 * bits + 5)) & low_mask);
+		out[3] = 0u; out[4] = 0u;
+	}
+}
+
+/* A texel that does not leave as an RGBA8 pixel built from integers: error and constant-colour blocks, LNS endpoints,
+ * FP16 / FP32 output, the Z swizzle.  cv = the four interpolated 16-bit values (blocks with a payload).
+ * `at` = index of the texel's first component.  (ref: decode_texel :66, store_image_block :345) */
+WV_FN void store_texel_general(const DecodeImage& img, const DecodeBatch& s, int k, uint32_t flags, int p, const int cv[4], size_t at)
+{
+	const int profile = (int)img.profile;
+	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
+	float r, g, bl, a;
+	if (flags & 2u)
+	{
+		r = g = bl = a = int_as_float((int)0xFFFFE000u);
+	}
+	else if (flags & 4u)
+	{
+		r = int_as_float((int)s.ep[k][0]); g = int_as_float((int)s.ep[k][1]); bl = int_as_float((int)s.ep[k][2]); a = int_as_float((int)s.ep[k][3]);
+	}
+	else
+	{
+		const uint32_t lns = s.lns[k][p];
+		int hf[4];
+		for (int q = 0; q < 4; q++)
+		{
+			int cval = cv[q];
+			if (u8_out) cval = (cval >> 8) * 257;
+			const bool is_lns = (lns & (q == 3 ? 2u : 1u)) != 0u;
+			hf[q] = is_lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
+		}
+		// FP16 output through the identity swizzle: binary16 -> float -> binary16 gives every finite value back
+		// unchanged, so the four halves are stored as they are (infinities / NaNs take the general route)
+		const bool halves_out = img.data_type == 1 && img.swz[0] == 0 && img.swz[1] == 1 && img.swz[2] == 2 && img.swz[3] == 3;
+		if (halves_out && ((hf[0] & 0x7C00) != 0x7C00) && ((hf[1] & 0x7C00) != 0x7C00) && ((hf[2] & 0x7C00) != 0x7C00) && ((hf[3] & 0x7C00) != 0x7C00))
+		{
+			const uint32_t lo = (uint32_t)(hf[0] & 0xFFFF) | ((uint32_t)hf[1] << 16), hi = (uint32_t)(hf[2] & 0xFFFF) | ((uint32_t)hf[3] << 16);
+			const uint64_t px = ((uint64_t)hi << 32) | lo;
+			__builtin_memcpy(static_cast<uint8_t*>(img.data) + at * 2, &px, 8);
+			return;
+		}
+		r = half_to_float((uint16_t)hf[0]); g = half_to_float((uint16_t)hf[1]); bl = half_to_float((uint16_t)hf[2]); a = half_to_float((uint16_t)hf[3]);
+	}
+	store_texel_at(img, at, r, g, bl, a);
+}
+
+/* The RGBA8 pixel of four interpolation results x[q] = endpoint record [q] + [4 + q] * weight (byte 2 = the value's top
+ * byte, byte 3 = 0) through a swizzle that picks channels or constants (sel = swizzle_selector). */
+WV_FN uint32_t pixel_from_lerps(uint32_t sel, const uint32_t x[4])
+{
+	const uint32_t rg = byte_perm(x[1], x[0], 0x0C0C0602u), ba = byte_perm(x[3], x[2], 0x0C0C0602u);   // byte 2 of each, side by side
+	return byte_perm(ba, rg, sel);
+}
+
+/* The texel phase of a run of 2D blocks: the image rows the run covers, one after the other.  kMulti / kDual: the run
+ * has blocks with more than one partition / with two weight planes (wave-uniform; a run without them skips the partition
+ * hash and reads its endpoints once per column / reads one plane).  kGeneral: some texel of the run does not leave as an
+ * integer-built RGBA8 pixel (store_texel_general); the builds without it are the RGBA8 decoder's inner loops. */
+template <bool kMulti, bool kDual, bool kGeneral>
+WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, uint32_t bz, int count, DecodeBatch& s)
+{
+	const int block_x = (int)img.block_x, block_y = (int)img.block_y;
+	const bool small_block = block_x * block_y < 31;
+	const bool bytes_out = img.data_type == 0;
+	const uint32_t swz_sel = swizzle_selector(img.swz);
+	const uint32_t y0 = by * (uint32_t)block_y;
+	const int rows = (int)(img.dim_y - y0 < (uint32_t)block_y ? img.dim_y - y0 : (uint32_t)block_y);
+	const int row_len = count * block_x;
+	const uint32_t x0 = bx0 * (uint32_t)block_x;
+	for (int c0 = 0; c0 < row_len; c0 += 64)
+	{
+		WV_FOR64(l, i_min(64, row_len - c0))
+		{
+			const int col = c0 + l;
+			const int k = (int)(umul24((uint32_t)col, img.bx_inv16) >> 16);
+			const int tx = col - mul24(k, block_x);
+			const uint32_t xi = x0 + (uint32_t)col;
+			if (xi >= img.dim_x) continue;
+			const U32x4 rec = load_u32x4_aligned(s.rec[k]);
+			const uint32_t ra = rec.x, rc = rec.z, cpx = rec.w;
+			const bool fast = !kGeneral || (bytes_out && (ra & 8u) != 0u);         // the pixel comes from integers (or is the block's constant one)
+			const bool payload = (ra & 1u) == 0u;
+			const int wx = (int)(rc & 15u), wy = (int)((rc >> 4) & 15u);
+			const bool dual = kDual && (rc & 0x1000u) != 0u;
+			const int parts = (int)((rc >> 13) & 7u);
+			const int plane2 = dual ? (int)((rc >> 16) & 3u) : -1;
+			// infill: the column's share (ref: unpack_weights :89 via init_decimation_info_2d, astcenc_block_sizes.cpp:261-330)
+			const int gs = mad24(mul24((int)img.ds, tx), wx - 1, 32) >> 6;
+			const int js = gs >> 4, fs = gs & 0xF;
+			const int stride = dual ? 2 : 1;
+			const uint8_t* wcol = s.weights[k] + mul24(js, stride);
+			const int wrow = mul24(wx, stride);
+			const int dty = mul24((int)img.dt, wy - 1);
+			// partition hash: the column's share of the four terms
+			uint32_t hx[4] = { 0u, 0u, 0u, 0u }, hy[4] = { 0u, 0u, 0u, 0u };
+			if (kMulti)
+			{
+				const uint32_t xs = (uint32_t)(small_block ? tx << 1 : tx);
+				const U32x4 ht = load_u32x4_aligned(s.hash[k]);
+				const uint32_t term[4] = { ht.x, ht.y, ht.z, ht.w };
+				for (int q = 0; q < 4; q++)
+				{
+					hx[q] = umad24(term[q] & 0xFFu, xs, term[q] >> 24);
+					hy[q] = (term[q] >> 8) & 0xFFu;
+				}
+			}
+			const uint32_t* epk = s.ep[k];
+			U32x4 e0 = { 0u, 0u, 0u, 0u }, e1 = { 0u, 0u, 0u, 0u };
+			if (!kMulti) { e0 = load_u32x4_aligned(epk); e1 = load_u32x4_aligned(epk + 4); }
+			size_t at = (((size_t)bz * img.dim_y + y0) * img.dim_x + xi) * 4;      // (2D blocks: layer bz of the stream is slice bz of the image)
+			for (int ty = 0; ty < rows; ty++, at += (size_t)img.dim_x * 4)
+			{
+				int cv[4] = { 0, 0, 0, 0 };
+				uint32_t px = cpx;
+				int p = 0;
+				if (payload)
+				{
+					const int gt = mad24(dty, ty, 32) >> 6;
+					const int jt = gt >> 4, ft = gt & 0xF;
+					const int w11 = mad24(fs, ft, 8) >> 4;
+					const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
+					// A tap whose factor is zero may lie past the grid (the last row / column interpolates with factor 0): its product is
+					// zero whatever is read there, and the read stays inside the scratch -- so the four taps are read unconditionally.
+					const uint8_t* g = wcol + mul24(jt, wrow);
+					const int w0 = mad24(g[wrow + stride], w11, mad24(g[wrow], w10, mad24(g[stride], w01, mad24(g[0], w00, 8)))) >> 4;
+					int w1 = w0;
+					if (kDual && dual) w1 = mad24(g[wrow + 3], w11, mad24(g[wrow + 1], w10, mad24(g[3], w01, mad24(g[1], w00, 8)))) >> 4;
+					if (kMulti)
+					{
+						if (parts > 1)
+						{
+							const uint32_t ys = (uint32_t)(small_block ? ty << 1 : ty);
+							const uint32_t a = umad24(hy[0], ys, hx[0]) & 0x3Fu, b = umad24(hy[1], ys, hx[1]) & 0x3Fu;
+							const uint32_t c = umad24(hy[2], ys, hx[2]) & 0x3Fu, d = umad24(hy[3], ys, hx[3]) & 0x3Fu;
+							p = (a >= b && a >= c && a >= d) ? 0 : (b >= c && b >= d) ? 1 : c >= d ? 2 : 3;
+						}
+						e0 = load_u32x4_aligned(epk + p * 8); e1 = load_u32x4_aligned(epk + p * 8 + 4);
+					}
+					// (ref: lerp_color_int :37; the step (endpoint1 - endpoint0) * 4 and the weight fit 24 bits)
+					uint32_t x[4];
+					x[0] = (uint32_t)mad24((int)e1.x, kDual && plane2 == 0 ? w1 : w0, (int)e0.x);
+					x[1] = (uint32_t)mad24((int)e1.y, kDual && plane2 == 1 ? w1 : w0, (int)e0.y);
+					x[2] = (uint32_t)mad24((int)e1.z, kDual && plane2 == 2 ? w1 : w0, (int)e0.z);
+					x[3] = (uint32_t)mad24((int)e1.w, kDual && plane2 == 3 ? w1 : w0, (int)e0.w);
+					if (fast) px = pixel_from_lerps(swz_sel, x);
+					else for (int q = 0; q < 4; q++) cv[q] = (int)(x[q] >> 8);
+				}
+				if (fast) __builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
+				else store_texel_general(img, s, k, ra, p, cv, at);
+			}
+		}
+	}
+}
+
+/* Decode blocks bx0 .. bx0 + count - 1 (count <= DECODE_BATCH) of block row `by`, layer `bz` of the stream into the image.
+ * All 64 lanes call this.  Same arithmetic as decode_block(), block by block. */
+WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint32_t bx0, uint32_t by, uint32_t bz, int count, DecodeBatch& s)
 {
 	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
 	const int T = block_x * block_y * block_z;
 	const int profile = (int)img.profile;
 	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
 	const float error_nan = int_as_float((int)0xFFFFE000u);
+	// RGBA8 output whose swizzle only picks channels or constants: a decoded UNORM16 value v leaves as the byte
+	// v >> 8 (exact: for every byte b, b * 257 -> FP16 -> float -> * 255 + 0.5 -> int gives b back, which is the
+	// reference's route, astcenc_image.cpp:345-420 after decompress_symbolic.cpp:66-120), so the texel is built
+	// from integers alone; LNS (HDR) endpoints and the Z swizzle take the general route.
+	const bool bytes_swz = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
+	const size_t first = ((size_t)bz * img.blocks_y + by) * img.blocks_x + bx0;
+
+	// ---- the weight unquantization table of this wave ----
+	WV_FOR(i, 12 * 32 / 4)
+	{
+		const uint32_t v = weight_unquant_lut_word(i);
+		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
+	}
 
 	// ---- headers and constant colours: one lane per block ----
-	WV_FOR(k, count)
+	bool multi_part = false, dual_part = false;      // per-lane partials, folded below
+	WV_FOR64(k, count)
 	{
 		Bits128 blk;
-		const uint32_t* p = reinterpret_cast<const uint32_t*>(blocks + (size_t)(first + (uint32_t)k) * 16);
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(blocks + (first + (size_t)k) * 16);
 		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
-		const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z);
+		const DecodeTables* tabs = img.tabs;
+#if WV_DEVICE
+		__builtin_assume(tabs != nullptr);       // (the launch always passes the tables: no arithmetic fallback in the kernel)
+#endif
+		const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z, tabs);
 		bool error = h.error;
 		float cc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 		if (h.constant && !error)
@@ -986,225 +1372,197 @@ WV_FN void decode_block_batch(const DecodeImage& img, const uint8_t* blocks, uin
 				}
 			}
 		}
+		const bool skip = error || h.constant;
+		const Btq wq = btq_of(h.wquant), cq = btq_of(skip ? 0 : h.cquant);
+		const int wkind = wq.trits ? 1 : wq.quints ? 2 : 0, ckind = cq.trits ? 1 : cq.quints ? 2 : 0;
+		const int wcount = h.wx * h.wy * h.wz;
+		const int real_wcount = h.dual ? 2 * wcount : wcount;
+		const int wgroups = skip ? 0 : ise_group_count(real_wcount, wkind), cgroups = skip ? 0 : ise_group_count(h.nvals, ckind);
+		const int wglen = wkind == 1 ? 5 * wq.bits + 8 : wkind == 2 ? 3 * wq.bits + 7 : 4 * wq.bits;
+		uint32_t cpx = 0u;
+		if (skip && img.data_type == 0) cpx = error ? pack_texel_u8(img, error_nan, error_nan, error_nan, error_nan) : pack_texel_u8(img, cc[0], cc[1], cc[2], cc[3]);
+		// (fast: the texel phase forms -- or, for these two kinds of block, already has -- the RGBA8 pixel; LNS endpoints clear the flag)
+		const bool fast = skip ? img.data_type == 0 : bytes_swz;
+		s.rec[k][0] = (skip ? 1u : 0u) | (error ? 2u : 0u) | ((h.constant && !error) ? 4u : 0u) | (fast ? 8u : 0u) | ((uint32_t)wq.bits << 4) | ((uint32_t)wkind << 8) |
+		              ((uint32_t)h.wquant << 12) | ((uint32_t)wgroups << 16) | ((uint32_t)wglen << 24);
+		s.rec[k][1] = (uint32_t)cq.bits | ((uint32_t)ckind << 4) | ((uint32_t)(skip ? 0 : h.cquant) << 8) | ((uint32_t)h.nvals << 16) | ((uint32_t)h.color_start << 24);
+		s.rec[k][2] = (uint32_t)h.wx | ((uint32_t)h.wy << 4) | ((uint32_t)h.wz << 8) | ((h.dual ? 1u : 0u) << 12) | ((uint32_t)h.parts << 13) |
+		              (((uint32_t)h.plane2 & 3u) << 16) | ((uint32_t)cgroups << 20);
+		s.rec[k][3] = cpx;
+		if (!skip && h.parts > 1)
 		{
-			// (one lane per block: the two divides here replace two per texel)
-			const uint32_t b = first + (uint32_t)k;
-			const uint32_t row = b / img.blocks_x;
-			const uint32_t bxi = b - row * img.blocks_x;
-			const uint32_t bzi = row / img.blocks_y;
-			const uint32_t byi = row - bzi * img.blocks_y;
-			s.rec[k].origin[0] = bxi * (uint32_t)block_x; s.rec[k].origin[1] = byi * (uint32_t)block_y; s.rec[k].origin[2] = bzi * (uint32_t)block_z;
+			const PartitionHash ph = partition_hash_setup(h.seed, h.parts);
+			for (int q = 0; q < 4; q++) s.hash[k][q] = ph.term[q];
 		}
+		else for (int q = 0; q < 4; q++) s.hash[k][q] = 0u;
+		for (int q = 0; q < 4; q++) { s.lns[k][q] = 0; s.fmt[k][q] = (uint8_t)h.fmt[q]; }
+		if (h.constant && !error)
 		{
-			const Btq wq = btq_of(h.wquant), cq = btq_of(h.cquant);
-			const int wcount = h.wx * h.wy * h.wz;
-			const uint32_t skip = ((error || h.constant) ? 1u : 0u) | (error ? 2u : 0u) | (h.constant ? 4u : 0u);
-			DecodeBlockRec& r = s.rec[k];
-			r.a = skip | ((uint32_t)wq.bits << 8) | ((wq.trits ? 1u : wq.quints ? 2u : 0u) << 16) | ((uint32_t)h.wquant << 24);
-			r.b = (uint32_t)cq.bits | ((cq.trits ? 1u : cq.quints ? 2u : 0u) << 8) | ((uint32_t)h.cquant << 16) | ((uint32_t)h.nvals << 24);
-			r.c = (uint32_t)(h.dual ? 2 * wcount : wcount) | ((h.dual ? 1u : 0u) << 8) | ((uint32_t)h.color_start << 16) | ((uint32_t)h.parts << 24);
-			r.d = (uint32_t)h.wx | ((uint32_t)h.wy << 8) | ((uint32_t)h.wz << 16) | (((uint32_t)h.plane2 & 0xFFu) << 24);
-			r.pad = 0u;
-			if (!skip && h.parts > 1) r.hash = partition_hash_setup(h.seed, h.parts);
-			else { r.hash.term[0] = 0u; r.hash.term[1] = 0u; r.hash.term[2] = 0u; r.hash.term[3] = 0u; }
+			for (int q = 0; q < 4; q++) s.ep[k][q] = (uint32_t)float_as_int(cc[q]);
 		}
+		if (!skip)
 		{
+			uint32_t* bits = decode_batch_bits(s, k);
+			uint32_t* ws = decode_batch_wstream(s, k);
 			const Bits128 rv = bits_reversed(blk);
-			for (int q = 0; q < 4; q++) { s.bits[k][q] = blk.w[q]; s.rev[k][q] = rv.w[q]; }
-			s.bits[k][4] = 0u; s.bits[k][5] = 0u; s.rev[k][4] = 0u; s.rev[k][5] = 0u;
+			for (int q = 0; q < 4; q++) bits[q] = blk.w[q];
+			bits[4] = 0u; bits[5] = 0u;
+			// the weight stream is 24..96 bits long: bits past its end read as zeros, so that a short last group needs no mask
+			for (int q = 0; q < 3; q++)
+			{
+				const int left = h.wbits - 32 * q;
+				ws[q] = left >= 32 ? rv.w[q] : left <= 0 ? 0u : rv.w[q] & ((1u << left) - 1u);
+			}
+			ws[3] = 0u;
+			multi_part = multi_part || h.parts > 1;
+			dual_part = dual_part || h.dual;
 		}
-		for (int q = 0; q < 4; q++) { s.constant[k][q] = cc[q]; s.fmt[k][q] = (uint8_t)h.fmt[q]; }
 	}
+	const bool any_multi = wv_any(multi_part), any_dual = wv_any(dual_part);
 	WV_SYNC();
 
-	// ---- weights and colour values: one lane per (block, BISE group), as many lanes per block as the fullest block needs ----
-	int wmax_part = 0, cmax_part = 0;                 // per-lane partial maxima (lane k looked at block k), folded below
-	WV_FOR(k, count)
+	// ---- weights and colour values: lane l works on block l & 31, on every second group of it from group l >> 5 on ----
+	WV_FOR64(l, 64)
 	{
-		const DecodeBlockRec& r = s.rec[k];
-		if (!(r.a & 1u))
+		const int k = l & 31;
+		if (k >= count) continue;
+		const uint32_t ra = s.rec[k][0];
+		const int groups = (int)((ra >> 16) & 63u);
+		const int bits = (int)((ra >> 4) & 7u), kind = (int)((ra >> 8) & 3u), per = ise_group_size(kind), glen = (int)((ra >> 24) & 31u);
+		const uint32_t* ws = decode_batch_wstream(s, k);
+		const uint8_t* unq = s.wunq + ((ra >> 12) & 15u) * 32u;
+		for (int g = l >> 5; g < groups; g += 2)
 		{
-			const int wper = ise_group_size((int)((r.a >> 16) & 0xFFu)), cper = ise_group_size((int)((r.b >> 8) & 0xFFu));
-			wmax_part = i_max(wmax_part, ((int)(r.c & 0xFFu) + wper - 1) / wper);
-			cmax_part = i_max(cmax_part, ((int)(r.b >> 24) + cper - 1) / cper);
+			uint32_t sym[5];
+			weight_group_lut(ws, mul24(g, glen), bits, kind, sym);
+			// (the table reads first, then the stores: in program order they would wait for one another)
+			const uint8_t w0 = unq[sym[0]], w1 = unq[sym[1]], w2 = unq[sym[2]], w3 = unq[sym[3]], w4 = unq[sym[4]];
+			uint8_t* out = s.weights[k] + mul24(g, per);
+			out[0] = w0; out[1] = w1; out[2] = w2;
+			if (per > 3) out[3] = w3;
+			if (per > 4) out[4] = w4;
 		}
 	}
-	const int wmax = wv_all_imax(wmax_part), cmax = wv_all_imax(cmax_part);      // groups per block, at most 32 / 8
-	if (wmax > 0)
+	WV_FOR64(l, 64)
 	{
-		const uint32_t winv = ((1u << 20) + (uint32_t)wmax - 1u) / (uint32_t)wmax;      // j / wmax == (j * winv) >> 20 for j < count * wmax (one divide per batch)
-		WV_FOR(j, count * wmax)
+		const int k = l & 31;
+		if (k >= count) continue;
+		const uint32_t rb = s.rec[k][1];
+		const int groups = (int)((s.rec[k][2] >> 20) & 7u);
+		const int nvals = (int)((rb >> 16) & 31u);
+		const int kind = (int)((rb >> 4) & 3u), per = ise_group_size(kind);
+		for (int g = l >> 5; g < groups; g += 2)
 		{
-			const int k = (int)(((uint32_t)j * winv) >> 20), g = j - k * wmax;
-			const uint32_t ra = s.rec[k].a, rc = s.rec[k].c;
-			const int real_wcount = (int)(rc & 0xFFu);
-			const int kind = (int)((ra >> 16) & 0xFFu), per = ise_group_size(kind);
-			if ((ra & 1u) || g * per >= real_wcount) continue;
 			int sym[5];
-			const int n = ise_group_lut(s.rev[k], 0, (int)((ra >> 8) & 0xFFu), kind, real_wcount, g, sym);
+			const int n = ise_group_lut(decode_batch_bits(s, k), (int)((rb >> 24) & 31u), (int)(rb & 15u), kind, nvals, g, sym);
 			for (int e = 0; e < 5; e++)
 			{
 				if (e >= n) break;
-				const int i = g * per + e;
-				const int w = weight_unquant_lut((int)(ra >> 24), sym[e]);
-				if (rc & 0x100u) s.payload[k].weights[i & 1][i >> 1] = (uint8_t)w;
-				else s.payload[k].weights[0][i] = (uint8_t)w;
-			}
-		}
-	}
-	if (cmax > 0)
-	{
-		const uint32_t cinv = ((1u << 20) + (uint32_t)cmax - 1u) / (uint32_t)cmax;
-		WV_FOR(j, count * cmax)
-		{
-			const int k = (int)(((uint32_t)j * cinv) >> 20), g = j - k * cmax;
-			const uint32_t ra = s.rec[k].a, rb = s.rec[k].b, rc = s.rec[k].c;
-			const int nvals = (int)(rb >> 24);
-			const int kind = (int)((rb >> 8) & 0xFFu), per = ise_group_size(kind);
-			if ((ra & 1u) || g * per >= nvals) continue;
-			int sym[5];
-			const int n = ise_group_lut(s.bits[k], (int)((rc >> 16) & 0xFFu), (int)(rb & 0xFFu), kind, nvals, g, sym);
-			for (int e = 0; e < 5; e++)
-			{
-				if (e >= n) break;
-				s.payload[k].colors[g * per + e] = (uint8_t)color_unquant_lut((int)((rb >> 16) & 0xFFu), sym[e]);
+				s.colors[k][g * per + e] = (uint8_t)color_unquant_lut((int)((rb >> 8) & 31u), sym[e]);
 			}
 		}
 	}
 	WV_SYNC();
-	// ---- endpoints: one lane per (block, partition) ----
-	WV_FOR(j, count * 4)
+	// ---- endpoints: lane l works on block l & 31, partitions l >> 5 and (l >> 5) + 2 ----
+	WV_FOR64(l, 64)
 	{
-		const int k = j >> 2, p = j & 3;
-		const DecodeBlockRec& r = s.rec[k];
-		if ((r.a & 1u) || p >= (int)(r.c >> 24)) continue;
-		DecodeScratch& ps = s.payload[k];
-		int start = 0;
-		for (int i = 0; i < 4; i++) start += i < p ? 2 * (s.fmt[k][i] >> 2) + 2 : 0;
-		const int f = s.fmt[k][p];
-		uint8_t in[8];
-		const int n = 2 * (f >> 2) + 2;
-		for (int q = 0; q < 8; q++) in[q] = q < n ? ps.colors[start + q] : 0;
-		i4 e0, e1;
-		unpack_color_endpoints(profile, f, in, e0, e1);
-		uint16_t* o = ps.ep[p];
-		o[0] = (uint16_t)e0.x; o[1] = (uint16_t)e0.y; o[2] = (uint16_t)e0.z; o[3] = (uint16_t)e0.w;
-		o[4] = (uint16_t)e1.x; o[5] = (uint16_t)e1.y; o[6] = (uint16_t)e1.z; o[7] = (uint16_t)e1.w;
-		bool rgb_lns, alpha_lns;
-		endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
-		ps.lns[p][0] = rgb_lns ? 1 : 0;
-		ps.lns[p][1] = alpha_lns ? 1 : 0;
+		const int k = l & 31;
+		if (k >= count) continue;
+		const uint32_t ra = s.rec[k][0];
+		if (ra & 1u) continue;
+		const int parts = (int)((s.rec[k][2] >> 13) & 7u);
+		for (int p = l >> 5; p < parts; p += 2)
+		{
+			int start = 0;
+			for (int i = 0; i < 4; i++) start += i < p ? 2 * (s.fmt[k][i] >> 2) + 2 : 0;
+			const int f = s.fmt[k][p];
+			uint8_t in[8];
+			const int n = 2 * (f >> 2) + 2;
+			for (int q = 0; q < 8; q++) in[q] = q < n ? s.colors[k][start + q] : 0;
+			i4 e0, e1;
+			unpack_color_endpoints(profile, f, in, e0, e1);
+			bool rgb_lns, alpha_lns;
+			endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
+			s.lns[k][p] = (uint8_t)((rgb_lns ? 1 : 0) | (alpha_lns ? 2 : 0));
+			uint32_t* o = s.ep[k] + p * 8;
+			o[0] = (uint32_t)(e0.x * 256 + 128); o[1] = (uint32_t)(e0.y * 256 + 128); o[2] = (uint32_t)(e0.z * 256 + 128); o[3] = (uint32_t)(e0.w * 256 + 128);
+			o[4] = (uint32_t)((e1.x - e0.x) * 4); o[5] = (uint32_t)((e1.y - e0.y) * 4); o[6] = (uint32_t)((e1.z - e0.z) * 4); o[7] = (uint32_t)((e1.w - e0.w) * 4);
+		}
 	}
 	WV_SYNC();
-
-	// ---- texels: one lane per (block, texel) ----
-	const bool small_block = T < 31;
-	const uint32_t t_inv = img.t_inv24;
-	// RGBA8 output whose swizzle only picks channels or constants: a decoded UNORM16 value v leaves as the byte
-	// v >> 8 (exact: for every byte b, b * 257 -> FP16 -> float -> * 255 + 0.5 -> int gives b back, which is the
-	// reference's route, astcenc_image.cpp:345-420 after decompress_symbolic.cpp:66-120), so the texel is built
-	// from integers alone; LNS (HDR) endpoints, error and constant blocks and the Z swizzle take the general route.
-	const bool bytes_out = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
-	const bool identity_swz = img.swz[0] == 0 && img.swz[1] == 1 && img.swz[2] == 2 && img.swz[3] == 3;
-	const bool halves_out = img.data_type == 1 && identity_swz;
-	// 2D blocks: lanes in (texel row, block, column) order, so that consecutive lanes write consecutive pixels of
-	// an image row across the blocks of the batch (which are neighbours in x unless the batch wraps a block row)
-	const int row_len = count * block_x;
-	const uint32_t row_inv22 = block_z == 1 ? ((1u << 22) + (uint32_t)row_len - 1u) / (uint32_t)row_len : 0u;   // (one divide per batch)
-	WV_FOR(j, count * T)
+	// (a block with LNS endpoints in any partition leaves the integer pixel path)
+	bool general_part = false;
+	WV_FOR64(k, count)
 	{
-		int k, tx, ty, tz;
-		if (block_z == 1)
+		uint32_t any_lns;
+		__builtin_memcpy(&any_lns, s.lns[k], 4);
+		uint32_t ra = s.rec[k][0];
+		if (any_lns) { ra &= ~8u; s.rec[k][0] = ra; }
+		general_part = general_part || !(ra & 8u);
+	}
+	const bool any_general = wv_any(general_part);
+	WV_SYNC();
+
+	// ---- texels ----
+	if (block_z == 1)
+	{
+		if (any_general) decode_row_texels<true, true, true>(img, bx0, by, bz, count, s);
+		else if (any_multi)
 		{
-			ty = (int)(((uint32_t)j * row_inv22) >> 22);
-			const int rem = j - ty * row_len;
-			k = (int)(((uint32_t)rem * img.bx_inv16) >> 16);
-			tx = rem - k * block_x;
-			tz = 0;
+			if (any_dual) decode_row_texels<true, true, false>(img, bx0, by, bz, count, s);
+			else decode_row_texels<true, false, false>(img, bx0, by, bz, count, s);
 		}
 		else
 		{
-			k = (int)(((uint32_t)j * t_inv) >> 24);
+			if (any_dual) decode_row_texels<false, true, false>(img, bx0, by, bz, count, s);
+			else decode_row_texels<false, false, false>(img, bx0, by, bz, count, s);
+		}
+	}
+	else
+	{
+		// 3D blocks: one lane per (block, texel)
+		const bool small_block = T < 31;
+		const uint32_t swz_sel = swizzle_selector(img.swz);
+		WV_FOR(j, count * T)
+		{
+			const int k = (int)(((uint32_t)j * img.t_inv24) >> 24);
 			const int t = j - k * T;
-			tz = (int)(((uint32_t)t * img.bxy_inv16) >> 16);
+			const int tz = (int)(((uint32_t)t * img.bxy_inv16) >> 16);
 			const int trem = t - tz * (block_x * block_y);
-			ty = (int)(((uint32_t)trem * img.bx_inv16) >> 16);
-			tx = trem - ty * block_x;
-		}
-		const DecodeBlockRec& rec = s.rec[k];
-		const uint32_t xi = rec.origin[0] + (uint32_t)tx;
-		const uint32_t yi = rec.origin[1] + (uint32_t)ty;
-		const uint32_t zi = rec.origin[2] + (uint32_t)tz;
-		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
-		const size_t texel_index = ((size_t)zi * img.dim_y + yi) * img.dim_x + xi;
-
-		float r, g, bl, a;
-		const uint32_t flags = rec.a;
-		if (flags & 2u)
-		{
-			r = g = bl = a = error_nan;
-		}
-		else if (flags & 4u)
-		{
-			r = s.constant[k][0]; g = s.constant[k][1]; bl = s.constant[k][2]; a = s.constant[k][3];
-		}
-		else
-		{
-			const DecodeScratch& ps = s.payload[k];
-			const uint32_t rc = rec.c, rd = rec.d;
-			const bool dual = (rc & 0x100u) != 0;
-			const int parts = (int)(rc >> 24);
-			const int plane2 = dual ? (int)(rd >> 24) : -1;
-			int wp[2];
-			infill_texel_weights((int)(rd & 0xFFu), (int)((rd >> 8) & 0xFFu), (int)((rd >> 16) & 0xFFu), dual, ps.weights,
-			                     (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
-			const int p = parts == 1 ? 0 : partition_from_hash(rec.hash, tx, ty, tz, small_block);
-			const uint16_t* e = ps.ep[p];
-			int cv[4];
-			for (int q = 0; q < 4; q++)
+			const int ty = (int)(((uint32_t)trem * img.bx_inv16) >> 16);
+			const int tx = trem - ty * block_x;
+			const uint32_t xi = (bx0 + (uint32_t)k) * (uint32_t)block_x + (uint32_t)tx;
+			const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
+			const uint32_t zi = bz * (uint32_t)block_z + (uint32_t)tz;
+			if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
+			const size_t at = (((size_t)zi * img.dim_y + yi) * img.dim_x + xi) * 4;
+			const uint32_t ra = s.rec[k][0], rc = s.rec[k][2];
+			const bool fast = img.data_type == 0 && (ra & 8u) != 0u;
+			uint32_t px = s.rec[k][3];
+			int cv[4] = { 0, 0, 0, 0 };
+			int p = 0;
+			if (!(ra & 1u))
 			{
-				const int wk = q == plane2 ? wp[1] : wp[0];
-				cv[q] = (e[q] * (64 - wk) + e[4 + q] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
-			}
-			if (bytes_out && !(ps.lns[p][0] | ps.lns[p][1]))
-			{
-				uint32_t px = 0;
-				if (identity_swz)
+				const bool dual = (rc & 0x1000u) != 0u;
+				const int parts = (int)((rc >> 13) & 7u);
+				const int plane2 = dual ? (int)((rc >> 16) & 3u) : -1;
+				int wp[2];
+				infill_texel_weights((int)(rc & 15u), (int)((rc >> 4) & 15u), (int)((rc >> 8) & 15u), dual, s.weights[k], s.weights[k] + (dual ? 1 : 0), dual ? 2 : 1,
+				                     (int)img.ds, (int)img.dt, (int)img.dr, block_z, tx, ty, tz, wp);
+				if (parts > 1)
 				{
-					px = (uint32_t)(cv[0] >> 8) | ((uint32_t)(cv[1] >> 8) << 8) | ((uint32_t)(cv[2] >> 8) << 16) | ((uint32_t)(cv[3] >> 8) << 24);
+					PartitionHash ph;
+					for (int q = 0; q < 4; q++) ph.term[q] = s.hash[k][q];
+					p = partition_from_hash(ph, tx, ty, tz, small_block);
 				}
-				else
-				{
-					for (int q = 0; q < 4; q++)
-					{
-						const uint32_t sw = img.swz[q];
-						const uint32_t v = sw == 4 ? 0u : sw == 5 ? 255u : (uint32_t)(cv[sw & 3] >> 8);
-						px |= v << (8 * q);
-					}
-				}
-				__builtin_memcpy(static_cast<uint8_t*>(img.data) + texel_index * 4, &px, 4);
-				continue;
+				uint32_t x[4];
+				for (int q = 0; q < 4; q++) x[q] = s.ep[k][p * 8 + q] + s.ep[k][p * 8 + 4 + q] * (uint32_t)(q == plane2 ? wp[1] : wp[0]);      // (ref: lerp_color_int :37)
+				if (fast) px = pixel_from_lerps(swz_sel, x);
+				else for (int q = 0; q < 4; q++) cv[q] = (int)(x[q] >> 8);
 			}
-			int hf[4];
-			for (int q = 0; q < 4; q++)
-			{
-				int cval = cv[q];
-				if (u8_out) cval = (cval >> 8) * 257;
-				const bool lns = ps.lns[p][q == 3 ? 1 : 0] != 0;
-				hf[q] = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
-			}
-			// FP16 output through the identity swizzle: binary16 -> float -> binary16 gives every finite value back
-			// unchanged, so the four halves are stored as they are (infinities / NaNs take the general route)
-			if (halves_out && ((hf[0] & 0x7C00) != 0x7C00) && ((hf[1] & 0x7C00) != 0x7C00) && ((hf[2] & 0x7C00) != 0x7C00) && ((hf[3] & 0x7C00) != 0x7C00))
-			{
-				const uint32_t lo = (uint32_t)(hf[0] & 0xFFFF) | ((uint32_t)hf[1] << 16), hi = (uint32_t)(hf[2] & 0xFFFF) | ((uint32_t)hf[3] << 16);
-				const uint64_t px = ((uint64_t)hi << 32) | lo;
-				__builtin_memcpy(static_cast<uint8_t*>(img.data) + texel_index * 8, &px, 8);
-				continue;
-			}
-			r = half_to_float((uint16_t)hf[0]); g = half_to_float((uint16_t)hf[1]); bl = half_to_float((uint16_t)hf[2]); a = half_to_float((uint16_t)hf[3]);
+			if (fast) __builtin_memcpy(static_cast<uint8_t*>(img.data) + at, &px, 4);
+			else store_texel_general(img, s, k, ra, p, cv, at);
 		}
-		store_texel(img, xi, yi, zi, r, g, bl, a);
 	}
 	WV_SYNC();          // the batch scratch is reused by the next call
 }

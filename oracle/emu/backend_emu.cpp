@@ -202,15 +202,19 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	img.blocks_z = (dim_z + root->dim_z - 1) / root->dim_z;
 	img.profile = b->cfg.profile;
 	decode_image_prepare(img);
-	// the same batched routine the kernel runs (decode_block_batch), DECODE_BATCH blocks at a time
+	// the same batched routine the kernel runs (decode_row_batch): runs of DECODE_BATCH blocks of a block row
+	std::vector<DecodeTables> tabs(1);
+	decode_tables_build(tabs[0], (int)root->dim_x, (int)root->dim_y, (int)root->dim_z);
+	img.tabs = tabs.data();
 	std::vector<DecodeBatch> batch(1);
 	memset(static_cast<void*>(batch.data()), 0xCD, sizeof(DecodeBatch));
-	const uint32_t nblocks = img.blocks_x * img.blocks_y * img.blocks_z;
-	for (uint32_t first = 0; first < nblocks; first += (uint32_t)DECODE_BATCH)
-	{
-		const uint32_t left = nblocks - first;
-		decode_block_batch(img, job.host_blocks, first, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch[0]);
-	}
+	for (uint32_t bz = 0; bz < img.blocks_z; bz++)
+		for (uint32_t by = 0; by < img.blocks_y; by++)
+			for (uint32_t bx0 = 0; bx0 < img.blocks_x; bx0 += (uint32_t)DECODE_BATCH)
+			{
+				const uint32_t left = img.blocks_x - bx0;
+				decode_row_batch(img, job.host_blocks, bx0, by, bz, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch[0]);
+			}
 	if (dim_z > 1)
 		for (uint32_t z = 0; z < dim_z; z++) memcpy(job.host_slices[z], volume.data() + z * slice_bytes, slice_bytes);
 	return 0;
