@@ -1101,6 +1101,11 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 #ifndef ASTC_DECODE_BATCH
 #define ASTC_DECODE_BATCH 32
 #endif
+// 1: the wave keeps the trit / quint group tables of the weight decode in LDS (768 bytes more per wave) instead of reading
+// them from HBM through the vector cache
+#ifndef ASTC_DECODE_GROUP_LUT_LDS
+#define ASTC_DECODE_GROUP_LUT_LDS 0
+#endif
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
 static_assert(DECODE_BATCH == 32, "the lane maps of decode_row_batch pair lane l with block l & 31");
 
@@ -1119,6 +1124,9 @@ struct alignas(16) DecodeBatch {
 	// A constant-colour block keeps its four floats in [0][0..3].  (Four pad words: consecutive blocks on different banks.)
 	uint32_t ep[DECODE_BATCH][4 * 8 + 4];
 	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
+#if ASTC_DECODE_GROUP_LUT_LDS
+	uint16_t glut[256 + 128];            // trit_group_lut, quint_group_lut, copied once per wave
+#endif
 };
 
 // rec[0]: bit 0 no payload (error or constant colour), bit 1 error, bit 2 constant colour, bit 3 fast (RGBA8 pixel from integers),
@@ -1127,12 +1135,16 @@ struct alignas(16) DecodeBatch {
 // rec[2]: 0..3 grid x, 4..7 y, 8..11 z, 12 dual plane, 13..15 partitions, 16..17 second plane's component, 20..22 colour groups
 // rec[3]: error / constant block with RGBA8 output: the pixel
 
+// (the 128-bit reads of load_u32x4_aligned)
+static_assert(__builtin_offsetof(DecodeBatch, rec) % 16 == 0 && __builtin_offsetof(DecodeBatch, hash) % 16 == 0 && __builtin_offsetof(DecodeBatch, ep) % 16 == 0 &&
+              sizeof(uint32_t[4 * 8 + 4]) % 16 == 0, "DecodeBatch: records read as four words are 16-byte aligned");
+
 WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k] + 16; }
 WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 24; }
 
 /* The symbols of group `g` of a weight stream whose bits past its end are zero (so a short last group needs no mask):
  * ise_group_lut for the weight levels, whose groups fit a 32-bit window (at most 5 * 3 + 8 bits). */
-WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, uint32_t out[5])
+WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, const uint16_t* glut, uint32_t out[5])
 {
 	const int word = at >> 5, sh = at & 31;
 	const uint32_t g = funnel_shift_right(ws[word + 1], ws[word], sh);
@@ -1146,7 +1158,7 @@ WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, uint
 	{
 		const uint32_t t8 = ((g >> bits) & 3u) | (((g >> (2 * bits + 2)) & 3u) << 2) | (((g >> (3 * bits + 4)) & 1u) << 4) |
 		                    (((g >> (4 * bits + 5)) & 3u) << 5) | (((g >> (5 * bits + 7)) & 1u) << 7);
-		const uint32_t trits = trit_group_lut(t8);
+		const uint32_t trits = glut ? glut[t8] : trit_group_lut(t8);
 		out[0] = (((trits) & 3u) << bits) | (g & low_mask);
 		out[1] = (((trits >> 2) & 3u) << bits) | ((g >> (bits + 2)) & low_mask);
 		out[2] = (((trits >> 4) & 3u) << bits) | ((g >> (2 * bits + 4)) & low_mask);
@@ -1156,7 +1168,7 @@ WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, uint
 	else
 	{
 		const uint32_t q7 = ((g >> bits) & 7u) | (((g >> (2 * bits + 3)) & 3u) << 3) | (((g >> (3 * bits + 5)) & 3u) << 5);
-		const uint32_t quints = quint_group_lut(q7);
+		const uint32_t quints = glut ? glut[256 + q7] : quint_group_lut(q7);
 		out[0] = (((quints) & 7u) << bits) | (g & low_mask);
 		out[1] = (((quints >> 3) & 7u) << bits) | ((g >> (bits + 3)) & low_mask);
 		out[2] = (((quints >> 6) & 7u) << bits) | ((g >> (2 * bits + 5)) & low_mask);
@@ -1253,7 +1265,8 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 			const uint8_t* wcol = s.weights[k] + mul24(js, stride);
 			const int wrow = mul24(wx, stride);
 			const int dty = mul24((int)img.dt, wy - 1);
-			// partition hash: the column's share of the four terms
+			// partition hash: the column's share of the four terms, times four -- (hx + hy * y) & 0xFC is a term's six bits above
+			// two bits that rank the terms, so that the first of the largest terms is the largest key
 			uint32_t hx[4] = { 0u, 0u, 0u, 0u }, hy[4] = { 0u, 0u, 0u, 0u };
 			if (kMulti)
 			{
@@ -1262,8 +1275,8 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 				const uint32_t term[4] = { ht.x, ht.y, ht.z, ht.w };
 				for (int q = 0; q < 4; q++)
 				{
-					hx[q] = umad24(term[q] & 0xFFu, xs, term[q] >> 24);
-					hy[q] = (term[q] >> 8) & 0xFFu;
+					hx[q] = umad24(term[q] & 0xFFu, xs, term[q] >> 24) << 2;
+					hy[q] = ((term[q] >> 8) & 0xFFu) << 2;
 				}
 			}
 			const uint32_t* epk = s.ep[k];
@@ -1292,9 +1305,11 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 						if (parts > 1)
 						{
 							const uint32_t ys = (uint32_t)(small_block ? ty << 1 : ty);
-							const uint32_t a = umad24(hy[0], ys, hx[0]) & 0x3Fu, b = umad24(hy[1], ys, hx[1]) & 0x3Fu;
-							const uint32_t c = umad24(hy[2], ys, hx[2]) & 0x3Fu, d = umad24(hy[3], ys, hx[3]) & 0x3Fu;
-							p = (a >= b && a >= c && a >= d) ? 0 : (b >= c && b >= d) ? 1 : c >= d ? 2 : 3;
+							// (ref: select_partition, astcenc_partition_tables.cpp:216-245: a >= b && a >= c && a >= d -> 0, b >= c && b >= d -> 1, c >= d -> 2, else 3)
+							const uint32_t a = (umad24(hy[0], ys, hx[0]) & 0xFCu) | 3u, b = (umad24(hy[1], ys, hx[1]) & 0xFCu) | 2u;
+							const uint32_t c = (umad24(hy[2], ys, hx[2]) & 0xFCu) | 1u, d = umad24(hy[3], ys, hx[3]) & 0xFCu;
+							const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+							p = 3 - (int)((ab > cd ? ab : cd) & 3u);
 						}
 						e0 = load_u32x4_aligned(epk + p * 8); e1 = load_u32x4_aligned(epk + p * 8 + 4);
 					}
@@ -1336,6 +1351,14 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		const uint32_t v = weight_unquant_lut_word(i);
 		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
 	}
+#if ASTC_DECODE_GROUP_LUT_LDS
+	WV_FOR(i, (256 + 128) / 2)
+	{
+		const uint32_t v = i < 128 ? trit_group_lut(2u * (uint32_t)i) | (trit_group_lut(2u * (uint32_t)i + 1u) << 16)
+		                           : quint_group_lut(2u * (uint32_t)(i - 128)) | (quint_group_lut(2u * (uint32_t)(i - 128) + 1u) << 16);
+		__builtin_memcpy(s.glut + 2 * i, &v, 4);
+	}
+#endif
 
 	// ---- headers and constant colours: one lane per block ----
 	bool multi_part = false, dual_part = false;      // per-lane partials, folded below
@@ -1431,10 +1454,15 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		const int bits = (int)((ra >> 4) & 7u), kind = (int)((ra >> 8) & 3u), per = ise_group_size(kind), glen = (int)((ra >> 24) & 31u);
 		const uint32_t* ws = decode_batch_wstream(s, k);
 		const uint8_t* unq = s.wunq + ((ra >> 12) & 15u) * 32u;
+#if ASTC_DECODE_GROUP_LUT_LDS
+		const uint16_t* glut = s.glut;
+#else
+		const uint16_t* glut = nullptr;
+#endif
 		for (int g = l >> 5; g < groups; g += 2)
 		{
 			uint32_t sym[5];
-			weight_group_lut(ws, mul24(g, glen), bits, kind, sym);
+			weight_group_lut(ws, mul24(g, glen), bits, kind, glut, sym);
 			// (the table reads first, then the stores: in program order they would wait for one another)
 			const uint8_t w0 = unq[sym[0]], w1 = unq[sym[1]], w2 = unq[sym[2]], w3 = unq[sym[3]], w4 = unq[sym[4]];
 			uint8_t* out = s.weights[k] + mul24(g, per);

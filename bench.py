@@ -379,32 +379,38 @@ def device_quality(lib, ctx, cfg, d_img, d_blocks, dev):
     swz = A.Swizzle(*A.SWZ_RGBA)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ttype = A.TYPE_F16 if cfg["hdr"] else A.TYPE_U8
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     def timed(call, repeats=3):
         """Best wall time in ms of a synchronous device-API call (launch, kernel(s), the host's wait; the comparison
-        also copies 18 doubles back)."""
-        best = 1e9
+        also copies 18 doubles back), and the best time between two events on the call's stream around it (the kernel
+        plus the launch gap, without the host's wait)."""
+        best = best_ev = 1e9
         for _ in range(repeats):
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
+            ev0.record()
             assert call() == 0
+            ev1.record()
             torch.cuda.synchronize(dev)
             best = min(best, (time.perf_counter() - t0) * 1e3)
-        return best
+            best_ev = min(best_ev, ev0.elapsed_time(ev1))
+        return best, best_ev
 
     decode = lambda: lib.lib.astcenc_amd_decompress_image_device(ctx, d_blocks.data_ptr(), d_blocks.numel(), d_dec.data_ptr(), size, size, 1,
                                                                 ttype, ctypes.byref(swz), stream)
-    decode_ms = timed(decode)
+    decode_ms, decode_ev_ms = timed(decode, repeats=5)
     texel_bytes = d_img.element_size() * 4
     decode_bytes = d_blocks.numel() + size * size * texel_bytes
     timing = {"decode_ms": round(decode_ms, 3), "decode_gbps": round(decode_bytes / decode_ms / 1e6, 1),
-              "decode_hbm_frac": round(decode_bytes / decode_ms / 1e6 / 8000.0, 4)}
+              "decode_hbm_frac": round(decode_bytes / decode_ms / 1e6 / 8000.0, 4),
+              "decode_events_ms": round(decode_ev_ms, 3), "decode_events_hbm_frac": round(decode_bytes / decode_ev_ms / 1e6 / 8000.0, 4)}
     sums = A.ErrorSums()
     if not cfg["hdr"]:
         compare = lambda: lib.lib.astcenc_amd_compare_images_device(ctx, d_img.data_ptr(), ttype, d_dec.data_ptr(), ttype, size, size, 1, stream,
                                                                    ctypes.byref(sums))
-        compare_ms = timed(compare)
+        compare_ms, _ = timed(compare)
         timing.update({"compare_ms": round(compare_ms, 3), "compare_gbps": round(2 * size * size * texel_bytes / compare_ms / 1e6, 1),
-                       "what": "wall time of the synchronous astcenc_amd_decompress_image_device / _compare_images_device calls, best of 3"})
+                       "what": "decode_ms / compare_ms: wall time of the synchronous astcenc_amd_decompress_image_device / _compare_images_device calls (best of 5 / 3); decode_events_ms: between two events on the stream around the decode call"})
         return {"psnr_db_on_device": round(sums.psnr(), 4), "decode_compare_timing": timing}
     hdr = A.HdrErrorSums()
     e = lib.lib.astcenc_amd_compare_images_hdr_device(ctx, d_img.data_ptr(), ttype, d_dec.data_ptr(), ttype, size, size, 1, -10, 10, stream,
