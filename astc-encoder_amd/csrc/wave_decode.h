@@ -1106,6 +1106,11 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 #ifndef ASTC_DECODE_GROUP_LUT_LDS
 #define ASTC_DECODE_GROUP_LUT_LDS 0
 #endif
+// measurement builds (tools/build_variant.sh): leave decode_row_batch after phase n (1 headers, 2 weights, 3 colour values,
+// 4 endpoints); the product is built without it
+#ifndef ASTC_DECODE_STOP_AFTER
+#define ASTC_DECODE_STOP_AFTER 0
+#endif
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
 static_assert(DECODE_BATCH == 32, "the lane maps of decode_row_batch pair lane l with block l & 31");
 
@@ -1443,6 +1448,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	}
 	const bool any_multi = wv_any(multi_part), any_dual = wv_any(dual_part);
 	WV_SYNC();
+	if (ASTC_DECODE_STOP_AFTER == 1) return;
 
 	// ---- weights and colour values: lane l works on block l & 31, on every second group of it from group l >> 5 on ----
 	WV_FOR64(l, 64)
@@ -1471,6 +1477,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			if (per > 4) out[4] = w4;
 		}
 	}
+	if (ASTC_DECODE_STOP_AFTER == 2) return;
 	WV_FOR64(l, 64)
 	{
 		const int k = l & 31;
@@ -1491,6 +1498,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		}
 	}
 	WV_SYNC();
+	if (ASTC_DECODE_STOP_AFTER == 3) return;
 	// ---- endpoints: lane l works on block l & 31, partitions l >> 5 and (l >> 5) + 2 ----
 	WV_FOR64(l, 64)
 	{
@@ -1530,6 +1538,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	}
 	const bool any_general = wv_any(general_part);
 	WV_SYNC();
+	if (ASTC_DECODE_STOP_AFTER == 4) return;
 
 	// ---- texels ----
 	if (block_z == 1)

@@ -2,7 +2,7 @@
 """Same-process A/B of the decompression kernel: the streams the product library produces (-medium, several footprints,
 RGBA8 and RGBA16F output, an HDR stream) decoded by every library named on the command line; per library the best wall
 time of the synchronous device call, the time between two events on the stream around it, and whether the decoded image
-equals the first library's byte for byte.  usage: time_decode_ab.py <size> <lib.so> [<lib.so> ...]"""
+equals the first library's byte for byte.  usage: [AB_CASES=n] time_decode_ab.py <size> <lib.so> [<lib.so> ...]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
@@ -52,7 +52,7 @@ CASES = [("ldr 6x6 -medium -> U8", A.PRF_LDR, 6, 60.0, ldr, size, A.TYPE_U8, tor
          ("ldr 12x12 -medium -> U8", A.PRF_LDR, 12, 60.0, ldr, size, A.TYPE_U8, torch.uint8),
          ("ldr 6x6 -medium -> F16", A.PRF_LDR, 6, 60.0, ldr, size, A.TYPE_F16, torch.float16),
          ("hdr 6x6 -medium -> F16", A.PRF_HDR, 6, 60.0, hdr, hsize, A.TYPE_F16, torch.float16)]
-for name, profile, b, quality, img, n, ttype, tdtype in CASES:
+for name, profile, b, quality, img, n, ttype, tdtype in CASES[:int(os.environ.get("AB_CASES", len(CASES)))]:
     first = None
     blocks = None
     for lname, lib in libs:
