@@ -122,6 +122,17 @@ WV_FN uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
+/* a.lo16 * b.lo16 + a.hi16 * b.hi16 + c (v_dot2_u32_u16). */
+WV_FN uint32_t udot2(uint32_t a, uint32_t b, uint32_t c)
+{
+#if WV_DEVICE
+	typedef unsigned short wv_u16x2 __attribute__((ext_vector_type(2)));
+	return __builtin_amdgcn_udot2(__builtin_bit_cast(wv_u16x2, a), __builtin_bit_cast(wv_u16x2, b), c, false);
+#else
+	return (a & 0xFFFFu) * (b & 0xFFFFu) + (a >> 16) * (b >> 16) + c;
+#endif
+}
+
 /* Four consecutive words at a 16-byte aligned address: one 128-bit LDS read on the device. */
 struct U32x4 { uint32_t x, y, z, w; };
 WV_FN U32x4 load_u32x4_aligned(const uint32_t* p)
@@ -459,6 +470,15 @@ WV_FN int ise_symbol_lut(const uint32_t* w, int offset, int bits, int kind, int 
 /* Symbols per lane in the batched decoder: one BISE group (five trits or three quints share packed bits, so the
  * group is the natural unit: its window and its table entry are fetched once), four symbols for plain bit fields. */
 WV_FN int ise_group_size(int kind) { return kind == 1 ? 5 : kind == 2 ? 3 : 4; }
+/* btq_of without table reads: symbol bits | kind << 4 (kind 0 plain bits, 1 trits, 2 quints) of quant level q, out of
+ * packed constants (spec table C.2.7: four bits per level for the bit counts, two for the kinds). */
+WV_FN uint32_t btq_packed(int q)
+{
+	const uint64_t kinds = 0x6186186184ull, bits_lo = 0x4643532421310201ull;
+	const uint32_t bits_hi = 0x86575u;
+	const uint32_t bits = q < 16 ? (uint32_t)(bits_lo >> (4 * q)) & 15u : (bits_hi >> (4 * (q - 16))) & 15u;
+	return bits | (((uint32_t)(kinds >> (2 * q)) & 3u) << 4);
+}
 /* groups of a sequence of `count` symbols (count < 128), without a division */
 WV_FN int ise_group_count(int count, int kind) { return kind == 1 ? ((count + 4) * 205) >> 10 : kind == 2 ? ((count + 2) * 171) >> 9 : (count + 3) >> 2; }
 
@@ -1112,7 +1132,9 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 #define ASTC_DECODE_STOP_AFTER 0
 #endif
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
-static_assert(DECODE_BATCH == 32, "the lane maps of decode_row_batch pair lane l with block l & 31");
+static_assert(DECODE_BATCH == 32 || DECODE_BATCH == 16, "the lane maps of decode_row_batch pair lane l with block l & (DECODE_BATCH - 1)");
+constexpr int DECODE_SLOTS = 64 / DECODE_BATCH;             // lanes per block in the element phases
+constexpr int DECODE_BATCH_LOG2 = DECODE_BATCH == 32 ? 5 : 4;
 
 /* Per-wave scratch (LDS).  Strides are chosen so that lanes on neighbouring blocks fall on different banks. */
 struct alignas(16) DecodeBatch {
@@ -1122,12 +1144,12 @@ struct alignas(16) DecodeBatch {
 	uint8_t  fmt[DECODE_BATCH][4];       // colour endpoint mode per partition
 	uint8_t  weights[DECODE_BATCH][76];  // unquantized grid weights in stream order (the two planes of a dual-plane block interleaved), 0..64
 	uint8_t  colors[DECODE_BATCH][28];   // unquantized colour values, 0..255
-	// Endpoints per partition as the interpolation wants them: [0..3] = endpoint0 * 256 + 128, [4..7] = (endpoint1 - endpoint0) * 4
-	// per channel, so that [q] + [4 + q] * weight is the interpolated 16-bit value in bits 8..23 (its top byte in byte 2).
-	// Until the endpoint phase writes them the records of partitions 2 and 3 hold the block's bit streams: [2][0..5] the
-	// block and two zero words (see bits_window), [3][0..3] the weight stream (the block bit-reversed, cut off at its length).
-	// A constant-colour block keeps its four floats in [0][0..3].  (Four pad words: consecutive blocks on different banks.)
-	uint32_t ep[DECODE_BATCH][4 * 8 + 4];
+	// Endpoints per partition, one word per channel: endpoint0 | endpoint1 << 16 (16-bit values).  With the weight pair
+	// (256 - 4 w) | 4 w << 16 one dot product per channel, plus 128, is the interpolated 16-bit value in bits 8..23 (its top
+	// byte in byte 2).  Until the endpoint phase writes them the words hold the block's bit streams: [0..5] the block and two
+	// zero words (see bits_window), [8..11] the weight stream (the block bit-reversed, cut off at its length).
+	// A constant-colour block keeps its four floats in [0..3].
+	uint32_t ep[DECODE_BATCH][4 * 4];
 	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
 #if ASTC_DECODE_GROUP_LUT_LDS
 	uint16_t glut[256 + 128];            // trit_group_lut, quint_group_lut, copied once per wave
@@ -1141,11 +1163,11 @@ struct alignas(16) DecodeBatch {
 // rec[3]: error / constant block with RGBA8 output: the pixel
 
 // (the 128-bit reads of load_u32x4_aligned)
-static_assert(__builtin_offsetof(DecodeBatch, rec) % 16 == 0 && __builtin_offsetof(DecodeBatch, hash) % 16 == 0 && __builtin_offsetof(DecodeBatch, ep) % 16 == 0 &&
-              sizeof(uint32_t[4 * 8 + 4]) % 16 == 0, "DecodeBatch: records read as four words are 16-byte aligned");
+static_assert(__builtin_offsetof(DecodeBatch, rec) % 16 == 0 && __builtin_offsetof(DecodeBatch, hash) % 16 == 0 && __builtin_offsetof(DecodeBatch, ep) % 16 == 0,
+              "DecodeBatch: records read as four words are 16-byte aligned");
 
-WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k] + 16; }
-WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 24; }
+WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k]; }
+WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 8; }
 
 /* The symbols of group `g` of a weight stream whose bits past its end are zero (so a short last group needs no mask):
  * ise_group_lut for the weight levels, whose groups fit a 32-bit window (at most 5 * 3 + 8 bits). */
@@ -1223,8 +1245,13 @@ WV_FN void store_texel_general(const DecodeImage& img, const DecodeBatch& s, int
 	store_texel_at(img, at, r, g, bl, a);
 }
 
-/* The RGBA8 pixel of four interpolation results x[q] = endpoint record [q] + [4 + q] * weight (byte 2 = the value's top
+/* The RGBA8 pixel of four interpolation results x[q] = lerp_terms(endpoint word q, weight pair) (byte 2 = the value's top
  * byte, byte 3 = 0) through a swizzle that picks channels or constants (sel = swizzle_selector). */
+/* (ref: lerp_color_int :37)  The weight w as the pair (256 - 4 w) | 4 w << 16, and (e0 (64 - w) + e1 w + 32) * 4 from an
+ * endpoint word e0 | e1 << 16: the reference's value (... + 32) >> 6 is bits 8..23 of it. */
+WV_FN uint32_t lerp_weight_pair(int w) { return umad24((uint32_t)w, 4u * 0xFFFFu, 256u); }
+WV_FN uint32_t lerp_terms(uint32_t endpoints, uint32_t weight_pair) { return udot2(endpoints, weight_pair, 128u); }
+
 WV_FN uint32_t pixel_from_lerps(uint32_t sel, const uint32_t x[4])
 {
 	const uint32_t rg = byte_perm(x[1], x[0], 0x0C0C0602u), ba = byte_perm(x[3], x[2], 0x0C0C0602u);   // byte 2 of each, side by side
@@ -1285,8 +1312,8 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 				}
 			}
 			const uint32_t* epk = s.ep[k];
-			U32x4 e0 = { 0u, 0u, 0u, 0u }, e1 = { 0u, 0u, 0u, 0u };
-			if (!kMulti) { e0 = load_u32x4_aligned(epk); e1 = load_u32x4_aligned(epk + 4); }
+			U32x4 e = { 0u, 0u, 0u, 0u };
+			if (!kMulti) e = load_u32x4_aligned(epk);
 			size_t at = (((size_t)bz * img.dim_y + y0) * img.dim_x + xi) * 4;      // (2D blocks: layer bz of the stream is slice bz of the image)
 			for (int ty = 0; ty < rows; ty++, at += (size_t)img.dim_x * 4)
 			{
@@ -1316,14 +1343,14 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 							const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
 							p = 3 - (int)((ab > cd ? ab : cd) & 3u);
 						}
-						e0 = load_u32x4_aligned(epk + p * 8); e1 = load_u32x4_aligned(epk + p * 8 + 4);
+						e = load_u32x4_aligned(epk + p * 4);
 					}
-					// (ref: lerp_color_int :37; the step (endpoint1 - endpoint0) * 4 and the weight fit 24 bits)
+					const uint32_t wp0 = lerp_weight_pair(w0), wp1 = kDual ? lerp_weight_pair(w1) : wp0;
 					uint32_t x[4];
-					x[0] = (uint32_t)mad24((int)e1.x, kDual && plane2 == 0 ? w1 : w0, (int)e0.x);
-					x[1] = (uint32_t)mad24((int)e1.y, kDual && plane2 == 1 ? w1 : w0, (int)e0.y);
-					x[2] = (uint32_t)mad24((int)e1.z, kDual && plane2 == 2 ? w1 : w0, (int)e0.z);
-					x[3] = (uint32_t)mad24((int)e1.w, kDual && plane2 == 3 ? w1 : w0, (int)e0.w);
+					x[0] = lerp_terms(e.x, kDual && plane2 == 0 ? wp1 : wp0);
+					x[1] = lerp_terms(e.y, kDual && plane2 == 1 ? wp1 : wp0);
+					x[2] = lerp_terms(e.z, kDual && plane2 == 2 ? wp1 : wp0);
+					x[3] = lerp_terms(e.w, kDual && plane2 == 3 ? wp1 : wp0);
 					if (fast) px = pixel_from_lerps(swz_sel, x);
 					else for (int q = 0; q < 4; q++) cv[q] = (int)(x[q] >> 8);
 				}
@@ -1401,19 +1428,19 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			}
 		}
 		const bool skip = error || h.constant;
-		const Btq wq = btq_of(h.wquant), cq = btq_of(skip ? 0 : h.cquant);
-		const int wkind = wq.trits ? 1 : wq.quints ? 2 : 0, ckind = cq.trits ? 1 : cq.quints ? 2 : 0;
+		const uint32_t wq = btq_packed(h.wquant), cq = btq_packed(skip ? 0 : h.cquant);
+		const int wkind = (int)(wq >> 4), ckind = (int)(cq >> 4), wqbits = (int)(wq & 15u), cqbits = (int)(cq & 15u);
 		const int wcount = h.wx * h.wy * h.wz;
 		const int real_wcount = h.dual ? 2 * wcount : wcount;
 		const int wgroups = skip ? 0 : ise_group_count(real_wcount, wkind), cgroups = skip ? 0 : ise_group_count(h.nvals, ckind);
-		const int wglen = wkind == 1 ? 5 * wq.bits + 8 : wkind == 2 ? 3 * wq.bits + 7 : 4 * wq.bits;
+		const int wglen = wkind == 1 ? 5 * wqbits + 8 : wkind == 2 ? 3 * wqbits + 7 : 4 * wqbits;
 		uint32_t cpx = 0u;
 		if (skip && img.data_type == 0) cpx = error ? pack_texel_u8(img, error_nan, error_nan, error_nan, error_nan) : pack_texel_u8(img, cc[0], cc[1], cc[2], cc[3]);
 		// (fast: the texel phase forms -- or, for these two kinds of block, already has -- the RGBA8 pixel; LNS endpoints clear the flag)
 		const bool fast = skip ? img.data_type == 0 : bytes_swz;
-		s.rec[k][0] = (skip ? 1u : 0u) | (error ? 2u : 0u) | ((h.constant && !error) ? 4u : 0u) | (fast ? 8u : 0u) | ((uint32_t)wq.bits << 4) | ((uint32_t)wkind << 8) |
+		s.rec[k][0] = (skip ? 1u : 0u) | (error ? 2u : 0u) | ((h.constant && !error) ? 4u : 0u) | (fast ? 8u : 0u) | ((uint32_t)wqbits << 4) | ((uint32_t)wkind << 8) |
 		              ((uint32_t)h.wquant << 12) | ((uint32_t)wgroups << 16) | ((uint32_t)wglen << 24);
-		s.rec[k][1] = (uint32_t)cq.bits | ((uint32_t)ckind << 4) | ((uint32_t)(skip ? 0 : h.cquant) << 8) | ((uint32_t)h.nvals << 16) | ((uint32_t)h.color_start << 24);
+		s.rec[k][1] = (uint32_t)cqbits | ((uint32_t)ckind << 4) | ((uint32_t)(skip ? 0 : h.cquant) << 8) | ((uint32_t)h.nvals << 16) | ((uint32_t)h.color_start << 24);
 		s.rec[k][2] = (uint32_t)h.wx | ((uint32_t)h.wy << 4) | ((uint32_t)h.wz << 8) | ((h.dual ? 1u : 0u) << 12) | ((uint32_t)h.parts << 13) |
 		              (((uint32_t)h.plane2 & 3u) << 16) | ((uint32_t)cgroups << 20);
 		s.rec[k][3] = cpx;
@@ -1450,10 +1477,10 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	WV_SYNC();
 	if (ASTC_DECODE_STOP_AFTER == 1) return;
 
-	// ---- weights and colour values: lane l works on block l & 31, on every second group of it from group l >> 5 on ----
+	// ---- weights and colour values: lane l works on block l & (DECODE_BATCH - 1), on every DECODE_SLOTS-th group of it ----
 	WV_FOR64(l, 64)
 	{
-		const int k = l & 31;
+		const int k = l & (DECODE_BATCH - 1);
 		if (k >= count) continue;
 		const uint32_t ra = s.rec[k][0];
 		const int groups = (int)((ra >> 16) & 63u);
@@ -1465,7 +1492,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 #else
 		const uint16_t* glut = nullptr;
 #endif
-		for (int g = l >> 5; g < groups; g += 2)
+		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
 		{
 			uint32_t sym[5];
 			weight_group_lut(ws, mul24(g, glen), bits, kind, glut, sym);
@@ -1480,13 +1507,13 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	if (ASTC_DECODE_STOP_AFTER == 2) return;
 	WV_FOR64(l, 64)
 	{
-		const int k = l & 31;
+		const int k = l & (DECODE_BATCH - 1);
 		if (k >= count) continue;
 		const uint32_t rb = s.rec[k][1];
 		const int groups = (int)((s.rec[k][2] >> 20) & 7u);
 		const int nvals = (int)((rb >> 16) & 31u);
 		const int kind = (int)((rb >> 4) & 3u), per = ise_group_size(kind);
-		for (int g = l >> 5; g < groups; g += 2)
+		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
 		{
 			int sym[5];
 			const int n = ise_group_lut(decode_batch_bits(s, k), (int)((rb >> 24) & 31u), (int)(rb & 15u), kind, nvals, g, sym);
@@ -1499,15 +1526,15 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	}
 	WV_SYNC();
 	if (ASTC_DECODE_STOP_AFTER == 3) return;
-	// ---- endpoints: lane l works on block l & 31, partitions l >> 5 and (l >> 5) + 2 ----
+	// ---- endpoints: lane l works on block l & (DECODE_BATCH - 1), on every DECODE_SLOTS-th partition of it ----
 	WV_FOR64(l, 64)
 	{
-		const int k = l & 31;
+		const int k = l & (DECODE_BATCH - 1);
 		if (k >= count) continue;
 		const uint32_t ra = s.rec[k][0];
 		if (ra & 1u) continue;
 		const int parts = (int)((s.rec[k][2] >> 13) & 7u);
-		for (int p = l >> 5; p < parts; p += 2)
+		for (int p = l >> DECODE_BATCH_LOG2; p < parts; p += DECODE_SLOTS)
 		{
 			int start = 0;
 			for (int i = 0; i < 4; i++) start += i < p ? 2 * (s.fmt[k][i] >> 2) + 2 : 0;
@@ -1520,9 +1547,9 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			bool rgb_lns, alpha_lns;
 			endpoint_lns_flags(profile, f, rgb_lns, alpha_lns);
 			s.lns[k][p] = (uint8_t)((rgb_lns ? 1 : 0) | (alpha_lns ? 2 : 0));
-			uint32_t* o = s.ep[k] + p * 8;
-			o[0] = (uint32_t)(e0.x * 256 + 128); o[1] = (uint32_t)(e0.y * 256 + 128); o[2] = (uint32_t)(e0.z * 256 + 128); o[3] = (uint32_t)(e0.w * 256 + 128);
-			o[4] = (uint32_t)((e1.x - e0.x) * 4); o[5] = (uint32_t)((e1.y - e0.y) * 4); o[6] = (uint32_t)((e1.z - e0.z) * 4); o[7] = (uint32_t)((e1.w - e0.w) * 4);
+			uint32_t* o = s.ep[k] + p * 4;
+			o[0] = (uint32_t)e0.x | ((uint32_t)e1.x << 16); o[1] = (uint32_t)e0.y | ((uint32_t)e1.y << 16);
+			o[2] = (uint32_t)e0.z | ((uint32_t)e1.z << 16); o[3] = (uint32_t)e0.w | ((uint32_t)e1.w << 16);
 		}
 	}
 	WV_SYNC();
@@ -1593,7 +1620,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 					p = partition_from_hash(ph, tx, ty, tz, small_block);
 				}
 				uint32_t x[4];
-				for (int q = 0; q < 4; q++) x[q] = s.ep[k][p * 8 + q] + s.ep[k][p * 8 + 4 + q] * (uint32_t)(q == plane2 ? wp[1] : wp[0]);      // (ref: lerp_color_int :37)
+				for (int q = 0; q < 4; q++) x[q] = lerp_terms(s.ep[k][p * 4 + q], lerp_weight_pair(q == plane2 ? wp[1] : wp[0]));
 				if (fast) px = pixel_from_lerps(swz_sel, x);
 				else for (int q = 0; q < 4; q++) cv[q] = (int)(x[q] >> 8);
 			}

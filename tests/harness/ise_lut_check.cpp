@@ -59,6 +59,52 @@ int main()
 				}
 			}
 		}
+		// the packed level description and the division-free group count of the batched decoder
+		{
+			const uint32_t pk = btq_packed(quant);
+			checked++;
+			if ((int)(pk & 15u) != q.bits || (int)(pk >> 4) != kind) { bad++; fprintf(stderr, "btq_packed %d\n", quant); }
+			for (int count = 1; count < 128; count++)
+			{
+				const int per = ise_group_size(kind);
+				checked++;
+				if (ise_group_count(count, kind) != (count + per - 1) / per) { bad++; fprintf(stderr, "group count %d %d\n", kind, count); }
+			}
+		}
+		// weight levels: the 32-bit-window group decode on a stream cut off at its length (what decode_row_batch stores)
+		if (quant <= 11)
+		{
+			for (int rep = 0; rep < 400; rep++)
+			{
+				Bits128 b;
+				const int count = 1 + (int)(rnd() % 64);
+				const int len = (int)ise_bitcount((unsigned)count, quant);
+				if (len > 96) continue;
+				uint32_t ws[4];
+				for (int k = 0; k < 4; k++) b.w[k] = rnd();
+				for (int k = 0; k < 3; k++)
+				{
+					const int left = len - 32 * k;
+					ws[k] = left >= 32 ? b.w[k] : left <= 0 ? 0u : b.w[k] & ((1u << left) - 1u);
+				}
+				ws[3] = 0u;
+				const int per = ise_group_size(kind);
+				const int glen = kind == 1 ? 5 * q.bits + 8 : kind == 2 ? 3 * q.bits + 7 : 4 * q.bits;
+				for (int group = 0; group * per < count; group++)
+				{
+					uint32_t sym[5];
+					weight_group_lut(ws, group * glen, q.bits, kind, nullptr, sym);
+					for (int e = 0; e < per && group * per + e < count; e++)
+					{
+						checked++;
+						if ((int)sym[e] != ise_symbol(b, 0, quant, count, group * per + e))
+						{
+							if (bad++ < 10) fprintf(stderr, "weight group: quant %d count %d group %d element %d\n", quant, count, group, e);
+						}
+					}
+				}
+			}
+		}
 		// unquantization tables: every symbol the level can produce
 		for (int v = 0; v < 256; v++)
 		{
