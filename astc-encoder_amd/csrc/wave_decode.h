@@ -65,12 +65,14 @@ WV_FN uint32_t bits_get(const Bits128& b, int off, int n)
 {
 	// n <= 16, may run past bit 127 (reads zeros there, like the reference's padded buffer)
 	if (n <= 0 || off >= 128) return 0u;
-	// (the words by selects, not by index: an indexed read of a register array would put the block in scratch memory)
-	const int word = off >> 5, sh = off & 31;
-	const uint32_t lo = word == 0 ? b.w[0] : word == 1 ? b.w[1] : word == 2 ? b.w[2] : b.w[3];
-	const uint32_t hi = word == 0 ? b.w[1] : word == 1 ? b.w[2] : word == 2 ? b.w[3] : 0u;
-	const uint64_t v = ((uint64_t)lo | ((uint64_t)hi << 32)) >> sh;
-	return (uint32_t)v & ((1u << n) - 1u);
+	// The two words the field lies in, picked with bit masks in two halving steps: an indexed read of a register array would
+	// put the block in scratch memory, and chains of ?: become chains of branches.
+	const uint32_t m64 = 0u - (((uint32_t)off >> 6) & 1u), m32 = 0u - (((uint32_t)off >> 5) & 1u);
+	const uint32_t a = (b.w[2] & m64) | (b.w[0] & ~m64), c = (b.w[3] & m64) | (b.w[1] & ~m64), d = b.w[2] & ~m64;    // words 0..2 of the string from bit (off & 64) on
+	const uint32_t lo = (c & m32) | (a & ~m32), hi = (d & m32) | (c & ~m32);
+	const int sh = off & 31;
+	const uint32_t v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+	return v & ((1u << n) - 1u);
 }
 
 WV_FN uint32_t rev32(uint32_t v)
@@ -396,8 +398,8 @@ WV_FN int unquant_color_symbol(int v, int quant)
 // ---------------------------------------------------------------------------------------------
 #include "decode_luts.inc"
 
-WV_FN uint32_t trit_group_lut(uint32_t t8) { const uint16_t t[256] = { ASTC_TRIT_LUT_VALUES }; return t[t8]; }
-WV_FN uint32_t quint_group_lut(uint32_t q7) { const uint16_t t[128] = { ASTC_QUINT_LUT_VALUES }; return t[q7]; }
+WV_FN uint32_t trit_group_lut(uint32_t t8) { const uint16_t t[256] = { ASTC_TRIT_LUT_VALUES }; return table_at(t, t8); }
+WV_FN uint32_t quint_group_lut(uint32_t q7) { const uint16_t t[128] = { ASTC_QUINT_LUT_VALUES }; return table_at(t, q7); }
 WV_FN int weight_unquant_lut(int quant, int sym) { const uint8_t t[12 * 32] = { ASTC_WEIGHT_UNQUANT_LUT_VALUES }; return t[quant * 32 + sym]; }
 /* four consecutive entries of the weight table as one word (entry 4 i in the low byte) */
 WV_FN uint32_t weight_unquant_lut_word(int i)
@@ -407,7 +409,7 @@ WV_FN uint32_t weight_unquant_lut_word(int i)
 	__builtin_memcpy(&v, t + 4 * i, 4);
 	return v;
 }
-WV_FN int color_unquant_lut(int quant, int sym) { const uint8_t t[21 * 256] = { ASTC_COLOR_UNQUANT_LUT_VALUES }; return t[quant * 256 + sym]; }
+WV_FN int color_unquant_lut(int quant, int sym) { const uint8_t t[21 * 256] = { ASTC_COLOR_UNQUANT_LUT_VALUES }; return table_at(t, (uint32_t)(quant * 256 + sym)); }
 
 /* (hi:lo) >> sh, low 32 bits; sh in 0..31. */
 WV_FN uint32_t funnel_shift_right(uint32_t hi, uint32_t lo, int sh)
@@ -1146,8 +1148,9 @@ struct alignas(16) DecodeBatch {
 	uint8_t  colors[DECODE_BATCH][28];   // unquantized colour values, 0..255
 	// Endpoints per partition, one word per channel: endpoint0 | endpoint1 << 16 (16-bit values).  With the weight pair
 	// (256 - 4 w) | 4 w << 16 one dot product per channel, plus 128, is the interpolated 16-bit value in bits 8..23 (its top
-	// byte in byte 2).  Until the endpoint phase writes them the words hold the block's bit streams: [0..5] the block and two
-	// zero words (see bits_window), [8..11] the weight stream (the block bit-reversed, cut off at its length).
+	// byte in byte 2).  Until the endpoint phase writes them the words hold the block's bit streams, both cut off at their
+	// lengths: [0..4] the block up to the end of its colour values and a zero word, [8..11] the weight stream (the block
+	// bit-reversed).
 	// A constant-colour block keeps its four floats in [0..3].
 	uint32_t ep[DECODE_BATCH][4 * 4];
 	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
@@ -1199,6 +1202,49 @@ WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, cons
 		out[0] = (((quints) & 7u) << bits) | (g & low_mask);
 		out[1] = (((quints >> 3) & 7u) << bits) | ((g >> (bits + 3)) & low_mask);
 		out[2] = (((quints >> 6) & 7u) << bits) | ((g >> (2 * bits + 5)) & low_mask);
+		out[3] = 0u; out[4] = 0u;
+	}
+}
+
+/* 32 bits of a bit string from bit `at` on (the word after the last one read must exist). */
+WV_FN uint32_t bits_window32(const uint32_t* w, int at)
+{
+	const int word = at >> 5, sh = at & 31;
+	return funnel_shift_right(w[word + 1], w[word], sh);
+}
+
+/* The symbols of the group of colour values that starts at bit `at` of a colour stream whose bits past its end are zero
+ * (ise_group_lut for every colour level, in 32-bit pieces: a group of five trit symbols of up to six bits -- 38 bits --
+ * is read as its first three symbols and its last two). */
+WV_FN void color_group_lut(const uint32_t* cs, int at, int bits, int kind, uint32_t out[5])
+{
+	const uint32_t low_mask = (1u << bits) - 1u;
+	const uint32_t a = bits_window32(cs, at);
+	if (kind == 0)
+	{
+		// four symbols of up to eight bits
+		for (int e = 0; e < 4; e++) out[e] = (a >> (e * bits)) & low_mask;
+		out[4] = 0u;
+	}
+	else if (kind == 1)
+	{
+		const uint32_t b = bits_window32(cs, at + 3 * bits + 5);
+		const uint32_t t8 = ((a >> bits) & 3u) | (((a >> (2 * bits + 2)) & 3u) << 2) | (((a >> (3 * bits + 4)) & 1u) << 4) |
+		                    (((b >> bits) & 3u) << 5) | (((b >> (2 * bits + 2)) & 1u) << 7);
+		const uint32_t trits = trit_group_lut(t8);
+		out[0] = (((trits) & 3u) << bits) | (a & low_mask);
+		out[1] = (((trits >> 2) & 3u) << bits) | ((a >> (bits + 2)) & low_mask);
+		out[2] = (((trits >> 4) & 3u) << bits) | ((a >> (2 * bits + 4)) & low_mask);
+		out[3] = (((trits >> 6) & 3u) << bits) | (b & low_mask);
+		out[4] = (((trits >> 8) & 3u) << bits) | ((b >> (bits + 2)) & low_mask);
+	}
+	else
+	{
+		const uint32_t q7 = ((a >> bits) & 7u) | (((a >> (2 * bits + 3)) & 3u) << 3) | (((a >> (3 * bits + 5)) & 3u) << 5);
+		const uint32_t quints = quint_group_lut(q7);
+		out[0] = (((quints) & 7u) << bits) | (a & low_mask);
+		out[1] = (((quints >> 3) & 7u) << bits) | ((a >> (bits + 3)) & low_mask);
+		out[2] = (((quints >> 6) & 7u) << bits) | ((a >> (2 * bits + 5)) & low_mask);
 		out[3] = 0u; out[4] = 0u;
 	}
 }
@@ -1460,9 +1506,15 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			uint32_t* bits = decode_batch_bits(s, k);
 			uint32_t* ws = decode_batch_wstream(s, k);
 			const Bits128 rv = bits_reversed(blk);
-			for (int q = 0; q < 4; q++) bits[q] = blk.w[q];
-			bits[4] = 0u; bits[5] = 0u;
-			// the weight stream is 24..96 bits long: bits past its end read as zeros, so that a short last group needs no mask
+			// the colour values end at bit color_start + their BISE size; the weight stream is 24..96 bits long.  Bits past the
+			// end of either read as zeros, so that a short last group needs no mask
+			const int cend = h.color_start + h.nvals * cqbits + (ckind == 1 ? (8 * h.nvals + 4) / 5 : ckind == 2 ? (7 * h.nvals + 2) / 3 : 0);    // (ise_bitcount)
+			for (int q = 0; q < 4; q++)
+			{
+				const int left = cend - 32 * q;
+				bits[q] = left >= 32 ? blk.w[q] : left <= 0 ? 0u : blk.w[q] & ((1u << left) - 1u);
+			}
+			bits[4] = 0u;
 			for (int q = 0; q < 3; q++)
 			{
 				const int left = h.wbits - 32 * q;
@@ -1512,16 +1564,25 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		const uint32_t rb = s.rec[k][1];
 		const int groups = (int)((s.rec[k][2] >> 20) & 7u);
 		const int nvals = (int)((rb >> 16) & 31u);
-		const int kind = (int)((rb >> 4) & 3u), per = ise_group_size(kind);
+		const int bits = (int)(rb & 15u), kind = (int)((rb >> 4) & 3u), per = ise_group_size(kind);
+		const int glen = kind == 1 ? 5 * bits + 8 : kind == 2 ? 3 * bits + 7 : 4 * bits;
+		const int cquant = (int)((rb >> 8) & 31u), cstart = (int)((rb >> 24) & 31u);
+		const uint32_t* cs = decode_batch_bits(s, k);
 		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
 		{
-			int sym[5];
-			const int n = ise_group_lut(decode_batch_bits(s, k), (int)((rb >> 24) & 31u), (int)(rb & 15u), kind, nvals, g, sym);
-			for (int e = 0; e < 5; e++)
-			{
-				if (e >= n) break;
-				s.colors[k][g * per + e] = (uint8_t)color_unquant_lut((int)((rb >> 8) & 31u), sym[e]);
-			}
+			uint32_t sym[5];
+			color_group_lut(cs, cstart + mul24(g, glen), bits, kind, sym);
+			// (the five table reads side by side, then the stores: one wait instead of five; the symbols past a short group are
+			//  in range -- zero, or a trit / quint of zero bits)
+			const uint8_t c0 = (uint8_t)color_unquant_lut(cquant, (int)sym[0]), c1 = (uint8_t)color_unquant_lut(cquant, (int)sym[1]), c2 = (uint8_t)color_unquant_lut(cquant, (int)sym[2]);
+			const uint8_t c3 = (uint8_t)color_unquant_lut(cquant, (int)sym[3]), c4 = (uint8_t)color_unquant_lut(cquant, (int)sym[4]);
+			const int n = nvals - mul24(g, per);
+			uint8_t* out = s.colors[k] + mul24(g, per);
+			out[0] = c0;
+			if (n > 1) out[1] = c1;
+			if (n > 2) out[2] = c2;
+			if (n > 3 && per > 3) out[3] = c3;
+			if (n > 4 && per > 4) out[4] = c4;
 		}
 	}
 	WV_SYNC();

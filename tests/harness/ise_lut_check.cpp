@@ -105,6 +105,42 @@ int main()
 				}
 			}
 		}
+		// colour levels: the group decode in 32-bit pieces on a stream cut off at the end of the colour values
+		if (quant >= 4)
+		{
+			for (int rep = 0; rep < 400; rep++)
+			{
+				Bits128 b;
+				const int count = 2 * (1 + (int)(rnd() % 9));
+				const int start = (rep & 1) ? 17 : 29;
+				const int end = start + (int)ise_bitcount((unsigned)count, quant);
+				if (end > 128 - 24) continue;
+				uint32_t cs[5];
+				for (int k = 0; k < 4; k++) b.w[k] = rnd();
+				for (int k = 0; k < 4; k++)
+				{
+					const int left = end - 32 * k;
+					cs[k] = left >= 32 ? b.w[k] : left <= 0 ? 0u : b.w[k] & ((1u << left) - 1u);
+				}
+				cs[4] = 0u;
+				const int per = ise_group_size(kind);
+				const int glen = kind == 1 ? 5 * q.bits + 8 : kind == 2 ? 3 * q.bits + 7 : 4 * q.bits;
+				for (int group = 0; group * per < count; group++)
+				{
+					uint32_t sym[5];
+					color_group_lut(cs, start + group * glen, q.bits, kind, sym);
+					for (int e = 0; e < per && group * per + e < count; e++)
+					{
+						checked++;
+						if ((int)sym[e] != ise_symbol(b, start, quant, count, group * per + e))
+						{
+							if (bad++ < 10) fprintf(stderr, "colour group: quant %d count %d group %d element %d\n", quant, count, group, e);
+						}
+					}
+					for (int e = 0; e < 5; e++) if (sym[e] > 255u) { bad++; fprintf(stderr, "colour group: symbol out of range\n"); }
+				}
+			}
+		}
 		// unquantization tables: every symbol the level can produce
 		for (int v = 0; v < 256; v++)
 		{
