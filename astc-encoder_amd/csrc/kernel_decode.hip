@@ -9,16 +9,22 @@
 
 namespace astcd {
 
-/* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes a run of
- * DECODE_BATCH consecutive blocks of one block row and decodes them together (decode_row_batch).  The grid is
- * (runs per block row, block rows, layers of blocks): a run's place in the image needs no division. */
-__global__ void __launch_bounds__(64)
+/* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes runs of
+ * DECODE_BATCH consecutive blocks of one block row and decodes each run together (decode_row_batch) -- DECODE_RUNS_PER_WAVE
+ * of them one after the other, so that a wave's launch, its LDS allocation and its tables are paid for once per that many
+ * runs.  The grid is (waves per block row, block rows, layers of blocks): a run's place in the image needs no division. */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))      // (LDS allows 5.75 waves per SIMD: keep the registers under that)
 astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img)
 {
 	__shared__ DecodeBatch batch;
-	const uint32_t bx0 = blockIdx.x * (uint32_t)DECODE_BATCH;
-	const uint32_t left = img.blocks_x - bx0;
-	decode_row_batch(img, blocks, bx0, blockIdx.y, blockIdx.z, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
+	decode_batch_init(batch);
+	for (int run = 0; run < DECODE_RUNS_PER_WAVE; run++)
+	{
+		const uint32_t bx0 = (blockIdx.x * (uint32_t)DECODE_RUNS_PER_WAVE + (uint32_t)run) * (uint32_t)DECODE_BATCH;
+		if (bx0 >= img.blocks_x) break;
+		const uint32_t left = img.blocks_x - bx0;
+		decode_row_batch(img, blocks, bx0, blockIdx.y, blockIdx.z, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
+	}
 }
 
 size_t astc_decode_tables_bytes() { return sizeof(DecodeTables); }
@@ -44,7 +50,8 @@ int astc_decode_launch(const DecodeLaunch& d)
 	decode_image_prepare(img);
 	// (grid y / z hold block rows / layers: at most 65535 each, i.e. images of up to 196 605 texels in y at the smallest footprint)
 	if (img.blocks_y > 65535u || img.blocks_z > 65535u) return (int)hipErrorInvalidConfiguration;
-	const dim3 grid((img.blocks_x + (uint32_t)DECODE_BATCH - 1) / (uint32_t)DECODE_BATCH, img.blocks_y, img.blocks_z);
+	const uint32_t per_wave = (uint32_t)(DECODE_BATCH * DECODE_RUNS_PER_WAVE);
+	const dim3 grid((img.blocks_x + per_wave - 1) / per_wave, img.blocks_y, img.blocks_z);
 	hipLaunchKernelGGL(astc_decompress_blocks, grid, dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img);
 	return (int)hipGetLastError();
 }

@@ -1129,10 +1129,15 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 #define ASTC_DECODE_GROUP_LUT_LDS 0
 #endif
 // measurement builds (tools/build_variant.sh): leave decode_row_batch after phase n (1 headers, 2 weights, 3 colour values,
-// 4 endpoints); the product is built without it
+// 4 endpoints; 9: at once); the product is built without it
 #ifndef ASTC_DECODE_STOP_AFTER
 #define ASTC_DECODE_STOP_AFTER 0
 #endif
+// consecutive runs of a block row one wavefront decodes (its launch, its LDS and its tables are paid for once)
+#ifndef ASTC_DECODE_RUNS_PER_WAVE
+#define ASTC_DECODE_RUNS_PER_WAVE 4
+#endif
+constexpr int DECODE_RUNS_PER_WAVE = ASTC_DECODE_RUNS_PER_WAVE;
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
 static_assert(DECODE_BATCH == 32 || DECODE_BATCH == 16, "the lane maps of decode_row_batch pair lane l with block l & (DECODE_BATCH - 1)");
 constexpr int DECODE_SLOTS = 64 / DECODE_BATCH;             // lanes per block in the element phases
@@ -1407,8 +1412,27 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 	}
 }
 
+/* The tables a wave keeps in its scratch: once per wave, before its first run.  All 64 lanes call this. */
+WV_FN void decode_batch_init(DecodeBatch& s)
+{
+	WV_FOR(i, 12 * 32 / 4)
+	{
+		const uint32_t v = weight_unquant_lut_word(i);
+		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
+	}
+#if ASTC_DECODE_GROUP_LUT_LDS
+	WV_FOR(i, (256 + 128) / 2)
+	{
+		const uint32_t v = i < 128 ? trit_group_lut(2u * (uint32_t)i) | (trit_group_lut(2u * (uint32_t)i + 1u) << 16)
+		                           : quint_group_lut(2u * (uint32_t)(i - 128)) | (quint_group_lut(2u * (uint32_t)(i - 128) + 1u) << 16);
+		__builtin_memcpy(s.glut + 2 * i, &v, 4);
+	}
+#endif
+	WV_SYNC();
+}
+
 /* Decode blocks bx0 .. bx0 + count - 1 (count <= DECODE_BATCH) of block row `by`, layer `bz` of the stream into the image.
- * All 64 lanes call this.  Same arithmetic as decode_block(), block by block. */
+ * All 64 lanes call this, after decode_batch_init() on the scratch.  Same arithmetic as decode_block(), block by block. */
 WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint32_t bx0, uint32_t by, uint32_t bz, int count, DecodeBatch& s)
 {
 	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
@@ -1423,21 +1447,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	const bool bytes_swz = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
 	const size_t first = ((size_t)bz * img.blocks_y + by) * img.blocks_x + bx0;
 
-	// ---- the weight unquantization table of this wave ----
-	WV_FOR(i, 12 * 32 / 4)
-	{
-		const uint32_t v = weight_unquant_lut_word(i);
-		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
-	}
-#if ASTC_DECODE_GROUP_LUT_LDS
-	WV_FOR(i, (256 + 128) / 2)
-	{
-		const uint32_t v = i < 128 ? trit_group_lut(2u * (uint32_t)i) | (trit_group_lut(2u * (uint32_t)i + 1u) << 16)
-		                           : quint_group_lut(2u * (uint32_t)(i - 128)) | (quint_group_lut(2u * (uint32_t)(i - 128) + 1u) << 16);
-		__builtin_memcpy(s.glut + 2 * i, &v, 4);
-	}
-#endif
-
+	if (ASTC_DECODE_STOP_AFTER == 9) return;
 	// ---- headers and constant colours: one lane per block ----
 	bool multi_part = false, dual_part = false;      // per-lane partials, folded below
 	WV_FOR64(k, count)
