@@ -401,6 +401,9 @@ WV_FN int unquant_color_symbol(int v, int quant)
 WV_FN uint32_t trit_group_lut(uint32_t t8) { const uint16_t t[256] = { ASTC_TRIT_LUT_VALUES }; return table_at(t, t8); }
 WV_FN uint32_t quint_group_lut(uint32_t q7) { const uint16_t t[128] = { ASTC_QUINT_LUT_VALUES }; return table_at(t, q7); }
 WV_FN int weight_unquant_lut(int quant, int sym) { const uint8_t t[12 * 32] = { ASTC_WEIGHT_UNQUANT_LUT_VALUES }; return t[quant * 32 + sym]; }
+/* both group tables in one: trit groups at 0..255, quint groups at 256..383 (entry 0 -- all trits zero -- also serves the
+ * levels without trits or quints) */
+WV_FN uint32_t group_lut(uint32_t index) { const uint16_t t[256 + 128] = { ASTC_TRIT_LUT_VALUES ASTC_QUINT_LUT_VALUES }; return table_at(t, index); }
 /* four consecutive entries of the weight table as one word (entry 4 i in the low byte) */
 WV_FN uint32_t weight_unquant_lut_word(int i)
 {
@@ -1123,19 +1126,16 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 #ifndef ASTC_DECODE_BATCH
 #define ASTC_DECODE_BATCH 32
 #endif
-// 1: the wave keeps the trit / quint group tables of the weight decode in LDS (768 bytes more per wave) instead of reading
-// them from HBM through the vector cache
-#ifndef ASTC_DECODE_GROUP_LUT_LDS
-#define ASTC_DECODE_GROUP_LUT_LDS 0
-#endif
 // measurement builds (tools/build_variant.sh): leave decode_row_batch after phase n (1 headers, 2 weights, 3 colour values,
 // 4 endpoints; 9: at once); the product is built without it
 #ifndef ASTC_DECODE_STOP_AFTER
 #define ASTC_DECODE_STOP_AFTER 0
 #endif
-// consecutive runs of a block row one wavefront decodes (its launch, its LDS and its tables are paid for once)
+// consecutive runs of a block row one wavefront decodes.  Measured (profiles/r05zz/decode_runs_per_wave.log, 8192^2 6x6):
+// 1 run 0.258 ms, 2 runs 0.276, 4 runs 0.285, 8 runs 0.343 -- launching a wave and filling its table is 0.016 ms of the
+// 0.258, and longer-lived waves cost registers and a longer tail
 #ifndef ASTC_DECODE_RUNS_PER_WAVE
-#define ASTC_DECODE_RUNS_PER_WAVE 4
+#define ASTC_DECODE_RUNS_PER_WAVE 1
 #endif
 constexpr int DECODE_RUNS_PER_WAVE = ASTC_DECODE_RUNS_PER_WAVE;
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
@@ -1159,9 +1159,6 @@ struct alignas(16) DecodeBatch {
 	// A constant-colour block keeps its four floats in [0..3].
 	uint32_t ep[DECODE_BATCH][4 * 4];
 	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
-#if ASTC_DECODE_GROUP_LUT_LDS
-	uint16_t glut[256 + 128];            // trit_group_lut, quint_group_lut, copied once per wave
-#endif
 };
 
 // rec[0]: bit 0 no payload (error or constant colour), bit 1 error, bit 2 constant colour, bit 3 fast (RGBA8 pixel from integers),
@@ -1177,40 +1174,6 @@ static_assert(__builtin_offsetof(DecodeBatch, rec) % 16 == 0 && __builtin_offset
 WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k]; }
 WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 8; }
 
-/* The symbols of group `g` of a weight stream whose bits past its end are zero (so a short last group needs no mask):
- * ise_group_lut for the weight levels, whose groups fit a 32-bit window (at most 5 * 3 + 8 bits). */
-WV_FN void weight_group_lut(const uint32_t* ws, int at, int bits, int kind, const uint16_t* glut, uint32_t out[5])
-{
-	const int word = at >> 5, sh = at & 31;
-	const uint32_t g = funnel_shift_right(ws[word + 1], ws[word], sh);
-	const uint32_t low_mask = (1u << bits) - 1u;
-	if (kind == 0)
-	{
-		for (int e = 0; e < 4; e++) out[e] = (g >> (e * bits)) & low_mask;
-		out[4] = 0u;
-	}
-	else if (kind == 1)
-	{
-		const uint32_t t8 = ((g >> bits) & 3u) | (((g >> (2 * bits + 2)) & 3u) << 2) | (((g >> (3 * bits + 4)) & 1u) << 4) |
-		                    (((g >> (4 * bits + 5)) & 3u) << 5) | (((g >> (5 * bits + 7)) & 1u) << 7);
-		const uint32_t trits = glut ? glut[t8] : trit_group_lut(t8);
-		out[0] = (((trits) & 3u) << bits) | (g & low_mask);
-		out[1] = (((trits >> 2) & 3u) << bits) | ((g >> (bits + 2)) & low_mask);
-		out[2] = (((trits >> 4) & 3u) << bits) | ((g >> (2 * bits + 4)) & low_mask);
-		out[3] = (((trits >> 6) & 3u) << bits) | ((g >> (3 * bits + 5)) & low_mask);
-		out[4] = (((trits >> 8) & 3u) << bits) | ((g >> (4 * bits + 7)) & low_mask);
-	}
-	else
-	{
-		const uint32_t q7 = ((g >> bits) & 7u) | (((g >> (2 * bits + 3)) & 3u) << 3) | (((g >> (3 * bits + 5)) & 3u) << 5);
-		const uint32_t quints = glut ? glut[256 + q7] : quint_group_lut(q7);
-		out[0] = (((quints) & 7u) << bits) | (g & low_mask);
-		out[1] = (((quints >> 3) & 7u) << bits) | ((g >> (bits + 3)) & low_mask);
-		out[2] = (((quints >> 6) & 7u) << bits) | ((g >> (2 * bits + 5)) & low_mask);
-		out[3] = 0u; out[4] = 0u;
-	}
-}
-
 /* 32 bits of a bit string from bit `at` on (the word after the last one read must exist). */
 WV_FN uint32_t bits_window32(const uint32_t* w, int at)
 {
@@ -1218,40 +1181,63 @@ WV_FN uint32_t bits_window32(const uint32_t* w, int at)
 	return funnel_shift_right(w[word + 1], w[word], sh);
 }
 
-/* The symbols of the group of colour values that starts at bit `at` of a colour stream whose bits past its end are zero
- * (ise_group_lut for every colour level, in 32-bit pieces: a group of five trit symbols of up to six bits -- 38 bits --
- * is read as its first three symbols and its last two). */
-WV_FN void color_group_lut(const uint32_t* cs, int at, int bits, int kind, uint32_t out[5])
+/* What the decode of a BISE group needs to know about a quant level, as bit positions: the five symbols' low bits start at
+ * sym_at[e], the bits of the packed trit / quint word are `width[e]` bits at word_at[e] that go to bit word_to[e] of the
+ * table index, and a symbol's trit / quint is `digit_bits` bits of the table entry.  One straight-line routine then serves
+ * the three kinds of level (levels of plain bits have zero-width fields and read entry 0: all digits zero); a wave whose
+ * lanes work on levels of different kinds runs it once, not once per kind.
+ * (ref: decode_ise, astcenc_integer_sequence.cpp:651-739; the layout of a group: ASTC specification C.2.12) */
+struct GroupLayout {
+	int sym_at[5], word_at[5], width[5], word_to[5];
+	int bits, digit_bits, per;
+	uint32_t table_base;
+};
+WV_FN GroupLayout group_layout(int bits, int kind)
 {
-	const uint32_t low_mask = (1u << bits) - 1u;
-	const uint32_t a = bits_window32(cs, at);
-	if (kind == 0)
+	GroupLayout L;
+	const uint32_t to = kind == 1 ? 0x75420u : kind == 2 ? 0x00530u : 0u;                                   // four bits per symbol
+	const uint32_t wd = kind == 1 ? (2u | 2u << 2 | 1u << 4 | 2u << 6 | 1u << 8) : kind == 2 ? (3u | 2u << 2 | 2u << 4) : 0u;   // two bits per symbol
+	for (int e = 0; e < 5; e++)
 	{
-		// four symbols of up to eight bits
-		for (int e = 0; e < 4; e++) out[e] = (a >> (e * bits)) & low_mask;
-		out[4] = 0u;
+		L.word_to[e] = (int)((to >> (4 * e)) & 15u);
+		L.sym_at[e] = e * bits + L.word_to[e];
+		L.word_at[e] = L.sym_at[e] + bits;
+		L.width[e] = (int)((wd >> (2 * e)) & 3u);
 	}
-	else if (kind == 1)
-	{
-		const uint32_t b = bits_window32(cs, at + 3 * bits + 5);
-		const uint32_t t8 = ((a >> bits) & 3u) | (((a >> (2 * bits + 2)) & 3u) << 2) | (((a >> (3 * bits + 4)) & 1u) << 4) |
-		                    (((b >> bits) & 3u) << 5) | (((b >> (2 * bits + 2)) & 1u) << 7);
-		const uint32_t trits = trit_group_lut(t8);
-		out[0] = (((trits) & 3u) << bits) | (a & low_mask);
-		out[1] = (((trits >> 2) & 3u) << bits) | ((a >> (bits + 2)) & low_mask);
-		out[2] = (((trits >> 4) & 3u) << bits) | ((a >> (2 * bits + 4)) & low_mask);
-		out[3] = (((trits >> 6) & 3u) << bits) | (b & low_mask);
-		out[4] = (((trits >> 8) & 3u) << bits) | ((b >> (bits + 2)) & low_mask);
-	}
-	else
-	{
-		const uint32_t q7 = ((a >> bits) & 7u) | (((a >> (2 * bits + 3)) & 3u) << 3) | (((a >> (3 * bits + 5)) & 3u) << 5);
-		const uint32_t quints = quint_group_lut(q7);
-		out[0] = (((quints) & 7u) << bits) | (a & low_mask);
-		out[1] = (((quints >> 3) & 7u) << bits) | ((a >> (bits + 3)) & low_mask);
-		out[2] = (((quints >> 6) & 7u) << bits) | ((a >> (2 * bits + 5)) & low_mask);
-		out[3] = 0u; out[4] = 0u;
-	}
+	L.bits = bits;
+	L.digit_bits = kind == 1 ? 2 : kind == 2 ? 3 : 0;
+	L.per = ise_group_size(kind);
+	L.table_base = kind == 2 ? 256u : 0u;
+	return L;
+}
+/* The five symbols of the group in the 32-bit window g (bits past the end of the stream zero; a symbol past the group's
+ * last one comes out as some value below 32: in range of the unquantization table, never stored). */
+WV_FN void group_symbols(const GroupLayout& L, uint32_t g, uint32_t out[5])
+{
+	uint32_t index = 0;
+	for (int e = 0; e < 5; e++) index |= ((g >> L.word_at[e]) & ((1u << L.width[e]) - 1u)) << L.word_to[e];
+	const uint32_t digits = group_lut(L.table_base + index);
+	const uint32_t low_mask = (1u << L.bits) - 1u, digit_mask = (1u << L.digit_bits) - 1u;
+	for (int e = 0; e < 5; e++) out[e] = (((digits >> (e * L.digit_bits)) & digit_mask) << L.bits) | ((g >> L.sym_at[e]) & low_mask);
+}
+
+/* The same for the colour levels, whose groups can be longer than a window (five trit symbols of six bits: 38 bits): the
+ * first three symbols out of the window a at the group's first bit, the last two out of the window b at the fourth symbol's
+ * first bit (sym_at[3] of the unsplit layout, returned in `second_window_at`). */
+WV_FN GroupLayout group_layout_split(int bits, int kind, int& second_window_at)
+{
+	GroupLayout L = group_layout(bits, kind);
+	second_window_at = L.sym_at[3];
+	for (int e = 3; e < 5; e++) { L.sym_at[e] -= second_window_at; L.word_at[e] -= second_window_at; }
+	return L;
+}
+WV_FN void group_symbols_split(const GroupLayout& L, uint32_t a, uint32_t b, uint32_t out[5])
+{
+	uint32_t index = 0;
+	for (int e = 0; e < 5; e++) index |= (((e < 3 ? a : b) >> L.word_at[e]) & ((1u << L.width[e]) - 1u)) << L.word_to[e];
+	const uint32_t digits = group_lut(L.table_base + index);
+	const uint32_t low_mask = (1u << L.bits) - 1u, digit_mask = (1u << L.digit_bits) - 1u;
+	for (int e = 0; e < 5; e++) out[e] = (((digits >> (e * L.digit_bits)) & digit_mask) << L.bits) | (((e < 3 ? a : b) >> L.sym_at[e]) & low_mask);
 }
 
 /* A texel that does not leave as an RGBA8 pixel built from integers: error and constant-colour blocks, LNS endpoints,
@@ -1420,14 +1406,6 @@ WV_FN void decode_batch_init(DecodeBatch& s)
 		const uint32_t v = weight_unquant_lut_word(i);
 		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
 	}
-#if ASTC_DECODE_GROUP_LUT_LDS
-	WV_FOR(i, (256 + 128) / 2)
-	{
-		const uint32_t v = i < 128 ? trit_group_lut(2u * (uint32_t)i) | (trit_group_lut(2u * (uint32_t)i + 1u) << 16)
-		                           : quint_group_lut(2u * (uint32_t)(i - 128)) | (quint_group_lut(2u * (uint32_t)(i - 128) + 1u) << 16);
-		__builtin_memcpy(s.glut + 2 * i, &v, 4);
-	}
-#endif
 	WV_SYNC();
 }
 
@@ -1546,24 +1524,20 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		if (k >= count) continue;
 		const uint32_t ra = s.rec[k][0];
 		const int groups = (int)((ra >> 16) & 63u);
-		const int bits = (int)((ra >> 4) & 7u), kind = (int)((ra >> 8) & 3u), per = ise_group_size(kind), glen = (int)((ra >> 24) & 31u);
+		const int glen = (int)((ra >> 24) & 31u);
+		const GroupLayout L = group_layout((int)((ra >> 4) & 7u), (int)((ra >> 8) & 3u));
 		const uint32_t* ws = decode_batch_wstream(s, k);
 		const uint8_t* unq = s.wunq + ((ra >> 12) & 15u) * 32u;
-#if ASTC_DECODE_GROUP_LUT_LDS
-		const uint16_t* glut = s.glut;
-#else
-		const uint16_t* glut = nullptr;
-#endif
 		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
 		{
 			uint32_t sym[5];
-			weight_group_lut(ws, mul24(g, glen), bits, kind, glut, sym);
+			group_symbols(L, bits_window32(ws, mul24(g, glen)), sym);
 			// (the table reads first, then the stores: in program order they would wait for one another)
 			const uint8_t w0 = unq[sym[0]], w1 = unq[sym[1]], w2 = unq[sym[2]], w3 = unq[sym[3]], w4 = unq[sym[4]];
-			uint8_t* out = s.weights[k] + mul24(g, per);
+			uint8_t* out = s.weights[k] + mul24(g, L.per);
 			out[0] = w0; out[1] = w1; out[2] = w2;
-			if (per > 3) out[3] = w3;
-			if (per > 4) out[4] = w4;
+			if (L.per > 3) out[3] = w3;
+			if (L.per > 4) out[4] = w4;
 		}
 	}
 	if (ASTC_DECODE_STOP_AFTER == 2) return;
@@ -1574,25 +1548,28 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		const uint32_t rb = s.rec[k][1];
 		const int groups = (int)((s.rec[k][2] >> 20) & 7u);
 		const int nvals = (int)((rb >> 16) & 31u);
-		const int bits = (int)(rb & 15u), kind = (int)((rb >> 4) & 3u), per = ise_group_size(kind);
+		const int bits = (int)(rb & 15u), kind = (int)((rb >> 4) & 3u);
 		const int glen = kind == 1 ? 5 * bits + 8 : kind == 2 ? 3 * bits + 7 : 4 * bits;
 		const int cquant = (int)((rb >> 8) & 31u), cstart = (int)((rb >> 24) & 31u);
+		int second_at;
+		const GroupLayout L = group_layout_split(bits, kind, second_at);
 		const uint32_t* cs = decode_batch_bits(s, k);
 		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
 		{
 			uint32_t sym[5];
-			color_group_lut(cs, cstart + mul24(g, glen), bits, kind, sym);
+			const int at = cstart + mul24(g, glen);
+			group_symbols_split(L, bits_window32(cs, at), bits_window32(cs, at + second_at), sym);
 			// (the five table reads side by side, then the stores: one wait instead of five; the symbols past a short group are
-			//  in range -- zero, or a trit / quint of zero bits)
+			//  in range -- below 256)
 			const uint8_t c0 = (uint8_t)color_unquant_lut(cquant, (int)sym[0]), c1 = (uint8_t)color_unquant_lut(cquant, (int)sym[1]), c2 = (uint8_t)color_unquant_lut(cquant, (int)sym[2]);
 			const uint8_t c3 = (uint8_t)color_unquant_lut(cquant, (int)sym[3]), c4 = (uint8_t)color_unquant_lut(cquant, (int)sym[4]);
-			const int n = nvals - mul24(g, per);
-			uint8_t* out = s.colors[k] + mul24(g, per);
+			const int n = nvals - mul24(g, L.per);
+			uint8_t* out = s.colors[k] + mul24(g, L.per);
 			out[0] = c0;
 			if (n > 1) out[1] = c1;
 			if (n > 2) out[2] = c2;
-			if (n > 3 && per > 3) out[3] = c3;
-			if (n > 4 && per > 4) out[4] = c4;
+			if (n > 3 && L.per > 3) out[3] = c3;
+			if (n > 4 && L.per > 4) out[4] = c4;
 		}
 	}
 	WV_SYNC();

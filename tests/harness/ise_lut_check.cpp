@@ -71,7 +71,7 @@ int main()
 				if (ise_group_count(count, kind) != (count + per - 1) / per) { bad++; fprintf(stderr, "group count %d %d\n", kind, count); }
 			}
 		}
-		// weight levels: the 32-bit-window group decode on a stream cut off at its length (what decode_row_batch stores)
+		// weight levels: the straight-line group decode (group_layout / group_symbols) on a stream cut off at its length (what decode_row_batch stores)
 		if (quant <= 11)
 		{
 			for (int rep = 0; rep < 400; rep++)
@@ -93,7 +93,8 @@ int main()
 				for (int group = 0; group * per < count; group++)
 				{
 					uint32_t sym[5];
-					weight_group_lut(ws, group * glen, q.bits, kind, nullptr, sym);
+					group_symbols(group_layout(q.bits, kind), bits_window32(ws, group * glen), sym);
+					for (int e = 0; e < 5; e++) if (sym[e] > 31u) { bad++; fprintf(stderr, "weight group: symbol out of range\n"); }
 					for (int e = 0; e < per && group * per + e < count; e++)
 					{
 						checked++;
@@ -105,7 +106,7 @@ int main()
 				}
 			}
 		}
-		// colour levels: the group decode in 32-bit pieces on a stream cut off at the end of the colour values
+		// colour levels: the straight-line group decode over two 32-bit windows (group_layout_split / group_symbols_split) on a stream cut off at the end of the colour values
 		if (quant >= 4)
 		{
 			for (int rep = 0; rep < 400; rep++)
@@ -128,7 +129,9 @@ int main()
 				for (int group = 0; group * per < count; group++)
 				{
 					uint32_t sym[5];
-					color_group_lut(cs, start + group * glen, q.bits, kind, sym);
+					int second_at;
+					const GroupLayout L = group_layout_split(q.bits, kind, second_at);
+					group_symbols_split(L, bits_window32(cs, start + group * glen), bits_window32(cs, start + group * glen + second_at), sym);
 					for (int e = 0; e < per && group * per + e < count; e++)
 					{
 						checked++;
