@@ -1528,16 +1528,24 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		const GroupLayout L = group_layout((int)((ra >> 4) & 7u), (int)((ra >> 8) & 3u));
 		const uint32_t* ws = decode_batch_wstream(s, k);
 		const uint8_t* unq = s.wunq + ((ra >> 12) & 15u) * 32u;
-		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
+		// Three groups per trip, side by side: the phase is a chain of dependent reads (stream window -> group table -> weight
+		// table) that a wave cannot overlap with anything but another group's chain.  A slot past the block's last group decodes
+		// the last group again and stores nothing.
+		for (int g0 = l >> DECODE_BATCH_LOG2; g0 < groups; g0 += 3 * DECODE_SLOTS)
 		{
-			uint32_t sym[5];
-			group_symbols(L, bits_window32(ws, mul24(g, glen)), sym);
-			// (the table reads first, then the stores: in program order they would wait for one another)
-			const uint8_t w0 = unq[sym[0]], w1 = unq[sym[1]], w2 = unq[sym[2]], w3 = unq[sym[3]], w4 = unq[sym[4]];
-			uint8_t* out = s.weights[k] + mul24(g, L.per);
-			out[0] = w0; out[1] = w1; out[2] = w2;
-			if (L.per > 3) out[3] = w3;
-			if (L.per > 4) out[4] = w4;
+			uint32_t sym[3][5];
+			for (int u = 0; u < 3; u++) group_symbols(L, bits_window32(ws, mul24(i_min(g0 + u * DECODE_SLOTS, groups - 1), glen)), sym[u]);
+			uint8_t w[3][5];
+			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) w[u][e] = unq[sym[u][e]];
+			for (int u = 0; u < 3; u++)
+			{
+				const int g = g0 + u * DECODE_SLOTS;
+				if (g >= groups) break;
+				uint8_t* out = s.weights[k] + mul24(g, L.per);
+				out[0] = w[u][0]; out[1] = w[u][1]; out[2] = w[u][2];
+				if (L.per > 3) out[3] = w[u][3];
+				if (L.per > 4) out[4] = w[u][4];
+			}
 		}
 	}
 	if (ASTC_DECODE_STOP_AFTER == 2) return;
@@ -1554,22 +1562,30 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		int second_at;
 		const GroupLayout L = group_layout_split(bits, kind, second_at);
 		const uint32_t* cs = decode_batch_bits(s, k);
-		for (int g = l >> DECODE_BATCH_LOG2; g < groups; g += DECODE_SLOTS)
+		// (three groups per trip, as for the weights; a block has at most six groups of colour values)
+		for (int g0 = l >> DECODE_BATCH_LOG2; g0 < groups; g0 += 3 * DECODE_SLOTS)
 		{
-			uint32_t sym[5];
-			const int at = cstart + mul24(g, glen);
-			group_symbols_split(L, bits_window32(cs, at), bits_window32(cs, at + second_at), sym);
-			// (the five table reads side by side, then the stores: one wait instead of five; the symbols past a short group are
-			//  in range -- below 256)
-			const uint8_t c0 = (uint8_t)color_unquant_lut(cquant, (int)sym[0]), c1 = (uint8_t)color_unquant_lut(cquant, (int)sym[1]), c2 = (uint8_t)color_unquant_lut(cquant, (int)sym[2]);
-			const uint8_t c3 = (uint8_t)color_unquant_lut(cquant, (int)sym[3]), c4 = (uint8_t)color_unquant_lut(cquant, (int)sym[4]);
-			const int n = nvals - mul24(g, L.per);
-			uint8_t* out = s.colors[k] + mul24(g, L.per);
-			out[0] = c0;
-			if (n > 1) out[1] = c1;
-			if (n > 2) out[2] = c2;
-			if (n > 3 && L.per > 3) out[3] = c3;
-			if (n > 4 && L.per > 4) out[4] = c4;
+			uint32_t sym[3][5];
+			for (int u = 0; u < 3; u++)
+			{
+				const int at = cstart + mul24(i_min(g0 + u * DECODE_SLOTS, groups - 1), glen);
+				group_symbols_split(L, bits_window32(cs, at), bits_window32(cs, at + second_at), sym[u]);
+			}
+			// (the table reads side by side, then the stores: one wait; the symbols past a short group are in range -- below 256)
+			uint8_t c[3][5];
+			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) c[u][e] = (uint8_t)color_unquant_lut(cquant, (int)sym[u][e]);
+			for (int u = 0; u < 3; u++)
+			{
+				const int g = g0 + u * DECODE_SLOTS;
+				if (g >= groups) break;
+				const int n = nvals - mul24(g, L.per);
+				uint8_t* out = s.colors[k] + mul24(g, L.per);
+				out[0] = c[u][0];
+				if (n > 1) out[1] = c[u][1];
+				if (n > 2) out[2] = c[u][2];
+				if (n > 3 && L.per > 3) out[3] = c[u][3];
+				if (n > 4 && L.per > 4) out[4] = c[u][4];
+			}
 		}
 	}
 	WV_SYNC();
