@@ -1154,8 +1154,8 @@ struct alignas(16) DecodeBatch {
 	// Endpoints per partition, one word per channel: endpoint0 | endpoint1 << 16 (16-bit values).  With the weight pair
 	// (256 - 4 w) | 4 w << 16 one dot product per channel, plus 128, is the interpolated 16-bit value in bits 8..23 (its top
 	// byte in byte 2).  Until the endpoint phase writes them the words hold the block's bit streams, both cut off at their
-	// lengths: [0..4] the block up to the end of its colour values and a zero word, [8..11] the weight stream (the block
-	// bit-reversed).
+	// lengths: five words -- the block up to the end of its colour values and a zero word -- and four -- the weight stream,
+	// i.e. the block bit-reversed -- at decode_batch_bits() / decode_batch_wstream().
 	// A constant-colour block keeps its four floats in [0..3].
 	uint32_t ep[DECODE_BATCH][4 * 4];
 	uint8_t  wunq[12 * 32];              // weight_unquant_lut, copied once per wave
@@ -1171,8 +1171,11 @@ struct alignas(16) DecodeBatch {
 static_assert(__builtin_offsetof(DecodeBatch, rec) % 16 == 0 && __builtin_offsetof(DecodeBatch, hash) % 16 == 0 && __builtin_offsetof(DecodeBatch, ep) % 16 == 0,
               "DecodeBatch: records read as four words are 16-byte aligned");
 
-WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k]; }
-WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + 8; }
+// The streams' place inside the block's sixteen words turns with the block index: the element phases have their lanes on
+// 32 different blocks, whose records are 16 words -- half the banks -- apart; unturned, every stream read is a 16-way bank
+// conflict (measured: the weight and colour phases did not get faster when their instructions were halved).
+WV_FN uint32_t* decode_batch_bits(DecodeBatch& s, int k) { return s.ep[k] + ((k >> 1) & 7); }
+WV_FN uint32_t* decode_batch_wstream(DecodeBatch& s, int k) { return s.ep[k] + ((k >> 1) & 7) + 5; }
 
 /* 32 bits of a bit string from bit `at` on (the word after the last one read must exist). */
 WV_FN uint32_t bits_window32(const uint32_t* w, int at)
