@@ -11,13 +11,11 @@ namespace astcd {
 
 /* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes runs of
  * DECODE_BATCH consecutive blocks of one block row and decodes each run together (decode_row_batch) -- DECODE_RUNS_PER_WAVE
- * of them one after the other, so that a wave's launch, its LDS allocation and its tables are paid for once per that many
- * runs.  The grid is (waves per block row, block rows, layers of blocks): a run's place in the image needs no division. */
+ * of them one after the other (one, as measured: wave_decode.h).  The grid is (waves per block row, block rows, layers of blocks): a run's place in the image needs no division. */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))      // (LDS allows 5.75 waves per SIMD: keep the registers under that)
 astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img)
 {
 	__shared__ DecodeBatch batch;
-	decode_batch_init(batch);
 	for (int run = 0; run < DECODE_RUNS_PER_WAVE; run++)
 	{
 		const uint32_t bx0 = (blockIdx.x * (uint32_t)DECODE_RUNS_PER_WAVE + (uint32_t)run) * (uint32_t)DECODE_BATCH;

@@ -6,13 +6,15 @@
 //        unpack_weights / lerp_color_int / decode_texel       :37-155
 //        store_image_block           Source/astcenc_image.cpp:345-573
 //
-// One wavefront decodes a batch of consecutive blocks (decode_block_batch).  Unlike the reference (and unlike the
-// encoder) nothing here depends on tables built for a block size or a preset: the decoder must accept every legal
-// block mode and partitioning, not just the ones a compression preset selects, so grid weights are infilled with the
-// format's arithmetic rule and texels are assigned to partitions with the hash function.  BISE symbols are unpacked per
-// element straight from the bit stream; the batched path looks trit / quint groups and unquantized values up in four
-// tables of format constants generated from the arithmetic routines below (decode_luts.inc).  Lanes own weights /
-// colour values while unpacking and texels while interpolating.
+// One wavefront decodes a run of 32 consecutive blocks of a block row (decode_row_batch): headers on a lane per block, BISE
+// groups of weights and colour values and endpoint pairs on two lanes per block, then the texels of the image rows the run
+// covers, a lane per column.  The decoder must accept every legal block mode and partitioning, not just the ones a
+// compression preset selects: grid weights are infilled with the format's arithmetic rule and texels are assigned to
+// partitions with the hash function.  What it reads from tables: per footprint, what a block mode field says and which colour
+// quant level a bit budget affords (DecodeTables, built on the host from the arithmetic routines below); as format
+// constants, the trit / quint groups and the unquantized weight and colour values (decode_luts.inc, generated from the
+// arithmetic routines below).  The single-block routines (parse_block_header without tables, unpack_block_payload) are what
+// astcenc_get_block_info runs on the host.
 #pragma once
 #include "wave_color.h"
 #include "wave_load.h"
@@ -121,6 +123,20 @@ WV_FN uint32_t umad24(uint32_t a, uint32_t b, uint32_t c)
 	uint32_t r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 #else
 	return a * b + c;
+#endif
+}
+
+/* 8 + t0 w0 + t1 w1 + t2 w2 + t3 w3 for factors that fit 24 bits: the weight infill's sum (one block of four multiply-adds
+ * on the device: separate ones are scheduled with idle states between them). */
+WV_FN int tap_sum4(int t0, int w0, int t1, int w1, int t2, int w2, int t3, int w3)
+{
+#if WV_DEVICE
+	int r;
+	asm("v_mad_i32_i24 %0, %1, %2, 8\n\tv_mad_i32_i24 %0, %3, %4, %0\n\tv_mad_i32_i24 %0, %5, %6, %0\n\tv_mad_i32_i24 %0, %7, %8, %0"
+	    : "=&v"(r) : "v"(t0), "v"(w0), "v"(t1), "v"(w1), "v"(t2), "v"(w2), "v"(t3), "v"(w3));
+	return r;
+#else
+	return 8 + t0 * w0 + t1 * w1 + t2 * w2 + t3 * w3;
 #endif
 }
 
@@ -1029,93 +1045,6 @@ WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int pr
 	WV_SYNC();
 }
 
-/* Decode block (bx, by, bz) of the stream into the image.  All 64 lanes call this. */
-WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx, uint32_t by, uint32_t bz, DecodeScratch& s)
-{
-	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
-	const int T = block_x * block_y * block_z;
-	const int profile = (int)img.profile;
-	const bool u8_out = img.data_type == 0 || profile == 0;        // (ref: get_u8_component_mask)
-	const float error_nan = int_as_float((int)0xFFFFE000u);
-
-	Bits128 blk;
-	{
-		const uint32_t* p = reinterpret_cast<const uint32_t*>(pcb);
-		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
-	}
-	const BlockHeader h = parse_block_header(blk, block_x, block_y, block_z);
-	bool error = h.error;
-
-	// constant colour (ref: decompress_symbolic.cpp:204-255)
-	float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
-	if (h.constant && !error)
-	{
-		if (h.constant_f16)
-		{
-			// FP16 constant colour: legal in the HDR profiles only
-			if (profile == 2 || profile == 3)
-			{
-				cr = half_to_float((uint16_t)h.const_color[0]); cg = half_to_float((uint16_t)h.const_color[1]);
-				cb = half_to_float((uint16_t)h.const_color[2]); ca = half_to_float((uint16_t)h.const_color[3]);
-			}
-			else error = true;
-		}
-		else
-		{
-			for (int k = 0; k < 4; k++)
-			{
-				int v = u8_out ? (h.const_color[k] >> 8) * 257 : h.const_color[k];
-				float f = half_to_float((uint16_t)unorm16_to_sf16(v));
-				if (k == 0) cr = f; else if (k == 1) cg = f; else if (k == 2) cb = f; else ca = f;
-			}
-		}
-	}
-	if (!error && !h.constant) unpack_block_payload(blk, h, profile, s);
-
-	// ---- texels ----
-	const bool small_block = T < 31;
-	WV_FOR(t, T)
-	{
-		const int tz = block_z > 1 ? t / (block_x * block_y) : 0;
-		const int trem = t - tz * (block_x * block_y);
-		const int ty = trem / block_x, tx = trem - ty * block_x;
-		const uint32_t xi = bx * (uint32_t)block_x + (uint32_t)tx;
-		const uint32_t yi = by * (uint32_t)block_y + (uint32_t)ty;
-		const uint32_t zi = bz * (uint32_t)block_z + (uint32_t)tz;
-		if (xi >= img.dim_x || yi >= img.dim_y || zi >= img.dim_z) continue;
-
-		float r, g, b, a;
-		if (error)
-		{
-			r = g = b = a = error_nan;
-		}
-		else if (h.constant)
-		{
-			r = cr; g = cg; b = cb; a = ca;
-		}
-		else
-		{
-			int wp[2];
-			infill_texel_weights(h, s.weights, (1024 + block_x / 2) / (block_x - 1), (1024 + block_y / 2) / (block_y - 1),
-			                     block_z > 1 ? (1024 + block_z / 2) / (block_z - 1) : 0, block_z, tx, ty, tz, wp);
-			const int p = h.parts == 1 ? 0 : partition_of_texel(h.seed, tx, ty, tz, h.parts, small_block);
-			const uint16_t* e = s.ep[p];
-			float out[4];
-			for (int k = 0; k < 4; k++)
-			{
-				const int wk = (h.dual && k == h.plane2) ? wp[1] : wp[0];
-				int cval = (e[k] * (64 - wk) + e[4 + k] * wk + 32) >> 6;      // (ref: lerp_color_int :37)
-				if (u8_out) cval = (cval >> 8) * 257;
-				const bool lns = s.lns[p][k == 3 ? 1 : 0] != 0;
-				const int hf = lns ? lns_to_sf16(cval) : unorm16_to_sf16(cval);  // (ref: decode_texel :66)
-				out[k] = half_to_float((uint16_t)hf);
-			}
-			r = out[0]; g = out[1]; b = out[2]; a = out[3];
-		}
-		store_texel(img, xi, yi, zi, r, g, b, a);
-	}
-}
-
 #if !defined(ASTC_DECODE_NO_LUTS)
 /* A run of consecutive blocks of one block row decoded together by one wavefront.  Decoding one block keeps few lanes
  * busy (a header, <= 64 weights, <= 18 colour values, <= 4 endpoint pairs, T texels, one after the other); over a run
@@ -1130,6 +1059,10 @@ WV_FN void decode_block(const DecodeImage& img, const uint8_t* pcb, uint32_t bx,
 // 4 endpoints; 9: at once); the product is built without it
 #ifndef ASTC_DECODE_STOP_AFTER
 #define ASTC_DECODE_STOP_AFTER 0
+#endif
+// measurement builds that leave work out (wrong output): 1 no colour table reads, 2 one weight store per group, 3 no weight table reads
+#ifndef ASTC_DECODE_EXP
+#define ASTC_DECODE_EXP 0
 #endif
 // consecutive runs of a block row one wavefront decodes.  Measured (profiles/r05zz/decode_runs_per_wave.log, 8192^2 6x6):
 // 1 run 0.258 ms, 2 runs 0.276, 4 runs 0.285, 8 runs 0.343 -- launching a wave and filling its table is 0.016 ms of the
@@ -1299,10 +1232,10 @@ WV_FN uint32_t pixel_from_lerps(uint32_t sel, const uint32_t x[4])
 }
 
 /* The texel phase of a run of 2D blocks: the image rows the run covers, one after the other.  kMulti / kDual: the run
- * has blocks with more than one partition / with two weight planes (wave-uniform; a run without them skips the partition
- * hash and reads its endpoints once per column / reads one plane).  kGeneral: some texel of the run does not leave as an
+ * has blocks with more than one partition (1: with two at most, 2: with three or four) / with two weight planes
+ * (wave-uniform; a run without them skips the partition hash and reads its endpoints once per column / reads one plane).  kGeneral: some texel of the run does not leave as an
  * integer-built RGBA8 pixel (store_texel_general); the builds without it are the RGBA8 decoder's inner loops. */
-template <bool kMulti, bool kDual, bool kGeneral>
+template <int kMulti, bool kDual, bool kGeneral>
 WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, uint32_t bz, int count, DecodeBatch& s)
 {
 	const int block_x = (int)img.block_x, block_y = (int)img.block_y;
@@ -1355,33 +1288,42 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 			U32x4 e = { 0u, 0u, 0u, 0u };
 			if (!kMulti) e = load_u32x4_aligned(epk);
 			size_t at = (((size_t)bz * img.dim_y + y0) * img.dim_x + xi) * 4;      // (2D blocks: layer bz of the stream is slice bz of the image)
-			for (int ty = 0; ty < rows; ty++, at += (size_t)img.dim_x * 4)
+			int gt64 = 32;                                                          // dt * ty * (wy - 1) + 32, row by row
+			for (int ty = 0; ty < rows; ty++, at += (size_t)img.dim_x * 4, gt64 += dty)
 			{
 				int cv[4] = { 0, 0, 0, 0 };
 				uint32_t px = cpx;
 				int p = 0;
 				if (payload)
 				{
-					const int gt = mad24(dty, ty, 32) >> 6;
+					const int gt = gt64 >> 6;
 					const int jt = gt >> 4, ft = gt & 0xF;
 					const int w11 = mad24(fs, ft, 8) >> 4;
 					const int w10 = ft - w11, w01 = fs - w11, w00 = 16 - fs - ft + w11;
 					// A tap whose factor is zero may lie past the grid (the last row / column interpolates with factor 0): its product is
 					// zero whatever is read there, and the read stays inside the scratch -- so the four taps are read unconditionally.
 					const uint8_t* g = wcol + mul24(jt, wrow);
-					const int w0 = mad24(g[wrow + stride], w11, mad24(g[wrow], w10, mad24(g[stride], w01, mad24(g[0], w00, 8)))) >> 4;
+					const int w0 = tap_sum4(g[0], w00, g[stride], w01, g[wrow], w10, g[wrow + stride], w11) >> 4;
 					int w1 = w0;
-					if (kDual && dual) w1 = mad24(g[wrow + 3], w11, mad24(g[wrow + 1], w10, mad24(g[3], w01, mad24(g[1], w00, 8)))) >> 4;
+					if (kDual && dual) w1 = tap_sum4(g[1], w00, g[3], w01, g[wrow + 1], w10, g[wrow + 3], w11) >> 4;
 					if (kMulti)
 					{
 						if (parts > 1)
 						{
 							const uint32_t ys = (uint32_t)(small_block ? ty << 1 : ty);
 							// (ref: select_partition, astcenc_partition_tables.cpp:216-245: a >= b && a >= c && a >= d -> 0, b >= c && b >= d -> 1, c >= d -> 2, else 3)
-							const uint32_t a = (umad24(hy[0], ys, hx[0]) & 0xFCu) | 3u, b = (umad24(hy[1], ys, hx[1]) & 0xFCu) | 2u;
-							const uint32_t c = (umad24(hy[2], ys, hx[2]) & 0xFCu) | 1u, d = umad24(hy[3], ys, hx[3]) & 0xFCu;
-							const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-							p = 3 - (int)((ab > cd ? ab : cd) & 3u);
+							if (kMulti == 1)
+							{
+								// (two partitions at most in this run: the terms c and d are zero)
+								p = (umad24(hy[1], ys, hx[1]) & 0xFCu) > (umad24(hy[0], ys, hx[0]) & 0xFCu) ? 1 : 0;
+							}
+							else
+							{
+								const uint32_t a = (umad24(hy[0], ys, hx[0]) & 0xFCu) | 3u, b = (umad24(hy[1], ys, hx[1]) & 0xFCu) | 2u;
+								const uint32_t c = (umad24(hy[2], ys, hx[2]) & 0xFCu) | 1u, d = umad24(hy[3], ys, hx[3]) & 0xFCu;
+								const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+								p = 3 - (int)((ab > cd ? ab : cd) & 3u);
+							}
 						}
 						e = load_u32x4_aligned(epk + p * 4);
 					}
@@ -1401,19 +1343,9 @@ WV_FN void decode_row_texels(const DecodeImage& img, uint32_t bx0, uint32_t by, 
 	}
 }
 
-/* The tables a wave keeps in its scratch: once per wave, before its first run.  All 64 lanes call this. */
-WV_FN void decode_batch_init(DecodeBatch& s)
-{
-	WV_FOR(i, 12 * 32 / 4)
-	{
-		const uint32_t v = weight_unquant_lut_word(i);
-		__builtin_memcpy(s.wunq + 4 * i, &v, 4);
-	}
-	WV_SYNC();
-}
-
 /* Decode blocks bx0 .. bx0 + count - 1 (count <= DECODE_BATCH) of block row `by`, layer `bz` of the stream into the image.
- * All 64 lanes call this, after decode_batch_init() on the scratch.  Same arithmetic as decode_block(), block by block. */
+ * All 64 lanes call this.  The arithmetic, block by block, is that of the single-block routines above (parse_block_header,
+ * unpack_block_payload, infill_texel_weights: what astcenc_get_block_info runs on the host). */
 WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint32_t bx0, uint32_t by, uint32_t bz, int count, DecodeBatch& s)
 {
 	const int block_x = (int)img.block_x, block_y = (int)img.block_y, block_z = (int)img.block_z;
@@ -1430,12 +1362,20 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 
 	if (ASTC_DECODE_STOP_AFTER == 9) return;
 	// ---- headers and constant colours: one lane per block ----
-	bool multi_part = false, dual_part = false;      // per-lane partials, folded below
-	WV_FOR64(k, count)
+	bool multi_part = false, many_part = false, dual_part = false;      // per-lane partials, folded below
+	WV_FOR64(k, 64)
 	{
+		// (every lane loads a block -- the lanes past the run's last block that one again -- and its share of the weight
+		//  unquantization table the wave keeps in LDS, so that all these loads are in flight together)
 		Bits128 blk;
-		const uint32_t* p = reinterpret_cast<const uint32_t*>(blocks + (first + (size_t)k) * 16);
+		const uint32_t* p = reinterpret_cast<const uint32_t*>(blocks + (first + (size_t)i_min(k, count - 1)) * 16);
 		blk.w[0] = p[0]; blk.w[1] = p[1]; blk.w[2] = p[2]; blk.w[3] = p[3];
+		{
+			const uint32_t t0 = weight_unquant_lut_word(k), t1 = weight_unquant_lut_word(64 + (k & 31));
+			__builtin_memcpy(s.wunq + 4 * k, &t0, 4);
+			if (k < 32) __builtin_memcpy(s.wunq + 4 * (64 + k), &t1, 4);
+		}
+		if (k >= count) continue;
 		const DecodeTables* tabs = img.tabs;
 #if WV_DEVICE
 		__builtin_assume(tabs != nullptr);       // (the launch always passes the tables: no arithmetic fallback in the kernel)
@@ -1513,10 +1453,11 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			}
 			ws[3] = 0u;
 			multi_part = multi_part || h.parts > 1;
+			many_part = many_part || h.parts > 2;
 			dual_part = dual_part || h.dual;
 		}
 	}
-	const bool any_multi = wv_any(multi_part), any_dual = wv_any(dual_part);
+	const bool any_multi = wv_any(multi_part), any_many = wv_any(many_part), any_dual = wv_any(dual_part);
 	WV_SYNC();
 	if (ASTC_DECODE_STOP_AFTER == 1) return;
 
@@ -1539,15 +1480,23 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			uint32_t sym[3][5];
 			for (int u = 0; u < 3; u++) group_symbols(L, bits_window32(ws, mul24(i_min(g0 + u * DECODE_SLOTS, groups - 1), glen)), sym[u]);
 			uint8_t w[3][5];
+#if ASTC_DECODE_EXP == 3
+			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) w[u][e] = (uint8_t)sym[u][e];      // (measurement: no table reads)
+#else
 			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) w[u][e] = unq[sym[u][e]];
+#endif
 			for (int u = 0; u < 3; u++)
 			{
 				const int g = g0 + u * DECODE_SLOTS;
 				if (g >= groups) break;
 				uint8_t* out = s.weights[k] + mul24(g, L.per);
+#if ASTC_DECODE_EXP == 2
+				out[0] = (uint8_t)(w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3] ^ w[u][4]);      // (measurement: one store per group)
+#else
 				out[0] = w[u][0]; out[1] = w[u][1]; out[2] = w[u][2];
 				if (L.per > 3) out[3] = w[u][3];
 				if (L.per > 4) out[4] = w[u][4];
+#endif
 			}
 		}
 	}
@@ -1576,7 +1525,11 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			}
 			// (the table reads side by side, then the stores: one wait; the symbols past a short group are in range -- below 256)
 			uint8_t c[3][5];
+#if ASTC_DECODE_EXP == 1
+			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) c[u][e] = (uint8_t)(sym[u][e] + (uint32_t)cquant);      // (measurement: no table reads)
+#else
 			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) c[u][e] = (uint8_t)color_unquant_lut(cquant, (int)sym[u][e]);
+#endif
 			for (int u = 0; u < 3; u++)
 			{
 				const int g = g0 + u * DECODE_SLOTS;
@@ -1637,16 +1590,21 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	// ---- texels ----
 	if (block_z == 1)
 	{
-		if (any_general) decode_row_texels<true, true, true>(img, bx0, by, bz, count, s);
+		if (any_general) decode_row_texels<2, true, true>(img, bx0, by, bz, count, s);
+		else if (any_many)
+		{
+			if (any_dual) decode_row_texels<2, true, false>(img, bx0, by, bz, count, s);
+			else decode_row_texels<2, false, false>(img, bx0, by, bz, count, s);
+		}
 		else if (any_multi)
 		{
-			if (any_dual) decode_row_texels<true, true, false>(img, bx0, by, bz, count, s);
-			else decode_row_texels<true, false, false>(img, bx0, by, bz, count, s);
+			if (any_dual) decode_row_texels<1, true, false>(img, bx0, by, bz, count, s);
+			else decode_row_texels<1, false, false>(img, bx0, by, bz, count, s);
 		}
 		else
 		{
-			if (any_dual) decode_row_texels<false, true, false>(img, bx0, by, bz, count, s);
-			else decode_row_texels<false, false, false>(img, bx0, by, bz, count, s);
+			if (any_dual) decode_row_texels<0, true, false>(img, bx0, by, bz, count, s);
+			else decode_row_texels<0, false, false>(img, bx0, by, bz, count, s);
 		}
 	}
 	else

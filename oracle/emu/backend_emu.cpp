@@ -208,7 +208,6 @@ int backend_decompress(Backend* b, const DecompressJob& job)
 	img.tabs = tabs.data();
 	std::vector<DecodeBatch> batch(1);
 	memset(static_cast<void*>(batch.data()), 0xCD, sizeof(DecodeBatch));
-	decode_batch_init(batch[0]);
 	for (uint32_t bz = 0; bz < img.blocks_z; bz++)
 		for (uint32_t by = 0; by < img.blocks_y; by++)
 			for (uint32_t bx0 = 0; bx0 < img.blocks_x; bx0 += (uint32_t)DECODE_BATCH)
