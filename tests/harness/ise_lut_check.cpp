@@ -1,5 +1,6 @@
 // SPDX-License-Identifier: Apache-2.0
-// Test infrastructure: the batched decoder's table-driven BISE symbol decode (ise_symbol_lut, *_unquant_lut) against
+// Test infrastructure: the batched decoder's table-driven routines -- BISE symbol decode (ise_symbol_lut, group_symbols,
+// *_unquant_lut), the packed quant-level constants, the header parse from DecodeTables -- against
 // the arithmetic per-element routines it replaces (ise_symbol, unquant_*_symbol), which are the ones the single-block
 // decoder and astcenc_get_block_info use and which are pinned to the reference decoder by tests/test_decode.py.
 //   g++ -std=c++17 -O1 -DASTC_WAVE_EMU=1 -I astc-encoder_amd/csrc tests/harness/ise_lut_check.cpp -o ise_lut_check
@@ -152,6 +153,40 @@ int main()
 			if (!valid) continue;
 			if (quant <= 11 && v < 32) { checked++; if (weight_unquant_lut(quant, v) != unquant_weight_symbol(v, quant)) { bad++; fprintf(stderr, "weight unquant %d %d\n", quant, v); } }
 			if (quant >= 4) { checked++; if (color_unquant_lut(quant, v) != unquant_color_symbol(v, quant)) { bad++; fprintf(stderr, "colour unquant %d %d\n", quant, v); } }
+		}
+	}
+	// the table-driven header parse of the batched decoder (DecodeTables, built from the arithmetic routines) against the
+	// arithmetic one, field by field, on random blocks -- reserved modes, void extents, every partition count
+	{
+		const int foot[8][3] = { { 4, 4, 1 }, { 6, 6, 1 }, { 8, 5, 1 }, { 10, 6, 1 }, { 12, 12, 1 }, { 3, 3, 3 }, { 4, 4, 3 }, { 6, 6, 6 } };
+		static DecodeTables tabs;
+		for (int f = 0; f < 8; f++)
+		{
+			decode_tables_build(tabs, foot[f][0], foot[f][1], foot[f][2]);
+			for (int rep = 0; rep < 40000; rep++)
+			{
+				Bits128 b;
+				for (int k = 0; k < 4; k++) b.w[k] = rnd();
+				if (rep % 7 == 0) b.w[0] = (b.w[0] & ~0x1FFu) | 0x1FCu;          // void extent
+				if (rep % 5 == 1) b.w[0] &= ~0x1800u;                            // one partition
+				if (rep % 9 == 2) b.w[0] = (b.w[0] & ~3u) | 1u;                  // the common rows of the mode table
+				const BlockHeader x = parse_block_header(b, foot[f][0], foot[f][1], foot[f][2], &tabs);
+				const BlockHeader y = parse_block_header(b, foot[f][0], foot[f][1], foot[f][2], nullptr);
+				checked++;
+				bool same = x.error == y.error && x.constant == y.constant;
+				if (same && !x.error && x.constant)
+				{
+					same = x.constant_f16 == y.constant_f16;
+					for (int k = 0; k < 4; k++) same = same && x.const_color[k] == y.const_color[k];
+				}
+				if (same && !x.error && !x.constant)
+				{
+					same = x.wx == y.wx && x.wy == y.wy && x.wz == y.wz && x.wquant == y.wquant && x.wbits == y.wbits && x.dual == y.dual && x.parts == y.parts &&
+					       x.seed == y.seed && x.plane2 == y.plane2 && x.nvals == y.nvals && x.cquant == y.cquant && x.color_start == y.color_start;
+					for (int k = 0; k < x.parts; k++) same = same && x.fmt[k] == y.fmt[k];
+				}
+				if (!same && bad++ < 10) fprintf(stderr, "header: footprint %dx%dx%d block %08x %08x %08x %08x\n", foot[f][0], foot[f][1], foot[f][2], b.w[0], b.w[1], b.w[2], b.w[3]);
+			}
 		}
 	}
 	printf("%ld checks, %ld mismatches\n", checked, bad);

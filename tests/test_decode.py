@@ -56,6 +56,20 @@ def test_decode_ldr_matches_reference(lib, ref, A, block):
             assert same(want, got), (name, out_type, np.argwhere(want != got)[:3])
 
 
+@pytest.mark.parametrize("block", [(4, 4), (6, 6), (8, 8), (10, 5), (12, 12)])
+def test_decode_wide_images_in_full_runs(lib, ref, A, block):
+    """The decoder takes runs of 32 blocks of a block row: images wide enough for two full runs and a tail, real
+    encoder output (multi-partition, dual-plane and constant blocks), a partial last block column and row."""
+    w, h = block[0] * 70 + 3, block[1] * 2 + 1
+    im = images.ALL["noisy"](w, h)
+    im[: block[1], : 40 * block[0]] = (9, 200, 31, 255)         # a stretch of constant blocks inside the first run
+    data = ref.compress(im, block, 60.0)
+    for out_type in (np.uint8, np.float16):
+        want = decode(ref, A, data, w, h, block, out_type=out_type)
+        got = decode(lib, A, data, w, h, block, out_type=out_type)
+        assert same(want, got), (out_type, np.argwhere(want != got)[:3])
+
+
 def test_decode_srgb_and_swizzles(lib, ref, A):
     block, (w, h) = (6, 6), (40, 31)
     data = ref.compress(images.noisy(w, h, 4), block, 60.0, profile=A.PRF_LDR_SRGB)
@@ -188,9 +202,12 @@ def test_get_block_info_matches_reference(lib, ref, A, profile_name, block):
 
 
 def test_symbol_tables_match_the_arithmetic_decode(tmp_path):
-    """The batched decoder looks BISE groups and unquantized values up in generated tables (decode_luts.inc); the
-    single-block decoder and astcenc_get_block_info compute them.  tests/harness/ise_lut_check.cpp runs both over
-    random bit patterns for every quant level, offset and count (1.1 M symbols) and over every table entry."""
+    """The batched decoder looks BISE groups and unquantized values up in generated tables (decode_luts.inc) and block modes
+    and colour quant levels in per-footprint tables built on the host (DecodeTables); astcenc_get_block_info computes them.
+    tests/harness/ise_lut_check.cpp runs both over random bit patterns: every quant level, offset and count (1.1 M symbols),
+    every table entry, the straight-line group routines of the weight and colour phases on streams cut off at their
+    lengths, the packed level constants, and the table-driven header parse against the arithmetic one field by field
+    (eight footprints x 40 k blocks)."""
     import os, shutil, subprocess
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if shutil.which("g++") is None:
