@@ -440,55 +440,7 @@ WV_FN uint32_t funnel_shift_right(uint32_t hi, uint32_t lo, int sh)
 #endif
 }
 
-/* 64 bits of a 128-bit stream from bit `at` on.  `w` = the four words followed by two zero words (bits past
- * 127 read as zeros, like the reference's padded buffer). */
-WV_FN uint64_t bits_window(const uint32_t* w, int at)
-{
-	if (at >= 128) return 0ull;
-	const int word = at >> 5, sh = at & 31;
-	const uint32_t w0 = w[word], w1 = w[word + 1], w2 = w[word + 2];
-	return ((uint64_t)funnel_shift_right(w2, w1, sh) << 32) | funnel_shift_right(w1, w0, sh);
-}
-
-/* ise_symbol() with the group fetched as one bit window and the trits / quints looked up.
- * bits / kind = btq_of(quant) (kind 0 plain bits, 1 trits, 2 quints). */
-WV_FN int ise_symbol_lut(const uint32_t* w, int offset, int bits, int kind, int count, int index)
-{
-	const uint32_t low_mask = (1u << bits) - 1u;
-	if (kind == 0)
-	{
-		return (int)((uint32_t)bits_window(w, offset + index * bits) & low_mask);
-	}
-	if (kind == 1)
-	{
-		// element k of a group starts at bit k * bits + {0, 2, 4, 5, 7}[k]; a group of n elements is n * bits + {0, 2, 4, 5, 7, 8}[n] bits long
-		const int group = (index * 205) >> 10, pos = index - group * 5;          // index / 5 (index < 1024)
-		const int in_group = i_min(5, count - group * 5);
-		const int glen = in_group * bits + (int)((0x875420u >> (4 * in_group)) & 0xFu);
-		uint64_t g = bits_window(w, offset + group * (5 * bits + 8));
-		g &= (1ull << glen) - 1ull;                                               // (the missing elements of a short last group read as zeros)
-		const uint32_t t8 = ((uint32_t)(g >> bits) & 3u) | (((uint32_t)(g >> (2 * bits + 2)) & 3u) << 2) |
-		                    (((uint32_t)(g >> (3 * bits + 4)) & 1u) << 4) | (((uint32_t)(g >> (4 * bits + 5)) & 3u) << 5) |
-		                    (((uint32_t)(g >> (5 * bits + 7)) & 1u) << 7);
-		const uint32_t m = (uint32_t)(g >> (pos * bits + (int)((0x75420u >> (4 * pos)) & 0xFu))) & low_mask;
-		const uint32_t trit = (trit_group_lut(t8) >> (2 * pos)) & 3u;
-		return (int)((trit << bits) | m);
-	}
-	{
-		// quints: element k starts at bit k * bits + {0, 3, 5}[k]; n elements are n * bits + {0, 3, 5, 7}[n] bits
-		const int group = (index * 171) >> 9, pos = index - group * 3;            // index / 3 (index < 512)
-		const int in_group = i_min(3, count - group * 3);
-		const int glen = in_group * bits + (int)((0x7530u >> (4 * in_group)) & 0xFu);
-		uint64_t g = bits_window(w, offset + group * (3 * bits + 7));
-		g &= (1ull << glen) - 1ull;
-		const uint32_t q7 = ((uint32_t)(g >> bits) & 7u) | (((uint32_t)(g >> (2 * bits + 3)) & 3u) << 3) |
-		                    (((uint32_t)(g >> (3 * bits + 5)) & 3u) << 5);
-		const uint32_t m = (uint32_t)(g >> (pos * bits + (int)((0x530u >> (4 * pos)) & 0xFu))) & low_mask;
-		const uint32_t quint = (quint_group_lut(q7) >> (3 * pos)) & 7u;
-		return (int)((quint << bits) | m);
-	}
-}
-/* Symbols per lane in the batched decoder: one BISE group (five trits or three quints share packed bits, so the
+/* Symbols per lane-trip in the batched decoder: one BISE group (five trits or three quints share packed bits, so the
  * group is the natural unit: its window and its table entry are fetched once), four symbols for plain bit fields. */
 WV_FN int ise_group_size(int kind) { return kind == 1 ? 5 : kind == 2 ? 3 : 4; }
 /* btq_of without table reads: symbol bits | kind << 4 (kind 0 plain bits, 1 trits, 2 quints) of quant level q, out of
@@ -503,52 +455,6 @@ WV_FN uint32_t btq_packed(int q)
 /* groups of a sequence of `count` symbols (count < 128), without a division */
 WV_FN int ise_group_count(int count, int kind) { return kind == 1 ? ((count + 4) * 205) >> 10 : kind == 2 ? ((count + 2) * 171) >> 9 : (count + 3) >> 2; }
 
-/* The symbols of group `group` of a BISE sequence (same results as ise_symbol_lut for each of them); returns how many
- * of out[0..4] are real (the last group may be short). */
-WV_FN int ise_group_lut(const uint32_t* w, int offset, int bits, int kind, int count, int group, int out[5])
-{
-	const uint32_t low_mask = (1u << bits) - 1u;
-	const int per = ise_group_size(kind);
-	const int n = i_min(per, count - group * per);
-	if (kind == 0)
-	{
-		const uint64_t g = bits_window(w, offset + group * 4 * bits);              // 4 * bits <= 32
-		for (int e = 0; e < 4; e++) out[e] = (int)((uint32_t)(g >> (e * bits)) & low_mask);
-		out[4] = 0;
-		return n;
-	}
-	if (kind == 1)
-	{
-		const int glen = n * bits + (int)((0x875420u >> (4 * n)) & 0xFu);
-		uint64_t g = bits_window(w, offset + group * (5 * bits + 8));
-		g &= (1ull << glen) - 1ull;
-		const uint32_t t8 = ((uint32_t)(g >> bits) & 3u) | (((uint32_t)(g >> (2 * bits + 2)) & 3u) << 2) |
-		                    (((uint32_t)(g >> (3 * bits + 4)) & 1u) << 4) | (((uint32_t)(g >> (4 * bits + 5)) & 3u) << 5) |
-		                    (((uint32_t)(g >> (5 * bits + 7)) & 1u) << 7);
-		const uint32_t trits = trit_group_lut(t8);
-		for (int e = 0; e < 5; e++)
-		{
-			const uint32_t m = (uint32_t)(g >> (e * bits + (int)((0x75420u >> (4 * e)) & 0xFu))) & low_mask;
-			out[e] = (int)((((trits >> (2 * e)) & 3u) << bits) | m);
-		}
-		return n;
-	}
-	{
-		const int glen = n * bits + (int)((0x7530u >> (4 * n)) & 0xFu);
-		uint64_t g = bits_window(w, offset + group * (3 * bits + 7));
-		g &= (1ull << glen) - 1ull;
-		const uint32_t q7 = ((uint32_t)(g >> bits) & 7u) | (((uint32_t)(g >> (2 * bits + 3)) & 3u) << 3) |
-		                    (((uint32_t)(g >> (3 * bits + 5)) & 3u) << 5);
-		const uint32_t quints = quint_group_lut(q7);
-		for (int e = 0; e < 3; e++)
-		{
-			const uint32_t m = (uint32_t)(g >> (e * bits + (int)((0x530u >> (4 * e)) & 0xFu))) & low_mask;
-			out[e] = (int)((((quints >> (3 * e)) & 7u) << bits) | m);
-		}
-		out[3] = 0; out[4] = 0;
-		return n;
-	}
-}
 #endif // !ASTC_DECODE_NO_LUTS
 
 /* Block mode field -> grid size, planes, weight quant.  False for reserved / oversized modes.

@@ -1,6 +1,6 @@
 // SPDX-License-Identifier: Apache-2.0
-// Test infrastructure: the batched decoder's table-driven routines -- BISE symbol decode (ise_symbol_lut, group_symbols,
-// *_unquant_lut), the packed quant-level constants, the header parse from DecodeTables -- against
+// Test infrastructure: the batched decoder's table-driven routines -- BISE group decode (group_layout / group_symbols /
+// group_symbols_split, *_unquant_lut), the packed quant-level constants, the header parse from DecodeTables -- against
 // the arithmetic per-element routines it replaces (ise_symbol, unquant_*_symbol), which are the ones the single-block
 // decoder and astcenc_get_block_info use and which are pinned to the reference decoder by tests/test_decode.py.
 //   g++ -std=c++17 -O1 -DASTC_WAVE_EMU=1 -I astc-encoder_amd/csrc tests/harness/ise_lut_check.cpp -o ise_lut_check
@@ -22,44 +22,6 @@ int main()
 	{
 		const Btq q = btq_of(quant);
 		const int kind = q.trits ? 1 : q.quints ? 2 : 0;
-		for (int rep = 0; rep < 400; rep++)
-		{
-			Bits128 b;
-			uint32_t w[6];
-			for (int k = 0; k < 4; k++) { b.w[k] = rnd(); if (rep % 5 == 0) b.w[k] &= rnd(); w[k] = b.w[k]; }
-			w[4] = 0; w[5] = 0;
-			const int offsets[4] = { 0, 17, 29, (int)(rnd() % 100) };
-			for (int oi = 0; oi < 4; oi++)
-			{
-				const int count = 1 + (int)(rnd() % 64);
-				for (int index = 0; index < count; index++)
-				{
-					const int want = ise_symbol(b, offsets[oi], quant, count, index);
-					const int got = ise_symbol_lut(w, offsets[oi], q.bits, kind, count, index);
-					checked++;
-					if (want != got)
-					{
-						if (bad++ < 10) fprintf(stderr, "quant %d offset %d count %d index %d: %d != %d\n", quant, offsets[oi], count, index, got, want);
-					}
-				}
-				// the same sequence group by group (what a lane of the batched decoder does)
-				const int per = ise_group_size(kind);
-				for (int group = 0; group * per < count; group++)
-				{
-					int sym[5];
-					const int n = ise_group_lut(w, offsets[oi], q.bits, kind, count, group, sym);
-					if (n != (count - group * per < per ? count - group * per : per)) { bad++; fprintf(stderr, "group size\n"); }
-					for (int e = 0; e < n; e++)
-					{
-						checked++;
-						if (sym[e] != ise_symbol(b, offsets[oi], quant, count, group * per + e))
-						{
-							if (bad++ < 10) fprintf(stderr, "group: quant %d offset %d count %d group %d element %d\n", quant, offsets[oi], count, group, e);
-						}
-					}
-				}
-			}
-		}
 		// the packed level description and the division-free group count of the batched decoder
 		{
 			const uint32_t pk = btq_packed(quant);
@@ -75,7 +37,7 @@ int main()
 		// weight levels: the straight-line group decode (group_layout / group_symbols) on a stream cut off at its length (what decode_row_batch stores)
 		if (quant <= 11)
 		{
-			for (int rep = 0; rep < 400; rep++)
+			for (int rep = 0; rep < 4000; rep++)
 			{
 				Bits128 b;
 				const int count = 1 + (int)(rnd() % 64);
@@ -110,7 +72,7 @@ int main()
 		// colour levels: the straight-line group decode over two 32-bit windows (group_layout_split / group_symbols_split) on a stream cut off at the end of the colour values
 		if (quant >= 4)
 		{
-			for (int rep = 0; rep < 400; rep++)
+			for (int rep = 0; rep < 4000; rep++)
 			{
 				Bits128 b;
 				const int count = 2 * (1 + (int)(rnd() % 9));

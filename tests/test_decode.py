@@ -204,10 +204,10 @@ def test_get_block_info_matches_reference(lib, ref, A, profile_name, block):
 def test_symbol_tables_match_the_arithmetic_decode(tmp_path):
     """The batched decoder looks BISE groups and unquantized values up in generated tables (decode_luts.inc) and block modes
     and colour quant levels in per-footprint tables built on the host (DecodeTables); astcenc_get_block_info computes them.
-    tests/harness/ise_lut_check.cpp runs both over random bit patterns: every quant level, offset and count (1.1 M symbols),
-    every table entry, the straight-line group routines of the weight and colour phases on streams cut off at their
-    lengths, the packed level constants, and the table-driven header parse against the arithmetic one field by field
-    (eight footprints x 40 k blocks)."""
+    tests/harness/ise_lut_check.cpp runs both over random bit patterns: the straight-line group routines of the weight and
+    colour phases on streams cut off at their lengths against the per-element arithmetic decode (every quant level and
+    count), every entry of the unquantization tables, the packed level constants, and the table-driven header
+    parse against the arithmetic one field by field (eight footprints x 40 k blocks)."""
     import os, shutil, subprocess
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if shutil.which("g++") is None:
