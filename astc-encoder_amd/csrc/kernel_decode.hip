@@ -46,11 +46,23 @@ int astc_decode_launch(const DecodeLaunch& d)
 	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
 	decode_image_prepare(img);
-	// (grid y / z hold block rows / layers: at most 65535 each, i.e. images of up to 196 605 texels in y at the smallest footprint)
-	if (img.blocks_y > 65535u || img.blocks_z > 65535u) return (int)hipErrorInvalidConfiguration;
 	const uint32_t per_wave = (uint32_t)(DECODE_BATCH * DECODE_RUNS_PER_WAVE);
-	const dim3 grid((img.blocks_x + per_wave - 1) / per_wave, img.blocks_y, img.blocks_z);
-	hipLaunchKernelGGL(astc_decompress_blocks, grid, dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img);
+	// Grid y / z hold block rows / layers, at most 65535 each.  A taller 2D image (more than 262 140 texel rows at the
+	// smallest footprint) is decoded in bands of 65535 block rows: a band is an image of its own -- its rows, its blocks.
+	if (img.blocks_z > 65535u || (img.blocks_y > 65535u && img.blocks_z > 1u)) return (int)hipErrorInvalidConfiguration;
+	const size_t texel_bytes = d.data_type == 0 ? 4 : d.data_type == 1 ? 8 : 16;
+	for (uint32_t row0 = 0; row0 < img.blocks_y; row0 += 65535u)
+	{
+		DecodeImage band = img;
+		const uint32_t rows = img.blocks_y - row0 < 65535u ? img.blocks_y - row0 : 65535u;
+		const uint32_t y0 = row0 * d.block_y;
+		band.blocks_y = rows;
+		band.dim_y = d.dim_y - y0 < rows * d.block_y ? d.dim_y - y0 : rows * d.block_y;
+		band.data = static_cast<uint8_t*>(d.d_image) + (size_t)y0 * d.dim_x * texel_bytes;
+		const uint8_t* blocks = d.d_blocks + (size_t)row0 * img.blocks_x * 16;
+		const dim3 grid((img.blocks_x + per_wave - 1) / per_wave, rows, img.blocks_z);
+		hipLaunchKernelGGL(astc_decompress_blocks, grid, dim3(64), 0, static_cast<hipStream_t>(d.stream), blocks, band);
+	}
 	return (int)hipGetLastError();
 }
 
