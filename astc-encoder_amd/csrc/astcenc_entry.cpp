@@ -711,6 +711,11 @@ const char* astcenc_amd_backend_name(void)
 	return backend_name();
 }
 
+void astcenc_amd_set_log_callback(void (*callback)(const char* message))
+{
+	backend_set_log_callback(callback);
+}
+
 int astcenc_amd_context_device_count(const astcenc_context* ctx)
 {
 	return ctx && ctx->backend ? backend_device_count(ctx->backend) : 0;

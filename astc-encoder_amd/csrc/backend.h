@@ -78,6 +78,8 @@ int backend_decompress(Backend* b, const DecompressJob& job);
 int backend_decompress_device(Backend* b, const DecompressDeviceJob& job);
 int backend_compare(Backend* b, const CompareJob& job);
 const char* backend_name();
+/* Where the library's diagnostics go (null: nowhere, the default; see include/astcenc_amd.h). */
+void backend_set_log_callback(void (*callback)(const char* message));
 
 
 /* One kernel launch over blocks [first, first + count) of an image.  The kernel exists in two

@@ -9,6 +9,7 @@
 #include "backend.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdarg>
 #include <cstdio>
 #include <sched.h>
 #include <atomic>
@@ -83,8 +84,28 @@ constexpr size_t ALLOC_SLACK = 4096;
 constexpr size_t TRACE_WORDS_PER_BLOCK_HOST = 1024;   // = TRACE_WORDS_PER_BLOCK (wave_ctx.h)
 #endif
 
+/* Diagnostics.  The library reports through return codes only; what it has to say beyond them -- which HIP call failed,
+ * why a device was skipped -- goes to a callback the host application may install (astcenc_amd_set_log_callback,
+ * include/astcenc_amd.h), or to stderr when ASTCENC_AMD_LOG=stderr is in the environment.  Nothing is printed otherwise. */
+static std::atomic<void (*)(const char*)> g_log_callback{nullptr};
+void backend_set_log_callback(void (*cb)(const char*)) { g_log_callback.store(cb); }
+static void log_msg(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+static void log_msg(const char* fmt, ...)
+{
+	void (*cb)(const char*) = g_log_callback.load();
+	static const bool to_stderr = []() { const char* e = getenv("ASTCENC_AMD_LOG"); return e && strcmp(e, "stderr") == 0; }();
+	if (!cb && !to_stderr) return;
+	char line[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(line, sizeof(line), fmt, ap);
+	va_end(ap);
+	if (cb) cb(line);
+	else fprintf(stderr, "astcenc_amd: %s\n", line);
+}
+
 #define HIP_TRY(expr, fail) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-	fprintf(stderr, "astcenc_amd: %s -> %s\n", #expr, hipGetErrorString(e_)); fail; } } while (0)
+	log_msg("%s -> %s", #expr, hipGetErrorString(e_)); fail; } } while (0)
 
 const char* backend_name() { return "hip:gfx950"; }
 
@@ -296,7 +317,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 		int prc = kernel_prepare(b, &lds_bytes, layout, &layout_bytes);
 		if (prc != 0)
 		{
-			fprintf(stderr, "astcenc_amd: kernel setup failed on device %d (hip error %d)\n", device, prc);
+			log_msg("kernel setup failed on device %d (hip error %d)", device, prc);
 			slot_destroy(s); *status = 2; return nullptr;
 		}
 	}
@@ -343,7 +364,7 @@ std::vector<int> device_list(int ndev)
 			long v = strtol(p, &e, 10);
 			if (e == p) break;
 			if (v >= 0 && v < ndev) out.push_back((int)v);
-			else fprintf(stderr, "astcenc_amd: ASTCENC_AMD_DEVICES names device %ld, %d visible; ignored\n", v, ndev);
+			else log_msg("ASTCENC_AMD_DEVICES names device %ld, %d visible; ignored", v, ndev);
 			p = e;
 			while (*p == ',' || *p == ' ') p++;
 		}
@@ -389,7 +410,7 @@ bool pick_stream(const DeviceSlot* s, void* caller_stream, hipStream_t* out)
 	if (hipStreamGetDevice(stream, &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = s->device; }
 	if ((int)sdev != s->device)
 	{
-		fprintf(stderr, "astcenc_amd: the stream belongs to device %d, the buffers to device %d\n", (int)sdev, s->device);
+		log_msg("the stream belongs to device %d, the buffers to device %d", (int)sdev, s->device);
 		return false;
 	}
 	*out = stream;
@@ -418,7 +439,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 	{
-		fprintf(stderr, "astcenc_amd: no HIP device available; this library has no CPU fallback\n");
+		log_msg("no HIP device available; this library has no CPU fallback");
 		*status = 2;
 		return nullptr;
 	}
@@ -437,13 +458,13 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		int prc = kernel_prepare(b, &b->lds_bytes, layout, &layout_bytes);
 		if (prc != 0)
 		{
-			fprintf(stderr, "astcenc_amd: kernel setup failed (hip error %d)\n", prc);
+			log_msg("kernel setup failed (hip error %d)", prc);
 			delete b; *status = 2; return nullptr;
 		}
 	}
 	if (b->lds_bytes > 160 * 1024)
 	{
-		fprintf(stderr, "astcenc_amd: block working set %u B; a CU has 160 KiB of LDS\n", b->lds_bytes);
+		log_msg("block working set %u B; a CU has 160 KiB of LDS", b->lds_bytes);
 		delete b; *status = 2; return nullptr;
 	}
 
@@ -463,7 +484,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 		if (!s)
 		{
 			if (b->slots.empty()) { delete b; *status = st; return nullptr; }
-			fprintf(stderr, "astcenc_amd: device %d not usable, continuing with %zu device(s)\n", device, b->slots.size());
+			log_msg("device %d not usable, continuing with %zu device(s)", device, b->slots.size());
 			continue;
 		}
 		// (every device but the first gets its parked host thread: the record here, the thread itself on first use)
@@ -594,7 +615,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 		const size_t scratch = astc_alpha_scratch_bytes(job.dim_x, rows_with_halo, dim_z, job.a_scale_radius, &a.scratch_workgroups);
 		if (scratch == (size_t)-1)
 		{
-			fprintf(stderr, "astcenc_amd: a_scale_radius %u needs more than 1 GiB of pre-pass scratch per tile: refused\n", job.a_scale_radius);
+			log_msg("a_scale_radius %u needs more than 1 GiB of pre-pass scratch per tile: refused", job.a_scale_radius);
 			return 1;
 		}
 		if (scratch)
@@ -609,7 +630,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 			a.d_scratch = s->d_alpha_scratch;
 		}
 		int arc = astc_alpha_launch(a);
-		if (arc != 0) { fprintf(stderr, "astcenc_amd: alpha pre-pass launch failed (hip error %d)\n", arc); return 2; }
+		if (arc != 0) { log_msg("alpha pre-pass launch failed (hip error %d)", arc); return 2; }
 		img.alpha_avg = s->d_alpha + (size_t)halo_above * job.dim_x;
 		// (a large scratch is not kept for the life of the context: the pre-pass runs once per call, its scratch goes back
 		//  as soon as the stream is past the kernel -- hipFree waits for that)
@@ -713,7 +734,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 		k.d_tab = s->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
 		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = s->d_prof;
 		int lrc = kernel_launch(b, k);
-		if (lrc != 0) { fprintf(stderr, "astcenc_amd: kernel launch failed (hip error %d)\n", lrc); return 2; }
+		if (lrc != 0) { log_msg("kernel launch failed (hip error %d)", lrc); return 2; }
 		launched = first + n;
 		if (banded)
 		{
@@ -935,7 +956,7 @@ static int decompress_on_slot(Backend* bk, DeviceSlot* b, const DecompressJob& j
 	d.profile = bk->cfg.profile;
 	d.stream = b->stream;
 	int lrc = astc_decode_launch(d);
-	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
+	if (lrc != 0) { log_msg("decode kernel launch failed (hip error %d)", lrc); return 2; }
 	for (uint32_t z = 0; z < dim_z; z++)
 		HIP_TRY(hipMemcpyAsync(job.host_slices[z], static_cast<uint8_t*>(b->d_image) + z * slice_bytes, slice_bytes, hipMemcpyDeviceToHost, b->stream), return 2);
 	HIP_TRY(hipStreamSynchronize(b->stream), return 2);
@@ -1026,7 +1047,7 @@ int backend_decompress_device(Backend* bk, const DecompressDeviceJob& job)
 	d.profile = bk->cfg.profile;
 	d.stream = stream;
 	int lrc = astc_decode_launch(d);
-	if (lrc != 0) { fprintf(stderr, "astcenc_amd: decode kernel launch failed (hip error %d)\n", lrc); return 2; }
+	if (lrc != 0) { log_msg("decode kernel launch failed (hip error %d)", lrc); return 2; }
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
 	return 0;
 }
@@ -1047,7 +1068,7 @@ int backend_compare(Backend* bk, const CompareJob& job)
 	c.texels = job.texels; c.d_sums = b->d_sums; c.stream = stream;
 	c.hdr = job.hdr; c.fstop_lo = job.fstop_lo; c.fstop_hi = job.fstop_hi;
 	int lrc = astc_compare_launch(c);
-	if (lrc != 0) { fprintf(stderr, "astcenc_amd: compare kernel launch failed (hip error %d)\n", lrc); return 2; }
+	if (lrc != 0) { log_msg("compare kernel launch failed (hip error %d)", lrc); return 2; }
 	HIP_TRY(hipMemcpyAsync(job.sums, b->d_sums, METRIC_SUMS_HOST * sizeof(double), hipMemcpyDeviceToHost, stream), return 2);
 	HIP_TRY(hipStreamSynchronize(stream), return 2);
 	return 0;

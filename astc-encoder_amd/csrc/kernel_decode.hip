@@ -6,23 +6,21 @@
 #include "backend.h"
 #include "wave_decode.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace astcd {
 
-/* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes runs of
- * DECODE_BATCH consecutive blocks of one block row and decodes each run together (decode_row_batch) -- DECODE_RUNS_PER_WAVE
- * of them one after the other (one, as measured: wave_decode.h).  The grid is (waves per block row, block rows, layers of blocks): a run's place in the image needs no division. */
+/* One block is a few hundred instructions that keep under half of a wavefront busy, so every wavefront takes a run of
+ * DECODE_BATCH consecutive blocks of one block row and decodes it together (decode_row_batch).  The grid is (runs per block
+ * row, block rows, layers of blocks): a run's place in the image needs no division.  `row0` / `layer0`: the launch covers
+ * block rows [row0, row0 + gridDim.y) and layers [layer0, layer0 + gridDim.z) of the stream (astc_decode_launch). */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))      // (LDS allows 5.75 waves per SIMD: keep the registers under that)
-astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img)
+astc_decompress_blocks(const uint8_t* __restrict__ blocks, DecodeImage img, uint32_t row0, uint32_t layer0)
 {
 	__shared__ DecodeBatch batch;
-	for (int run = 0; run < DECODE_RUNS_PER_WAVE; run++)
-	{
-		const uint32_t bx0 = (blockIdx.x * (uint32_t)DECODE_RUNS_PER_WAVE + (uint32_t)run) * (uint32_t)DECODE_BATCH;
-		if (bx0 >= img.blocks_x) break;
-		const uint32_t left = img.blocks_x - bx0;
-		decode_row_batch(img, blocks, bx0, blockIdx.y, blockIdx.z, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
-	}
+	const uint32_t bx0 = blockIdx.x * (uint32_t)DECODE_BATCH;
+	const uint32_t left = img.blocks_x - bx0;
+	decode_row_batch(img, blocks, bx0, row0 + blockIdx.y, layer0 + blockIdx.z, (int)(left < (uint32_t)DECODE_BATCH ? left : (uint32_t)DECODE_BATCH), batch);
 }
 
 size_t astc_decode_tables_bytes() { return sizeof(DecodeTables); }
@@ -46,22 +44,24 @@ int astc_decode_launch(const DecodeLaunch& d)
 	img.blocks_z = (d.dim_z + d.block_z - 1) / d.block_z;
 	img.profile = d.profile;
 	decode_image_prepare(img);
-	const uint32_t per_wave = (uint32_t)(DECODE_BATCH * DECODE_RUNS_PER_WAVE);
-	// Grid y / z hold block rows / layers, at most 65535 each.  A taller 2D image (more than 262 140 texel rows at the
-	// smallest footprint) is decoded in bands of 65535 block rows: a band is an image of its own -- its rows, its blocks.
-	if (img.blocks_z > 65535u || (img.blocks_y > 65535u && img.blocks_z > 1u)) return (int)hipErrorInvalidConfiguration;
-	const size_t texel_bytes = d.data_type == 0 ? 4 : d.data_type == 1 ? 8 : 16;
-	for (uint32_t row0 = 0; row0 < img.blocks_y; row0 += 65535u)
+	// Grid y / z hold block rows / layers of blocks, at most 65535 each: a taller stream (more than 262 140 texel rows at the
+	// smallest footprint, or as many slices) is covered by several launches, each told where its rows and layers start.  The
+	// image record stays the whole image's, so every address is formed from the real dimensions.
+	// (ASTCENC_AMD_DECODE_GRID_LIMIT: a smaller limit for tests/test_decode.py, which cannot allocate a 262 144-row image)
+	static const uint32_t limit = []() {
+		const char* e = getenv("ASTCENC_AMD_DECODE_GRID_LIMIT");
+		const long v = e ? strtol(e, nullptr, 10) : 0;
+		return (uint32_t)(v >= 1 && v < 65535 ? v : 65535);
+	}();
+	const uint32_t runs = (img.blocks_x + (uint32_t)DECODE_BATCH - 1u) / (uint32_t)DECODE_BATCH;
+	for (uint32_t layer0 = 0; layer0 < img.blocks_z; layer0 += limit)
 	{
-		DecodeImage band = img;
-		const uint32_t rows = img.blocks_y - row0 < 65535u ? img.blocks_y - row0 : 65535u;
-		const uint32_t y0 = row0 * d.block_y;
-		band.blocks_y = rows;
-		band.dim_y = d.dim_y - y0 < rows * d.block_y ? d.dim_y - y0 : rows * d.block_y;
-		band.data = static_cast<uint8_t*>(d.d_image) + (size_t)y0 * d.dim_x * texel_bytes;
-		const uint8_t* blocks = d.d_blocks + (size_t)row0 * img.blocks_x * 16;
-		const dim3 grid((img.blocks_x + per_wave - 1) / per_wave, rows, img.blocks_z);
-		hipLaunchKernelGGL(astc_decompress_blocks, grid, dim3(64), 0, static_cast<hipStream_t>(d.stream), blocks, band);
+		const uint32_t layers = img.blocks_z - layer0 < limit ? img.blocks_z - layer0 : limit;
+		for (uint32_t row0 = 0; row0 < img.blocks_y; row0 += limit)
+		{
+			const uint32_t rows = img.blocks_y - row0 < limit ? img.blocks_y - row0 : limit;
+			hipLaunchKernelGGL(astc_decompress_blocks, dim3(runs, rows, layers), dim3(64), 0, static_cast<hipStream_t>(d.stream), d.d_blocks, img, row0, layer0);
+		}
 	}
 	return (int)hipGetLastError();
 }

@@ -116,6 +116,14 @@ int ASTC_PREPARE_NAME(const TableRoot& root, const DeviceConfig& cfg, uint32_t* 
 
 int ASTC_LAUNCH_NAME(const KernelLaunch& k)
 {
+#if defined(ASTC_LDS_PAD_ENV)
+	// (occupancy experiment builds only: extra dynamic LDS per workgroup from the environment)
+	static const unsigned pad = getenv("ASTC_LDS_PAD") ? (unsigned)atoi(getenv("ASTC_LDS_PAD")) : 0u;
+	if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ASTC_KERNEL_NAME), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(k.lds_bytes + pad));
+	hipLaunchKernelGGL(ASTC_KERNEL_NAME, dim3(k.count), dim3(64), k.lds_bytes + pad, static_cast<hipStream_t>(k.stream),
+	                   k.d_tab, k.img, k.d_out, k.first, k.count, k.d_prof);
+	return (int)hipGetLastError();
+#endif
 	hipLaunchKernelGGL(ASTC_KERNEL_NAME, dim3(k.count), dim3(64), k.lds_bytes, static_cast<hipStream_t>(k.stream),
 	                   k.d_tab, k.img, k.d_out, k.first, k.count, k.d_prof);
 	return (int)hipGetLastError();

@@ -242,6 +242,19 @@ WV_FN float f_med3(float v, float mn, float mx)
 }
 #endif
 
+/* acc + d * m for a mask m that is exactly 1.0f or 0.0f: the product d * m is d or a zero -- exact either way -- so the fused
+ * form rounds once where the two-instruction form rounds once too, to the same bits (a zero product added to acc gives acc,
+ * whose sums here are never -0); one instruction instead of two on the device.  (The translation units are built with
+ * -ffp-contract=off: this is the one place where a fused multiply-add is asked for by name.) */
+WV_FN float f_add_masked(float acc, float d, float m)
+{
+#if WV_DEVICE
+	return __builtin_fmaf(d, m, acc);
+#else
+	return acc + d * m;
+#endif
+}
+
 /* astc::clamp (ref: astcenc_mathlib.h:271) */
 WV_FN float f_clamp(float v, float mn, float mx)
 {

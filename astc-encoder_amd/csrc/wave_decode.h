@@ -961,22 +961,10 @@ WV_FN void unpack_block_payload(const Bits128& blk, const BlockHeader& h, int pr
 #ifndef ASTC_DECODE_BATCH
 #define ASTC_DECODE_BATCH 32
 #endif
-// measurement builds (tools/build_variant.sh): leave decode_row_batch after phase n (1 headers, 2 weights, 3 colour values,
-// 4 endpoints; 9: at once); the product is built without it
-#ifndef ASTC_DECODE_STOP_AFTER
-#define ASTC_DECODE_STOP_AFTER 0
-#endif
-// measurement builds that leave work out (wrong output): 1 no colour table reads, 2 one weight store per group, 3 no weight table reads
-#ifndef ASTC_DECODE_EXP
-#define ASTC_DECODE_EXP 0
-#endif
-// consecutive runs of a block row one wavefront decodes.  Measured (profiles/r05zz/decode_runs_per_wave.log, 8192^2 6x6):
-// 1 run 0.258 ms, 2 runs 0.276, 4 runs 0.285, 8 runs 0.343 -- launching a wave and filling its table is 0.016 ms of the
-// 0.258, and longer-lived waves cost registers and a longer tail
-#ifndef ASTC_DECODE_RUNS_PER_WAVE
-#define ASTC_DECODE_RUNS_PER_WAVE 1
-#endif
-constexpr int DECODE_RUNS_PER_WAVE = ASTC_DECODE_RUNS_PER_WAVE;
+// (one run per wavefront.  Measured in round 5, profiles/r05zz/decode_runs_per_wave.log, 8192^2 6x6: 1 run 0.258 ms, 2 runs
+//  0.276, 4 runs 0.285, 8 runs 0.343 -- launching a wave and filling its table is 0.016 ms of the 0.258, and longer-lived
+//  waves cost registers and a longer tail.  The phase-by-phase timings of profiles/r05zz came from measurement switches
+//  that are no longer in this source.)
 constexpr int DECODE_BATCH = ASTC_DECODE_BATCH;
 static_assert(DECODE_BATCH == 32 || DECODE_BATCH == 16, "the lane maps of decode_row_batch pair lane l with block l & (DECODE_BATCH - 1)");
 constexpr int DECODE_SLOTS = 64 / DECODE_BATCH;             // lanes per block in the element phases
@@ -1266,7 +1254,6 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	const bool bytes_swz = img.data_type == 0 && img.swz[0] < 6 && img.swz[1] < 6 && img.swz[2] < 6 && img.swz[3] < 6;
 	const size_t first = ((size_t)bz * img.blocks_y + by) * img.blocks_x + bx0;
 
-	if (ASTC_DECODE_STOP_AFTER == 9) return;
 	// ---- headers and constant colours: one lane per block ----
 	bool multi_part = false, many_part = false, dual_part = false;      // per-lane partials, folded below
 	WV_FOR64(k, 64)
@@ -1365,7 +1352,6 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	}
 	const bool any_multi = wv_any(multi_part), any_many = wv_any(many_part), any_dual = wv_any(dual_part);
 	WV_SYNC();
-	if (ASTC_DECODE_STOP_AFTER == 1) return;
 
 	// ---- weights and colour values: lane l works on block l & (DECODE_BATCH - 1), on every DECODE_SLOTS-th group of it ----
 	WV_FOR64(l, 64)
@@ -1386,27 +1372,18 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			uint32_t sym[3][5];
 			for (int u = 0; u < 3; u++) group_symbols(L, bits_window32(ws, mul24(i_min(g0 + u * DECODE_SLOTS, groups - 1), glen)), sym[u]);
 			uint8_t w[3][5];
-#if ASTC_DECODE_EXP == 3
-			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) w[u][e] = (uint8_t)sym[u][e];      // (measurement: no table reads)
-#else
 			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) w[u][e] = unq[sym[u][e]];
-#endif
 			for (int u = 0; u < 3; u++)
 			{
 				const int g = g0 + u * DECODE_SLOTS;
 				if (g >= groups) break;
 				uint8_t* out = s.weights[k] + mul24(g, L.per);
-#if ASTC_DECODE_EXP == 2
-				out[0] = (uint8_t)(w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3] ^ w[u][4]);      // (measurement: one store per group)
-#else
 				out[0] = w[u][0]; out[1] = w[u][1]; out[2] = w[u][2];
 				if (L.per > 3) out[3] = w[u][3];
 				if (L.per > 4) out[4] = w[u][4];
-#endif
 			}
 		}
 	}
-	if (ASTC_DECODE_STOP_AFTER == 2) return;
 	WV_FOR64(l, 64)
 	{
 		const int k = l & (DECODE_BATCH - 1);
@@ -1431,11 +1408,7 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 			}
 			// (the table reads side by side, then the stores: one wait; the symbols past a short group are in range -- below 256)
 			uint8_t c[3][5];
-#if ASTC_DECODE_EXP == 1
-			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) c[u][e] = (uint8_t)(sym[u][e] + (uint32_t)cquant);      // (measurement: no table reads)
-#else
 			for (int u = 0; u < 3; u++) for (int e = 0; e < 5; e++) c[u][e] = (uint8_t)color_unquant_lut(cquant, (int)sym[u][e]);
-#endif
 			for (int u = 0; u < 3; u++)
 			{
 				const int g = g0 + u * DECODE_SLOTS;
@@ -1451,7 +1424,6 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 		}
 	}
 	WV_SYNC();
-	if (ASTC_DECODE_STOP_AFTER == 3) return;
 	// ---- endpoints: lane l works on block l & (DECODE_BATCH - 1), on every DECODE_SLOTS-th partition of it ----
 	WV_FOR64(l, 64)
 	{
@@ -1491,7 +1463,6 @@ WV_FN void decode_row_batch(const DecodeImage& img, const uint8_t* blocks, uint3
 	}
 	const bool any_general = wv_any(general_part);
 	WV_SYNC();
-	if (ASTC_DECODE_STOP_AFTER == 4) return;
 
 	// ---- texels ----
 	if (block_z == 1)

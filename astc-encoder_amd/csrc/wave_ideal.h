@@ -49,8 +49,7 @@ WV_FN void compute_avgs_and_dirs(const Ctx& c, const PartView& pv, const CompSel
 			{
 				// (`in partition p ? d : 0` as d * (1 or 0): the texel data are non-negative numbers, so d * 0 is +0 like the
 				//  reference's masked lane -- and the read is not hidden behind a lane mask)
-				float v = d[i] * (pv.of_texel[i] == p ? 1.0f : 0.0f);
-				acc = acc + v;
+				acc = f_add_masked(acc, d[i], pv.of_texel[i] == p ? 1.0f : 0.0f);
 			});
 			tr.fbox[k] = acc;
 		}

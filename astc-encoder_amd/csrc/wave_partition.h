@@ -407,10 +407,10 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, float we
 				{
 					if (ch >= n) break;
 					const float* d = c.data(ch) + i;
-					acc[ch][0] = acc[ch][0] + d[0] * m0;
-					acc[ch][1] = acc[ch][1] + d[1] * m1;
-					acc[ch][2] = acc[ch][2] + d[2] * m2;
-					acc[ch][3] = acc[ch][3] + d[3] * m3;
+					acc[ch][0] = f_add_masked(acc[ch][0], d[0], m0);
+					acc[ch][1] = f_add_masked(acc[ch][1], d[1], m1);
+					acc[ch][2] = f_add_masked(acc[ch][2], d[2], m2);
+					acc[ch][3] = f_add_masked(acc[ch][3], d[3], m3);
 				}
 			}
 			#pragma unroll
@@ -456,10 +456,11 @@ WV_FN void score_partitioning(const Ctx& c, int pc, const PartView& pv, float we
 			f4 d = mk4(c.data(0)[t], c.data(1)[t], c.data(2)[t], n == 4 ? c.data(3)[t] : 0.0f) - average;
 			// (`above ? sum + d : sum` as sum + d * m, m = 1.0 / 0.0: d is finite -- every searched partitioning has texels in
 			//  all its partitions, so the average is a number -- and a sum is never -0, so adding d * 0 = +-0 changes nothing)
-			sum[0] = sum[0] + d * (d.x > 0.0f ? 1.0f : 0.0f);
-			sum[1] = sum[1] + d * (d.y > 0.0f ? 1.0f : 0.0f);
-			sum[2] = sum[2] + d * (d.z > 0.0f ? 1.0f : 0.0f);
-			if (n == 4) sum[3] = sum[3] + d * (d.w > 0.0f ? 1.0f : 0.0f);
+			auto add_masked4 = [](f4 acc, f4 v, float m) { return mk4(f_add_masked(acc.x, v.x, m), f_add_masked(acc.y, v.y, m), f_add_masked(acc.z, v.z, m), f_add_masked(acc.w, v.w, m)); };
+			sum[0] = add_masked4(sum[0], d, d.x > 0.0f ? 1.0f : 0.0f);
+			sum[1] = add_masked4(sum[1], d, d.y > 0.0f ? 1.0f : 0.0f);
+			sum[2] = add_masked4(sum[2], d, d.z > 0.0f ? 1.0f : 0.0f);
+			if (n == 4) sum[3] = add_masked4(sum[3], d, d.w > 0.0f ? 1.0f : 0.0f);
 		}
 		f4 best_vector = sum[0];
 		float best_sum = dot_s(sum[0], sum[0]);

@@ -90,7 +90,8 @@ EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_ima
            "astcenc_context_free", "astcenc_get_block_info", "astcenc_get_error_string"]
 EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
                "astcenc_amd_compare_images_device", "astcenc_amd_backend_name", "astcenc_amd_context_device_count",
-               "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device", "astcenc_amd_context_kernel_name"]
+               "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device", "astcenc_amd_context_kernel_name",
+               "astcenc_amd_set_log_callback"]
 OPT_PER_SLICE_FAST_LOAD = 1
 
 

@@ -114,6 +114,13 @@ ASTCENC_PUBLIC enum astcenc_error astcenc_amd_compare_images_hdr_device(
 /* "hip:gfx950" for the product library. */
 ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 
+/* Diagnostics.  The library reports through the reference's error codes and prints nothing.  What it knows beyond the code
+ * -- which HIP call failed, why a device of ASTCENC_AMD_DEVICES was skipped -- is handed, one line per event and without a
+ * trailing newline, to the callback installed here (process-wide; null, the default, switches it off; the callback may be
+ * called from any thread that is inside a library call).  ASTCENC_AMD_LOG=stderr in the environment prints the same
+ * lines to stderr when no callback is installed. */
+ASTCENC_PUBLIC void astcenc_amd_set_log_callback(void (*callback)(const char* message));
+
 /* Number of GPUs the context shards host images over.  By default astcenc_context_alloc() prepares the calling
  * thread's current device only (one process per GPU is the usual deployment, and a context must not touch its
  * neighbours' GPUs).  With the environment variable ASTCENC_AMD_DEVICES = "all" or a list of ordinals ("0,1,2,3")

@@ -84,6 +84,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 void backend_destroy(Backend* b) { delete b; }
 int backend_device_count(const Backend*) { return 1; }
 const char* backend_name() { return "emu:cpu"; }
+void backend_set_log_callback(void (*)(const char*)) {}      // (the sequential build has nothing to report)
 const char* backend_kernel_name(const Backend*) { return "emu"; }
 
 int backend_compress(Backend* b, const CompressJob& job)

@@ -57,3 +57,28 @@ def test_no_device_means_no_context(product, A):
     err, ctx = product.context_alloc(cfg, 1)
     assert err != A.SUCCESS and not ctx.value
     assert product.error_string(err) is not None
+
+
+def test_diagnostics_go_to_the_callback_not_to_stderr(product, A, capfd):
+    """The library prints nothing by itself: the reason behind an error code reaches the
+    application through astcenc_amd_set_log_callback only."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU: context_alloc succeeds and has nothing to report")
+    lines = []
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_char_p)
+    cb = CB(lambda msg: lines.append(msg.decode()))
+    product.lib.astcenc_amd_set_log_callback.restype = None
+    product.lib.astcenc_amd_set_log_callback.argtypes = [CB]
+    err, cfg = product.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_MEDIUM, 0)
+    err, ctx = product.context_alloc(cfg, 1)              # no callback installed: silent
+    assert err != A.SUCCESS
+    assert "astcenc_amd" not in capfd.readouterr().err
+    product.lib.astcenc_amd_set_log_callback(cb)
+    try:
+        err, ctx = product.context_alloc(cfg, 1)
+        assert err != A.SUCCESS
+        assert any("no HIP device" in l for l in lines), lines
+        assert "astcenc_amd" not in capfd.readouterr().err
+    finally:
+        product.lib.astcenc_amd_set_log_callback(CB(0))

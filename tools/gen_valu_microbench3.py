@@ -83,6 +83,23 @@ row("v_add_f32 dependent chain (1 chain)", "v_add_f32 v32, {a}, v32")
 row("v_max_f32 dependent chain (1 chain)", "v_max_f32 v32, {a}, v32")
 row("v_fma_f32 dependent chain (1 chain)", "v_fma_f32 v32, {a}, {b}, v32")
 
+# round 6: is the scalar unit a pipe of its own (one instruction per ~4.3 cycles per SIMD beside the vector issue) or does a
+# scalar / LDS instruction take a vector issue slot?  two and three fast vector instructions per scalar one decide.
+row("2 x v_add_f32 + s_and_b64 (2 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=2)
+row("3 x v_add_f32 + s_and_b64 (3 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n v_add_f32 {d}, {b}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=3)
+row("3 x v_add_f32 + s_add_u32 independent (3 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n v_add_f32 {d}, {b}, {d}\\n s_add_u32 s25, s24, 1", n=3)
+row("3 x v_add_f32 + v_max_f32 + s_and_b64 (4 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n v_add_f32 {d}, {b}, {d}\\n v_max_f32 {d}, {b}, {d}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=4)
+row("v_add_f32 + ds_read_b32 (1 valu)", "v_add_f32 {d}, {a}, {d}\\n ds_read_b32 v20, v21", n=1)
+row("3 x v_add_f32 + ds_read_b32 (3 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n v_add_f32 {d}, {b}, {d}\\n ds_read_b32 v20, v21", n=3)
+row("3 x v_add_f32 + ds_read_b128 (3 valu)", "v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}\\n v_add_f32 {d}, {b}, {d}\\n ds_read_b128 v[24:27], v21", n=3)
+row("v_pk_add_f32 + v_add_f32 alternating (2 insts)", "v_pk_add_f32 {D}, {A}, {D}\\n v_add_f32 {d}, {a}, {d}", n=2)
+row("v_pk_mul_f32 + 2 x v_add_f32 (3 insts)", "v_pk_mul_f32 {D}, {A}, {D}\\n v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}", n=3)
+row("v_pk_add_f32 + s_and_b64 (1 valu)", "v_pk_add_f32 {D}, {A}, {D}\\n s_and_b64 s[26:27], s[26:27], s[20:21]", n=1)
+row("v_pk_add_f32 + v_max_f32 alternating (2 insts)", "v_pk_add_f32 {D}, {A}, {D}\\n v_max_f32 {d}, {b}, {d}", n=2)
+row("v_fmac_f32 + v_max_f32 alternating (2)", "v_fmac_f32 {d}, {a}, {b}\\n v_max_f32 {d}, {b}, {d}", n=2)
+row("v_cndmask_b32 vcc alone", "v_cndmask_b32 {d}, {d}, {a}, vcc")
+row("v_cmp_lt_f32 vcc + 2 x v_add_f32 (3)", "v_cmp_lt_f32 vcc, {a}, {d}\\n v_add_f32 {d}, {a}, {d}\\n v_mul_f32 {d}, {b}, {d}", n=3)
+
 def body(tmpl, same_bank):
     out = []
     for rep in range(4):
@@ -111,7 +128,7 @@ HDR = r'''// SPDX-License-Identifier: Apache-2.0
 #include <algorithm>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 extern __shared__ unsigned char dyn_lds[];
-#define CLOBBERS "v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19", \
+#define CLOBBERS "v20","v21","v24","v25","v26","v27","v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19", \
 	"v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47", \
 	"v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79", \
 	"v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95", \
@@ -121,7 +138,7 @@ extern __shared__ unsigned char dyn_lds[];
 	"v_mov_b32 v12, 1.0\n v_mov_b32 v13, 0.5\n v_mov_b32 v14, 2.0\n v_mov_b32 v15, 4.0\n" \
 	"v_mov_b32 v16, 1.0\n v_mov_b32 v17, 0.5\n v_mov_b32 v18, 2.0\n v_mov_b32 v19, 1.0\n" \
 	"s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x33333333\n s_mov_b32 s24, 0x3f800000\n s_mov_b64 s[26:27], -1\n" \
-	"s_mov_b32 s25, 0\n"
+	"s_mov_b32 s25, 0\n v_mov_b32 v21, 0\n"
 '''
 
 KERNEL = r'''
@@ -218,11 +235,13 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     parts = [HDR]
     rows = []
-    for idx, (label, tmpl, n, sb, setup) in enumerate(ROWS):
+    only = os.environ.get("MB_FROM")
+    rows_sel = ROWS[[r[0] for r in ROWS].index(only):] if only else ROWS
+    for idx, (label, tmpl, n, sb, setup) in enumerate(rows_sel):
         parts.append(KERNEL % {"idx": idx, "body": body(tmpl, sb)})
         rows.append('\t\t{ "%s", k%d, %d },\n' % (label, idx, 64 * n))
     parts.append(MAIN % {"rows": "".join(rows)})
-    with open(os.path.join(here, "valu_microbench3.hip"), "w") as f:
+    with open(os.path.join(here, os.environ.get("MB_OUT", "valu_microbench3.hip")), "w") as f:
         f.write("".join(parts))
 
 if __name__ == "__main__":
