@@ -7,7 +7,16 @@
 // 14.7 MB, fixed 216x64 strides).  Here arrays are sized to the real texel/weight counts and only
 // the entries the compressor can select are kept (a few hundred KB, L2 resident).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#include <stddef.h>
+#else
+// The run-time compiler (hipRTC, kernel_jit.cpp) has no C library headers: the fixed-width types by hand.
+typedef unsigned char uint8_t; typedef signed char int8_t; typedef unsigned short uint16_t; typedef short int16_t;
+typedef unsigned int uint32_t; typedef int int32_t; typedef unsigned long uint64_t; typedef long int64_t;
+typedef unsigned long size_t; typedef unsigned long uintptr_t; typedef long ptrdiff_t;
+#define offsetof(type, member) __builtin_offsetof(type, member)
+#endif
 
 #if defined(__HIPCC__)
 	#define ASTC_HD __host__ __device__

@@ -716,6 +716,12 @@ void astcenc_amd_set_log_callback(void (*callback)(const char* message))
 	backend_set_log_callback(callback);
 }
 
+astcenc_error astcenc_amd_context_specialize(astcenc_context* ctx)
+{
+	if (!ctx || !ctx->backend) return ASTCENC_ERR_BAD_CONTEXT;
+	return backend_specialize(ctx->backend) == 0 ? ASTCENC_SUCCESS : ASTCENC_ERR_NOT_IMPLEMENTED;
+}
+
 int astcenc_amd_context_device_count(const astcenc_context* ctx)
 {
 	return ctx && ctx->backend ? backend_device_count(ctx->backend) : 0;

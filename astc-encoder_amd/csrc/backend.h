@@ -117,6 +117,10 @@ ASTC_DECLARE_KERNEL_VARIANT(ldr_8x8t)
 ASTC_DECLARE_KERNEL_VARIANT(hdr_6x6m)
 #undef ASTC_DECLARE_KERNEL_VARIANT
 const char* backend_kernel_name(const Backend* b);   // the build of the compression kernel this context launches
+/* Waits for the context's specialised build (compiling it now if that has not started) and switches every device of the
+ * context to it.  0: the context launches a specialised build (one of the library's fixed-context builds or its own run-time
+ * build); 1: it stays on the generic build (kernel_jit.h says when). */
+int backend_specialize(Backend* b);
 
 /* Alpha-average pre-pass launch (kernel_alpha.hip).  The padded tile of a region lives in LDS while it fits
  * (ALPHA_LDS_LIMIT) and otherwise in d_scratch: astc_alpha_scratch_bytes() says how much of it and for how many

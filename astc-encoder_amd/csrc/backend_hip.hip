@@ -7,6 +7,7 @@
 // instead of threads pulling 16-block tickets from an atomic counter, the block range of a chunk
 // is one kernel launch; chunks give the host cancel/progress points.
 #include "backend.h"
+#include "kernel_jit.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdarg>
@@ -62,6 +63,11 @@ struct DeviceSlot {
 	std::mutex busy;              // one call at a time per slot: the staging buffers and events are shared state
 	std::vector<int> local_cpus;  // host CPUs on the device's NUMA node (Linux sysfs); empty: unknown, no binding
 	SlotWorker* worker;           // the slot's parked host thread (slots 1.. of a multi-device context), or null
+	// the context's run-time specialised build on this device (kernel_jit.h): loaded once it is ready, then launched
+	// instead of the library's own generic build
+	hipModule_t jit_module;
+	hipFunction_t jit_fn;
+	bool jit_tried;
 };
 
 struct Backend {
@@ -75,6 +81,11 @@ struct Backend {
 	bool hdr;
 	TableRoot root;
 	int variant;                      // index into kernel_variants (chosen by the first kernel_prepare)
+	JitKernel* jit;                   // the context's run-time build (null: none asked for -- a fixed-context build of the library
+	                                  // serves this context, ASTCENC_AMD_JIT=off, an instrumentation build, no hipRTC)
+	JitMode jit_mode;
+	std::atomic<unsigned long long> blocks_done;     // blocks this context has compressed (JIT_LAZY's trigger)
+	std::atomic<bool> jit_active;     // some slot launches the run-time build
 };
 
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
@@ -157,9 +168,38 @@ int kernel_prepare(Backend* b, uint32_t* lds_bytes, void* layout_out, uint32_t* 
 	}
 	return (int)hipErrorInvalidDeviceFunction;
 }
-int kernel_launch(const Backend* b, const KernelLaunch& k)
+int kernel_launch(const Backend* b, const DeviceSlot* s, const KernelLaunch& k)
 {
+	if (s->jit_fn)
+	{
+		// the run-time build: same parameters as the library's builds (kernel_device.h), launched through the module API
+		KernelLaunch a = k;
+		void* args[] = { &a.d_tab, &a.img, &a.d_out, &a.first, &a.count, &a.d_prof };
+		return (int)hipModuleLaunchKernel(s->jit_fn, k.count, 1, 1, 64, 1, 1, k.lds_bytes, static_cast<hipStream_t>(k.stream), args, nullptr);
+	}
 	return kernel_variants[b->variant].launch(k);
+}
+
+/* Loads the context's run-time build on the slot's device once the compiler has delivered it (current device = the slot's).
+ * Anything that goes wrong leaves the slot on the library's generic build. */
+void slot_adopt_jit(Backend* b, DeviceSlot* s)
+{
+	if (!b->jit || s->jit_tried || jit_state(b->jit) != JIT_READY) return;
+	s->jit_tried = true;
+	size_t bytes = 0;
+	const void* code = jit_code(b->jit, &bytes);
+	hipModule_t mod = nullptr;
+	hipFunction_t fn = nullptr;
+	if (hipModuleLoadData(&mod, code) != hipSuccess || hipModuleGetFunction(&fn, mod, JIT_ENTRY_POINT) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		if (mod) (void)hipModuleUnload(mod);
+		log_msg("run-time build %s does not load on device %d: the generic build stays", jit_kernel_name(b->jit), s->device);
+		return;
+	}
+	s->jit_module = mod;
+	s->jit_fn = fn;
+	b->jit_active.store(true);
 }
 
 void worker_stop(SlotWorker* w)
@@ -191,6 +231,7 @@ void slot_destroy(DeviceSlot* s)
 		if (e) (void)hipEventDestroy(e);
 	if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
 	if (s->stream) (void)hipStreamDestroy(s->stream);
+	if (s->jit_module) (void)hipModuleUnload(s->jit_module);
 	if (s->d_base) (void)hipFree(s->d_base);
 	delete s;
 }
@@ -310,6 +351,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 	s->d_alpha_scratch = nullptr; s->alpha_scratch_cap = 0;
 	s->d_prof = nullptr; s->trace_cap = 0; s->d_sums = nullptr;
 	s->worker = nullptr;
+	s->jit_module = nullptr; s->jit_fn = nullptr; s->jit_tried = false;
 #define SLOT_TRY(expr, code) HIP_TRY(expr, { slot_destroy(s); *status = code; return nullptr; })
 	SLOT_TRY(hipSetDevice(device), 2);
 	{
@@ -341,6 +383,7 @@ DeviceSlot* slot_create(Backend* b, int device, int* status)
 #endif
 #undef SLOT_TRY
 	s->local_cpus = device_local_cpus(device);
+	slot_adopt_jit(b, s);      // (a slot created after the build arrived: devices joined on first use)
 	*status = 0;
 	return s;
 }
@@ -451,6 +494,7 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	b->hdr = cfg.profile >= 2;
 	b->lds_bytes = 0;
 	b->variant = -1;
+	b->jit = nullptr; b->jit_mode = JIT_OFF; b->blocks_done.store(0); b->jit_active.store(false);
 	uint8_t layout[CTX_LAYOUT_BACK - CTX_CONFIG_BACK];
 	uint32_t layout_bytes = 0;
 	{
@@ -477,13 +521,30 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	memcpy(b->full.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK), &b->cfg, sizeof(DeviceConfig));
 	memcpy(b->full.data() + CTX_LAYOUT_BACK, blob, blob_bytes);
 
+#if !defined(ASTC_TRACE) && !defined(ASTC_DUPSTAGE) && !defined(ASTC_PROFILE) && !defined(ASTC_LDS_PAD_ENV)
+	// A context that none of the library's fixed-context builds serves gets its own (kernel_jit.h): found in the disk cache,
+	// or compiled in the background -- by default once the context has shown that it is used for more than a thumbnail.
+	{
+		const char* want = getenv("ASTCENC_AMD_KERNEL");
+		b->jit_mode = want && strcmp(want, "generic") == 0 ? JIT_OFF : jit_mode_from_environment();
+		if (b->jit_mode != JIT_OFF && !kernel_variants[b->variant].fixed)
+		{
+			int dev = 0;
+			hipDeviceProp_t prop;
+			if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+				b->jit = jit_acquire(layout, layout_bytes, b->cfg, b->root, b->hdr, prop.gcnArchName, [](const char* line) { log_msg("%s", line); });
+			if (b->jit && b->jit_mode == JIT_EAGER) jit_start(b->jit);
+			if (b->jit && b->jit_mode == JIT_SYNC) (void)jit_wait(b->jit);
+		}
+	}
+#endif
 	for (int device : device_list(ndev))
 	{
 		int st = 0;
 		DeviceSlot* s = slot_create(b, device, &st);
 		if (!s)
 		{
-			if (b->slots.empty()) { delete b; *status = st; return nullptr; }
+			if (b->slots.empty()) { jit_release(b->jit); delete b; *status = st; return nullptr; }
 			log_msg("device %d not usable, continuing with %zu device(s)", device, b->slots.size());
 			continue;
 		}
@@ -501,11 +562,29 @@ void backend_destroy(Backend* b)
 	DeviceGuard guard;
 	for (DeviceSlot* s : b->slots) slot_destroy(s);
 	for (DeviceSlot* s : b->extra) slot_destroy(s);
+	jit_release(b->jit);
 	delete b;
 }
 
 int backend_device_count(const Backend* b) { return (int)b->slots.size(); }
-const char* backend_kernel_name(const Backend* b) { return b->variant >= 0 ? kernel_variants[b->variant].name : ""; }
+const char* backend_kernel_name(const Backend* b)
+{
+	if (b->jit && b->jit_active.load()) return jit_kernel_name(b->jit);
+	return b->variant >= 0 ? kernel_variants[b->variant].name : "";
+}
+
+int backend_specialize(Backend* b)
+{
+	if (b->variant >= 0 && kernel_variants[b->variant].fixed) return 0;
+	if (!b->jit || jit_wait(b->jit) != JIT_READY) return 1;
+	DeviceGuard guard;
+	for (DeviceSlot* s : b->slots)
+	{
+		std::lock_guard<std::mutex> busy(s->busy);
+		if (hipSetDevice(s->device) == hipSuccess) slot_adopt_jit(b, s);
+	}
+	return b->jit_active.load() ? 0 : 1;
+}
 
 static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob& job, Progress* progress);
 
@@ -535,6 +614,10 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	const uint32_t blocks_y = (job.dim_y + bsy - 1) / bsy;
 	const uint32_t blocks_z = (dim_z + bsz - 1) / bsz;
 	const size_t nblocks = (size_t)blocks_x * blocks_y * blocks_z;
+	// the context's run-time build: adopted as soon as the compiler has delivered it; asked for (JIT_LAZY) once the context
+	// has compressed enough to be worth a compile
+	slot_adopt_jit(b, s);
+	if (b->jit && b->jit_mode == JIT_LAZY && b->blocks_done.fetch_add(nblocks) + nblocks >= JIT_LAZY_BLOCKS) jit_start(b->jit);
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
 	// (a shard of the alpha-scale split carries halo rows around its own: they are uploaded and averaged, not compressed)
 	const uint32_t halo_above = dim_z == 1 && job.a_scale_radius != 0 ? job.halo_above : 0u;
@@ -733,7 +816,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 		KernelLaunch k;
 		k.d_tab = s->d_tab; k.lds_bytes = b->lds_bytes; k.img = img; k.d_out = d_out;
 		k.first = (uint32_t)first; k.count = (uint32_t)n; k.stream = stream; k.d_prof = s->d_prof;
-		int lrc = kernel_launch(b, k);
+		int lrc = kernel_launch(b, s, k);
 		if (lrc != 0) { log_msg("kernel launch failed (hip error %d)", lrc); return 2; }
 		launched = first + n;
 		if (banded)

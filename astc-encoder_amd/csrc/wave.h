@@ -22,7 +22,7 @@
 //   * min/max are compare-selects with the reference's operand order (NaN -> second operand);
 //   * 4-lane horizontal sums use the reference's (l0 + l2) + (l1 + l3) order.
 #pragma once
-#include <stdint.h>
+#include "astc_tables.h"      // (fixed-width integer types, also for the run-time compiler)
 
 // Build variant: the LDR and HDR kernels are separate translation units of the same source so that
 // the HDR endpoint coders do not weigh on the register allocation of the LDR hot path.
@@ -32,7 +32,7 @@
 #ifndef ASTC_ENABLE_HDR
 	#define ASTC_ENABLE_HDR 1
 #endif
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && !defined(__HIPCC_RTC__)      // (the run-time compiler brings the HIP device API with it)
 #include <hip/hip_runtime.h>
 #endif
 

@@ -6,8 +6,8 @@
 //        prepare_block_statistics                        :1047-1159
 // All control flow here is wave-uniform: every decision is taken on values read back from LDS.
 #pragma once
-#include <stddef.h>
 #if !defined(__HIP_DEVICE_COMPILE__)
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #endif

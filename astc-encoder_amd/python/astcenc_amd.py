@@ -91,7 +91,7 @@ EXPORTS = ["astcenc_config_init", "astcenc_context_alloc", "astcenc_compress_ima
 EXPORTS_AMD = ["astcenc_amd_compress_image_device", "astcenc_amd_compress_volume_device", "astcenc_amd_decompress_image_device",
                "astcenc_amd_compare_images_device", "astcenc_amd_backend_name", "astcenc_amd_context_device_count",
                "astcenc_amd_context_set_option", "astcenc_amd_compare_images_hdr_device", "astcenc_amd_context_kernel_name",
-               "astcenc_amd_set_log_callback"]
+               "astcenc_amd_set_log_callback", "astcenc_amd_context_specialize"]
 OPT_PER_SLICE_FAST_LOAD = 1
 
 
@@ -184,6 +184,9 @@ class Library:
         if hasattr(L, "astcenc_amd_context_kernel_name"):
             L.astcenc_amd_context_kernel_name.argtypes = [C.c_void_p]
             L.astcenc_amd_context_kernel_name.restype = C.c_char_p
+        if hasattr(L, "astcenc_amd_context_specialize"):
+            L.astcenc_amd_context_specialize.argtypes = [C.c_void_p]
+            L.astcenc_amd_context_specialize.restype = C.c_int
         if hasattr(L, "astcenc_amd_compress_volume_device"):
             L.astcenc_amd_compress_volume_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_int,
                                                              C.POINTER(Swizzle), C.c_void_p, C.c_size_t, C.c_void_p,
@@ -224,10 +227,12 @@ class Library:
         return self.lib.astcenc_compress_image(ctx, C.byref(img), C.byref(swz), out.ctypes.data,
                                                out.nbytes if data_len is None else data_len, thread_index)
 
-    def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None, options=None):
+    def compress(self, pixels, block=(6, 6), quality=PRE_MEDIUM, profile=PRF_LDR, flags=0, swizzle=SWZ_RGBA, tweak=None, options=None,
+                 specialize=False):
         """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16].
         block is (x, y) or (x, y, z); pixels is [H, W, 4] or [D, H, W, 4]; options: {OPT_*: value} for
-        astcenc_amd_context_set_option (product library only)."""
+        astcenc_amd_context_set_option (product library only); specialize: wait for the context's specialised kernel
+        build first (astcenc_amd_context_specialize) -- self.last_kernel then names the build that ran."""
         bz = block[2] if len(block) > 2 else 1
         err, cfg = self.config_init(profile, block[0], block[1], bz, quality, flags)
         if err:
@@ -242,6 +247,12 @@ class Library:
                 err = self.lib.astcenc_amd_context_set_option(ctx, opt, value)
                 if err:
                     raise AstcError(err, "astcenc_amd_context_set_option")
+            if specialize:
+                err = self.lib.astcenc_amd_context_specialize(ctx)
+                if err:
+                    raise AstcError(err, "astcenc_amd_context_specialize")
+            if hasattr(self.lib, "astcenc_amd_context_kernel_name"):
+                self.last_kernel = self.lib.astcenc_amd_context_kernel_name(ctx).decode()
             d = pixels.shape[0] if pixels.ndim == 4 else 1
             h, w = pixels.shape[-3], pixels.shape[-2]
             bx, by = (w + block[0] - 1) // block[0], (h + block[1] - 1) // block[1]

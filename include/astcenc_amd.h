@@ -141,6 +141,20 @@ ASTCENC_PUBLIC int astcenc_amd_context_device_count(const struct astcenc_context
  * generic builds. */
 ASTCENC_PUBLIC const char* astcenc_amd_context_kernel_name(const struct astcenc_context* context);
 
+/* Every other context gets a build of its own at run time: the library carries its device source, writes the context's
+ * records as constants, compiles the kernel with hipRTC for the device's architecture on a background thread and keeps the
+ * code object on disk (ASTCENC_AMD_CACHE_DIR, else $XDG_CACHE_HOME/astcenc_amd, else ~/.cache/astcenc_amd) under a hash of
+ * source, records, options and compiler version; the name is then "astc_compress_blocks_jit_<hash>".  Until that build is
+ * there the context runs the generic one -- same bytes.  ASTCENC_AMD_JIT in the environment: "lazy" (default: a cached
+ * build is used at once, a compile is started when the context has compressed 2^20 blocks), "eager" (started in
+ * astcenc_context_alloc), "sync" (finished inside astcenc_context_alloc), "off".
+ *
+ * astcenc_amd_context_specialize() waits for the context's specialised build -- starting the compile if need be -- and
+ * switches the context to it: ASTCENC_SUCCESS when the context now launches a specialised build (one of the library's own or
+ * its run-time build), ASTCENC_ERR_NOT_IMPLEMENTED when it stays generic (no hipRTC library on the box, "off", a compile
+ * error: astcenc_amd_set_log_callback says which).  Must not run concurrently with a compression on the same context. */
+ASTCENC_PUBLIC enum astcenc_error astcenc_amd_context_specialize(struct astcenc_context* context);
+
 /* Behaviour switches that have no counterpart in the reference API. */
 enum astcenc_amd_option {
 	/* Multi-slice RGBA8 input (image.dim_z > 1) with a 2D footprint, LDR profile and identity swizzle: the

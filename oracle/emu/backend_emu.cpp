@@ -6,6 +6,7 @@
 // debugged against oracle/_ref on machines without a GPU.  It is linked only into
 // oracle/emu/_build/libastcenc_emu.so and is never part of the product library.
 #include "backend.h"
+#include "kernel_jit.h"
 #include "wave_block.h"
 #include "wave_decode.h"
 #include "wave_alpha.h"
@@ -28,6 +29,7 @@ struct Backend {
 	std::vector<uint8_t> blob;      // tables + DeviceConfig + LdsLayout, like the device copy
 	DeviceConfig cfg;
 	LdsLayout layout;
+	JitKernel* jit = nullptr;       // (backend_specialize below: compile check only)
 };
 
 Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConfig& cfg, int* status)
@@ -81,11 +83,23 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	return b;
 }
 
-void backend_destroy(Backend* b) { delete b; }
+void backend_destroy(Backend* b) { if (b) jit_release(b->jit); delete b; }
 int backend_device_count(const Backend*) { return 1; }
 const char* backend_name() { return "emu:cpu"; }
 void backend_set_log_callback(void (*)(const char*)) {}      // (the sequential build has nothing to report)
-const char* backend_kernel_name(const Backend*) { return "emu"; }
+const char* backend_kernel_name(const Backend* b) { return b->jit && jit_state(b->jit) == JIT_READY ? jit_kernel_name(b->jit) : "emu"; }
+/* The run-time build of the context's kernel, compiled for gfx950 on this CPU-only box (hipRTC needs no device) but never
+ * launched: tests/test_jit.py checks on the CPU that the library's embedded device source compiles for a context's records. */
+int backend_specialize(Backend* b)
+{
+	if (!b->jit)
+	{
+		const TableRoot* root = reinterpret_cast<const TableRoot*>(b->blob.data() + CTX_LAYOUT_BACK);
+		const DeviceConfig* cfg = reinterpret_cast<const DeviceConfig*>(b->blob.data() + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
+		b->jit = jit_acquire(&b->layout, sizeof(b->layout), *cfg, *root, cfg->profile >= 2, "gfx950", [](const char* line) { fprintf(stderr, "emu jit: %s\n", line); });
+	}
+	return b->jit && jit_wait(b->jit) == JIT_READY ? 0 : 1;
+}
 
 int backend_compress(Backend* b, const CompressJob& job)
 {

@@ -13,6 +13,12 @@ import oracle_libs as O  # noqa: E402  (checker libraries: test infrastructure)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Run-time specialised kernel builds (csrc/kernel_jit.cpp): off for the session unless a test asks for them
+    # (tests/test_jit.py sets the mode and a cache directory of its own), so that which build a context launches -- asserted
+    # by name in tests/test_fixed_contexts.py -- does not depend on what an earlier test left in a disk cache, and the
+    # user's ~/.cache is never written by a test run.
+    os.environ.setdefault("ASTCENC_AMD_JIT", "off")
+    os.environ.setdefault("ASTCENC_AMD_CACHE_DIR", "")
 
 
 def _have(path):

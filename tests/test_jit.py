@@ -1,0 +1,187 @@
+# SPDX-License-Identifier: Apache-2.0
+"""Run-time specialised builds of the compression kernel (csrc/kernel_jit.cpp): a context none of
+the library's three fixed-context builds serves gets a build of its own -- the library's embedded device source compiled by
+hipRTC with the context's LdsLayout / DeviceConfig / TableRoot as constants, cached on disk.
+
+CPU: the embedded source compiles for a context's records (hipRTC needs no device; the sequential build of the library
+     drives the same kernel_jit.cpp), the code object has no scratch frame, the disk cache is hit the second time.
+GPU: contexts of other presets / footprints / profiles / flags launch "astc_compress_blocks_jit_<hash>" and produce the
+     reference's bytes; the default (lazy) mode starts on the generic build and switches; a sweep of footprints x presets x
+     profiles through the run-time builds matches the reference.  (The builds of the sweep are compiled side by side on the
+     box's CPUs through the sequential library -- same source, same records, same hash -- and found in the cache.)"""
+import concurrent.futures
+import multiprocessing
+import ctypes
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle_libs as O  # (path set up by conftest.py)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _specialize_on_cpu(args):
+    """Worker process: compile the context's run-time build through the sequential library into the shared cache."""
+    cache, profile, block, quality, flags = args
+    os.environ["ASTCENC_AMD_CACHE_DIR"] = cache
+    sys.path.insert(0, os.path.join(ROOT, "astc-encoder_amd", "python"))
+    import astcenc_amd as A
+    lib = A.Library(O.LIB_EMU)
+    bz = block[2] if len(block) > 2 else 1
+    err, cfg = lib.config_init(profile, block[0], block[1], bz, quality, flags)
+    assert err == 0
+    err, ctx = lib.context_alloc(cfg, 1)
+    assert err == 0
+    rc = lib.lib.astcenc_amd_context_specialize(ctx)
+    name = lib.lib.astcenc_amd_context_kernel_name(ctx).decode()
+    lib.context_free(ctx)
+    return rc, name
+
+
+def _prewarm(cache, contexts):
+    workers = max(1, min(len(contexts), len(os.sched_getaffinity(0))))
+    # (fresh interpreters: the parent may hold a HIP runtime, which does not survive a fork)
+    with concurrent.futures.ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("spawn")) as pool:
+        results = list(pool.map(_specialize_on_cpu, [(cache,) + c for c in contexts]))
+    assert all(rc == 0 and name.startswith("astc_compress_blocks_jit_") for rc, name in results), results
+    return [name for _, name in results]
+
+
+def test_embedded_source_compiles_and_is_cached(built, emu, A, tmp_path, monkeypatch):
+    if not os.path.exists("/opt/rocm/lib/libhiprtc.so"):
+        pytest.skip("no hipRTC on this box")
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ASTCENC_AMD_CACHE_DIR", cache)
+    t0 = time.time()
+    (name,) = _prewarm(cache, [(A.PRF_LDR, (6, 6), A.PRE_THOROUGH, 0)])
+    first = time.time() - t0
+    files = os.listdir(cache)
+    assert files == [name[len("astc_compress_blocks_jit_"):] + ".hsaco"], files
+    if os.path.exists(READELF):
+        notes = subprocess.run([READELF, "--notes", os.path.join(cache, files[0])], capture_output=True, text=True).stdout
+        assert ".name:           astc_compress_blocks_jit" in notes
+        assert ".private_segment_fixed_size: 0" in notes and ".vgpr_spill_count: 0" in notes, notes[-1500:]
+    # the second context with the same records: from the disk, same name; another flag: another build
+    t0 = time.time()
+    rc, again = _specialize_on_cpu((cache, A.PRF_LDR, (6, 6), A.PRE_THOROUGH, 0))
+    assert rc == 0 and again == name and time.time() - t0 < max(2.0, first / 3)
+    rc, other = _specialize_on_cpu((cache, A.PRF_LDR, (6, 6), A.PRE_THOROUGH, A.FLG_USE_PERCEPTUAL))
+    assert rc == 0 and other != name and len(os.listdir(cache)) == 2
+
+
+def _compress_both(product, ref, A, img, block, quality, profile, flags=0, tweak=None):
+    want = ref.compress(img, block, quality, profile=profile, flags=flags, tweak=tweak).reshape(-1, 16)
+    got = product.compress(img, block, quality, profile=profile, flags=flags, tweak=tweak, specialize=True).reshape(-1, 16)
+    return int((want != got).any(axis=1).sum()), product.last_kernel
+
+
+@pytest.mark.gpu
+def test_other_contexts_get_a_run_time_build(product, ref, A, tmp_path, monkeypatch):
+    """The four contexts VERDICT r05 names, a hand-edited tuning field, an HDR one: specialised, and the reference's bytes."""
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ASTCENC_AMD_CACHE_DIR", cache)
+    monkeypatch.setenv("ASTCENC_AMD_JIT", "sync")
+    img = A.synthetic_image(250, 190, 3)
+
+    def two_partitions(cfg):
+        cfg.tune_partition_count_limit = 2
+    cases = [(A.PRF_LDR, (6, 6), A.PRE_THOROUGH, 0, None), (A.PRF_LDR, (4, 4), A.PRE_MEDIUM, 0, None), (A.PRF_LDR_SRGB, (6, 6), A.PRE_MEDIUM, 0, None),
+             (A.PRF_LDR, (6, 6), A.PRE_MEDIUM, A.FLG_USE_PERCEPTUAL, None), (A.PRF_LDR, (6, 6), A.PRE_MEDIUM, 0, two_partitions)]
+    _prewarm(cache, [c[:4] for c in cases[:4]])      # (the fifth is compiled in astcenc_context_alloc: ASTCENC_AMD_JIT=sync)
+    names = set()
+    for profile, block, quality, flags, tweak in cases:
+        bad, name = _compress_both(product, ref, A, img, block, quality, profile, flags, tweak)
+        assert name.startswith("astc_compress_blocks_jit_"), name
+        assert bad == 0, (profile, block, quality, flags, bad)
+        names.add(name)
+    assert len(names) == len(cases)
+    hdr = A.synthetic_hdr_image(120, 90, 3)
+    bad, name = _compress_both(product, ref, A, hdr, (8, 8), A.PRE_MEDIUM, A.PRF_HDR)
+    assert name.startswith("astc_compress_blocks_jit_") and bad == 0
+    # the BASELINE contexts keep the builds the library ships
+    bad, name = _compress_both(product, ref, A, img, (6, 6), A.PRE_MEDIUM, A.PRF_LDR)
+    assert name == "astc_compress_blocks_ldr_6x6m" and bad == 0
+
+
+@pytest.mark.gpu
+def test_lazy_mode_starts_generic_and_switches(product, ref, A, tmp_path, monkeypatch):
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ASTCENC_AMD_CACHE_DIR", cache)
+    monkeypatch.setenv("ASTCENC_AMD_JIT", "lazy")
+    img = np.ascontiguousarray(A.synthetic_image(250, 190, 5))
+    err, cfg = product.config_init(A.PRF_LDR, 5, 5, 1, A.PRE_FAST, 0)
+    assert err == 0
+    err, ctx = product.context_alloc(cfg, 1)
+    assert err == 0
+    try:
+        name = lambda: product.lib.astcenc_amd_context_kernel_name(ctx).decode()
+        assert name() == "astc_compress_blocks_ldr64" and not os.path.exists(cache)      # nothing compiled for a thumbnail
+        out0 = np.zeros(50 * 38 * 16, dtype=np.uint8)
+        assert product.compress_raw(ctx, img, out0) == 0 and name() == "astc_compress_blocks_ldr64"
+        assert product.lib.astcenc_amd_context_specialize(ctx) == 0
+        assert name().startswith("astc_compress_blocks_jit_") and len(os.listdir(cache)) == 1
+        out1 = np.zeros_like(out0)
+        assert product.lib.astcenc_compress_reset(ctx) == 0
+        assert product.compress_raw(ctx, img, out1) == 0
+        assert np.array_equal(out0, out1)
+    finally:
+        product.context_free(ctx)
+    # a second context with the same records finds the build on disk: specialised from its first launch
+    err, ctx = product.context_alloc(cfg, 1)
+    assert err == 0
+    try:
+        assert product.lib.astcenc_amd_context_kernel_name(ctx).decode().startswith("astc_compress_blocks_jit_")
+    finally:
+        product.context_free(ctx)
+    want = ref.compress(img, (5, 5), A.PRE_FAST)
+    assert np.array_equal(want, out1)
+    # ... and "off" keeps the generic build whatever the cache holds
+    monkeypatch.setenv("ASTCENC_AMD_JIT", "off")
+    err, ctx = product.context_alloc(cfg, 1)
+    assert err == 0
+    try:
+        assert product.lib.astcenc_amd_context_kernel_name(ctx).decode() == "astc_compress_blocks_ldr64"
+        assert product.lib.astcenc_amd_context_specialize(ctx) == A.ERR_NOT_IMPLEMENTED
+    finally:
+        product.context_free(ctx)
+
+
+@pytest.mark.gpu
+def test_sweep_through_run_time_builds(product, ref, A, tmp_path, monkeypatch):
+    """Footprints (2D up to 12x12, 3D) x presets x profiles: every context on its own run-time build, bytes = the reference's."""
+    import images
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ASTCENC_AMD_CACHE_DIR", cache)
+    monkeypatch.setenv("ASTCENC_AMD_JIT", "sync")
+    contexts = []
+    for block in ((4, 4), (5, 5), (6, 6), (8, 6), (8, 8), (10, 10), (12, 12)):
+        for quality in (A.PRE_FASTEST, A.PRE_FAST, A.PRE_MEDIUM, A.PRE_THOROUGH):
+            for profile in (A.PRF_LDR, A.PRF_LDR_SRGB):
+                if (profile, block, quality) not in ((A.PRF_LDR, (6, 6), A.PRE_MEDIUM), (A.PRF_LDR, (8, 8), A.PRE_THOROUGH)):
+                    contexts.append((profile, block, quality, 0))
+        contexts.append((A.PRF_HDR_RGB_LDR_A, block, A.PRE_MEDIUM, 0))
+    contexts += [(A.PRF_LDR, (3, 3, 3), A.PRE_MEDIUM, 0), (A.PRF_LDR, (4, 4, 4), A.PRE_FAST, 0), (A.PRF_HDR, (6, 6, 6), A.PRE_FAST, 0)]
+    names = _prewarm(cache, contexts)
+    assert len(set(names)) == len(contexts)
+    noisy, rnd = images.noisy(120, 113, 21), images.random_u8(115, 120, 22)
+    hdr = list(images.hdr_variants(96, 90).values())[0].astype(np.float16)
+    vol = np.stack([images.noisy(40, 36, 40 + z) for z in range(12)])
+    vol_hdr = np.stack([hdr[:36, :40] for _ in range(12)])
+    bad = []
+    for (profile, block, quality, flags), name in zip(contexts, names):
+        if len(block) == 3:
+            imgs = [vol_hdr if profile == A.PRF_HDR else vol]
+        else:
+            imgs = [hdr] if profile == A.PRF_HDR_RGB_LDR_A else [noisy, rnd]
+        for img in imgs:
+            n, used = _compress_both(product, ref, A, img, block, quality, profile, flags)
+            assert used == name, (used, name)
+            if n:
+                bad.append((profile, block, quality, n))
+    assert not bad, bad

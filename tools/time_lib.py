@@ -23,7 +23,7 @@ for i in range(steps + 1):
     e = lib.lib.astcenc_amd_compress_image_device(ctx, img.data_ptr(), size, size, 0, ctypes.byref(swz), out.data_ptr(), out.numel(), torch.cuda.current_stream().cuda_stream, ctypes.byref(ms))
     assert e == 0
     if i > 0: best = min(best, ms.value)
-print("%s: %dx%d %dx%d q=%.0f kernel %.2f ms -> %.2f Mtexels/s" % (os.path.basename(sys.argv[1]), size, size, b, b, q, best, size * size / best / 1e3))
+print("%s [%s]: %dx%d %dx%d q=%.0f kernel %.2f ms -> %.2f Mtexels/s" % (os.path.basename(sys.argv[1]), lib.lib.astcenc_amd_context_kernel_name(ctx).decode(), size, size, b, b, q, best, size * size / best / 1e3))
 if os.environ.get("CHECK", "1") != "0":
     # byte parity of a block-aligned 384^2 corner against the reference (checker only)
     sys.path.insert(0, os.path.join(ROOT, "oracle")); import oracle_libs as O
