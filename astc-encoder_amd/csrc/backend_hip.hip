@@ -10,6 +10,7 @@
 #include "kernel_jit.h"
 
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <sched.h>
@@ -890,6 +891,9 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 /* Smallest shard worth a device of its own: below this a second GPU's fixed costs (its PCIe transfers start
  * later, its L2 has to fetch the tables again) outweigh the kernel time it takes over. */
 constexpr size_t MIN_BLOCKS_PER_DEVICE = 16384;
+/* Portions a sharded call is cut into per device (backend_compress): enough for a device that got cheap content to take
+ * over work from one that did not, few enough for the pipeline restart at a portion's first band not to show. */
+constexpr size_t DEAL_PORTIONS_PER_DEVICE = 4;
 
 int backend_compress(Backend* b, const CompressJob& job)
 {
@@ -937,14 +941,32 @@ int backend_compress(Backend* b, const CompressJob& job)
 	if (ndev <= 1) return compress_on_slot(b, b->slots[0], job, &progress);
 
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
-	const uint32_t units_per = (uint32_t)((units + ndev - 1) / ndev);
+	// The units are DEALT, not pre-assigned (ref: the reference's workers take blocks from one atomic ticket counter, 16 at a
+	// time, astcenc_internal_entry.h:225-236 / astcenc_entry.cpp:959 -- a worker that lands on cheap content takes more):
+	// block cost depends on content (a photograph runs three times faster per texel than noise), so with one contiguous range
+	// per device the device that got the hard part of the image sets the call's time.  The image is cut into portions --
+	// DEAL_PORTIONS_PER_DEVICE per device, none below MIN_BLOCKS_PER_DEVICE blocks -- and every device's host thread takes
+	// the next portion from one counter when it has finished its last; a portion runs the banded PCIe pipeline of the
+	// single-device path, so consecutive bands still overlap inside it.  ASTCENC_AMD_DEAL=static: one portion per device.
+	size_t nportions = ndev;
+	{
+		const char* deal = getenv("ASTCENC_AMD_DEAL");
+		if (!(deal && strcmp(deal, "static") == 0))
+		{
+			nportions = ndev * DEAL_PORTIONS_PER_DEVICE;
+			if (nportions > by_size) nportions = by_size;
+			if (nportions > units) nportions = units;
+			if (nportions < ndev) nportions = ndev;
+		}
+	}
+	const uint32_t units_per = (uint32_t)((units + nportions - 1) / nportions);
 	struct Shard { CompressJob job; std::vector<const void*> slices; int rc; };
 	std::vector<Shard> shards;
 	// The reference's fast loader reads slice 0 whatever the block's z (CompressJob::fast_load_slice0): a shard that
 	// starts further up the stack must then see the image's first slice as its own first slice.
 	const bool needs_swz = job.swz[0] != 0 || job.swz[1] != 1 || job.swz[2] != 2 || job.swz[3] != 3;
 	const bool slice0_quirk = dim_z > 1 && job.fast_load_slice0 && !needs_swz && b->cfg.profile < 2 && job.data_type == 0 && bsz == 1;
-	for (size_t g = 0; g < ndev; g++)
+	for (size_t g = 0; g < nportions; g++)
 	{
 		const uint32_t u0 = (uint32_t)g * units_per;
 		if (u0 >= units) break;
@@ -986,17 +1008,37 @@ int backend_compress(Backend* b, const CompressJob& job)
 		shards.push_back(std::move(sh));
 	}
 	for (Shard& sh : shards) sh.job.host_slices = sh.slices.data();      // (after the vector stopped growing)
-	// one host thread per further shard; a shard whose thread cannot be created (std::system_error must not cross the
-	// C ABI, and the earlier workers must still be joined) runs on the calling thread after its own
-	std::vector<size_t> on_workers, inline_shards;
-	for (size_t g = 1; g < shards.size(); g++)
+	// one host thread per further device; a device whose thread cannot be created (std::system_error must not cross the
+	// C ABI, and the earlier workers must still be joined) simply takes no portions: the others deal its share out
+	std::atomic<size_t> next_portion{0};
+	std::atomic<bool> failed{false};
+	const size_t nslots = ndev < shards.size() ? ndev : shards.size();
+	std::vector<double> busy_ms(nslots, 0.0);
+	std::vector<unsigned> taken(nslots, 0u);
+	auto deal = [&](size_t g)
 	{
-		if (worker_run(b->slots[g], [&, g]() { shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress); })) on_workers.push_back(g);
-		else inline_shards.push_back(g);
+		const auto t0 = std::chrono::steady_clock::now();
+		for (;;)
+		{
+			if (failed.load()) break;                          // (a failed portion fails the call: nobody starts another)
+			const size_t p = next_portion.fetch_add(1);
+			if (p >= shards.size()) break;
+			shards[p].rc = compress_on_slot(b, b->slots[g], shards[p].job, &progress);
+			if (shards[p].rc != 0) failed.store(true);
+			taken[g]++;
+		}
+		busy_ms[g] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	};
+	std::vector<size_t> on_workers;
+	for (size_t g = 1; g < nslots; g++)
+	{
+		// (building the task may allocate: nothing may be thrown across the C ABI -- ADVICE r05)
+		try { if (worker_run(b->slots[g], [&deal, g]() { deal(g); })) on_workers.push_back(g); }
+		catch (...) { }
 	}
-	shards[0].rc = compress_on_slot(b, b->slots[0], shards[0].job, &progress);
-	for (size_t g : inline_shards) shards[g].rc = compress_on_slot(b, b->slots[g], shards[g].job, &progress);
+	deal(0);
 	for (size_t g : on_workers) worker_wait(b->slots[g]);
+	for (size_t g = 0; g < nslots; g++) log_msg("compress: device slot %zu took %u of %zu portions, busy %.2f ms", g, taken[g], shards.size(), busy_ms[g]);
 	int rc = 0;
 	for (const Shard& sh : shards) if (sh.rc != 0 && (rc == 0 || sh.rc == 1)) rc = sh.rc;
 	return rc;

@@ -30,7 +30,9 @@ __device__ inline uint32_t xcd_block_remap(uint32_t b, uint32_t n)
 	return (b % 8u) * per + (b / 8u);
 }
 
-ASTC_KERNEL_LINKAGE __global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU)
+// (the occupancy bound twice: __launch_bounds__ is a macro of the HIP headers, and the run-time compiler of ROCm 7.0 drops its
+//  second argument -- 160 VGPRs, three waves per SIMD -- where hipcc and the ROCm 7.2 run-time compiler honour it)
+ASTC_KERNEL_LINKAGE __global__ void __launch_bounds__(64, ASTC_WAVES_PER_EU) __attribute__((amdgpu_waves_per_eu(ASTC_WAVES_PER_EU)))
 ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
                  uint8_t* __restrict__ out, uint32_t first_block, uint32_t num_blocks, unsigned long long* prof)
 {

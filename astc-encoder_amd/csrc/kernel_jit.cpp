@@ -5,8 +5,15 @@
 
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <link.h>
+#include <signal.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -40,6 +47,8 @@ ASTC_EMBED(astc_src_wave_refine, "wave_refine.h")
 ASTC_EMBED(astc_src_wave_batch, "wave_batch.h")
 ASTC_EMBED(astc_src_wave_partition, "wave_partition.h")
 ASTC_EMBED(astc_src_wave_pack, "wave_pack.h")
+
+extern char** environ;
 
 namespace astcd {
 namespace {
@@ -151,6 +160,122 @@ void make_dirs(const std::string& path)
 		if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
 }
 
+
+/* Where the library's own file lies: the compiler process (astcenc_amd_jitc, jitc_main.cpp) is installed next to it. */
+std::string helper_path()
+{
+	static const std::string path = []() {
+		const char* e = getenv("ASTCENC_AMD_JITC");
+		if (e) return std::string(e);                      // (set but empty: compile inside this process)
+		Dl_info info;
+		if (!dladdr(reinterpret_cast<const void*>(&helper_path), &info) || !info.dli_fname) return std::string();
+		std::string p(info.dli_fname);
+		const size_t slash = p.rfind('/');
+		p = (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/astcenc_amd_jitc";
+		return access(p.c_str(), X_OK) == 0 ? p : std::string();
+	}();
+	return path;
+}
+
+/* Runs the compiler process and waits for it; `pid_out` names it while it runs (the queue kills it when the library is
+ * unloaded).  stdout / stderr of the child end up in the given files (may be null: inherited). */
+std::atomic<pid_t> g_child{0};
+int run_helper(const std::vector<std::string>& args, const char* stdout_path, const char* stderr_path)
+{
+	std::vector<char*> argv;
+	for (const std::string& a : args) argv.push_back(const_cast<char*>(a.c_str()));
+	argv.push_back(nullptr);
+	posix_spawn_file_actions_t fa;
+	posix_spawn_file_actions_init(&fa);
+	if (stdout_path) posix_spawn_file_actions_addopen(&fa, 1, stdout_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (stderr_path) posix_spawn_file_actions_addopen(&fa, 2, stderr_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	pid_t pid = 0;
+	const int rc = posix_spawn(&pid, argv[0], &fa, nullptr, argv.data(), environ);
+	posix_spawn_file_actions_destroy(&fa);
+	if (rc != 0) return -1;
+	g_child.store(pid);
+	int status = 0;
+	while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
+	g_child.store(0);
+	return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+std::string slurp(const std::string& path)
+{
+	std::string out;
+	FILE* f = fopen(path.c_str(), "rb");
+	if (!f) return out;
+	char buf[65536];
+	size_t n;
+	while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);
+	fclose(f);
+	return out;
+}
+bool spill(const std::string& path, const void* data, size_t n)
+{
+	FILE* f = fopen(path.c_str(), "wb");
+	if (!f) return false;
+	const bool ok = fwrite(data, 1, n, f) == n;
+	return fclose(f) == 0 && ok;
+}
+std::string temp_dir()
+{
+	std::string base = cache_dir();
+	if (!base.empty()) make_dirs(base); else { const char* t = getenv("TMPDIR"); base = t && *t ? t : "/tmp"; }
+	std::string tmpl = base + "/jitXXXXXX";
+	return mkdtemp(&tmpl[0]) ? tmpl : std::string();
+}
+
+/* Names the compiler a build would come from (part of the cache key: hiprtcVersion() is the same constant for every ROCm
+ * release).  The compiler process says which hipRTC / comgr files it resolves; inside this process: the hipRTC file. */
+const std::string& compiler_identity()
+{
+	static const std::string id = []() {
+		const std::string helper = helper_path();
+		if (!helper.empty())
+		{
+			const std::string dir = temp_dir();
+			if (!dir.empty())
+			{
+				const std::string out = dir + "/identity.txt";
+				const int rc = run_helper({ helper, "--identity" }, out.c_str(), nullptr);
+				std::string text = rc == 0 ? slurp(out) : std::string();
+				(void)unlink(out.c_str());
+				(void)rmdir(dir.c_str());
+				if (!text.empty()) return "process " + text;
+			}
+		}
+		std::string text = "inprocess ";
+		struct link_map* lm = nullptr;
+		if (rtc().handle && dlinfo(rtc().handle, RTLD_DI_LINKMAP, &lm) == 0 && lm && lm->l_name)
+		{
+			struct stat st;
+			text += lm->l_name;
+			if (stat(lm->l_name, &st) == 0) text += " " + std::to_string((long)st.st_size);
+		}
+		return text;
+	}();
+	return id;
+}
+
+/* A value of the code object's kernel metadata (a msgpack map in the .note section: the key as a string, then an unsigned
+ * integer), or -1: ".vgpr_count", ".private_segment_fixed_size". */
+long metadata_value(const std::vector<char>& code, const char* key)
+{
+	const size_t klen = strlen(key);
+	for (size_t i = 0; i + klen + 1 < code.size(); i++)
+	{
+		if (memcmp(&code[i], key, klen) != 0) continue;
+		const uint8_t* p = reinterpret_cast<const uint8_t*>(&code[i + klen]);
+		const size_t left = code.size() - (i + klen);
+		if (p[0] <= 0x7f) return p[0];
+		if (p[0] == 0xcc && left > 1) return p[1];
+		if (p[0] == 0xcd && left > 2) return (long)p[1] << 8 | p[2];
+		if (p[0] == 0xce && left > 4) return (long)p[1] << 24 | (long)p[2] << 16 | (long)p[3] << 8 | p[4];
+	}
+	return -1;
+}
+
 } // namespace
 
 struct JitKernel {
@@ -183,23 +308,19 @@ struct Queue {
 	{
 		{ std::lock_guard<std::mutex> g(mu); quit = true; pending.clear(); }
 		cv.notify_all();
+		if (const pid_t child = g_child.load()) (void)kill(child, SIGKILL);      // (a compile nobody will use any more)
 		if (worker.joinable()) worker.join();
 	}
 };
 Queue& queue() { static Queue q; return q; }
 
-void say(const JitKernel* k, const char* fmt, const char* a, double b = 0.0, size_t c = 0)
-{
-	if (!k->log) return;
-	char line[768];
-	snprintf(line, sizeof(line), fmt, a, b, c);
-	k->log(line);
-}
+void say(const JitKernel* k, const std::string& line) { if (k->log) k->log(line.c_str()); }
 
-bool compile_now(JitKernel* k)
+/* In this process, through the hipRTC library found here (whatever compiler the host process already holds). */
+bool compile_in_process(JitKernel* k, std::string& diagnostics)
 {
 	const Rtc& r = rtc();
-	if (!r.ok) return false;
+	if (!r.ok) { diagnostics = "no hipRTC library"; return false; }
 	std::vector<const char*> texts, names;
 	for (int i = 0; i < kHeaderCount; i++) { texts.push_back(kHeaders[i].text); names.push_back(kHeaders[i].name); }
 	texts.push_back(k->records.c_str()); names.push_back("fixed_contexts.inc");
@@ -207,41 +328,92 @@ bool compile_now(JitKernel* k)
 	if (r.create(&prog, k->unit.c_str(), "astc_compress_blocks_jit.hip", (int)texts.size(), texts.data(), names.data()) != HIPRTC_SUCCESS) return false;
 	std::vector<const char*> opts;
 	for (const std::string& o : k->options) opts.push_back(o.c_str());
-	const auto t0 = std::chrono::steady_clock::now();
-	const hiprtcResult rc = r.compile(prog, (int)opts.size(), opts.data());
-	k->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	bool ok = rc == HIPRTC_SUCCESS;
+	bool ok = r.compile(prog, (int)opts.size(), opts.data()) == HIPRTC_SUCCESS;
 	if (!ok)
 	{
 		size_t n = 0;
-		std::string text;
-		if (r.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { text.resize(n); (void)r.log(prog, &text[0]); }
-		if (text.size() > 600) text.resize(600);
-		say(k, "run-time build %s failed to compile: %.600s", (k->name + " " + text).c_str());
+		if (r.log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) { diagnostics.resize(n); (void)r.log(prog, &diagnostics[0]); }
 	}
 	size_t bytes = 0;
 	if (ok) ok = r.code_size(prog, &bytes) == HIPRTC_SUCCESS && bytes > 0;
 	if (ok) { k->code.resize(bytes); ok = r.code(prog, k->code.data()) == HIPRTC_SUCCESS; }
 	(void)r.destroy(&prog);
-	if (!ok) { k->code.clear(); return false; }
+	return ok;
+}
+
+/* In the compiler process (jitc_main.cpp: why): the source goes through a scratch directory. */
+bool compile_in_helper(JitKernel* k, const std::string& helper, std::string& diagnostics)
+{
+	const std::string dir = temp_dir();
+	if (dir.empty()) { diagnostics = "no scratch directory"; return false; }
+	bool ok = true;
+	std::vector<std::string> files;
+	for (int i = 0; i < kHeaderCount && ok; i++)
+	{
+		files.push_back(dir + "/" + kHeaders[i].name);
+		ok = spill(files.back(), kHeaders[i].text, (size_t)(kHeaders[i].end - kHeaders[i].text) - 1);      // (without the terminating zero)
+	}
+	files.push_back(dir + "/fixed_contexts.inc");
+	ok = ok && spill(files.back(), k->records.data(), k->records.size());
+	files.push_back(dir + "/unit.hip");
+	ok = ok && spill(files.back(), k->unit.data(), k->unit.size());
+	const std::string out = dir + "/out.hsaco", err = dir + "/stderr.txt";
+	if (ok)
+	{
+		std::vector<std::string> args = { helper, dir + "/unit.hip", out };
+		for (const std::string& o : k->options) args.push_back(o);
+		args.push_back("-I" + dir);
+		ok = run_helper(args, nullptr, err.c_str()) == 0;
+		if (!ok) diagnostics = slurp(err);
+	}
+	if (ok)
+	{
+		const std::string code = slurp(out);
+		k->code.assign(code.begin(), code.end());
+		ok = !k->code.empty();
+	}
+	for (const std::string& f : files) (void)unlink(f.c_str());
+	(void)unlink(out.c_str()); (void)unlink(err.c_str());
+	(void)rmdir(dir.c_str());
+	return ok;
+}
+
+bool compile_now(JitKernel* k)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const std::string helper = helper_path();
+	std::string diagnostics;
+	bool ok = helper.empty() ? compile_in_process(k, diagnostics) : compile_in_helper(k, helper, diagnostics);
+	k->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (!ok)
+	{
+		k->code.clear();
+		say(k, "run-time build " + k->name + " failed to compile: " + diagnostics.substr(0, 600));
+		return false;
+	}
+	// A build is only worth having when it keeps the occupancy the kernel is laid out for: four waves per SIMD (128 VGPRs)
+	// and no scratch frame.  (The ROCm 7.0 compiler, met inside a PyTorch process, gives the stage functions 160 VGPRs and a
+	// frame: 18 % slower than the generic build of the library -- refused here.)
+	const long vgprs = metadata_value(k->code, ".vgpr_count"), scratch = metadata_value(k->code, ".private_segment_fixed_size");
+	if (vgprs < 0 || vgprs > 128 || scratch != 0)
+	{
+		say(k, "run-time build " + k->name + " refused: " + std::to_string(vgprs) + " VGPRs, " + std::to_string(scratch) + " bytes of scratch (compiler: " + compiler_identity() + "); the generic build stays");
+		k->code.clear();
+		return false;
+	}
 	// the disk cache: written under a temporary name, renamed into place (readers see a whole file or none)
 	const std::string dir = cache_dir();
 	if (!dir.empty())
 	{
 		make_dirs(dir);
 		const std::string path = dir + "/" + k->key + ".hsaco";
-		char tmp[32];
-		snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());
-		const std::string tpath = path + tmp;
-		FILE* f = fopen(tpath.c_str(), "wb");
-		if (f)
-		{
-			const bool wrote = fwrite(k->code.data(), 1, k->code.size(), f) == k->code.size();
-			if (fclose(f) == 0 && wrote) (void)rename(tpath.c_str(), path.c_str());
-			else (void)unlink(tpath.c_str());
-		}
+		const std::string tpath = path + ".tmp" + std::to_string((long)getpid());
+		if (spill(tpath, k->code.data(), k->code.size())) (void)rename(tpath.c_str(), path.c_str());
+		else (void)unlink(tpath.c_str());
 	}
-	say(k, "run-time build %s compiled in %.1f s (%zu bytes)", k->name.c_str(), k->seconds, k->code.size());
+	char line[256];
+	snprintf(line, sizeof(line), " compiled in %.1f s (%zu bytes, %ld VGPRs, %s)", k->seconds, k->code.size(), vgprs, helper.empty() ? "in process" : "compiler process");
+	say(k, "run-time build " + k->name + line);
 	return true;
 }
 
@@ -306,7 +478,7 @@ JitMode jit_mode_from_environment()
 JitKernel* jit_acquire(const void* layout, size_t layout_bytes, const DeviceConfig& cfg_in, const TableRoot& root, bool hdr, const char* arch,
                        void (*log)(const char*))
 {
-	if (layout_bytes != sizeof(LdsLayout) || !rtc().ok) return nullptr;
+	if (layout_bytes != sizeof(LdsLayout) || (helper_path().empty() && !rtc().ok)) return nullptr;
 	LdsLayout L;
 	memcpy(&L, layout, sizeof(L));
 	DeviceConfig cfg = cfg_in;
@@ -328,8 +500,7 @@ JitKernel* jit_acquire(const void* layout, size_t layout_bytes, const DeviceConf
 	h = fnv1a(h, k->records.data(), k->records.size());
 	h = fnv1a(h, k->unit.data(), k->unit.size());
 	for (const std::string& o : k->options) h = fnv1a(h, o.data(), o.size() + 1);
-	const int ver[2] = { rtc().major, rtc().minor };
-	h = fnv1a(h, ver, sizeof(ver));
+	h = fnv1a(h, compiler_identity().data(), compiler_identity().size());
 	char hex[24];
 	snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)h);
 	k->key = hex;
