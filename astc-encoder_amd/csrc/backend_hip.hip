@@ -894,6 +894,9 @@ constexpr size_t MIN_BLOCKS_PER_DEVICE = 16384;
 /* Portions a sharded call is cut into per device (backend_compress): enough for a device that got cheap content to take
  * over work from one that did not, few enough for the pipeline restart at a portion's first band not to show. */
 constexpr size_t DEAL_PORTIONS_PER_DEVICE = 4;
+/* ... and a portion is at least this many blocks (a 2048^2 image at 6x6): every portion starts its PCIe pipeline anew -- its
+ * first band crosses before anything is compressed -- which eight portions of 16 k blocks pay for visibly (profiles/r06z). */
+constexpr size_t MIN_BLOCKS_PER_PORTION = 4 * MIN_BLOCKS_PER_DEVICE;
 
 int backend_compress(Backend* b, const CompressJob& job)
 {
@@ -954,7 +957,8 @@ int backend_compress(Backend* b, const CompressJob& job)
 		if (!(deal && strcmp(deal, "static") == 0))
 		{
 			nportions = ndev * DEAL_PORTIONS_PER_DEVICE;
-			if (nportions > by_size) nportions = by_size;
+			const size_t by_portion_size = progress.total / MIN_BLOCKS_PER_PORTION;
+			if (nportions > by_portion_size) nportions = by_portion_size;
 			if (nportions > units) nportions = units;
 			if (nportions < ndev) nportions = ndev;
 		}

@@ -232,7 +232,8 @@ class Library:
         """Convenience: config_init -> context_alloc -> compress_image -> free. Returns uint8 [blocks*16].
         block is (x, y) or (x, y, z); pixels is [H, W, 4] or [D, H, W, 4]; options: {OPT_*: value} for
         astcenc_amd_context_set_option (product library only); specialize: wait for the context's specialised kernel
-        build first (astcenc_amd_context_specialize) -- self.last_kernel then names the build that ran."""
+        build first (astcenc_amd_context_specialize; "try": go on with the generic build if there is none) -- self.last_kernel then
+        names the build that ran."""
         bz = block[2] if len(block) > 2 else 1
         err, cfg = self.config_init(profile, block[0], block[1], bz, quality, flags)
         if err:
@@ -249,7 +250,7 @@ class Library:
                     raise AstcError(err, "astcenc_amd_context_set_option")
             if specialize:
                 err = self.lib.astcenc_amd_context_specialize(ctx)
-                if err:
+                if err and specialize != "try":          # ("try": a refused build leaves the context on the generic kernel)
                     raise AstcError(err, "astcenc_amd_context_specialize")
             if hasattr(self.lib, "astcenc_amd_context_kernel_name"):
                 self.last_kernel = self.lib.astcenc_amd_context_kernel_name(ctx).decode()

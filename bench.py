@@ -524,6 +524,45 @@ def run_extra_config(lib, name, dev, steps, warmup, shared_img, budget_s):
     return res
 
 
+def run_jit_config(lib, dev, img_host):
+    """A context none of the library's fixed-context builds serves (6x6 -thorough): the generic build against the build the
+    library compiles for the context at run time (csrc/kernel_jit.cpp), cold compile time included, on a 4096^2 crop of the
+    bench image; bytes compared."""
+    import tempfile
+    cfg = dict(CONFIGS["c2"], size=4096, quality=A.PRE_THOROUGH, label="4096x4096 RGBA8 LDR, 6x6 block, -thorough (crop of the bench image)")
+    img = np.ascontiguousarray(img_host[:4096, :4096])
+    d_img = to_device(img, dev)
+    nbx, nby = block_grid(cfg)
+    res = {"config": "run_time_build", "workload": cfg["label"]}
+    saved = {k: os.environ.get(k) for k in ("ASTCENC_AMD_JIT", "ASTCENC_AMD_CACHE_DIR")}
+    blocks = {}
+    try:
+        with tempfile.TemporaryDirectory() as cache:
+            os.environ["ASTCENC_AMD_CACHE_DIR"] = cache
+            for mode in ("off", "sync", "sync"):
+                os.environ["ASTCENC_AMD_JIT"] = mode
+                t0 = time.perf_counter()
+                ctx = make_context(lib, cfg)
+                alloc_ms = (time.perf_counter() - t0) * 1e3
+                d_out = torch.zeros(nbx * nby * 16, dtype=torch.uint8, device=dev)
+                elapsed, kms = time_device_resident(lib, ctx, cfg, d_img, d_out, dev, 2, 1, lambda: torch.cuda.synchronize(dev))
+                key = "generic" if mode == "off" else ("run_time_cold" if "run_time_cold" not in res else "run_time_cached")
+                res[key] = {"kernel": kernel_name_of(lib, ctx), "context_alloc_ms": round(alloc_ms, 1),
+                            "value": round(cfg["size"] ** 2 * 2 / elapsed / 1e6, 3), "unit": "Mtexels/s", "kernel_ms": round(sum(kms) / len(kms), 3)}
+                blocks[key] = d_out.cpu().numpy()
+                lib.context_free(ctx)
+                del d_out
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    res["identical_bytes"] = bool(np.array_equal(blocks["generic"], blocks["run_time_cold"]) and np.array_equal(blocks["generic"], blocks["run_time_cached"]))
+    res["speedup_run_time_vs_generic"] = round(res["run_time_cached"]["value"] / res["generic"]["value"], 3)
+    return res
+
+
 def time_host_api(lib, cfg, img, devices, repeats=2):
     """Mtexels/s through astcenc_compress_image: pageable host memory in and out, PCIe both ways inside the timing."""
     old = os.environ.get("ASTCENC_AMD_DEVICES")
@@ -591,7 +630,9 @@ def main():
 
     # one process per GPU: this rank's context lives on this rank's device only
     os.environ["ASTCENC_AMD_DEVICES"] = str(local_rank)
+    t_ctx = time.perf_counter()
     ctx = make_context(lib, cfg)
+    context_alloc_ms = (time.perf_counter() - t_ctx) * 1e3
 
     # synthetic input of BASELINE's shape, one image per rank (different seeds), resident in HBM
     img_host = make_image(cfg, 0x9E3779B1 + rank)
@@ -635,6 +676,10 @@ def main():
                                  "value_host_api is the rate of the reference's own entry point astcenc_compress_image, "
                                  "host pointers in and out, PCIe both ways inside the timing (SURVEY.md 8d)"},
             "roofline": roof,
+            "context": {"kernel": kernel_name_of(lib, ctx), "alloc_ms": round(context_alloc_ms, 1),
+                        "what": "astcenc_context_alloc: table blob built on the host and uploaded, streams and events; the BASELINE contexts "
+                                "launch a fixed-context build of the library, every other context gets one compiled at run time "
+                                "(extra_configs: run_time_build)"},
         }
         if world == 1 and not args.no_host_api:
             rate, ndev, host_blocks = time_host_api(lib, cfg, img_host, str(local_rank))
@@ -655,7 +700,17 @@ def main():
                 if world > 1:
                     out["speedup_vs_cpu_baseline_per_gpu"] = round(value / world / base["value"], 2)
                 if world == 1 and args.config == "c2" and not args.no_parity_full:
-                    out["parity_full"] = parity_full(cfg, img_host, gpu_blocks, base["threads_at_best"], base["x86_gathers_used"])
+                    par = parity_full(cfg, img_host, gpu_blocks, base["threads_at_best"], base["x86_gathers_used"])
+                    out["parity_full"] = par
+                    if par:
+                        # the baseline figure is the WHOLE image's (the parity leg pays for that run anyway);
+                        # the crop sweep above chose the thread count and the build, and stays in the line
+                        base["value_crop_best_of_3"] = base["value"]
+                        base["value"] = par["reference_mtexels_s_whole_image"]
+                        base["sample"] = ("astcenc-avx2 (oracle/_ref) on the WHOLE %dx%d bench image, one run, %d threads (%s); thread count and build "
+                                          "chosen on a %s" % (cfg["size"], cfg["size"], par["threads"], par["reference"], base["sample"]))
+                        base["mtexels_per_core_second"] = round(base["value"] / max(min(base["cpus_allowed"], base["threads_at_best"]), 1e-9), 4)
+                        out["speedup_vs_cpu_baseline"] = round(value / base["value"], 2)
         if world == 1 and not args.no_extra and args.config == "c2":
             del d_img, d_out
             extra = []
@@ -663,6 +718,7 @@ def main():
                 shared = img_host if name == "c3" else None           # c3 is the same RGBA8 image, other footprint / preset
                 extra.append(run_extra_config(lib, name, dev, 2, 1, shared, 60.0))
             extra.append(run_photo_config(lib, dev, 3, 1))
+            extra.append(run_jit_config(lib, dev, img_host))
             out["extra_configs"] = extra
         print(json.dumps(out), flush=True)
 

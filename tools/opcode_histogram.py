@@ -93,6 +93,7 @@ for l in lines:
     weights[b][re.sub(r"_e32$|_e64$|_sdwa$|_dpp$", lambda s: s.group(0) if s.group(0) in ("_sdwa", "_dpp") else "", op)] += 8.0 ** depth
 
 est = collections.Counter()
+est_by_bucket = collections.defaultdict(collections.Counter)
 for b, ops in weights.items():
     if b not in bucket_measured:
         continue
@@ -104,6 +105,7 @@ for b, ops in weights.items():
         for o, v in ops.items():
             if kind(o) == k:
                 est[o] += v * scale
+                est_by_bucket[b][o] += v * scale
 
 def hw_class(op):
     o = op.replace("_dpp", "").replace("_sdwa", "")
@@ -131,3 +133,47 @@ for c, v in cls.most_common():
 if len(sys.argv) > 3:
     t = json.load(open(sys.argv[3]))["configs"][sys.argv[4] if len(sys.argv) > 4 else "c2"].get("valu_class_insts_per_block")
     print("  measured classes:", t)
+
+
+# ---- count x measured issue cost, per stage ----------------------------------------------------------
+# Costs from the issue microbenchmarks on the device (profiles/r04z/valu_microbench3_with_scalar_rows.txt, profiles/r06a/
+# valu_microbench4.txt; SIMD cycles per wave-instruction with 4-8 waves on the SIMD):
+#   full-rate class (add / sub / mul / fma / fmac / mov / and / or / xor / add_u32 / sub_u32 / lshrrev ...)  2.1 - 2.2
+#   slow class (cndmask, every v_cmp, v_cvt_*, v_lshlrev, min / max, DPP and SDWA forms, lshl_add / add3 / bfe / mul_lo /
+#               mul_u32_u24 / mad_u32_u24, readlane / readfirstlane, packed fp32)                                  4.1 - 4.3
+#   transcendental (rcp, sqrt, rsq ...)                                                                           8.2
+# ... but the classes do NOT add up: alternating rows cost what the full-rate class costs ("v_add + v_max alternating" 2.13
+# per instruction, "3 x v_add + v_max" 2.06, "v_add + 3 x v_max" 3.11 = 12.4 / 4): a SIMD issues a slow-class instruction
+# every 4.15 cycles and, beside it, full-rate ones -- VALU cycles = max(2.1 x all VALU, 4.15 x slow class + 8.2 x trans).
+# The slow class costs extra only where it is more than HALF of the instructions in flight on the SIMD.
+# And a wave issues ONE instruction of any kind per ~5.5 - 6 cycles of its own time ("v_add_f32" alone on a SIMD: 5.99;
+# "3 x v_add + s_and_b64": 5.5 per instruction): with four waves per SIMD the instructions of a wave -- vector, scalar, LDS,
+# branch, waitcnt alike -- are a floor under its residency of about 1.4 quad-cycles each.
+FULL = 2.1; SLOW = 4.15; TRANS = 8.2; PER_WAVE = 5.5
+def is_trans(o): return hw_class(o) == "trans_f32"
+def is_slow(o):
+    b = o.replace("_e32", "").replace("_e64", "")
+    if is_trans(b): return False
+    if b.endswith(("_dpp", "_sdwa")): return True
+    return b.startswith(("v_cndmask", "v_cmp", "v_cmpx", "v_cvt_", "v_lshlrev", "v_min", "v_max", "v_med3", "v_lshl_add", "v_add3", "v_bfe", "v_bfi",
+                         "v_mul_lo", "v_mul_hi", "v_mul_u32_u24", "v_mul_i32_i24", "v_mad_u32_u24", "v_mad_i32_i24", "v_readlane", "v_readfirstlane",
+                         "v_writelane", "v_rndne", "v_pk_", "v_floor", "v_fract", "v_trunc", "v_ceil", "v_and_or", "v_or3", "v_lshl_or", "v_xad",
+                         "v_bcnt", "v_ffbh", "v_ffbl", "v_alignbit", "v_perm", "v_sad", "v_div_scale", "v_div_fmas", "v_div_fixup", "v_ldexp",
+                         "v_frexp", "v_ashrrev", "v_mbcnt", "v_dot"))
+print()
+print("--- count x measured issue cost per stage (estimate inside a stage, measured stage totals; cycles per block)")
+print("%-28s %8s %8s %6s %8s %8s | %9s %9s  %s" % ("stage", "VALU", "slow", "trans", "scalar", "LDS", "VALU port", "wave issue", "slow share"))
+tot = [0.0] * 7
+for b in sorted(est_by_bucket, key=lambda b: -sum(v for o, v in est_by_bucket[b].items() if kind(o) == 0)):
+    ops = est_by_bucket[b]
+    valu = sum(v for o, v in ops.items() if kind(o) == 0)
+    slow = sum(v for o, v in ops.items() if kind(o) == 0 and is_slow(o))
+    trans = sum(v for o, v in ops.items() if kind(o) == 0 and is_trans(o))
+    salu = sum(v for o, v in ops.items() if kind(o) == 1)
+    lds = sum(v for o, v in ops.items() if kind(o) == 2)
+    port = max(FULL * valu, SLOW * slow + TRANS * trans)
+    wave = PER_WAVE * (valu + salu + lds)
+    for i, x in enumerate((valu, slow, trans, salu, lds, port, wave)): tot[i] += x
+    print("%-28s %8.0f %8.0f %6.0f %8.0f %8.0f | %9.0f %9.0f  %4.0f%%%s" % (b, valu, slow, trans, salu, lds, port, wave, 100.0 * slow / max(valu, 1), "  <- slow class binds" if SLOW * slow + TRANS * trans > FULL * valu else ""))
+print("%-28s %8.0f %8.0f %6.0f %8.0f %8.0f | %9.0f %9.0f  %4.0f%%" % ("all", *tot, 100.0 * tot[1] / max(tot[0], 1)))
+print("VALU port, all stages: %.0f cycles per block = %.0f quad-cycles of a SIMD; one wave's own issue floor: %.0f cycles = %.0f quad-cycles of its residency" % (tot[5], tot[5] / 4, tot[6], tot[6] / 4))
