@@ -181,6 +181,67 @@ int kernel_launch(const Backend* b, const DeviceSlot* s, const KernelLaunch& k)
 	return kernel_variants[b->variant].launch(k);
 }
 
+/* The self-check of slot_adopt_jit: 16 x 16 blocks (volumes: 8 x 8 x 4) of deterministic RGBA8 content through `fn` and through
+ * the library's build of the context; true when the two block streams are byte-identical. */
+bool jit_self_check(Backend* b, DeviceSlot* s, hipFunction_t fn)
+{
+	const uint32_t bsx = b->root.dim_x, bsy = b->root.dim_y, bsz = b->root.dim_z;
+	const uint32_t nbx = bsz > 1 ? 8u : 16u, nby = bsz > 1 ? 8u : 16u, nbz = bsz > 1 ? 4u : 1u;
+	const uint32_t dim_x = nbx * bsx - 1u, dim_y = nby * bsy - 1u, dim_z = bsz > 1 ? nbz * bsz - 1u : 1u;      // (the last blocks are partial)
+	const size_t texels = (size_t)dim_x * dim_y * dim_z, nblocks = (size_t)nbx * nby * nbz;
+	std::vector<uint8_t> img(texels * 4);
+	uint32_t rng = 0x9E3779B1u;
+	for (uint32_t z = 0; z < dim_z; z++)
+		for (uint32_t y = 0; y < dim_y; y++)
+			for (uint32_t x = 0; x < dim_x; x++)
+			{
+				// per block-sized tile: noise amplitude 0 (ramps), 6, 40, 255 (pure noise), two colours, a constant
+				const uint32_t tile = (x / bsx + 3u * (y / bsy) + 5u * (z / bsz)) % 6u;
+				uint8_t* px = &img[(((size_t)z * dim_y + y) * dim_x + x) * 4];
+				for (int ch = 0; ch < 4; ch++)
+				{
+					rng = rng * 1664525u + 1013904223u;
+					const int noise = (int)(rng >> 24);
+					int v = (int)((x * (3u + ch) + y * (7u - ch) + z * 11u) & 255u);
+					if (tile == 1) v += (noise & 15) - 6;
+					else if (tile == 2) v += (noise & 63) - 24;
+					else if (tile == 3) v = noise;
+					else if (tile == 4) v = ((x + ch) ^ (y >> 1)) & 2 ? 220 - 20 * ch : 30 + 25 * ch;
+					else if (tile == 5) v = 40 + 50 * ch;
+					if (ch == 3 && tile != 3 && tile != 2) v = 255;
+					px[ch] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+				}
+			}
+	void* d_img = nullptr;
+	uint8_t* d_out = nullptr;
+	bool ok = hipMalloc(&d_img, img.size() + ALLOC_SLACK) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&d_out), 2 * nblocks * 16 + ALLOC_SLACK) == hipSuccess;
+	std::vector<uint8_t> out(2 * nblocks * 16);
+	if (ok)
+	{
+		KernelLaunch k;
+		k.d_tab = s->d_tab; k.lds_bytes = b->lds_bytes; k.d_prof = nullptr; k.stream = s->stream;
+		k.first = 0; k.count = (uint32_t)nblocks;
+		ImageDesc& im = k.img;
+		im.data = d_img; im.dim_x = dim_x; im.dim_y = dim_y; im.data_type = 0;
+		for (int i = 0; i < 4; i++) im.swz[i] = (uint32_t)i;
+		im.blocks_x = nbx; im.blocks_y = nby; im.dim_z = dim_z; im.blocks_z = nbz;
+		im.use_fast_load = (b->cfg.profile < 2 && bsz == 1) ? 1 : 0;
+		im.fast_load_slice0 = 0; im.alpha_avg = nullptr; im.a_scale_radius = 0;
+		ok = hipMemcpyAsync(d_img, img.data(), img.size(), hipMemcpyHostToDevice, s->stream) == hipSuccess;
+		k.d_out = d_out;
+		ok = ok && kernel_variants[b->variant].launch(k) == 0;
+		k.d_out = d_out + nblocks * 16;
+		void* args[] = { &k.d_tab, &k.img, &k.d_out, &k.first, &k.count, &k.d_prof };
+		ok = ok && hipModuleLaunchKernel(fn, k.count, 1, 1, 64, 1, 1, k.lds_bytes, s->stream, args, nullptr) == hipSuccess;
+		ok = ok && hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, s->stream) == hipSuccess;
+		ok = ok && hipStreamSynchronize(s->stream) == hipSuccess;
+		if (!ok) (void)hipGetLastError();
+	}
+	if (d_img) (void)hipFree(d_img);
+	if (d_out) (void)hipFree(d_out);
+	return ok && memcmp(out.data(), out.data() + nblocks * 16, nblocks * 16) == 0;
+}
+
 /* Loads the context's run-time build on the slot's device once the compiler has delivered it (current device = the slot's).
  * Anything that goes wrong leaves the slot on the library's generic build. */
 void slot_adopt_jit(Backend* b, DeviceSlot* s)
@@ -196,6 +257,19 @@ void slot_adopt_jit(Backend* b, DeviceSlot* s)
 		(void)hipGetLastError();
 		if (mod) (void)hipModuleUnload(mod);
 		log_msg("run-time build %s does not load on device %d: the generic build stays", jit_kernel_name(b->jit), s->device);
+		return;
+	}
+	// Trust, but verify: before the build takes over, it and the library's own build compress the same 256 blocks of built-in
+	// content -- noise of several amplitudes over ramps, flat and two-colour stretches, i.e. blocks that run every trial of the
+	// search -- and the bytes must be equal.  (A build is compiled from the same source with the same numerics flags, so they
+	// are -- unless the compiler did something with the constants that it does not do without them: the run-time builds of the
+	// 10x8 and 12x12 footprints do differ, DESIGN.md section 3.1, and are turned away here.)
+	// (ASTCENC_AMD_JIT_SELF_CHECK=0: debugging only -- tools/jit_debug4.py looks at a build the check turns away)
+	const char* check = getenv("ASTCENC_AMD_JIT_SELF_CHECK");
+	if (!(check && strcmp(check, "0") == 0) && !jit_self_check(b, s, fn))
+	{
+		(void)hipModuleUnload(mod);
+		log_msg("run-time build %s does not reproduce the generic build's bytes on the self-check image: the generic build stays", jit_kernel_name(b->jit));
 		return;
 	}
 	s->jit_module = mod;

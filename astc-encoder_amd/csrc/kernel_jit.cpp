@@ -469,6 +469,17 @@ void start_locked(Queue& q, JitKernel* k)
 
 } // namespace
 
+bool jit_write_records(const char* path, const void* layout, size_t layout_bytes, const DeviceConfig& cfg_in, const TableRoot& root)
+{
+	if (layout_bytes != sizeof(LdsLayout)) return false;
+	LdsLayout L;
+	memcpy(&L, layout, sizeof(L));
+	DeviceConfig cfg = cfg_in;
+	cfg.debug_dup_stage = 0;
+	const std::string text = records_text(L, cfg, root);
+	return spill(path, text.data(), text.size());
+}
+
 JitMode jit_mode_from_environment()
 {
 	const char* e = getenv("ASTCENC_AMD_JIT");
@@ -492,13 +503,27 @@ JitKernel* jit_acquire(const void* layout, size_t layout_bytes, const DeviceConf
 	k->records = records_text(L, cfg, root);
 	// the translation unit: what kernel_ldr_6x6m.hip is for its context, with the records from the "header" above
 	k->unit = std::string("#define ASTC_VARIANT v_jit\n") + (hdr ? "#define ASTC_ENABLE_HDR 1\n" : "#define ASTC_ENABLE_HDR 0\n") +
-	          (root.texel_count <= 64 ? "#define ASTC_TEXELS_LE_64 1\n" : "") +
-	          "#define ASTC_FIXED_CONTEXT 1\n#define ASTC_KERNEL_NAME astc_compress_blocks_jit\n#define ASTC_KERNEL_LINKAGE extern \"C\"\n#include \"kernel_device.h\"\n";
+	          (root.texel_count <= 64 ? "#define ASTC_TEXELS_LE_64 1\n" : "#define ASTC_FIXED_OPAQUE_TEXEL_COUNT 1\n") +
+	          // (ASTCENC_AMD_JIT_DEBUG=generic: the same source compiled WITHOUT the constants -- separates what the run-time route
+	          //  does from what the constants do when a build misbehaves)
+	          (getenv("ASTCENC_AMD_JIT_DEBUG") && strcmp(getenv("ASTCENC_AMD_JIT_DEBUG"), "generic") == 0 ? "" : "#define ASTC_FIXED_CONTEXT 1\n") +
+	          "#define ASTC_KERNEL_NAME astc_compress_blocks_jit\n#define ASTC_KERNEL_LINKAGE extern \"C\"\n#include \"kernel_device.h\"\n";
 	// the numerics flags of the Makefile are part of the bit-exactness contract (wave.h)
 	std::string a = arch && *arch ? arch : "gfx950";
 	a = a.substr(0, a.find(':'));
 	k->options = { "--offload-arch=" + a, "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-math-errno",
 	               "-fno-slp-vectorize", "-Wno-unused-function" };
+	// (ASTCENC_AMD_JIT_OPTIONS: further compiler options, space separated -- a debugging aid: the kernel of a context rebuilt
+	//  with another optimisation level or a -D switch of the source without rebuilding the library; part of the cache key)
+	if (const char* more = getenv("ASTCENC_AMD_JIT_OPTIONS"))
+	{
+		std::string word;
+		for (const char* p = more;; p++)
+		{
+			if (*p == ' ' || *p == 0) { if (!word.empty()) k->options.push_back(word); word.clear(); if (!*p) break; }
+			else word.push_back(*p);
+		}
+	}
 	uint64_t h = 14695981039346656037ull;
 	for (int i = 0; i < kHeaderCount; i++) h = fnv1a(h, kHeaders[i].text, (size_t)(kHeaders[i].end - kHeaders[i].text));
 	h = fnv1a(h, k->records.data(), k->records.size());

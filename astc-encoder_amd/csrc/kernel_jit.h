@@ -39,6 +39,9 @@ JitState jit_state(const JitKernel* k);
 const void* jit_code(const JitKernel* k, size_t* bytes);    // the code object (ready builds)
 const char* jit_kernel_name(const JitKernel* k);            // "astc_compress_blocks_jit_<hash>" (what astcenc_amd_context_kernel_name reports)
 double jit_compile_seconds(const JitKernel* k);             // 0 for a build that came from the disk cache
+/* The records of a context as the text a fixed-context build includes (what the run-time build is compiled with): written to
+ * `path` (test infrastructure: the sequential build compiled for one context, oracle/emu/Makefile `fixed`). */
+bool jit_write_records(const char* path, const void* layout, size_t layout_bytes, const DeviceConfig& cfg, const TableRoot& root);
 constexpr const char* JIT_ENTRY_POINT = "astc_compress_blocks_jit";      // the kernel's symbol in every such code object
 
 } // namespace astcd

@@ -58,8 +58,9 @@ WV_FN float infill_taps_at(const float* wts, const uint8_t* tab, uint32_t idx_of
 #ifndef ASTC_ANG_GROUP
 #define ASTC_ANG_GROUP 4
 #endif
-// ... and whether the next group's table loads are requested before the current group is added up (measured: +-0 in every
-// build, profiles/r05h; off)
+// ... and whether the next group's table loads are requested before the current group is added up: on in the decimation
+// sweeps (ASTC_DWI_PREFETCH: a weight of a coarse grid has up to six groups of taps, each an L2 round trip), off in the angular
+// search (ASTC_ANG_PREFETCH: measured +-0 in every build, profiles/r05h)
 #ifndef ASTC_DWI_PREFETCH
 #define ASTC_DWI_PREFETCH 1
 #endif

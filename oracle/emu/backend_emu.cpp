@@ -79,6 +79,19 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 			fclose(f);
 		}
 	}
+	// tests/test_emu_fixed.py: the context's records as a fixed-context build includes them (what its run-time build is compiled with)
+	if (const char* path = getenv("ASTC_EMU_DUMP_RECORDS")) (void)jit_write_records(path, &b->layout, sizeof(b->layout), cfg, *reinterpret_cast<const TableRoot*>(blob));
+#if ASTC_FIXED
+	// this library is compiled for ONE context (ASTC_FIXED_RECORDS_FILE): any other is refused, like a fixed-context kernel build does
+	{
+		DeviceConfig live = cfg;
+		live.debug_dup_stage = kFixedConfig.debug_dup_stage;
+		if (memcmp(&b->layout, &kFixedLayout, sizeof(LdsLayout)) != 0 || memcmp(&live, &kFixedConfig, sizeof(live)) != 0 || memcmp(blob, &kFixedRoot, sizeof(TableRoot)) != 0)
+		{
+			delete b; *status = 2; return nullptr;
+		}
+	}
+#endif
 	*status = 0;
 	return b;
 }
@@ -110,6 +123,9 @@ int backend_compress(Backend* b, const CompressJob& job)
 	c.root = root;
 	c.cfg = reinterpret_cast<const DeviceConfig*>(c.tab - CTX_CONFIG_BACK);
 	c.L = reinterpret_cast<const LdsLayout*>(c.tab - CTX_LAYOUT_BACK);
+#if ASTC_FIXED
+	c.root = &kFixedRoot; c.cfg = &kFixedConfig; c.L = &kFixedLayout;      // (as kernel_device.h does in a fixed-context build)
+#endif
 	// LDS starts out as garbage on the device: poison it (ASTC_EMU_POISON = byte value, or "rand")
 	std::vector<uint8_t> lds(c.L->total + 64, 0xCD);
 	if (const char* poison = getenv("ASTC_EMU_POISON"))
