@@ -117,7 +117,8 @@ ASTCENC_PUBLIC const char* astcenc_amd_backend_name(void);
 /* Diagnostics.  The library reports through the reference's error codes and prints nothing.  What it knows beyond the code
  * -- which HIP call failed, why a device of ASTCENC_AMD_DEVICES was skipped -- is handed, one line per event and without a
  * trailing newline, to the callback installed here (process-wide; null, the default, switches it off; the callback may be
- * called from any thread that is inside a library call).  ASTCENC_AMD_LOG=stderr in the environment prints the same
+ * called from any thread that is inside a library call, and from the library's own threads -- a device's host thread, the
+ * worker that waits for a run-time kernel build).  ASTCENC_AMD_LOG=stderr in the environment prints the same
  * lines to stderr when no callback is installed. */
 ASTCENC_PUBLIC void astcenc_amd_set_log_callback(void (*callback)(const char* message));
 
