@@ -63,23 +63,13 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 	c.root = &kFixedRoot;
 	c.cfg = &kFixedConfig;
 	c.L = &kFixedLayout;
-	// (debugging aid, ASTCENC_AMD_JIT_OPTIONS: one of the records read from the blob again)
-#if defined(ASTC_DEBUG_LIVE_ROOT)
-	c.root = reinterpret_cast<const TableRoot*>(tab);
-#endif
-#if defined(ASTC_DEBUG_LIVE_CONFIG)
-	c.cfg = reinterpret_cast<const DeviceConfig*>(base + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
-#endif
-#if defined(ASTC_DEBUG_LIVE_LAYOUT) || defined(ASTC_DEBUG_LIVE_LAYOUT_BODY)
-	c.L = reinterpret_cast<const LdsLayout*>(base);
-#endif
 #else
 	c.root = reinterpret_cast<const TableRoot*>(tab);
 	c.cfg = reinterpret_cast<const DeviceConfig*>(base + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
 	c.L = reinterpret_cast<const LdsLayout*>(base);
 #endif
 	c.T = (int)c.L->texel_count;
-#if defined(ASTC_FIXED_OPAQUE_TEXEL_COUNT) || defined(ASTC_DEBUG_OPAQUE_T)
+#if defined(ASTC_FIXED_OPAQUE_TEXEL_COUNT)
 	// (run-time builds for footprints of more than 64 texels, kernel_jit.cpp: the texel count of the lane loops is NOT a
 	//  compile-time constant there.  With it, the builds of the 10x8 and 12x12 footprints -- 80 and 144 texels: the last trip of
 	//  a texel loop has exactly sixteen lanes -- produce other bytes than the generic build on a quarter of noisy blocks; the
@@ -89,9 +79,6 @@ ASTC_KERNEL_NAME(const uint8_t* __restrict__ tab, ImageDesc img,
 #endif
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
-#if defined(ASTC_DEBUG_OPAQUE_TS)
-	c.Ts = wv_uniform(wv_opaque(c.Ts));
-#endif
 #if defined(ASTC_TRACE)
 	// trace builds: `prof` is the search trace buffer, one slice per block of the image (wave_ctx.h: TRACE_PUT)
 	if (prof) prof = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint32_t*>(prof) + (size_t)b * TRACE_WORDS_PER_BLOCK);

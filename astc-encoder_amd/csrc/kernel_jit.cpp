@@ -504,9 +504,7 @@ JitKernel* jit_acquire(const void* layout, size_t layout_bytes, const DeviceConf
 	// the translation unit: what kernel_ldr_6x6m.hip is for its context, with the records from the "header" above
 	k->unit = std::string("#define ASTC_VARIANT v_jit\n") + (hdr ? "#define ASTC_ENABLE_HDR 1\n" : "#define ASTC_ENABLE_HDR 0\n") +
 	          (root.texel_count <= 64 ? "#define ASTC_TEXELS_LE_64 1\n" : "#define ASTC_FIXED_OPAQUE_TEXEL_COUNT 1\n") +
-	          // (ASTCENC_AMD_JIT_DEBUG=generic: the same source compiled WITHOUT the constants -- separates what the run-time route
-	          //  does from what the constants do when a build misbehaves)
-	          (getenv("ASTCENC_AMD_JIT_DEBUG") && strcmp(getenv("ASTCENC_AMD_JIT_DEBUG"), "generic") == 0 ? "" : "#define ASTC_FIXED_CONTEXT 1\n") +
+	          "#define ASTC_FIXED_CONTEXT 1\n"
 	          "#define ASTC_KERNEL_NAME astc_compress_blocks_jit\n#define ASTC_KERNEL_LINKAGE extern \"C\"\n#include \"kernel_device.h\"\n";
 	// the numerics flags of the Makefile are part of the bit-exactness contract (wave.h)
 	std::string a = arch && *arch ? arch : "gfx950";

@@ -267,7 +267,7 @@ WV_FN void score_block_modes(const Ctx& c, int partition_count, int start, int e
 				// (the texel's record of the mode's grid: one 32-bit and one 128-bit load, whatever the tap count.  Every
 				//  grid goes through the four-tap form: a tap a grid does not have has index 0 and factor 0.0f in the tables
 				//  (ref: init_decimation_info_2d fills the unused entries with zeros), and (v0 + v1) + (0 + 0) is v0 + v1)
-#if ASTC_FIXED && !defined(ASTC_DEBUG_NO_FIXED_SCORE)
+#if ASTC_FIXED
 				auto texel_term = [&](const TexelTaps& taps, int t) -> float
 				{
 					const int i0 = (int)(taps.idx & 0xFFu), i1 = (int)((taps.idx >> 8) & 0xFFu), i2 = (int)((taps.idx >> 16) & 0xFFu), i3 = (int)(taps.idx >> 24);

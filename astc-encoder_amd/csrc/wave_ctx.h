@@ -432,7 +432,7 @@ struct Ctx {
 	// indexing costs one 32-bit offset per access instead of 64-bit pointer arithmetic
 	WV_FN const uint8_t* table(uint32_t off) const
 	{
-#if ASTC_FIXED && WV_DEVICE && !defined(ASTC_DEBUG_NO_FIXED_TABLE)
+#if ASTC_FIXED && WV_DEVICE
 		// `off` is a literal here (a field of the constant TableRoot).  Left to itself the compiler adds it to every lane's
 		// address -- scalar base + 32-bit lane offset + a constant too large for the load's immediate field becomes a 64-bit
 		// vector addition per access (v_lshl_add_u64, v_add_co_u32, v_addc_co_u32: four instructions where the generic
@@ -509,23 +509,8 @@ WV_FN uint8_t* lds_base()
 	return (uint8_t*)((lds_bytes)(uintptr_t)16 - 16);
 }
 
-/* (debugging aid of the run-time builds, ASTCENC_AMD_JIT_OPTIONS=-DASTC_DEBUG_LIVE_LAYOUT_IN="a,b": the stage functions whose
- *  names are listed read the LDS layout from the blob again instead of from the constant record; folded at compile time) */
-constexpr bool debug_name_listed(const char* list, const char* name)
-{
-	for (const char* p = list; *p; )
-	{
-		const char* q = name;
-		const char* r = p;
-		while (*r && *r != ',' && *q && *r == *q) { r++; q++; }
-		if ((*r == 0 || *r == ',') && *q == 0) return true;
-		while (*p && *p != ',') p++;
-		if (*p == ',') p++;
-	}
-	return false;
-}
 template <bool SCALAR_TABLES>
-WV_FN Ctx ctx_make_as(const char* caller)
+WV_FN Ctx ctx_make_as()
 {
 	uint8_t* const lds = lds_base();
 	const LdsHeader* h = reinterpret_cast<const LdsHeader*>(lds);
@@ -549,25 +534,13 @@ WV_FN Ctx ctx_make_as(const char* caller)
 	c.root = &kFixedRoot;
 	c.cfg = &kFixedConfig;
 	c.L = &kFixedLayout;
-#if defined(ASTC_DEBUG_LIVE_ROOT)
-	c.root = reinterpret_cast<const TableRoot*>(c.tab);
-#endif
-#if defined(ASTC_DEBUG_LIVE_CONFIG)
-	c.cfg = reinterpret_cast<const DeviceConfig*>(b + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
-#endif
-#if defined(ASTC_DEBUG_LIVE_LAYOUT)
-	c.L = reinterpret_cast<const LdsLayout*>(b);
-#endif
-#if defined(ASTC_DEBUG_LIVE_LAYOUT_IN)
-	if (debug_name_listed(ASTC_DEBUG_LIVE_LAYOUT_IN, caller)) c.L = reinterpret_cast<const LdsLayout*>(b);
-#endif
 #else
 	c.root = reinterpret_cast<const TableRoot*>(c.tab);
 	c.cfg = reinterpret_cast<const DeviceConfig*>(b + (CTX_LAYOUT_BACK - CTX_CONFIG_BACK));
 	c.L = reinterpret_cast<const LdsLayout*>(b);
 #endif
 	c.T = (int)c.L->texel_count;
-#if defined(ASTC_FIXED_OPAQUE_TEXEL_COUNT) || defined(ASTC_DEBUG_OPAQUE_T)
+#if defined(ASTC_FIXED_OPAQUE_TEXEL_COUNT)
 	// (run-time builds for footprints of more than 64 texels, kernel_jit.cpp: the texel count of the lane loops is NOT a
 	//  compile-time constant there.  With it, the builds of the 10x8 and 12x12 footprints -- 80 and 144 texels: the last trip of
 	//  a texel loop has exactly sixteen lanes -- produce other bytes than the generic build on a quarter of noisy blocks; the
@@ -577,13 +550,10 @@ WV_FN Ctx ctx_make_as(const char* caller)
 #endif
 	c.Tp = (c.T + 3) & ~3;
 	c.Ts = lds_row_stride(c.Tp);
-#if defined(ASTC_DEBUG_OPAQUE_TS)
-	c.Ts = wv_uniform(wv_opaque(c.Ts));
-#endif
 	return c;
 }
-WV_FN Ctx ctx_make(const char* caller = __builtin_FUNCTION()) { return ctx_make_as<true>(caller); }
-WV_FN Ctx ctx_make_vector_tables(const char* caller = __builtin_FUNCTION()) { return ctx_make_as<false>(caller); }
+WV_FN Ctx ctx_make() { return ctx_make_as<true>(); }
+WV_FN Ctx ctx_make_vector_tables() { return ctx_make_as<false>(); }
 #else
 WV_FN uint8_t* lds_base() { return nullptr; }        // (host pass of a kernel translation unit: never executed)
 extern thread_local const Ctx* g_wave_ctx;      // set by the CPU emulation backend around each block
@@ -597,14 +567,14 @@ WV_FN Ctx ctx_make_vector_tables() { return *g_wave_ctx; }
  * is exact and the compiler drops it), and everything else reads the block's record. */
 WV_FN float cw_of(const BlkInfo& blk, int k)
 {
-#if ASTC_FIXED && !defined(ASTC_DEBUG_NO_FIXED_CW)
+#if ASTC_FIXED
 	if ((kFixedConfig.flags & (1u << 2)) == 0) return k == 0 ? kFixedConfig.cw[0] : k == 1 ? kFixedConfig.cw[1] : k == 2 ? kFixedConfig.cw[2] : kFixedConfig.cw[3];
 #endif
 	return blk.cw[k];
 }
 WV_FN f4 cw4_of(const BlkInfo& blk)
 {
-#if ASTC_FIXED && !defined(ASTC_DEBUG_NO_FIXED_CW)
+#if ASTC_FIXED
 	if ((kFixedConfig.flags & (1u << 2)) == 0) return mk4(kFixedConfig.cw[0], kFixedConfig.cw[1], kFixedConfig.cw[2], kFixedConfig.cw[3]);
 #endif
 	return load4(blk.cw);
@@ -617,7 +587,7 @@ WV_FN f4 cw4_of(const BlkInfo& blk)
 template <typename Body>
 WV_FN void for_texels_of_quarter(int l, int T, Body body)
 {
-#if ASTC_FIXED && !defined(ASTC_DEBUG_NO_FIXED_QUARTER)
+#if ASTC_FIXED
 	(void)T;
 	constexpr int kT = (int)kFixedRoot.texel_count, kTrips = (kT + 3) >> 2;
 	#pragma unroll

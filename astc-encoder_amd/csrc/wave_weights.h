@@ -562,8 +562,9 @@ WV_FN void angular_endpoints(const Ctx& c, int nsets_all, SetFn get_set)
 				float svalrte = f_round(sval);
 				float diff = sval - svalrte;
 				errval += diff * diff;
-				if (svalrte == minidx) cut_low = cut_low + 1.0f - 2.0f * diff;
-				if (svalrte == maxidx) cut_high = cut_high + 1.0f + 2.0f * diff;
+				// (ref: (cut + 1) -/+ (2 dif), weight_align.cpp:212-224; |dif| <= 0.5, so 2 dif is exact and the fused form is the same float)
+				if (svalrte == minidx) cut_low = f_add_doubled(cut_low + 1.0f, diff, -2.0f);
+				if (svalrte == maxidx) cut_high = f_add_doubled(cut_high + 1.0f, diff, 2.0f);
 			};
 			{
 				int j = 0;
