@@ -46,6 +46,30 @@ WV_FN void metric_load_texel(const void* img, size_t texel, uint32_t data_type, 
 	}
 }
 
+/* The same for an RGBA8 texel that is already in a register (the four-texels-per-lane loop of kernel_metrics.hip). */
+WV_FN void metric_unpack_rgba8(uint32_t px, const float* unorm8, float c[4])
+{
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t v = (px >> (8 * k)) & 0xFFu;
+		c[k] = unorm8 ? unorm8[v] : (float)v / 255.0f;
+	}
+}
+
+/* Error terms of one texel pair whose components are loaded (see metric_texel_terms). */
+WV_FN float metric_terms_of(const float c1[4], const float c2[4], float e[8])
+{
+	for (int k = 0; k < 4; k++)
+	{
+		float d = c1[k] - c2[k];
+		e[k] = d * d;
+		float ds = k < 3 ? d * c1[3] : d;
+		e[4 + k] = ds * ds;
+	}
+	float m = c1[0] > c1[1] ? c1[0] : c1[1];
+	return m > c1[2] ? m : c1[2];
+}
+
 /* log2 as the reference's metric code evaluates it (ref: log2(vfloat4), astcenc_vecmathlib.h:416-440:
  * exponent + 5th degree polynomial in the mantissa, Horner form). */
 WV_FN float metric_log2(float x)
@@ -102,15 +126,7 @@ WV_FN float metric_texel_terms(const void* a, uint32_t type_a, const void* b, ui
 {
 	metric_load_texel(a, texel, type_a, unorm8, c1);
 	metric_load_texel(b, texel, type_b, unorm8, c2);
-	for (int k = 0; k < 4; k++)
-	{
-		float d = c1[k] - c2[k];
-		e[k] = d * d;
-		float ds = k < 3 ? d * c1[3] : d;
-		e[4 + k] = ds * ds;
-	}
-	float m = c1[0] > c1[1] ? c1[0] : c1[1];
-	return m > c1[2] ? m : c1[2];
+	return metric_terms_of(c1, c2, e);
 }
 
 } } // namespace astcd::ASTC_VARIANT
