@@ -1031,7 +1031,10 @@ int backend_compress(Backend* b, const CompressJob& job)
 		if (!(deal && strcmp(deal, "static") == 0))
 		{
 			nportions = ndev * DEAL_PORTIONS_PER_DEVICE;
-			const size_t by_portion_size = progress.total / MIN_BLOCKS_PER_PORTION;
+			// (ASTCENC_AMD_DEAL_MIN_BLOCKS: a smaller minimum, for tests/test_multi_device.py -- many portions on a small image)
+			size_t min_portion = MIN_BLOCKS_PER_PORTION;
+			if (const char* e = getenv("ASTCENC_AMD_DEAL_MIN_BLOCKS")) { const long v = strtol(e, nullptr, 10); if (v >= 1) min_portion = (size_t)v; }
+			const size_t by_portion_size = progress.total / min_portion;
 			if (nportions > by_portion_size) nportions = by_portion_size;
 			if (nportions > units) nportions = units;
 			if (nportions < ndev) nportions = ndev;

@@ -256,3 +256,38 @@ def test_alpha_scale_prepass_is_sharded_with_a_halo(product, ref, A, radius, slo
         assert np.array_equal(want, many)
     plain = product.compress(img, block, A.PRE_FAST, flags=A.FLG_USE_ALPHA_WEIGHT)
     assert (plain != many).any(), "the test image must contain blocks that the alpha test skips"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius", [0, 3, 40])
+def test_portions_are_dealt_from_one_counter(product, ref, A, monkeypatch, radius):
+    """Round 6: the devices TAKE portions of block rows from one counter (ref: the reference's workers take blocks from a
+    ticket counter, astcenc_internal_entry.h:225-236) instead of owning one range each.  With the minimum portion size
+    lowered (a test-only switch) a 96 000-block image on three slots is cut into twelve portions -- whichever slot takes
+    which, the stream is the one-device stream, with the alpha-scale pre-pass too (every portion carries its own halo),
+    and for a stack of slices (portions of layers)."""
+    monkeypatch.setenv("ASTCENC_AMD_DEAL_MIN_BLOCKS", "4096")
+    w, h, block = 1500, 2300, (6, 6)
+    img = images.noisy(w, h, 23)
+    img[:, :, 3] = 255
+    for y0, y1 in ((180, 200), (760, 1010), (1530, 1550), (2100, 2290)):
+        img[y0:y1, :, 3] = 0
+    flags = A.FLG_USE_ALPHA_WEIGHT if radius else 0
+    tweak = (lambda c: setattr(c, "a_scale_radius", radius)) if radius else None
+    with _Devices("0"):
+        one = product.compress(img, block, A.PRE_FAST, flags=flags, tweak=tweak)
+    for deal in ("dynamic", "static"):
+        monkeypatch.setenv("ASTCENC_AMD_DEAL", deal)
+        with _Devices("0,0,0"):
+            many = product.compress(img, block, A.PRE_FAST, flags=flags, tweak=tweak)
+        assert np.array_equal(one, many), (deal, radius)
+    if radius == 3:
+        assert np.array_equal(ref.compress(img, block, A.PRE_FAST, flags=flags, tweak=tweak), one)
+    if radius == 0:
+        monkeypatch.setenv("ASTCENC_AMD_DEAL", "dynamic")
+        stack = np.stack([A.synthetic_image(384, 256, 30 + z) for z in range(12)])            # 12 x 96 x 64 blocks at 4x4
+        with _Devices("0"):
+            one = product.compress(stack, (4, 4), A.PRE_FASTEST)
+        with _Devices("0,0,0"):
+            many = product.compress(stack, (4, 4), A.PRE_FASTEST)
+        assert np.array_equal(one, many)
