@@ -49,7 +49,18 @@ def main():
                 img = by_key.get((row["Image Set"], row["Name"]))
                 if img is not None:
                     img["ref_psnr"]["%s/%s" % (preset, row["Block Size"])] = float(row["PSNR"])
-    json.dump({"source": "reference Test/Images, astc_reference-5.0-avx2_*_results.csv", "images": images},
+    # ... and the coding rates the reference recorded for its current main branch on its own test machine (column "Coding
+    # Rate", Mtexels/s: tools/corpus_rates.py prints them next to what this library and the reference reach on this host)
+    for s in SETS:
+        for preset in PRESETS:
+            path = os.path.join(REF, s, "astc_reference-main-avx2_%s_results.csv" % preset)
+            if not os.path.exists(path):
+                continue
+            for row in csv.DictReader(open(path)):
+                img = by_key.get((row["Image Set"], row["Name"]))
+                if img is not None:
+                    img.setdefault("ref_coding_rate", {})["%s/%s" % (preset, row["Block Size"])] = float(row["Coding Rate"])
+    json.dump({"source": "reference Test/Images, astc_reference-5.0-avx2_*_results.csv (PSNR), astc_reference-main-avx2_*_results.csv (coding rate)", "images": images},
               open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print("fetched %d images into %s" % (len(images), os.path.relpath(DST)))
     return 0
