@@ -92,6 +92,11 @@ struct Backend {
 // The library's own device buffers end in a little slack, so that a buffer never stops exactly at the end
 // of a mapped page.
 constexpr size_t ALLOC_SLACK = 4096;
+/* Smallest host image whose PCIe transfers are pipelined against its kernels in bands (compress_on_slot_locked).  A band
+ * costs about half a millisecond of its own (a block takes 0.8 ms from load to store, so every kernel ends in a tail that does
+ * not fill the device); four bands pay for themselves once the image's transfers take longer than that: measured break-even
+ * near 4096 x 4096 at 6x6 (profiles/r06z/host_api_small_images.txt). */
+constexpr size_t BAND_MIN_BLOCKS = (size_t)1 << 18;
 #if defined(ASTC_TRACE)
 constexpr size_t TRACE_WORDS_PER_BLOCK_HOST = 1024;   // = TRACE_WORDS_PER_BLOCK (wave_ctx.h)
 #endif
@@ -806,9 +811,12 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	size_t chunk = chunked ? (size_t)1 << 18 : nblocks;
 	if (banded)
 	{
-		// whole block rows per band, at least four bands when the image has that many block rows
+		// whole block rows per band; at least four bands when the image is large enough for a band to fill the device.  (A
+		// block takes 0.8 ms from load to store whatever runs beside it -- its own instruction stream on one wave -- so a
+		// kernel over a band is never shorter than that: four bands of a 256 x 256 image were four times 0.8 ms one after
+		// the other, 3.4 ms for a call whose one launch takes 0.9; below BAND_MIN_BLOCKS the image is one band.)
 		size_t rows = chunk / blocks_x;
-		if (rows * 4 > blocks_y) rows = (blocks_y + 3) / 4;
+		if (rows * 4 > blocks_y) rows = nblocks >= BAND_MIN_BLOCKS ? (blocks_y + 3) / 4 : blocks_y;
 		if (rows < 1) rows = 1;
 		chunk = rows * blocks_x;
 	}
