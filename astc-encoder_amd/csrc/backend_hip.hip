@@ -86,6 +86,7 @@ struct Backend {
 	                                  // serves this context, ASTCENC_AMD_JIT=off, an instrumentation build, no hipRTC)
 	JitMode jit_mode;
 	std::atomic<unsigned long long> blocks_done;     // blocks this context has compressed (JIT_LAZY's trigger)
+	unsigned long long jit_lazy_blocks;              // ... and the count at which the compile is queued (JIT_LAZY_BLOCKS)
 	std::atomic<bool> jit_active;     // some slot launches the run-time build
 };
 
@@ -575,6 +576,9 @@ Backend* backend_create(const uint8_t* blob, size_t blob_bytes, const DeviceConf
 	b->lds_bytes = 0;
 	b->variant = -1;
 	b->jit = nullptr; b->jit_mode = JIT_OFF; b->blocks_done.store(0); b->jit_active.store(false);
+	b->jit_lazy_blocks = JIT_LAZY_BLOCKS;
+	// (ASTCENC_AMD_JIT_LAZY_BLOCKS: another trigger count -- tests/test_jit.py watches the background compile take over)
+	if (const char* e = getenv("ASTCENC_AMD_JIT_LAZY_BLOCKS")) { const long long v = strtoll(e, nullptr, 10); if (v >= 1) b->jit_lazy_blocks = (unsigned long long)v; }
 	uint8_t layout[CTX_LAYOUT_BACK - CTX_CONFIG_BACK];
 	uint32_t layout_bytes = 0;
 	{
@@ -697,7 +701,7 @@ static int compress_on_slot_locked(Backend* b, DeviceSlot* s, const CompressJob&
 	// the context's run-time build: adopted as soon as the compiler has delivered it; asked for (JIT_LAZY) once the context
 	// has compressed enough to be worth a compile
 	slot_adopt_jit(b, s);
-	if (b->jit && b->jit_mode == JIT_LAZY && b->blocks_done.fetch_add(nblocks) + nblocks >= JIT_LAZY_BLOCKS) jit_start(b->jit);
+	if (b->jit && b->jit_mode == JIT_LAZY && b->blocks_done.fetch_add(nblocks) + nblocks >= b->jit_lazy_blocks) jit_start(b->jit);
 	const size_t texel_bytes = job.data_type == 0 ? 4 : job.data_type == 1 ? 8 : 16;
 	// (a shard of the alpha-scale split carries halo rows around its own: they are uploaded and averaged, not compressed)
 	const uint32_t halo_above = dim_z == 1 && job.a_scale_radius != 0 ? job.halo_above : 0u;

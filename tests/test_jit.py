@@ -189,3 +189,39 @@ def test_sweep_through_run_time_builds(product, ref, A, tmp_path, monkeypatch):
             if n:
                 bad.append((profile, block, quality, n))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_background_compile_takes_over_by_itself(product, ref, A, tmp_path, monkeypatch):
+    """The default mode end to end: the context starts on the generic build, queues its compile once it has compressed enough
+    (the count lowered for the test), keeps compressing on the generic build while the compiler process works, and a later
+    call finds the build, verifies it and launches it -- same bytes before and after."""
+    cache = str(tmp_path / "cache")
+    monkeypatch.setenv("ASTCENC_AMD_CACHE_DIR", cache)
+    monkeypatch.setenv("ASTCENC_AMD_JIT", "lazy")
+    monkeypatch.setenv("ASTCENC_AMD_JIT_LAZY_BLOCKS", "3000")
+    img = np.ascontiguousarray(A.synthetic_image(250, 190, 8))
+    err, cfg = product.config_init(A.PRF_LDR, 8, 6, 1, A.PRE_FAST, 0)
+    assert err == 0
+    err, ctx = product.context_alloc(cfg, 1)
+    assert err == 0
+    try:
+        name = lambda: product.lib.astcenc_amd_context_kernel_name(ctx).decode()
+        first = np.zeros(32 * 32 * 16, dtype=np.uint8)
+        assert product.compress_raw(ctx, img, first) == 0 and name() == "astc_compress_blocks_ldr64"
+        deadline = time.time() + 120
+        calls = 1
+        out = np.zeros_like(first)
+        while not name().startswith("astc_compress_blocks_jit_") and time.time() < deadline:
+            assert product.lib.astcenc_compress_reset(ctx) == 0
+            assert product.compress_raw(ctx, img, out) == 0
+            assert np.array_equal(first, out)
+            calls += 1
+            time.sleep(0.05)
+        assert name().startswith("astc_compress_blocks_jit_"), "no run-time build after %d calls" % calls
+        assert calls >= 3                                   # (1024 blocks per call: the compile was not even queued before the third)
+        assert product.lib.astcenc_compress_reset(ctx) == 0
+        assert product.compress_raw(ctx, img, out) == 0 and np.array_equal(first, out)
+    finally:
+        product.context_free(ctx)
+    assert np.array_equal(ref.compress(img, (8, 6), A.PRE_FAST), first)
