@@ -15,7 +15,9 @@
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
 #include <link.h>
+#include <dirent.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,8 +99,23 @@ int main(int argc, char** argv)
 	if (code_size(p, &bytes) != HIPRTC_SUCCESS || bytes == 0) return 1;
 	std::vector<char> out(bytes);
 	if (code(p, out.data()) != HIPRTC_SUCCESS) return 1;
-	FILE* f = fopen(argv[2], "wb");
-	if (!f) { fprintf(stderr, "astcenc_amd_jitc: cannot write %s\n", argv[2]); return 1; }
+	// written under a temporary name and renamed into place: the output may be the library's disk cache, read by other processes
+	const std::string final_path = argv[2], tmp_path = final_path + ".tmp" + std::to_string((long)getpid());
+	FILE* f = fopen(tmp_path.c_str(), "wb");
+	if (!f) { fprintf(stderr, "astcenc_amd_jitc: cannot write %s\n", tmp_path.c_str()); return 1; }
 	const bool ok = fwrite(out.data(), 1, bytes, f) == bytes;
-	return fclose(f) == 0 && ok ? 0 : 1;
+	if (fclose(f) != 0 || !ok || rename(tmp_path.c_str(), final_path.c_str()) != 0) { (void)unlink(tmp_path.c_str()); return 1; }
+	// The library that started this process may be gone by now (a host that exits does not wait for its compile: the build is
+	// for the next run): the scratch directory with the source is this process's to remove.
+	if (const char* dir = getenv("ASTCENC_AMD_JITC_SCRATCH"))
+	{
+		if (DIR* d = opendir(dir))
+		{
+			while (struct dirent* e = readdir(d))
+				if (strcmp(e->d_name, ".") != 0 && strcmp(e->d_name, "..") != 0) (void)unlink((std::string(dir) + "/" + e->d_name).c_str());
+			closedir(d);
+			(void)rmdir(dir);
+		}
+	}
+	return 0;
 }

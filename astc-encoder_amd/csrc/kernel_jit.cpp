@@ -181,17 +181,29 @@ std::string helper_path()
 /* Runs the compiler process and waits for it; `pid_out` names it while it runs (the queue kills it when the library is
  * unloaded).  stdout / stderr of the child end up in the given files (may be null: inherited). */
 std::atomic<pid_t> g_child{0};
-int run_helper(const std::vector<std::string>& args, const char* stdout_path, const char* stderr_path)
+int run_helper(const std::vector<std::string>& args, const char* stdout_path, const char* stderr_path, const char* scratch_dir = nullptr)
 {
 	std::vector<char*> argv;
 	for (const std::string& a : args) argv.push_back(const_cast<char*>(a.c_str()));
 	argv.push_back(nullptr);
 	posix_spawn_file_actions_t fa;
 	posix_spawn_file_actions_init(&fa);
-	if (stdout_path) posix_spawn_file_actions_addopen(&fa, 1, stdout_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-	if (stderr_path) posix_spawn_file_actions_addopen(&fa, 2, stderr_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	// The child may outlive this process: it must not hold the host's standard streams or any other descriptor of the host
+	// (a pipe that somebody waits on to close) -- its own go to the given files or to /dev/null.
+	posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+	posix_spawn_file_actions_addopen(&fa, 1, stdout_path ? stdout_path : "/dev/null", O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	posix_spawn_file_actions_addopen(&fa, 2, stderr_path ? stderr_path : "/dev/null", O_WRONLY | O_CREAT | O_TRUNC, 0644);
+#if defined(__GLIBC__) && __GLIBC_PREREQ(2, 34)
+	posix_spawn_file_actions_addclosefrom_np(&fa, 3);
+#endif
 	pid_t pid = 0;
-	const int rc = posix_spawn(&pid, argv[0], &fa, nullptr, argv.data(), environ);
+	// (the child's environment: this process's, plus the scratch directory it is to remove when it is done)
+	std::vector<char*> envp;
+	std::string scratch_var;
+	for (char** e = environ; e && *e; e++) if (strncmp(*e, "ASTCENC_AMD_JITC_SCRATCH=", 25) != 0) envp.push_back(*e);
+	if (scratch_dir) { scratch_var = std::string("ASTCENC_AMD_JITC_SCRATCH=") + scratch_dir; envp.push_back(const_cast<char*>(scratch_var.c_str())); }
+	envp.push_back(nullptr);
+	const int rc = posix_spawn(&pid, argv[0], &fa, nullptr, argv.data(), envp.data());
 	posix_spawn_file_actions_destroy(&fa);
 	if (rc != 0) return -1;
 	g_child.store(pid);
@@ -278,6 +290,18 @@ long metadata_value(const std::vector<char>& code, const char* key)
 	return -1;
 }
 
+/* A build is only worth having when it keeps the occupancy the kernel is laid out for: four waves per SIMD, i.e. at most 128
+ * VGPRs.  (The ROCm 7.0 compiler, met inside a PyTorch process, gives the stage functions 160 VGPRs and a scratch frame: 18 %
+ * slower than the generic build of the library.)  A frame of a few bytes is accepted: some contexts (5x5 -medium) leave one
+ * stage function a scalar register short, which costs one 8-byte slot per lane and still measures faster than the generic
+ * build; anything bigger is a register allocation gone wrong. */
+bool acceptable(const std::vector<char>& code, long* vgprs, long* scratch)
+{
+	*vgprs = metadata_value(code, ".vgpr_count");
+	*scratch = metadata_value(code, ".private_segment_fixed_size");
+	return *vgprs >= 0 && *vgprs <= 128 && *scratch >= 0 && *scratch <= JIT_MAX_SCRATCH_BYTES;
+}
+
 } // namespace
 
 struct JitKernel {
@@ -306,15 +330,22 @@ struct Queue {
 	std::map<std::string, JitKernel*> by_key;
 	std::thread worker;
 	bool started = false, quit = false;
-	~Queue()
-	{
-		{ std::lock_guard<std::mutex> g(mu); quit = true; pending.clear(); }
-		cv.notify_all();
-		if (const pid_t child = g_child.load()) (void)kill(child, SIGKILL);      // (a compile nobody will use any more)
-		if (worker.joinable()) worker.join();
-	}
 };
-Queue& queue() { static Queue q; return q; }
+/* Never destroyed: the worker may be waiting for the compiler process when the host exits, and a host does not wait for a
+ * compile -- the compiler process finishes on its own and leaves the build in the disk cache (jitc_main.cpp).  Only a compile
+ * that runs INSIDE this process (no compiler process installed) is waited for at exit: LLVM must not be at work while the
+ * process tears its statics down. */
+std::atomic<bool> g_compiling_in_process{false};
+struct ExitGuard { ~ExitGuard(); };
+Queue& queue() { static Queue* q = new Queue; static ExitGuard guard; (void)guard; return *q; }
+ExitGuard::~ExitGuard()
+{
+	Queue& q = queue();
+	std::unique_lock<std::mutex> g(q.mu);
+	q.quit = true;
+	q.pending.clear();
+	q.cv.wait(g, [] { return !g_compiling_in_process.load(); });
+}
 
 void say(const JitKernel* k, const std::string& line) { if (k->log) k->log(line.c_str()); }
 
@@ -359,13 +390,17 @@ bool compile_in_helper(JitKernel* k, const std::string& helper, std::string& dia
 	ok = ok && spill(files.back(), k->records.data(), k->records.size());
 	files.push_back(dir + "/unit.hip");
 	ok = ok && spill(files.back(), k->unit.data(), k->unit.size());
-	const std::string out = dir + "/out.hsaco", err = dir + "/stderr.txt";
+	// With a disk cache the compiler process writes the build straight into it and removes the scratch directory itself: a
+	// host that exits before the compile is done leaves the process to finish, and the next run finds the build.
+	const std::string cache = cache_dir();
+	if (!cache.empty()) make_dirs(cache);
+	const std::string out = cache.empty() ? dir + "/out.hsaco" : cache + "/" + k->key + ".hsaco", err = dir + "/stderr.txt";
 	if (ok)
 	{
 		std::vector<std::string> args = { helper, dir + "/unit.hip", out };
 		for (const std::string& o : k->options) args.push_back(o);
 		args.push_back("-I" + dir);
-		ok = run_helper(args, nullptr, err.c_str()) == 0;
+		ok = run_helper(args, nullptr, err.c_str(), cache.empty() ? nullptr : dir.c_str()) == 0;
 		if (!ok) diagnostics = slurp(err);
 	}
 	if (ok)
@@ -374,8 +409,10 @@ bool compile_in_helper(JitKernel* k, const std::string& helper, std::string& dia
 		k->code.assign(code.begin(), code.end());
 		ok = !k->code.empty();
 	}
+	// (what the compiler process has not removed: everything without a cache or after a failure)
 	for (const std::string& f : files) (void)unlink(f.c_str());
-	(void)unlink(out.c_str()); (void)unlink(err.c_str());
+	if (cache.empty()) (void)unlink(out.c_str());
+	(void)unlink(err.c_str());
 	(void)rmdir(dir.c_str());
 	return ok;
 }
@@ -385,7 +422,9 @@ bool compile_now(JitKernel* k)
 	const auto t0 = std::chrono::steady_clock::now();
 	const std::string helper = helper_path();
 	std::string diagnostics;
+	if (helper.empty()) g_compiling_in_process.store(true);
 	bool ok = helper.empty() ? compile_in_process(k, diagnostics) : compile_in_helper(k, helper, diagnostics);
+	if (helper.empty()) { g_compiling_in_process.store(false); queue().cv.notify_all(); }
 	k->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	if (!ok)
 	{
@@ -393,21 +432,16 @@ bool compile_now(JitKernel* k)
 		say(k, "run-time build " + k->name + " failed to compile: " + diagnostics.substr(0, 600));
 		return false;
 	}
-	// A build is only worth having when it keeps the occupancy the kernel is laid out for: four waves per SIMD, i.e. at most
-	// 128 VGPRs.  (The ROCm 7.0 compiler, met inside a PyTorch process, gives the stage functions 160 VGPRs and a scratch
-	// frame: 18 % slower than the generic build of the library -- refused here.)  A frame of a few bytes is accepted: some
-	// contexts (5x5 -medium) leave one stage function a scalar register short, which costs one 8-byte slot per lane and still
-	// measures faster than the generic build; anything bigger is a register allocation gone wrong.
-	const long vgprs = metadata_value(k->code, ".vgpr_count"), scratch = metadata_value(k->code, ".private_segment_fixed_size");
-	if (vgprs < 0 || vgprs > 128 || scratch < 0 || scratch > JIT_MAX_SCRATCH_BYTES)
+	long vgprs = 0, scratch = 0;
+	if (!acceptable(k->code, &vgprs, &scratch))
 	{
 		say(k, "run-time build " + k->name + " refused: " + std::to_string(vgprs) + " VGPRs, " + std::to_string(scratch) + " bytes of scratch (compiler: " + compiler_identity() + "); the generic build stays");
 		k->code.clear();
 		return false;
 	}
-	// the disk cache: written under a temporary name, renamed into place (readers see a whole file or none)
+	// the disk cache (the compiler process has written it already): under a temporary name, renamed into place
 	const std::string dir = cache_dir();
-	if (!dir.empty())
+	if (!dir.empty() && helper.empty())
 	{
 		make_dirs(dir);
 		const std::string path = dir + "/" + k->key + ".hsaco";
@@ -537,7 +571,19 @@ JitKernel* jit_acquire(const void* layout, size_t layout_bytes, const DeviceConf
 	std::lock_guard<std::mutex> g(q.mu);
 	auto it = q.by_key.find(k->key);
 	if (it != q.by_key.end()) { delete k; it->second->refs++; return it->second; }
-	if (load_cached(k)) k->state = JIT_READY;
+	if (load_cached(k))
+	{
+		// (a build in the cache that misses the occupancy -- written by a compiler process whose host was gone before it could
+		//  look at the result -- is not compiled again by every process that comes by: it fails here, once per process)
+		long vgprs = 0, scratch = 0;
+		if (acceptable(k->code, &vgprs, &scratch)) k->state = JIT_READY;
+		else
+		{
+			say(k, "run-time build " + k->name + " in the disk cache refused: " + std::to_string(vgprs) + " VGPRs, " + std::to_string(scratch) + " bytes of scratch; the generic build stays");
+			k->code.clear();
+			k->state = JIT_FAILED;
+		}
+	}
 	k->refs = 1;
 	q.by_key[k->key] = k;
 	return k;

@@ -225,3 +225,42 @@ def test_background_compile_takes_over_by_itself(product, ref, A, tmp_path, monk
     finally:
         product.context_free(ctx)
     assert np.array_equal(ref.compress(img, (8, 6), A.PRE_FAST), first)
+
+
+ORPHAN_SCRIPT = r"""
+import sys, os, time, threading
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_libs as O, astcenc_amd as A
+lib = A.Library(O.LIB_EMU)
+err, cfg = lib.config_init(A.PRF_LDR, 5, 4, 1, A.PRE_FAST, 0); assert err == 0
+err, ctx = lib.context_alloc(cfg, 1); assert err == 0
+threading.Thread(target=lambda: lib.lib.astcenc_amd_context_specialize(ctx), daemon=True).start()
+time.sleep(0.7)                       # the compiler process is at work now
+print("leaving", sorted(os.listdir(os.environ["ASTCENC_AMD_CACHE_DIR"])))
+sys.exit(0)
+"""
+
+
+def test_a_host_that_exits_does_not_wait_and_the_build_is_there_next_time(built, emu, A, tmp_path):
+    """A compile in flight when the host process exits: the process leaves at once (it neither waits for the compiler
+    process nor kills it), the compiler process finishes on its own, writes the build into the disk cache and removes its
+    scratch directory -- the next run of the host finds the build."""
+    if not os.path.exists("/opt/rocm/lib/libhiprtc.so"):
+        pytest.skip("no hipRTC on this box")
+    cache = tmp_path / "cache"
+    env = dict(os.environ, ASTCENC_AMD_CACHE_DIR=str(cache), ASTCENC_AMD_JIT="lazy")
+    script = ORPHAN_SCRIPT % (os.path.join(ROOT, "astc-encoder_amd", "python"), os.path.join(ROOT, "oracle"))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=120)
+    left_after = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "leaving ['jit" in r.stdout and ".hsaco" not in r.stdout, r.stdout        # only the scratch directory so far
+    assert left_after < 6.0, left_after                                                # (a compile alone takes seven seconds here)
+    deadline = time.time() + 60
+    while time.time() < deadline and not [f for f in os.listdir(cache) if f.endswith(".hsaco")]:
+        time.sleep(0.5)
+    time.sleep(0.5)
+    assert [f for f in os.listdir(cache) if f.endswith(".hsaco")], os.listdir(cache)
+    assert not [f for f in os.listdir(cache) if f.startswith("jit")], os.listdir(cache)   # the scratch directory is gone
+    rc, name = _specialize_on_cpu((str(cache), A.PRF_LDR, (5, 4), A.PRE_FAST, 0))       # ... and the next run starts with the build
+    assert rc == 0 and name[len("astc_compress_blocks_jit_"):] + ".hsaco" in os.listdir(cache)
