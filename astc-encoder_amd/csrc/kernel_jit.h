@@ -5,7 +5,8 @@
 // (ref: astcenc_config_init treats them all alike, Source/astcenc_entry.cpp:504-724).  The library embeds its own device
 // source (kernel_device.h and the wave_*.h it includes), writes the context's records as `constexpr` initializers, compiles
 // the translation unit with hipRTC for the device's architecture on a background thread and keeps the code object on disk
-// under a hash of (source, records, options, compiler version).  Until the build is there -- and whenever it cannot be made:
+// under a hash of (source, records, options, the compiler's files).  A host that exits while a compile is running leaves at
+// once; the compiler process finishes on its own and the next run finds the build.  Until the build is there -- and whenever it cannot be made:
 // no hipRTC on the box, a compile error -- the context runs the generic build of its footprint class; both give the same
 // bytes (tests/test_jit.py).
 #pragma once
