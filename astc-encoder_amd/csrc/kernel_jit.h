@@ -24,7 +24,7 @@ enum JitMode {
 	JIT_EAGER = 2,     // ASTCENC_AMD_JIT=eager: queued when the context is created
 	JIT_SYNC = 3       // ASTCENC_AMD_JIT=sync: compiled inside astcenc_context_alloc
 };
-constexpr unsigned long long JIT_LAZY_BLOCKS = 1u << 20;
+constexpr unsigned long long JIT_LAZY_BLOCKS = 1u << 18;      // (one 3072 x 3072 texture at 6x6)
 
 enum JitState { JIT_IDLE = 0, JIT_QUEUED, JIT_COMPILING, JIT_READY, JIT_FAILED };
 

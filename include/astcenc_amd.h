@@ -147,7 +147,7 @@ ASTCENC_PUBLIC const char* astcenc_amd_context_kernel_name(const struct astcenc_
  * code object on disk (ASTCENC_AMD_CACHE_DIR, else $XDG_CACHE_HOME/astcenc_amd, else ~/.cache/astcenc_amd) under a hash of
  * source, records, options and compiler version; the name is then "astc_compress_blocks_jit_<hash>".  Until that build is
  * there the context runs the generic one -- same bytes.  ASTCENC_AMD_JIT in the environment: "lazy" (default: a cached
- * build is used at once, a compile is started when the context has compressed 2^20 blocks), "eager" (started in
+ * build is used at once, a compile is started when the context has compressed 2^18 blocks), "eager" (started in
  * astcenc_context_alloc), "sync" (finished inside astcenc_context_alloc), "off".
  *
  * astcenc_amd_context_specialize() waits for the context's specialised build -- starting the compile if need be -- and
