@@ -365,13 +365,15 @@ static void bind_worker_to_device(const DeviceSlot* s)
 }
 
 /* Hands `task` to the slot's parked thread (started on first use, bound to the device's CPUs once); false when no
- * thread can be had -- std::system_error must not cross the C ABI -- and the caller runs the task itself.  The worker
- * stays locked (w->mu) until worker_wait(). */
+ * thread can be had -- std::system_error must not cross the C ABI --, or when the thread is busy with another call on
+ * the same context (a second call used to wait here for the first call's whole shard before it even started its
+ * own first one): a compression then deals that device's share to the others, a decompression runs the shard itself.  The
+ * worker stays locked (w->mu) until worker_wait(). */
 static bool worker_run(DeviceSlot* s, std::function<void()> task)
 {
 	SlotWorker* w = s->worker;
 	if (!w) return false;
-	w->mu.lock();
+	if (!w->mu.try_lock()) return false;
 	if (!w->started)
 	{
 		try
@@ -1234,7 +1236,10 @@ int backend_decompress(Backend* bk, const DecompressJob& job)
 	std::vector<size_t> on_workers, inline_shards;
 	for (size_t g = 1; g < shards.size(); g++)
 	{
-		if (worker_run(bk->slots[g], [&, g]() { shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); })) on_workers.push_back(g);
+		bool handed = false;
+		try { handed = worker_run(bk->slots[g], [&shards, bk, g]() { shards[g].rc = decompress_on_slot(bk, bk->slots[g], shards[g].job); }); }
+		catch (...) { }                                     // (building the task may allocate: nothing is thrown across the C ABI)
+		if (handed) on_workers.push_back(g);
 		else inline_shards.push_back(g);
 	}
 	shards[0].rc = decompress_on_slot(bk, bk->slots[0], shards[0].job);

@@ -291,3 +291,37 @@ def test_portions_are_dealt_from_one_counter(product, ref, A, monkeypatch, radiu
         with _Devices("0,0,0"):
             many = product.compress(stack, (4, 4), A.PRE_FASTEST)
         assert np.array_equal(one, many)
+
+
+@pytest.mark.gpu
+def test_two_multi_device_contexts_at_once(product, A):
+    """Two host threads, each with its own three-slot context on the same devices, compress two images at the same time:
+    the contexts share nothing but the GPUs (own tables, streams, staging, host threads), portions are dealt inside each --
+    both streams equal the one-device streams, three times in a row."""
+    import threading
+    img_a, img_b = A.synthetic_image(1500, 1400, 41), A.synthetic_image(1400, 1500, 42)
+    with _Devices("0"):
+        want_a, want_b = product.compress(img_a, (6, 6), A.PRE_FAST), product.compress(img_b, (6, 6), A.PRE_FAST)
+    with _Devices("0,0,0"):
+        err, cfg = product.config_init(A.PRF_LDR, 6, 6, 1, A.PRE_FAST, 0)
+        assert err == 0
+        ctxs = []
+        for _ in range(2):
+            err, ctx = product.context_alloc(cfg, 1)
+            assert err == 0
+            ctxs.append(ctx)
+        outs = [np.zeros(want_a.size, dtype=np.uint8), np.zeros(want_b.size, dtype=np.uint8)]
+        rcs = [None, None]
+
+        def run(i, img):
+            rcs[i] = product.compress_raw(ctxs[i], np.ascontiguousarray(img), outs[i])
+        for _ in range(3):
+            ts = [threading.Thread(target=run, args=(0, img_a)), threading.Thread(target=run, args=(1, img_b))]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert rcs == [0, 0]
+            assert np.array_equal(outs[0], want_a) and np.array_equal(outs[1], want_b)
+            for ctx in ctxs:
+                assert product.lib.astcenc_compress_reset(ctx) == 0
+        for ctx in ctxs:
+            product.context_free(ctx)
