@@ -615,7 +615,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (ASTC_BENCH_FORCE_DIST=1: take the process-group path with ONE rank as well -- tests/test_bench_multirank.py runs the RCCL
+    #  calls of the N > 1 launch on the one GPU of the test box, where RCCL refuses two ranks)
+    use_dist = world > 1 or (os.environ.get("ASTC_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         if share_gpu:
             dist.init_process_group(backend="gloo")
@@ -642,13 +645,13 @@ def main():
     d_out = torch.zeros(nblocks * 16, dtype=torch.uint8, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
     elapsed, kms = time_device_resident(lib, ctx, cfg, d_img, d_out, dev, args.steps, args.warmup, barrier)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())

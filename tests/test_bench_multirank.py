@@ -39,3 +39,21 @@ def test_two_ranks_print_one_complete_line(built):
         assert key in line, sorted(line)
     assert line["roofline"]["kernel"] == "astcd::astc_compress_blocks_ldr_6x6m"
     assert line["cpu_baseline"]["blocks_mismatching_gpu"] == 0 and line["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_multi_rank_launch_with_one_rank(built):
+    """The RCCL leg itself -- init_process_group(backend="nccl", device_id=...), the barriers around the timed region, the
+    MAX all-reduce of the elapsed time on a device tensor, destroy_process_group -- cannot run with two ranks on one GPU; with
+    ONE rank under torch.distributed.run (ASTC_BENCH_FORCE_DIST=1) the same calls execute against the real RCCL."""
+    env = dict(os.environ, ASTC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    env.pop("ASTC_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-extra",
+           "--no-cpu-baseline", "--no-host-api"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and abs(line["value"] - 8192 * 8192 / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
